@@ -1,0 +1,146 @@
+/* nope_hip.h -- C ABI of libnope_hip.so: the MI355X (gfx950) implementation of the NOPE
+ * inference hot path (pose-conditioned U-Net template generation + template-bank scoring).
+ *
+ * The reference (nv-nguyen/nope) is pure Python on torch ops and has no FFI of its own; the
+ * drop-in boundary is its Python operator interface (src/model/model.py, u_net.py), mirrored
+ * by `nope_amd/` on top of THIS library.  Each entry point names the reference code whose
+ * arithmetic it replaces (paths relative to the reference tree).  See INTEGRATION.md for the
+ * ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer unless it says "host";
+ *   - the caller owns all buffers; only nope_unet_create allocates (packed weights);
+ *   - `stream` is a hipStream_t passed as void*; all work is asynchronous on it;
+ *   - re-entrant per stream, no global state; returns 0 or a negative NOPE_ERR_* code;
+ *   - nothing here ever falls back to the host: without a GPU the calls fail.
+ */
+#ifndef NOPE_HIP_H
+#define NOPE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { NOPE_F32 = 0, NOPE_BF16 = 1 };
+enum { NOPE_CONV_PLAIN = 0, NOPE_CONV_UP2 = 1, NOPE_CONV_DOWN2 = 2 };
+enum {
+    NOPE_OK = 0,
+    NOPE_ERR_ARG = -1,        /* bad argument (null pointer, unsupported size/dtype) */
+    NOPE_ERR_LAUNCH = -2,     /* HIP reported a launch error */
+    NOPE_ERR_WORKSPACE = -3,  /* workspace too small */
+    NOPE_ERR_WEIGHT = -4,     /* missing / mis-shaped state-dict entry */
+    NOPE_ERR_ALLOC = -5,
+    NOPE_ERR_UNSUPPORTED = -6
+};
+
+typedef void* nope_stream_t;
+
+const char* nope_strerror(int code);
+int nope_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Template-bank scoring.  Replaces PoseConditional.retrieval's "l2" metric,
+ * src/model/model.py:257-262:
+ *     score[b,n] = - sum_{h,w} sqrt( sum_c (q[b,c,h,w] - t[b,n,c,h,w])^4 )
+ * without materialising the repeated query (model.py:258).
+ *   q       (B,C,H,W) f32, contiguous
+ *   bank    (B,N,C,H,W) of `bank_dtype` (NOPE_F32 | NOPE_BF16); sample stride `bank_stride_b`
+ *           ELEMENTS (0 = one bank shared by every query)
+ *   scores  f32, row b at scores + b*score_ld  (score_ld >= N; lets a rank write its
+ *           N/G slice of a gathered (B,N) matrix in place)
+ * HW*sizeof(elt) must be a multiple of 16 bytes. */
+int nope_similarity(const float* q, const void* bank, int bank_dtype, float* scores, int B, int N, int C, int H,
+                    int W, int64_t bank_stride_b, int score_ld, nope_stream_t stream);
+
+/* Top-k over each row.  Replaces `similarity.topk(k=5, dim=1)`, model.py:265.
+ * Order: descending score; ties -> lowest index (argmax semantics); NaN ranks highest.
+ *   idx   (B,k) int64;  vals (B,k) f32 or NULL.   1 <= k <= 16, k <= N. */
+int nope_topk(const float* scores, int64_t* idx, float* vals, int B, int N, int k, int score_ld,
+              nope_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pose-conditioned U-Net.  Replaces UNet.__init__/forward,
+ * src/model/u_net/denoising_diffusion_pytorch/u_net.py:27-198 and the blocks of
+ * model_utils.py:161-172,198-279,367-418.
+ */
+typedef struct nope_unet nope_unet;
+
+typedef struct {
+    const char* name;      /* host: reference state-dict key, e.g. "downs.0.0.block1.proj.weight" */
+    const float* data;     /* device: f32, contiguous, torch layout (Conv2d: [Cout,Cin,kh,kw]) */
+    int ndim;
+    int64_t shape[4];
+} nope_tensor_desc;
+
+typedef struct {
+    int u_net_dim;         /* 192  (configs/model/template_base.yaml:4) */
+    int channels;          /* encoder.latent_dim, 8 (u_net.py:45) */
+    int out_dim;           /* = channels (u_net.py:50) */
+    int pose_dim;          /* rot_representation_dim, 6 */
+    int n_levels;          /* len(dim_mults) = 4 */
+    int dim_mults[8];      /* (1,2,4,8) */
+    int groups;            /* resnet_block_groups = 8 */
+    int heads, dim_head;   /* 4, 32 (model_utils.py:368,394) */
+    int pose_mlp_layers;   /* 1 = "single_layer", 2 = "two_layers" (u_net.py:63-72) */
+    int compute_dtype;     /* NOPE_F32: f32 storage + f32-input MFMA (bit-faithful fp32 sums);
+                              NOPE_BF16: bf16 storage + bf16 MFMA, f32 accumulate / statistics */
+} nope_unet_config;
+
+/* Validates and repacks the reference state dict for the device (the only allocating call). */
+int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensors, int n_tensors,
+                     nope_stream_t stream, nope_unet** out);
+void nope_unet_destroy(nope_unet* net);
+
+size_t nope_unet_workspace_bytes(const nope_unet* net, int n_hyp, int n_src, int H, int W);
+
+/* out[j] = UNet(x[j / x_rep], pose[j])  for j in [0, n_hyp).
+ *   x     (n_src, channels, H, W) f32 NCHW, n_src * x_rep == n_hyp.  x_rep = 1 is
+ *         UNet.forward(x, pose) (u_net.py:160); x_rep = N evaluates N pose hypotheses per
+ *         reference embedding, the batched form of the template loop (model.py:212-222).
+ *   pose  (n_hyp, pose_dim) f32
+ *   out   (n_hyp, out_dim, H, W) NCHW of `out_dtype` -- i.e. directly a slice of the
+ *         (B,N,C,h,w) template bank.
+ * H and W must be divisible by 2^(n_levels-1). */
+int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep, const float* pose, int n_hyp,
+                      int H, int W, void* out, int out_dtype, void* workspace, size_t workspace_bytes,
+                      nope_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator-level entry points (NHWC activations of `dtype`), exported so that each block of
+ * model_utils.py can be parity-tested in isolation.  Weights for nope_op_conv are packed
+ * [Cout][ntaps][Cin] by nope_op_pack_conv_weight.
+ */
+int nope_op_nchw_to_nhwc(int dtype, const float* x_nchw, void* y_nhwc, int n, int C, int HW, nope_stream_t s);
+int nope_op_nhwc_to_nchw(int dtype, const void* x_nhwc, float* y_nchw, int n, int C, int HW, nope_stream_t s);
+int nope_op_pack_conv_weight(int dtype, const float* w, void* packed, int Cout, int Cin, int ntaps, int mode,
+                             nope_stream_t s);
+/* conv3x3(pad1) / conv1x1 / nearest-x2+conv3x3 (HardUpsample, model_utils.py:161-165) /
+ * space-to-depth+conv1x1 (HardDownsample, :168-172) over a virtual channel concat
+ * (torch.cat((x, skip), dim=1), u_net.py:186,189,194) as one implicit GEMM. */
+int nope_op_conv(int dtype, const void* src1, int C1, int rep1, const void* src2, int C2, int rep2, int Hs, int Ws,
+                 int mode, int ntaps, const void* w_packed, const float* bias, const void* resid, void* out,
+                 int Cout, int n_hyp, int out_nchw, int out_dtype, nope_stream_t s);
+/* GroupNorm(G, C) [+ SiLU] [+ emb[hyp, c]] [+ resid]: Block.norm/act (model_utils.py:241-252),
+ * the conditioning add (:274-276), PreNorm (:226-234) and Residual (:198-204).
+ * `partial` scratch: n_hyp * nope_op_gn_chunks() * G * 2 floats. */
+int nope_op_gn_chunks(int dtype, int HW, int C);
+int nope_op_group_norm(int dtype, const void* x, void* y, float* partial, const float* gamma, const float* beta,
+                       int n_hyp, int HW, int C, int G, int act_silu, const float* emb, int emb_stride,
+                       const void* resid, nope_stream_t s);
+/* LinearAttention core (model_utils.py:403-416) and Attention core (:376-389) on a fused
+ * qkv tensor [n_hyp][HW][3*heads*dim_head]; out [n_hyp][HW][heads*dim_head]. */
+int nope_op_linear_attention(int dtype, const void* qkv, void* out, int n_hyp, int HW, int heads, int dim_head,
+                             nope_stream_t s);
+int nope_op_attention(int dtype, const void* qkv, void* out, int n_hyp, int HW, int heads, int dim_head,
+                      nope_stream_t s);
+/* out[m, n] = sum_k act(in[m,k]) * w[n,k] + bias[n]  (f32; act_in: 0 none, 1 SiLU, 2 GELU):
+ * pose_mlp (u_net.py:63-72) and ResnetBlock.mlp (model_utils.py:261-265). */
+int nope_op_linear(const float* in, const float* w, const float* bias, float* out, int M, int N, int K, int act_in,
+                   nope_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NOPE_HIP_H */

@@ -1,0 +1,64 @@
+"""Build libnope_hip.so for gfx950 with hipcc (no torch headers, no hipify).
+
+    python -m nope_amd.csrc.build            # or __graft_entry__.build()
+
+Sources are compiled in parallel to object files under build/ and linked into
+nope_amd/csrc/libnope_hip.so (git-ignored; travels to the GPU box with the snapshot).
+"""
+from __future__ import annotations
+
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SOURCES = ["kernels_gemm.hip", "kernels_norm.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_retrieval.hip",
+           "unet_runtime.hip", "capi.hip"]
+LIB = os.path.join(HERE, "libnope_hip.so")
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = _hipcc()
+    objdir = os.path.join(ROOT, "build", "hip")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(HERE, "nope_common.h"), os.path.join(ROOT, "include", "nope_hip.h")]
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        path = os.path.join(HERE, src)
+        if not force and _newer(obj, [path] + headers):
+            return obj
+        cmd = [hipcc] + flags + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or not _newer(LIB, objs):
+        subprocess.run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,81 @@
+// extern "C" entry points of libnope_hip.so that are thin argument checks over the kernel
+// launchers (the U-Net entry points live in unet_runtime.hip).  See include/nope_hip.h.
+#include "nope_common.h"
+
+using namespace nope;
+
+extern "C" {
+
+int nope_abi_version(void) { return 1; }
+
+const char* nope_strerror(int code) {
+    switch (code) {
+        case NOPE_OK: return "ok";
+        case NOPE_ERR_ARG: return "invalid argument";
+        case NOPE_ERR_LAUNCH: return "HIP launch/runtime error";
+        case NOPE_ERR_WORKSPACE: return "workspace too small";
+        case NOPE_ERR_WEIGHT: return "missing or mis-shaped state-dict tensor";
+        case NOPE_ERR_ALLOC: return "device allocation failed";
+        case NOPE_ERR_UNSUPPORTED: return "unsupported size or dtype";
+        default: return "unknown error";
+    }
+}
+
+int nope_similarity(const float* q, const void* bank, int bank_dtype, float* scores, int B, int N, int C, int H, int W,
+                    int64_t bank_stride_b, int score_ld, nope_stream_t stream) {
+    if (H <= 0 || W <= 0) return NOPE_ERR_ARG;
+    return launch_similarity(q, bank, bank_dtype, scores, B, N, C, H * W, (long long)bank_stride_b, score_ld, (hipStream_t)stream);
+}
+
+int nope_topk(const float* scores, int64_t* idx, float* vals, int B, int N, int k, int score_ld, nope_stream_t stream) {
+    return launch_topk(scores, (long long*)idx, vals, B, N, k, score_ld, (hipStream_t)stream);
+}
+
+int nope_op_nchw_to_nhwc(int dtype, const float* x, void* y, int n, int C, int HW, nope_stream_t s) {
+    return launch_nchw_to_nhwc(dtype, x, y, n, C, HW, (hipStream_t)s);
+}
+int nope_op_nhwc_to_nchw(int dtype, const void* x, float* y, int n, int C, int HW, nope_stream_t s) {
+    return launch_nhwc_to_nchw_f32(dtype, x, y, n, C, HW, (hipStream_t)s);
+}
+int nope_op_pack_conv_weight(int dtype, const float* w, void* packed, int Cout, int Cin, int ntaps, int mode, nope_stream_t s) {
+    return launch_pack_conv_w(dtype, w, packed, Cout, Cin, ntaps, mode, (hipStream_t)s);
+}
+
+int nope_op_conv(int dtype, const void* src1, int C1, int rep1, const void* src2, int C2, int rep2, int Hs, int Ws, int mode,
+                 int ntaps, const void* w_packed, const float* bias, const void* resid, void* out, int Cout, int n_hyp,
+                 int out_nchw, int out_dtype, nope_stream_t s) {
+    ConvArgs a;
+    a.src1 = src1; a.C1 = C1; a.rep1 = rep1; a.src2 = src2; a.C2 = C2; a.rep2 = rep2 > 0 ? rep2 : 1;
+    a.Hs = Hs; a.Ws = Ws; a.mode = mode; a.ntaps = ntaps;
+    a.Ho = mode == NOPE_CONV_UP2 ? 2 * Hs : (mode == NOPE_CONV_DOWN2 ? Hs / 2 : Hs);
+    a.Wo = mode == NOPE_CONV_UP2 ? 2 * Ws : (mode == NOPE_CONV_DOWN2 ? Ws / 2 : Ws);
+    if (mode == NOPE_CONV_DOWN2 && ((Hs | Ws) & 1)) return NOPE_ERR_ARG;
+    a.w = w_packed; a.bias = bias; a.resid = resid; a.out = out; a.Cout = Cout; a.nhyp = n_hyp;
+    a.out_nchw = out_nchw; a.out_dt = out_dtype;
+    return launch_conv(dtype, a, (hipStream_t)s);
+}
+
+int nope_op_gn_chunks(int dtype, int HW, int C) { return gn_stats_chunks(HW, C, dtype); }
+
+int nope_op_group_norm(int dtype, const void* x, void* y, float* partial, const float* gamma, const float* beta, int n_hyp, int HW,
+                       int C, int G, int act_silu, const float* emb, int emb_stride, const void* resid, nope_stream_t s) {
+    const int nch = gn_stats_chunks(HW, C, dtype);
+    int e = launch_gn_stats(dtype, x, partial, n_hyp, HW, C, G, nch, (hipStream_t)s);
+    if (e) return e;
+    GnApplyArgs a;
+    a.x = x; a.y = y; a.partial = partial; a.nchunk = nch; a.gamma = gamma; a.beta = beta;
+    a.nhyp = n_hyp; a.HW = HW; a.C = C; a.G = G; a.act = act_silu; a.emb = emb; a.emb_stride = emb_stride; a.resid = resid;
+    return launch_gn_apply(dtype, a, (hipStream_t)s);
+}
+
+int nope_op_linear_attention(int dtype, const void* qkv, void* out, int n_hyp, int HW, int heads, int dim_head, nope_stream_t s) {
+    return launch_linattn(dtype, qkv, out, n_hyp, HW, heads, dim_head, (hipStream_t)s);
+}
+int nope_op_attention(int dtype, const void* qkv, void* out, int n_hyp, int HW, int heads, int dim_head, nope_stream_t s) {
+    return launch_attn(dtype, qkv, out, n_hyp, HW, heads, dim_head, (hipStream_t)s);
+}
+int nope_op_linear(const float* in, const float* w, const float* bias, float* out, int M, int N, int K, int act_in, nope_stream_t s) {
+    return launch_linear_naive(in, w, bias, out, M, N, K, act_in, N, (hipStream_t)s);
+}
+
+}  // extern "C"

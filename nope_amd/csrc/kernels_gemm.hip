@@ -1,0 +1,272 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): every conv / linear of the NOPE U-Net.
+//
+//   out[m, n] = sum_{tap, c} A[m, tap, c] * W[n, tap, c] + bias[n] (+ resid[m, n])
+//
+// m = (hypothesis, oy, ox) over NHWC activations, n = output channel, K = taps x Cin.
+// The A operand is never materialised: the loader walks taps and channel chunks directly
+// over one or two NHWC sources (virtual torch.cat, u_net.py:186,189,194), optionally through
+// a nearest-x2 upsample (HardUpsample, model_utils.py:161-165) or a 2x2 space-to-depth
+// (HardDownsample, :168-172; the weight's K axis is re-ordered at pack time so each of the 4
+// taps reads a contiguous channel run), and sources may be shared by `rep` consecutive
+// hypotheses (the reference embedding feeding all N pose hypotheses, model.py:219).
+//
+// Tiling (64-wide wavefronts): 128 x 192 output tile per 256-thread workgroup, 4 waves as
+// 2(M) x 2(N), each wave 64 x 96 = 4 x 6 MFMA 16x16 tiles (96 accumulator VGPRs).  192
+// divides every Cout of the network (192/384/768/1536 and the 384-wide qkv).  K step = 128
+// bytes per row (64 bf16 / 32 f32), staged global -> VGPR -> LDS with the next step's global
+// loads in flight under the current step's MFMAs.  LDS rows are 128 B = 8 x 16-B slots,
+// XOR-swizzled by (row >> 1) & 7 so both the ds_write_b128 staging writes (8 consecutive
+// lanes = one row) and the ds_read_b128 fragment reads (16 rows x one slot per lane group)
+// are bank-conflict free (MI355X_MICROARCH.md, LDS table).
+//
+// MFMA: bf16 -> v_mfma_f32_16x16x32_bf16; f32 -> v_mfma_f32_16x16x4_f32 (exact f32 fma
+// chain; gfx950 has no xf32).  For f32 each lane's 16-byte fragment holds 4 consecutive
+// channels that feed 4 successive 16x16x4 steps - the reduction order inside a 32-channel
+// chunk is permuted identically for A and W, which only reorders the fp32 sum.
+//
+// Workgroup -> tile map is XCD-aware: blocks that land on one XCD (blockIdx % 8) share the
+// weight panel (tile_n), so at the deep levels (8 N-tiles of 8 MB each) every XCD's L2
+// streams one panel instead of all eight.
+#include "nope_common.h"
+
+namespace nope {
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BN = 192;
+constexpr int NT = 256;
+constexpr int ROWB = 128;  // bytes per LDS row
+constexpr int A_ITERS = BM / 32;
+constexpr int B_ITERS = BN / 32;
+constexpr int MT = 4;  // 16-row tiles per wave (64 rows)
+constexpr int NTL = 6; // 16-col tiles per wave (96 cols)
+
+struct ConvParams {
+    const unsigned char* src1; const unsigned char* src2;
+    int C1, C2, rep1, rep2;
+    int Hs, Ws, Ho, Wo;
+    int mode, ntaps;
+    const unsigned char* w;
+    const float* bias;
+    const unsigned char* resid;
+    unsigned char* out;
+    int Cout, M;
+    int out_nchw, out_dt;
+    int tiles_m, tiles_n, xcd_map;
+};
+
+template <class T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+        f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <class T>
+__global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr int BK = 8 * VEC;
+    constexpr int ES = (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(BM + BN) * ROWB];
+    unsigned char* ldsA = lds;
+    unsigned char* ldsB = lds + BM * ROWB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int tile_m, tile_n;
+    {
+        const int g = blockIdx.x;
+        if (p.xcd_map) {   // tiles_n in {1,2,4,8}, tiles_m % (8 / tiles_n) == 0
+            const int x = g & 7, j = g >> 3;
+            const int per = 8 / p.tiles_n;
+            tile_n = x % p.tiles_n;
+            tile_m = j * per + x / p.tiles_n;
+        } else {
+            tile_n = g % p.tiles_n;
+            tile_m = g / p.tiles_n;
+        }
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int slot = tid & 7;
+    const int rbase = tid >> 3;
+    const int HWo = p.Ho * p.Wo;
+    const int Cin = p.C1 + p.C2;
+
+    int a_s1[A_ITERS], a_s2[A_ITERS], a_oy[A_ITERS], a_ox[A_ITERS];
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+        const int m = m0 + rbase + 32 * i;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / HWo;
+        const int r = mm - b * HWo;
+        const int oy = r / p.Wo;
+        a_oy[i] = ok ? oy : -100000;   // poisons the bounds test for rows beyond M
+        a_ox[i] = r - oy * p.Wo;
+        a_s1[i] = b / p.rep1;
+        a_s2[i] = b / p.rep2;
+    }
+
+    const int kc_per_tap = (Cin + BK - 1) / BK;
+    const int nk = p.ntaps * kc_per_tap;
+
+    u32x4 ra[A_ITERS], rb[B_ITERS];
+    int ld_tap = 0, ld_kc = 0;
+
+    auto load_step = [&]() {
+        const int c = ld_kc * BK + slot * VEC;
+        int dy = 0, dx = 0;
+        if (p.mode == NOPE_CONV_DOWN2) { dy = ld_tap >> 1; dx = ld_tap & 1; }
+        else if (p.ntaps == 9) { dy = ld_tap / 3 - 1; dx = ld_tap - (ld_tap / 3) * 3 - 1; }
+        const bool c_ok = c < Cin;
+        const bool first = c < p.C1;
+        const unsigned char* sbase = first ? p.src1 : p.src2;
+        const int cs = first ? c : c - p.C1;
+        const int Cs = first ? p.C1 : p.C2;
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            int iy, ix;
+            bool ok;
+            if (p.mode == NOPE_CONV_DOWN2) {
+                iy = 2 * a_oy[i] + dy; ix = 2 * a_ox[i] + dx;
+                ok = a_oy[i] >= 0;
+            } else if (p.mode == NOPE_CONV_UP2) {
+                const int uy = a_oy[i] + dy, ux = a_ox[i] + dx;
+                ok = uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
+                iy = uy >> 1; ix = ux >> 1;
+            } else {
+                iy = a_oy[i] + dy; ix = a_ox[i] + dx;
+                ok = iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+            }
+            ok = ok && c_ok;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                const int sb = first ? a_s1[i] : a_s2[i];
+                const size_t pix = ((size_t)sb * p.Hs + iy) * p.Ws + ix;
+                v = ld16(sbase + (pix * Cs + cs) * ES);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_ITERS; ++j) {
+            const int n = n0 + rbase + 32 * j;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (n < p.Cout && c_ok) v = ld16(p.w + (((size_t)n * p.ntaps + ld_tap) * Cin + c) * ES);
+            rb[j] = v;
+        }
+        if (++ld_kc == kc_per_tap) { ld_kc = 0; ++ld_tap; }
+    };
+
+    f32x4 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_step();
+    for (int ks = 0; ks < nk; ++ks) {
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) st16(ldsA + lds_off(rbase + 32 * i, slot), ra[i]);
+#pragma unroll
+        for (int j = 0; j < B_ITERS; ++j) st16(ldsB + lds_off(rbase + 32 * j, slot), rb[j]);
+        __syncthreads();
+        if (ks + 1 < nk) load_step();   // global loads for step ks+1 fly under the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4 af[MT], bfr[NTL];
+            const int s = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = ld16(ldsA + lds_off(wm * 64 + i * 16 + (lane & 15), s));
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) bfr[j] = ld16(ldsB + lds_off(wn * 96 + j * 16 + (lane & 15), s));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D map col = lane & 15, row = (lane >> 4) * 4 + r
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* resid = reinterpret_cast<const T*>(p.resid);
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+        const int n = n0 + wn * 96 + j * 16 + (lane & 15);
+        if (n >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (resid) v += Elt<T>::ld(resid + (size_t)m * p.Cout + n);
+                if (p.out_nchw) {
+                    const int b = m / HWo;
+                    const int pix = m - b * HWo;
+                    const size_t o = ((size_t)b * p.Cout + n) * HWo + pix;
+                    if (p.out_dt == NOPE_F32) reinterpret_cast<float*>(p.out)[o] = v;
+                    else reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(v);
+                } else {
+                    Elt<T>::st(out + (size_t)m * p.Cout + n, v);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
+    if (!a.src1 || !a.w || !a.out || a.C1 <= 0 || a.Cout <= 0 || a.nhyp <= 0) return NOPE_ERR_ARG;
+    if (a.C2 > 0 && !a.src2) return NOPE_ERR_ARG;
+    const int vec = dt == NOPE_F32 ? 4 : 8;
+    if (dt != NOPE_F32 && dt != NOPE_BF16) return NOPE_ERR_UNSUPPORTED;
+    if (a.C1 % vec || a.C2 % vec) return NOPE_ERR_UNSUPPORTED;
+    if (a.rep1 < 1 || a.rep2 < 1) return NOPE_ERR_ARG;
+    if (a.mode == NOPE_CONV_PLAIN) {
+        if ((a.ntaps != 1 && a.ntaps != 9) || a.Hs != a.Ho || a.Ws != a.Wo) return NOPE_ERR_ARG;
+    } else if (a.mode == NOPE_CONV_UP2) {
+        if (a.ntaps != 9 || a.Ho != 2 * a.Hs || a.Wo != 2 * a.Ws) return NOPE_ERR_ARG;
+    } else if (a.mode == NOPE_CONV_DOWN2) {
+        if (a.ntaps != 4 || a.Hs != 2 * a.Ho || a.Ws != 2 * a.Wo) return NOPE_ERR_ARG;
+    } else return NOPE_ERR_ARG;
+    const long long M = (long long)a.nhyp * a.Ho * a.Wo;
+    if (M > 0x7fffffffLL) return NOPE_ERR_UNSUPPORTED;
+
+    ConvParams p;
+    p.src1 = (const unsigned char*)a.src1; p.src2 = (const unsigned char*)a.src2;
+    p.C1 = a.C1; p.C2 = a.C2; p.rep1 = a.rep1; p.rep2 = a.rep2;
+    p.Hs = a.Hs; p.Ws = a.Ws; p.Ho = a.Ho; p.Wo = a.Wo;
+    p.mode = a.mode; p.ntaps = a.ntaps;
+    p.w = (const unsigned char*)a.w; p.bias = a.bias; p.resid = (const unsigned char*)a.resid;
+    p.out = (unsigned char*)a.out; p.Cout = a.Cout; p.M = (int)M;
+    p.out_nchw = a.out_nchw; p.out_dt = a.out_dt;
+    p.tiles_m = cdiv((int)M, BM); p.tiles_n = cdiv(a.Cout, BN);
+    const int tn = p.tiles_n;
+    p.xcd_map = (tn == 1 || tn == 2 || tn == 4 || tn == 8) && (p.tiles_m % (8 / tn) == 0) ? 1 : 0;
+    const long long nblocks = (long long)p.tiles_m * p.tiles_n;
+    if (nblocks > 0x7fffffffLL) return NOPE_ERR_UNSUPPORTED;
+    if (dt == NOPE_F32) hipLaunchKernelGGL((conv_gemm_kernel<float>), dim3((unsigned)nblocks), dim3(NT), 0, s, p);
+    else hipLaunchKernelGGL((conv_gemm_kernel<bf16_t>), dim3((unsigned)nblocks), dim3(NT), 0, s, p);
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+}  // namespace nope

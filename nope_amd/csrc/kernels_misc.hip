@@ -1,0 +1,156 @@
+// Small data-movement kernels around the U-Net: layout changes at the NCHW API boundary,
+// one-time weight repacking, and the tiny f32 linears of the pose embedding path.
+#include "nope_common.h"
+
+namespace nope {
+
+namespace {
+
+constexpr int NT = 256;
+
+// (n, C, HW) f32 NCHW -> [n][HW][C] T.  C is small (8 latent channels) at this boundary.
+template <class T>
+__global__ __launch_bounds__(NT) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int C, int HW, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        const size_t t = i / C;
+        const int p = (int)(t % HW);
+        const size_t b = t / HW;
+        Elt<T>::st(y + i, x[(b * C + c) * HW + p]);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(NT) void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int C, int HW, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
+        const int p = (int)(i % HW);
+        const size_t t = i / HW;
+        const int c = (int)(t % C);
+        const size_t b = t / C;
+        y[i] = Elt<T>::ld(x + (b * HW + p) * C + c);
+    }
+}
+
+// torch Conv2d weight [Cout][Cin_t][kh][kw] f32 -> packed [Cout][tap][Cin] T.
+//   PLAIN / UP2: Cin_t = Cin, tap = kh*3 + kw (or the single 1x1 tap).
+//   DOWN2: the conv is 1x1 over the space-to-depth tensor whose channel index is
+//          c*4 + p1*2 + p2 (einops "b (c p1 p2) h w", model_utils.py:170); tap = p1*2 + p2.
+template <class T>
+__global__ __launch_bounds__(NT) void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ out, int Cin, int ntaps, int mode,
+                                                         size_t total) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % Cin);
+        const size_t t = i / Cin;
+        const int tap = (int)(t % ntaps);
+        const size_t co = t / ntaps;
+        size_t src;
+        if (mode == NOPE_CONV_DOWN2) src = co * ((size_t)Cin * 4) + (size_t)c * 4 + tap;
+        else src = (co * Cin + c) * ntaps + tap;
+        Elt<T>::st(out + i, w[src]);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(NT) void cast_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) Elt<T>::st(out + i, in[i]);
+}
+
+__global__ __launch_bounds__(NT) void silu_f32_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) out[i] = silu_f<false>(in[i]);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// out[m][n] = sum_k act(in[m][k]) * w[n][k] + bias[n]; one wave per output element row-chunk:
+// each wave owns (m, 64 consecutive n?) -- no: K is the contiguous axis of both operands, so a
+// wave owns one (m, n) pair group: lane l accumulates k = l, l+64, ... and the wave reduces.
+__global__ __launch_bounds__(NT) void linear_naive_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int M, int N, int K,
+                                                          int act_in, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * NT + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * NT) >> 6;
+    for (size_t o = wave; o < (size_t)M * N; o += nwaves) {
+        const int m = (int)(o / N), n = (int)(o % N);
+        float a = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            float x = in[(size_t)m * K + k];
+            if (act_in == 1) x = silu_f<false>(x);
+            else if (act_in == 2) x = gelu_erf(x);
+            a += x * w[(size_t)n * K + k];
+        }
+        a = wave_sum(a);
+        if (lane == 0) out[(size_t)m * ldo + n] = a + (bias ? bias[n] : 0.f);
+    }
+}
+
+inline unsigned grid_for(size_t n) {
+    size_t g = (n + NT - 1) / NT;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+int launch_nchw_to_nhwc(int dt, const float* x, void* y, int n, int C, int HW, hipStream_t s) {
+    if (!x || !y || n <= 0 || C <= 0 || HW <= 0) return NOPE_ERR_ARG;
+    const size_t total = (size_t)n * C * HW;
+    if (dt == NOPE_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(grid_for(total)), dim3(NT), 0, s, x, (float*)y, C, HW, total);
+    else if (dt == NOPE_BF16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(grid_for(total)), dim3(NT), 0, s, x, (bf16_t*)y, C, HW, total);
+    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_nhwc_to_nchw_f32(int dt, const void* x, float* y, int n, int C, int HW, hipStream_t s) {
+    if (!x || !y || n <= 0 || C <= 0 || HW <= 0) return NOPE_ERR_ARG;
+    const size_t total = (size_t)n * C * HW;
+    if (dt == NOPE_F32) hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), dim3(grid_for(total)), dim3(NT), 0, s, (const float*)x, y, C, HW, total);
+    else if (dt == NOPE_BF16) hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16_t>), dim3(grid_for(total)), dim3(NT), 0, s, (const bf16_t*)x, y, C, HW, total);
+    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || ntaps <= 0) return NOPE_ERR_ARG;
+    if (mode == NOPE_CONV_DOWN2 && ntaps != 4) return NOPE_ERR_ARG;
+    const size_t total = (size_t)Cout * ntaps * Cin;
+    if (dt == NOPE_F32) hipLaunchKernelGGL((pack_conv_w_kernel<float>), dim3(grid_for(total)), dim3(NT), 0, s, w, (float*)out, Cin, ntaps, mode, total);
+    else if (dt == NOPE_BF16) hipLaunchKernelGGL((pack_conv_w_kernel<bf16_t>), dim3(grid_for(total)), dim3(NT), 0, s, w, (bf16_t*)out, Cin, ntaps, mode, total);
+    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_cast(int dt, const float* in, void* out, size_t n, hipStream_t s) {
+    if (!in || !out) return NOPE_ERR_ARG;
+    if (n == 0) return NOPE_OK;
+    if (dt == NOPE_F32) hipLaunchKernelGGL((cast_kernel<float>), dim3(grid_for(n)), dim3(NT), 0, s, in, (float*)out, n);
+    else if (dt == NOPE_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t>), dim3(grid_for(n)), dim3(NT), 0, s, in, (bf16_t*)out, n);
+    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_silu_f32(const float* in, float* out, size_t n, hipStream_t s) {
+    if (!in || !out) return NOPE_ERR_ARG;
+    if (n == 0) return NOPE_OK;
+    hipLaunchKernelGGL(silu_f32_kernel, dim3(grid_for(n)), dim3(NT), 0, s, in, out, n);
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_linear_naive(const float* in, const float* w, const float* bias, float* out, int M, int N, int K, int act_in, int ldo,
+                        hipStream_t s) {
+    if (!in || !w || !out || M <= 0 || N <= 0 || K <= 0) return NOPE_ERR_ARG;
+    const size_t outs = (size_t)M * N;
+    size_t blocks = (outs + 3) / 4;   // 4 waves per block, one output per wave per iteration
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(linear_naive_kernel, dim3((unsigned)blocks), dim3(NT), 0, s, in, w, bias, out, M, N, K, act_in, ldo);
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+}  // namespace nope

@@ -1,0 +1,202 @@
+// GroupNorm over NHWC activations, in two HBM passes:
+//   gn_stats_kernel : per (hypothesis, pixel-chunk, group) partial (sum, sum of squares), f32,
+//                     written to a scratch table -- no atomics, so results are run-to-run
+//                     deterministic;
+//   gn_apply_kernel : folds the chunk partials into (mean, rstd), then
+//                     y = act((x - mean) * rstd * gamma + beta) [+ emb[hyp, c]] [+ resid]
+// which covers Block.norm + SiLU (model_utils.py:241-252), the pose-embedding add that
+// follows block1 (:274-276), the residual add of ResnetBlock (:279), PreNorm's
+// GroupNorm(1, C) (:226-234) and Residual (:198-204).  Both passes are pure streaming
+// (16-byte loads, every byte touched once), i.e. HBM-bound.
+#include "nope_common.h"
+
+namespace nope {
+
+namespace {
+
+constexpr int NT = 256;
+
+// Each thread owns one 16-byte channel vector (tid % tpr) and walks the chunk's pixels with
+// stride `rows`.  FASTG: C/VEC <= 256 and channels-per-group is a multiple of VEC, so a
+// vector belongs to exactly one group; partials are folded by two fixed-shape LDS trees
+// (over pixel rows, then over the vectors of a group) -- deterministic, no atomics.
+template <class T, bool FASTG>
+__global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ partial, int HW, int C,
+                                                      int G, int nchunk) {
+    constexpr int VEC = Elt<T>::VEC;
+    __shared__ float red_s[FASTG ? NT : 2048];
+    __shared__ float red_q[FASTG ? NT : 2048];
+    const int hyp = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    const int tid = threadIdx.x;
+    const int pchunk = (HW + nchunk - 1) / nchunk;
+    const int p0 = chunk * pchunk;
+    const int p1 = (p0 + pchunk < HW) ? p0 + pchunk : HW;
+    const int cpg = C / G;
+    const T* xb = x + (size_t)hyp * HW * C;
+    float* outp = partial + ((size_t)hyp * nchunk + chunk) * G * 2;
+
+    if (FASTG) {
+        const int tpr = C / VEC;          // <= NT
+        const int rows = NT / tpr;
+        const int row = tid / tpr, lc = tid % tpr;
+        const int vpg = cpg / VEC;        // vectors per group
+        float s = 0.f, q = 0.f;
+        if (row < rows) {
+            for (int pix = p0 + row; pix < p1; pix += rows) {
+                float v[VEC];
+                Elt<T>::unpack(ld16(xb + (size_t)pix * C + lc * VEC), v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { s += v[e]; q += v[e] * v[e]; }
+            }
+        }
+        red_s[tid] = s; red_q[tid] = q;
+        __syncthreads();
+        int st = 1;
+        while (st < rows) st <<= 1;
+        for (st >>= 1; st >= 1; st >>= 1) {            // tree over pixel rows
+            if (row < st && row + st < rows) {
+                red_s[row * tpr + lc] += red_s[(row + st) * tpr + lc];
+                red_q[row * tpr + lc] += red_q[(row + st) * tpr + lc];
+            }
+            __syncthreads();
+        }
+        const int j = lc % vpg;
+        st = 1;
+        while (st < vpg) st <<= 1;
+        for (st >>= 1; st >= 1; st >>= 1) {            // tree over the vectors of a group
+            if (row == 0 && j < st && j + st < vpg) {
+                red_s[lc] += red_s[lc + st];
+                red_q[lc] += red_q[lc + st];
+            }
+            __syncthreads();
+        }
+        for (int g = tid; g < G; g += NT) { outp[g * 2] = red_s[g * vpg]; outp[g * 2 + 1] = red_q[g * vpg]; }
+    } else {
+        // generic path (C/VEC > 256, tiny or odd channel counts): per-channel sums with
+        // coalesced scalar loads, then a per-group fold.  C <= 2048.
+        for (int c = tid; c < C; c += NT) {
+            float s = 0.f, q = 0.f;
+            for (int pix = p0; pix < p1; ++pix) {
+                const float v = Elt<T>::ld(xb + (size_t)pix * C + c);
+                s += v; q += v * v;
+            }
+            red_s[c] = s; red_q[c] = q;
+        }
+        __syncthreads();
+        for (int g = tid; g < G; g += NT) {
+            float S = 0.f, Q = 0.f;
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { S += red_s[c]; Q += red_q[c]; }
+            outp[g * 2] = S; outp[g * 2 + 1] = Q;
+        }
+    }
+}
+
+template <class T, bool FAST>
+__global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ partial,
+                                                      int nchunk, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int HW, int C, int G, int act, const float* __restrict__ emb, int emb_stride,
+                                                      const T* __restrict__ resid, float eps, int blocks_per_hyp, int x_rep, int resid_rep) {
+    constexpr int VEC = Elt<T>::VEC;
+    __shared__ float s_mean[64];
+    __shared__ float s_rstd[64];
+    const int hyp = blockIdx.x / blocks_per_hyp, blk = blockIdx.x % blocks_per_hyp;
+    const int tid = threadIdx.x;
+    const int cpg = C / G;
+    const int xs = hyp / x_rep;
+    for (int g = tid; g < G; g += NT) {
+        float S = 0.f, Q = 0.f;
+        for (int k = 0; k < nchunk; ++k) {
+            const float* pp = partial + ((size_t)xs * nchunk + k) * G * 2 + g * 2;
+            S += pp[0]; Q += pp[1];
+        }
+        const float cnt = (float)cpg * (float)HW;
+        const float mean = S / cnt;
+        float var = Q / cnt - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        s_mean[g] = mean;
+        s_rstd[g] = 1.0f / sqrtf(var + eps);
+    }
+    __syncthreads();
+    const size_t nvec = (size_t)HW * C / VEC;
+    const size_t per = (nvec + blocks_per_hyp - 1) / blocks_per_hyp;
+    const size_t v0 = (size_t)blk * per;
+    const size_t v1 = v0 + per < nvec ? v0 + per : nvec;
+    const T* xb = x + (size_t)xs * HW * C;
+    T* yb = y + (size_t)hyp * HW * C;
+    const T* rb = resid ? resid + (size_t)(hyp / resid_rep) * HW * C : nullptr;
+    const float* eb = emb ? emb + (size_t)hyp * emb_stride : nullptr;
+    const int cvecs = C / VEC;
+    for (size_t i = v0 + tid; i < v1; i += NT) {
+        const int c0 = (int)(i % cvecs) * VEC;
+        float v[VEC], r[VEC];
+        Elt<T>::unpack(ld16(xb + i * VEC), v);
+        if (rb) Elt<T>::unpack(ld16(rb + i * VEC), r);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int c = c0 + e;
+            const int g = c / cpg;
+            float t = (v[e] - s_mean[g]) * s_rstd[g] * gamma[c] + beta[c];
+            if (act) t = silu_f<FAST>(t);
+            if (eb) t += eb[c];
+            if (rb) t += r[e];
+            v[e] = t;
+        }
+        st16(yb + i * VEC, Elt<T>::pack(v));
+    }
+}
+
+}  // namespace
+
+int gn_stats_chunks(int HW, int C, int dt) {
+    // aim for >= ~32 KB of streaming per workgroup while keeping thousands of workgroups
+    const size_t bytes = (size_t)HW * C * (dt == NOPE_F32 ? 4 : 2);
+    int n = (int)(bytes / (64 * 1024));
+    if (n < 1) n = 1;
+    if (n > 16) n = 16;
+    while (n > 1 && HW / n < 1) --n;
+    return n;
+}
+
+int launch_gn_stats(int dt, const void* x, float* partial, int nhyp, int HW, int C, int G, int nchunk, hipStream_t s) {
+    if (!x || !partial || nhyp <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G || nchunk < 1) return NOPE_ERR_ARG;
+    const int vec = dt == NOPE_F32 ? 4 : 8;
+    if (C % vec) return NOPE_ERR_UNSUPPORTED;
+    if (G > 64) return NOPE_ERR_UNSUPPORTED;
+    const int cpg = C / G;
+    const int cvecs = C / vec;
+    const bool fast = (cpg % vec == 0) && (cvecs <= NT);
+    if (!fast && C > 2048) return NOPE_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)(nhyp * nchunk)), block(NT);
+    if (dt == NOPE_F32) {
+        if (fast) hipLaunchKernelGGL((gn_stats_kernel<float, true>), grid, block, 0, s, (const float*)x, partial, HW, C, G, nchunk);
+        else hipLaunchKernelGGL((gn_stats_kernel<float, false>), grid, block, 0, s, (const float*)x, partial, HW, C, G, nchunk);
+    } else if (dt == NOPE_BF16) {
+        if (fast) hipLaunchKernelGGL((gn_stats_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)x, partial, HW, C, G, nchunk);
+        else hipLaunchKernelGGL((gn_stats_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)x, partial, HW, C, G, nchunk);
+    } else return NOPE_ERR_UNSUPPORTED;
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
+    if (!a.x || !a.y || !a.partial || !a.gamma || !a.beta || a.nhyp <= 0 || a.C % a.G) return NOPE_ERR_ARG;
+    const int vec = dt == NOPE_F32 ? 4 : 8;
+    if (a.C % vec || a.G > 64) return NOPE_ERR_UNSUPPORTED;
+    if (a.x_rep < 1 || a.resid_rep < 1) return NOPE_ERR_ARG;
+    const size_t bytes = (size_t)a.HW * a.C * (dt == NOPE_F32 ? 4 : 2);
+    int bph = (int)(bytes / (32 * 1024));
+    if (bph < 1) bph = 1;
+    if (bph > 64) bph = 64;
+    dim3 grid((unsigned)(a.nhyp * bph)), block(NT);
+    if (dt == NOPE_F32)
+        hipLaunchKernelGGL((gn_apply_kernel<float, false>), grid, block, 0, s, (const float*)a.x, (float*)a.y, a.partial, a.nchunk,
+                           a.gamma, a.beta, a.HW, a.C, a.G, a.act, a.emb, a.emb_stride, (const float*)a.resid, a.eps, bph, a.x_rep, a.resid_rep);
+    else if (dt == NOPE_BF16)
+        hipLaunchKernelGGL((gn_apply_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)a.x, (bf16_t*)a.y, a.partial, a.nchunk,
+                           a.gamma, a.beta, a.HW, a.C, a.G, a.act, a.emb, a.emb_stride, (const bf16_t*)a.resid, a.eps, bph, a.x_rep, a.resid_rep);
+    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+}  // namespace nope

@@ -1,0 +1,236 @@
+// Template-bank scoring (the HBM-roofline kernel of the path) and top-k.
+//
+//   score[b,n] = - sum_{pixels} sqrt( sum_c (q[b,c,p] - t[b,n,c,p])^4 )      model.py:257-262
+//
+// The bank keeps the API layout (B,N,C,h,w): for a fixed channel the h*w plane is contiguous,
+// so lane i of a workgroup owns pixel-vector i (16 bytes) and issues C independent, fully
+// coalesced 16-byte loads (1 KiB per wave instruction) -- one per channel plane -- before it
+// touches any of them.  The query tile lives in registers for the whole n-loop (it is the
+// same for every template of a sample; the reference materialises it N times, model.py:258),
+// so HBM traffic is the algorithmic minimum: C*h*w*sizeof(elt) per hypothesis + 4 bytes out.
+// Arithmetic is ~1.2 flop/byte: far below the VALU ridge, purely HBM-bound.
+// Accumulation is f32; reductions are fixed-shape (wave xor-tree + ordered LDS fold), so
+// scores are run-to-run deterministic.
+#include "nope_common.h"
+
+namespace nope {
+
+namespace {
+
+constexpr int NT = 256;
+
+template <class T>
+__device__ __forceinline__ void accum_quartic(const u32x4& raw, const float* q, float* acc) {
+    constexpr int VEC = Elt<T>::VEC;
+    float t[VEC];
+    Elt<T>::unpack(raw, t);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const float d = q[e] - t[e];
+        const float d2 = d * d;
+        acc[e] += d2 * d2;
+    }
+}
+
+// P = HW / VEC pixel-vectors per plane; requires P <= 256 and 256 % P == 0.
+// hpi = 256 / P hypotheses are scored per iteration (thread -> (sub-hypothesis, pixel-vector)).
+template <class T, int CMAX>
+__global__ __launch_bounds__(NT) void sim_reg_kernel(const float* __restrict__ q, const T* __restrict__ bank, float* __restrict__ scores,
+                                                     int N, int C, int HW, long long bank_stride_b, int score_ld, int nsplit) {
+    constexpr int VEC = Elt<T>::VEC;
+    __shared__ float s_part[2][NT / 64];
+    const int P = HW / VEC;
+    const int hpi = NT / P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = tid / P, pv = tid - sub * P;
+    const int b = blockIdx.x / nsplit, split = blockIdx.x - b * nsplit;
+    // contiguous template range of this workgroup, in units of hpi
+    const int groups = (N + hpi - 1) / hpi;
+    const int gper = (groups + nsplit - 1) / nsplit;
+    const int g0 = split * gper;
+    const int g1 = (g0 + gper < groups) ? g0 + gper : groups;
+
+    float qr[CMAX][VEC];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        if (c < C) {
+            const float* qp = q + ((size_t)b * C + c) * HW + (size_t)pv * VEC;
+#pragma unroll
+            for (int v4 = 0; v4 < VEC / 4; ++v4) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(qp + 4 * v4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qr[c][4 * v4 + e] = x[e];
+            }
+        }
+    }
+    const T* bb = bank + (size_t)b * bank_stride_b;
+    const size_t hyp_elems = (size_t)C * HW;
+    int buf = 0;
+    for (int g = g0; g < g1; ++g) {
+        const int n = g * hpi + sub;
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        if (n < N) {
+            const T* tp = bb + (size_t)n * hyp_elems + (size_t)pv * VEC;
+            u32x4 raw[CMAX];
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) raw[c] = ld16(tp + (size_t)c * HW);
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) accum_quartic<T>(raw[c], qr[c], acc);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += sqrtf(acc[e]);
+        // reduce over the P threads of this sub-hypothesis
+        if (P >= 64) {
+            s = wave_sum(s);
+            if (lane == 0) s_part[buf][wave] = s;
+            __syncthreads();
+            if (pv == 0 && n < N) {
+                const int w0 = sub * (P / 64);
+                float tot = 0.f;
+                for (int w = 0; w < P / 64; ++w) tot += s_part[buf][w0 + w];
+                scores[(size_t)b * score_ld + n] = -tot;
+            }
+            buf ^= 1;   // double-buffered partials: one barrier per iteration
+        } else {
+            for (int o = P >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (pv == 0 && n < N) scores[(size_t)b * score_ld + n] = -s;
+        }
+    }
+}
+
+// Generic shapes: one hypothesis per iteration, query tile in LDS (C*HW*4 <= 64 KiB).
+template <class T>
+__global__ __launch_bounds__(NT) void sim_lds_kernel(const float* __restrict__ q, const T* __restrict__ bank, float* __restrict__ scores,
+                                                     int N, int C, int HW, long long bank_stride_b, int score_ld, int nsplit) {
+    constexpr int VEC = Elt<T>::VEC;
+    __shared__ __attribute__((aligned(16))) float s_q[16384];
+    __shared__ float s_part[NT / 64];
+    const int P = HW / VEC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / nsplit, split = blockIdx.x - b * nsplit;
+    const int nper = (N + nsplit - 1) / nsplit;
+    const int n0 = split * nper;
+    const int n1 = (n0 + nper < N) ? n0 + nper : N;
+    for (int i = tid; i < C * HW; i += NT) s_q[i] = q[(size_t)b * C * HW + i];
+    __syncthreads();
+    const T* bb = bank + (size_t)b * bank_stride_b;
+    for (int n = n0; n < n1; ++n) {
+        const T* tp = bb + (size_t)n * C * HW;
+        float s = 0.f;
+        for (int pv = tid; pv < P; pv += NT) {
+            float acc[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+            for (int c = 0; c < C; ++c)
+                accum_quartic<T>(ld16(tp + (size_t)c * HW + (size_t)pv * VEC), &s_q[c * HW + pv * VEC], acc);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s += sqrtf(acc[e]);
+        }
+        s = wave_sum(s);
+        if (lane == 0) s_part[wave] = s;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) tot += s_part[w];
+            scores[(size_t)b * score_ld + n] = -tot;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- top-k: k rounds of (value desc, index asc) arg-max with exclusion ------------------------
+constexpr int KMAX = 16;
+
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+__global__ __launch_bounds__(NT) void topk_kernel(const float* __restrict__ scores, long long* __restrict__ idx, float* __restrict__ vals,
+                                                  int N, int k, int ld) {
+    __shared__ int s_chosen[KMAX];
+    __shared__ float s_bv[NT / 64];
+    __shared__ int s_bi[NT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = scores + (size_t)b * ld;
+    const float INF = __builtin_huge_valf();
+    for (int r = 0; r < k; ++r) {
+        float bv = -INF;
+        int bi = 0x7fffffff;
+        for (int n = tid; n < N; n += NT) {
+            bool taken = false;
+            for (int j = 0; j < r; ++j) taken = taken || (s_chosen[j] == n);
+            if (taken) continue;
+            float v = row[n];
+            if (v != v) v = INF;             // NaN ranks highest (torch.topk convention)
+            if (bi == 0x7fffffff || better(v, n, bv, bi)) { bv = v; bi = n; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || better(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_bv[wave] = bv; s_bi[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float fv = s_bv[0];
+            int fi = s_bi[0];
+            for (int w = 1; w < NT / 64; ++w)
+                if (s_bi[w] != 0x7fffffff && (fi == 0x7fffffff || better(s_bv[w], s_bi[w], fv, fi))) { fv = s_bv[w]; fi = s_bi[w]; }
+            s_chosen[r] = fi;
+            idx[(size_t)b * k + r] = fi;
+            if (vals) vals[(size_t)b * k + r] = row[fi];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int launch_similarity(const float* q, const void* bank, int bank_dt, float* scores, int B, int N, int C, int HW,
+                      long long bank_stride_b, int score_ld, hipStream_t s) {
+    if (!q || !bank || !scores || B <= 0 || N <= 0 || C <= 0 || HW <= 0 || score_ld < N || bank_stride_b < 0) return NOPE_ERR_ARG;
+    if (bank_dt != NOPE_F32 && bank_dt != NOPE_BF16) return NOPE_ERR_UNSUPPORTED;
+    const int vec = bank_dt == NOPE_F32 ? 4 : 8;
+    if (HW % vec) return NOPE_ERR_UNSUPPORTED;
+    const int P = HW / vec;
+    const bool reg_ok = (P <= NT) && (NT % P == 0) && (C <= 16);
+    int nsplit;
+    if (reg_ok) {
+        const int hpi = NT / P;
+        const int groups = cdiv(N, hpi);
+        nsplit = cdiv(4096, B);
+        if (nsplit > groups) nsplit = groups;
+        if (nsplit < 1) nsplit = 1;
+        dim3 grid((unsigned)((long long)B * nsplit)), block(NT);
+        if (bank_dt == NOPE_F32) {
+            if (C <= 8) hipLaunchKernelGGL((sim_reg_kernel<float, 8>), grid, block, 0, s, q, (const float*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
+            else hipLaunchKernelGGL((sim_reg_kernel<float, 16>), grid, block, 0, s, q, (const float*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
+        } else {
+            if (C <= 8) hipLaunchKernelGGL((sim_reg_kernel<bf16_t, 8>), grid, block, 0, s, q, (const bf16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
+            else hipLaunchKernelGGL((sim_reg_kernel<bf16_t, 16>), grid, block, 0, s, q, (const bf16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
+        }
+    } else {
+        if ((size_t)C * HW > 16384) return NOPE_ERR_UNSUPPORTED;
+        nsplit = cdiv(4096, B);
+        if (nsplit > N) nsplit = N;
+        dim3 grid((unsigned)((long long)B * nsplit)), block(NT);
+        if (bank_dt == NOPE_F32) hipLaunchKernelGGL((sim_lds_kernel<float>), grid, block, 0, s, q, (const float*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
+        else hipLaunchKernelGGL((sim_lds_kernel<bf16_t>), grid, block, 0, s, q, (const bf16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
+    }
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_topk(const float* scores, long long* idx, float* vals, int B, int N, int k, int ld, hipStream_t s) {
+    if (!scores || !idx || B <= 0 || N <= 0 || k < 1 || k > KMAX || k > N || ld < N) return NOPE_ERR_ARG;
+    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)B), dim3(NT), 0, s, scores, idx, vals, N, k, ld);
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+}  // namespace nope

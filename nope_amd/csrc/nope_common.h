@@ -1,0 +1,156 @@
+// Shared device/host helpers for the gfx950 kernels of the NOPE hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/nope_hip.h"
+
+namespace nope {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef unsigned short bf16_t;   // raw bfloat16 bits
+
+constexpr int kWave = 64;
+
+// ---- bfloat16 <-> f32 (round-to-nearest-even, NaN preserved) ----------------------------
+__device__ __host__ __forceinline__ float bf16_to_f32(bf16_t h) {
+    union { unsigned u; float f; } v;
+    v.u = (unsigned)h << 16;
+    return v.f;
+}
+__device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    union { unsigned u; float f; } v;
+    v.f = f;
+    unsigned u = v.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+// Element traits: VEC = elements per 16-byte vector.
+template <class T> struct Elt;
+template <> struct Elt<float> {
+    static constexpr int VEC = 4;
+    static constexpr int DT = NOPE_F32;
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+    static __device__ __forceinline__ void unpack(const u32x4& v, float* o) {
+        union { u32x4 u; float f[4]; } x; x.u = v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = x.f[i];
+    }
+    static __device__ __forceinline__ u32x4 pack(const float* o) {
+        union { u32x4 u; float f[4]; } x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x.f[i] = o[i];
+        return x.u;
+    }
+};
+template <> struct Elt<bf16_t> {
+    static constexpr int VEC = 8;
+    static constexpr int DT = NOPE_BF16;
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+    static __device__ __forceinline__ void unpack(const u32x4& v, float* o) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            union { unsigned u; float f; } lo, hi;
+            lo.u = v[i] << 16;
+            hi.u = v[i] & 0xffff0000u;
+            o[2 * i] = lo.f;
+            o[2 * i + 1] = hi.f;
+        }
+    }
+    static __device__ __forceinline__ u32x4 pack(const float* o) {
+        u32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (unsigned)f32_to_bf16(o[2 * i]) | ((unsigned)f32_to_bf16(o[2 * i + 1]) << 16);
+        return v;
+    }
+};
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <bool FAST> __device__ __forceinline__ float silu_f(float x) {
+    if (FAST) return x * __frcp_rn(1.0f + __expf(-x));
+    return x / (1.0f + expf(-x));
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+#define NOPE_CHECK_LAUNCH()                                      \
+    do {                                                         \
+        hipError_t e__ = hipGetLastError();                      \
+        if (e__ != hipSuccess) return NOPE_ERR_LAUNCH;           \
+    } while (0)
+
+// ---- launchers implemented in the kernels_*.hip files (host side) ---------------------
+struct ConvArgs {
+    const void* src1 = nullptr; const void* src2 = nullptr;   // NHWC activations
+    int C1 = 0, C2 = 0;          // channels per source; Cin = C1 + C2 (virtual concat, src1 first)
+    int rep1 = 1, rep2 = 1;      // source sample = hypothesis / rep  (broadcast of shared tensors)
+    int Hs = 1, Ws = 1;          // source spatial size
+    int Ho = 1, Wo = 1;          // output spatial size
+    int mode = NOPE_CONV_PLAIN;  // NOPE_CONV_PLAIN | NOPE_CONV_UP2 | NOPE_CONV_DOWN2
+    int ntaps = 1;               // 1 or 9 (PLAIN), 9 (UP2), 4 (DOWN2)
+    const void* w = nullptr;     // packed [Cout][ntaps][Cin]
+    const float* bias = nullptr; // [Cout] or null
+    const void* resid = nullptr; // optional NHWC [M][Cout] added in the epilogue
+    void* out = nullptr;
+    int Cout = 0;
+    int nhyp = 0;                // M = nhyp * Ho * Wo
+    int out_nchw = 0;            // 1: write (nhyp, Cout, Ho, Wo) with dtype out_dt
+    int out_dt = NOPE_F32;       // only for out_nchw
+};
+int launch_conv(int dt, const ConvArgs& a, hipStream_t s);
+
+int launch_gn_stats(int dt, const void* x, float* partial, int nhyp, int HW, int C, int G, int nchunk, hipStream_t s);
+struct GnApplyArgs {
+    const void* x = nullptr; void* y = nullptr;
+    const float* partial = nullptr; int nchunk = 1;
+    const float* gamma = nullptr; const float* beta = nullptr;
+    int nhyp = 0, HW = 0, C = 0, G = 1;
+    int act = 0;                       // 1 = SiLU
+    const float* emb = nullptr; int emb_stride = 0;   // optional per-(hyp, channel) add after the activation
+    const void* resid = nullptr;       // optional NHWC tensor added last
+    int x_rep = 1;                     // x (and its statistics) shared by x_rep consecutive hypotheses
+    int resid_rep = 1;                 // resid shared by resid_rep consecutive hypotheses
+    float eps = 1e-5f;
+};
+int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s);
+int gn_stats_chunks(int HW, int C, int dt);
+
+int launch_linattn(int dt, const void* qkv, void* out, int nhyp, int HW, int heads, int dim_head, hipStream_t s);
+int launch_attn(int dt, const void* qkv, void* out, int nhyp, int HW, int heads, int dim_head, hipStream_t s);
+
+int launch_nchw_to_nhwc(int dt, const float* x, void* y, int n, int C, int HW, hipStream_t s);
+int launch_nhwc_to_nchw_f32(int dt, const void* x, float* y, int n, int C, int HW, hipStream_t s);
+int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s);
+int launch_linear_naive(const float* in, const float* w, const float* bias, float* out, int M, int N, int K, int act_in,
+                        int ldo, hipStream_t s);
+int launch_silu_f32(const float* in, float* out, size_t n, hipStream_t s);
+int launch_cast(int dt, const float* in, void* out, size_t n, hipStream_t s);
+
+int launch_similarity(const float* q, const void* bank, int bank_dt, float* scores, int B, int N, int C, int HW,
+                      long long bank_stride_b, int score_ld, hipStream_t s);
+int launch_topk(const float* scores, long long* idx, float* vals, int B, int N, int k, int ld, hipStream_t s);
+
+}  // namespace nope

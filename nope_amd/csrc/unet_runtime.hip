@@ -1,0 +1,514 @@
+// Host-side runtime of the pose-conditioned U-Net: weight repacking (nope_unet_create) and
+// the launch schedule of one forward over a batch of pose hypotheses (nope_unet_forward).
+//
+// Op order follows UNet.forward, u_net.py:160-198, exactly (mid block twice with shared
+// weights :177-183, final_conv.0 without the embedding :154-157,197).  What differs is the
+// execution model, chosen for MI355X:
+//   * NHWC activations, every conv/linear an implicit GEMM on MFMA (kernels_gemm.hip);
+//     torch.cat / nn.Upsample / Rearrange are folded into that kernel's loader, so none of
+//     those tensors ever exists in HBM;
+//   * all N pose hypotheses of a reference image run as ONE batch (n_hyp = B*N): at the 4x4
+//     bottleneck a single hypothesis has only 16 GEMM rows, the batch has 16*n_hyp;
+//   * pose-independent work is done once per reference image instead of once per template:
+//     init_conv, the skip `r`, and conv+GroupNorm+SiLU of downs[0][0].block1 (the embedding is
+//     only added after that activation, model_utils.py:272-276) -- the reference re-runs all
+//     of it, and the ResNet encoder, N times (model.py:115,219);
+//   * the 19 per-block `Linear(SiLU(c))` embeddings (model_utils.py:261-265,274-275) are one
+//     f32 GEMM against the row-concatenated weights;
+//   * a bump arena over caller-provided workspace: no allocation, no host sync, one stream.
+#include <cstdio>
+#include <initializer_list>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "nope_common.h"
+
+using namespace nope;
+
+namespace {
+
+struct Conv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; };
+struct Norm { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
+struct Res { Conv c1, c2, res; Norm n1, n2; bool has_res = false; int emb_off = -1; };
+struct LinAttn { Norm pre, post; Conv qkv, out; };
+struct Attn { Norm pre; Conv qkv, out; };
+struct Level { Res r0, r1; LinAttn attn; Conv resample; };
+
+struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, rep = 1; };
+
+}  // namespace
+
+struct nope_unet {
+    nope_unet_config cfg;
+    int dt = NOPE_F32;
+    std::vector<void*> allocs;
+    int dims[9];
+    int classes = 0;
+    Conv init_conv, final_conv1;
+    Level downs[8], ups[8];
+    Res mid1, mid2, final_res, final_conv0;
+    Attn mid_attn;
+    float *pose_w0 = nullptr, *pose_b0 = nullptr, *pose_w2 = nullptr, *pose_b2 = nullptr;
+    float *emb_w = nullptr, *emb_b = nullptr;
+    int emb_total = 0;
+};
+
+namespace {
+
+struct Loader {
+    nope_unet* net;
+    hipStream_t s;
+    std::map<std::string, const nope_tensor_desc*> tab;
+    int err = NOPE_OK;
+    std::string missing;
+
+    const nope_tensor_desc* get(const std::string& name, std::initializer_list<int64_t> shape) {
+        auto it = tab.find(name);
+        if (it == tab.end() || !it->second->data) { fail(name); return nullptr; }
+        const nope_tensor_desc* d = it->second;
+        if (d->ndim != (int)shape.size()) { fail(name); return nullptr; }
+        int i = 0;
+        for (int64_t v : shape) if (d->shape[i++] != v) { fail(name); return nullptr; }
+        return d;
+    }
+    void fail(const std::string& n) { if (err == NOPE_OK) { err = NOPE_ERR_WEIGHT; missing = n; } }
+    void* dmalloc(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { if (err == NOPE_OK) err = NOPE_ERR_ALLOC; return nullptr; }
+        net->allocs.push_back(p);
+        return p;
+    }
+    float* copy_f32(const std::string& name, std::initializer_list<int64_t> shape) {
+        const nope_tensor_desc* d = get(name, shape);
+        if (!d) return nullptr;
+        size_t n = 1;
+        for (int64_t v : shape) n *= (size_t)v;
+        float* p = (float*)dmalloc(n * 4);
+        if (p) hipMemcpyAsync(p, d->data, n * 4, hipMemcpyDeviceToDevice, s);
+        return p;
+    }
+    Conv conv(const std::string& pfx, int Cin, int Cout, int ksz, int mode, bool has_bias) {
+        Conv c;
+        c.Cin = Cin; c.Cout = Cout; c.mode = mode;
+        c.ntaps = mode == NOPE_CONV_DOWN2 ? 4 : ksz * ksz;
+        const nope_tensor_desc* d = mode == NOPE_CONV_DOWN2 ? get(pfx + "weight", {Cout, (int64_t)Cin * 4, 1, 1})
+                                                            : get(pfx + "weight", {Cout, Cin, ksz, ksz});
+        if (d) {
+            const size_t es = net->dt == NOPE_F32 ? 4 : 2;
+            c.w = dmalloc((size_t)Cout * c.ntaps * Cin * es);
+            if (c.w) { int e = launch_pack_conv_w(net->dt, d->data, c.w, Cout, Cin, c.ntaps, mode, s); if (e && err == NOPE_OK) err = e; }
+        }
+        if (has_bias) c.bias = copy_f32(pfx + "bias", {Cout});
+        return c;
+    }
+    Norm norm(const std::string& pfx, int C) {
+        Norm n;
+        n.C = C;
+        n.gamma = copy_f32(pfx + "weight", {C});
+        n.beta = copy_f32(pfx + "bias", {C});
+        return n;
+    }
+    Res res(const std::string& pfx, int Cin, int Cout, bool use_emb, std::vector<std::pair<std::string, int>>& embs) {
+        Res r;
+        r.c1 = conv(pfx + "block1.proj.", Cin, Cout, 3, NOPE_CONV_PLAIN, true);
+        r.n1 = norm(pfx + "block1.norm.", Cout);
+        r.c2 = conv(pfx + "block2.proj.", Cout, Cout, 3, NOPE_CONV_PLAIN, true);
+        r.n2 = norm(pfx + "block2.norm.", Cout);
+        r.has_res = Cin != Cout;
+        if (r.has_res) r.res = conv(pfx + "res_conv.", Cin, Cout, 1, NOPE_CONV_PLAIN, true);
+        if (use_emb) { r.emb_off = net->emb_total; net->emb_total += Cout; embs.push_back({pfx + "mlp.1.", Cout}); }
+        return r;
+    }
+};
+
+struct Arena {
+    unsigned char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    bool dry = false;
+    void* alloc(size_t bytes) {
+        const size_t o = align_up(off, 256);
+        off = o + bytes;
+        if (off > peak) peak = off;
+        if (dry) return (void*)(uintptr_t)(0x1000 + o);   // never dereferenced
+        if (off > cap) return nullptr;
+        return base + o;
+    }
+};
+
+struct Fwd {
+    const nope_unet* net;
+    hipStream_t s;
+    Arena ar;
+    int nhyp = 0, err = NOPE_OK;
+    size_t es = 4;
+    float* gn_partial = nullptr;
+    const float* emb_all = nullptr;
+
+    bool dry() const { return ar.dry; }
+    void chk(int e) { if (e != NOPE_OK && err == NOPE_OK) err = e; }
+    void* alloc_act(size_t elems) {
+        void* p = ar.alloc(elems * es);
+        if (!p && err == NOPE_OK) err = NOPE_ERR_WORKSPACE;
+        return p;
+    }
+    bool live() const { return !ar.dry && err == NOPE_OK; }
+
+    // out = conv(a [cat b]) (+bias) (+resid);  n = number of samples computed (nhyp or fewer)
+    void conv(const Conv& c, const Act& a, const Act* b, void* out, int Ho, int Wo, int n, int rep1, int rep2,
+              const void* resid = nullptr, int out_nchw = 0, int out_dt = NOPE_F32) {
+        if (!live()) return;
+        ConvArgs ca;
+        ca.src1 = a.p; ca.C1 = a.C; ca.rep1 = rep1;
+        if (b) { ca.src2 = b->p; ca.C2 = b->C; ca.rep2 = rep2; }
+        ca.Hs = a.H; ca.Ws = a.W; ca.Ho = Ho; ca.Wo = Wo;
+        ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.bias = c.bias; ca.resid = resid;
+        ca.out = out; ca.Cout = c.Cout; ca.nhyp = n; ca.out_nchw = out_nchw; ca.out_dt = out_dt;
+        if (a.C + (b ? b->C : 0) != c.Cin) { chk(NOPE_ERR_ARG); return; }
+        chk(launch_conv(net->dt, ca, s));
+    }
+    // y = act(GN(x)) [+emb] [+resid]; x holds n_x = nhyp / x_rep samples
+    void gn(const Norm& nm, int G, const void* x, int x_rep, void* y, int HW, int act, int emb_off, const void* resid,
+            int resid_rep) {
+        if (!live()) return;
+        const int nx = nhyp / x_rep;
+        const int nch = gn_stats_chunks(HW, nm.C, net->dt);
+        chk(launch_gn_stats(net->dt, x, gn_partial, nx, HW, nm.C, G, nch, s));
+        GnApplyArgs ga;
+        ga.x = x; ga.y = y; ga.partial = gn_partial; ga.nchunk = nch; ga.gamma = nm.gamma; ga.beta = nm.beta;
+        ga.nhyp = nhyp; ga.HW = HW; ga.C = nm.C; ga.G = G; ga.act = act;
+        if (emb_off >= 0) { ga.emb = emb_all + emb_off; ga.emb_stride = net->emb_total; }
+        ga.resid = resid; ga.x_rep = x_rep; ga.resid_rep = resid_rep;
+        chk(launch_gn_apply(net->dt, ga, s));
+    }
+
+    // ResnetBlock, model_utils.py:271-279.  `a` may be shared by a.rep hypotheses (rep > 1 only
+    // for the very first block, where b == nullptr).
+    void resnet(const Res& R, const Act& a, const Act* b, bool use_emb, void* out) {
+        const int HW = a.H * a.W, G = net->cfg.groups;
+        const size_t M = (size_t)nhyp * HW;
+        const size_t mark = ar.off;
+        void* t1 = alloc_act(M * R.c1.Cout);
+        const int emb_off = use_emb ? R.emb_off : -1;
+        if (a.rep > 1 && !b) {
+            // pose-independent prefix: conv + GN statistics once per reference sample
+            const int ns = nhyp / a.rep;
+            void* t1s = alloc_act((size_t)ns * HW * R.c1.Cout);
+            conv(R.c1, a, nullptr, t1s, a.H, a.W, ns, 1, 1);
+            gn(R.n1, G, t1s, a.rep, t1, HW, 1, emb_off, nullptr, 1);
+        } else {
+            conv(R.c1, a, b, t1, a.H, a.W, nhyp, a.rep, b ? b->rep : 1);
+            gn(R.n1, G, t1, 1, t1, HW, 1, emb_off, nullptr, 1);
+        }
+        Act h{t1, R.c1.Cout, a.H, a.W, 1};
+        conv(R.c2, h, nullptr, out, a.H, a.W, nhyp, 1, 1);
+        const void* resid = a.p;
+        int resid_rep = a.rep;
+        if (R.has_res) {
+            void* t3 = alloc_act(M * R.res.Cout);
+            conv(R.res, a, b, t3, a.H, a.W, nhyp, a.rep, b ? b->rep : 1);
+            resid = t3; resid_rep = 1;
+        } else if (b) { chk(NOPE_ERR_ARG); }
+        gn(R.n2, G, out, 1, out, HW, 1, -1, resid, resid_rep);
+        ar.off = mark;
+    }
+
+    // Residual(PreNorm(LinearAttention)), model_utils.py:198-204,226-234,393-418
+    void linattn(const LinAttn& L, const Act& x, void* out) {
+        const int HW = x.H * x.W, heads = net->cfg.heads, dh = net->cfg.dim_head;
+        const size_t M = (size_t)nhyp * HW;
+        const size_t mark = ar.off;
+        void* y = alloc_act(M * x.C);
+        void* qkv = alloc_act(M * 3 * heads * dh);
+        void* a = alloc_act(M * heads * dh);
+        gn(L.pre, 1, x.p, 1, y, HW, 0, -1, nullptr, 1);
+        Act ya{y, x.C, x.H, x.W, 1};
+        conv(L.qkv, ya, nullptr, qkv, x.H, x.W, nhyp, 1, 1);
+        if (live()) chk(launch_linattn(net->dt, qkv, a, nhyp, HW, heads, dh, s));
+        Act aa{a, heads * dh, x.H, x.W, 1};
+        conv(L.out, aa, nullptr, y, x.H, x.W, nhyp, 1, 1);
+        gn(L.post, 1, y, 1, out, HW, 0, -1, x.p, 1);
+        ar.off = mark;
+    }
+
+    // Residual(PreNorm(Attention)), model_utils.py:367-390
+    void attn(const Attn& A, const Act& x, void* out) {
+        const int HW = x.H * x.W, heads = net->cfg.heads, dh = net->cfg.dim_head;
+        const size_t M = (size_t)nhyp * HW;
+        const size_t mark = ar.off;
+        void* y = alloc_act(M * x.C);
+        void* qkv = alloc_act(M * 3 * heads * dh);
+        void* a = alloc_act(M * heads * dh);
+        gn(A.pre, 1, x.p, 1, y, HW, 0, -1, nullptr, 1);
+        Act ya{y, x.C, x.H, x.W, 1};
+        conv(A.qkv, ya, nullptr, qkv, x.H, x.W, nhyp, 1, 1);
+        if (live()) chk(launch_attn(net->dt, qkv, a, nhyp, HW, heads, dh, s));
+        Act aa{a, heads * dh, x.H, x.W, 1};
+        conv(A.out, aa, nullptr, out, x.H, x.W, nhyp, 1, 1, /*resid=*/x.p);
+        ar.off = mark;
+    }
+};
+
+int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, const float* pose, int n_hyp, int H, int W,
+                void* out, int out_dtype, void* ws, size_t ws_bytes, hipStream_t s, bool dry, size_t* peak) {
+    const nope_unet_config& cfg = net->cfg;
+    const int L = cfg.n_levels;
+    Fwd f;
+    f.net = net; f.s = s; f.nhyp = n_hyp; f.es = net->dt == NOPE_F32 ? 4 : 2;
+    f.ar.base = (unsigned char*)ws; f.ar.cap = ws_bytes; f.ar.dry = dry;
+    const int HW = H * W;
+    const int* dims = net->dims;
+
+    // ---- persistent buffers ------------------------------------------------------------------
+    void* x_in = f.alloc_act((size_t)n_src * HW * cfg.channels);
+    void* x0 = f.alloc_act((size_t)n_src * HW * dims[0]);
+    float* c0 = (float*)f.ar.alloc((size_t)n_hyp * net->classes * 4);
+    float* c1 = (float*)f.ar.alloc((size_t)n_hyp * net->classes * 4);
+    float* emb_all = (float*)f.ar.alloc((size_t)n_hyp * net->emb_total * 4);
+    f.gn_partial = (float*)f.ar.alloc((size_t)n_hyp * 16 * (cfg.groups > 1 ? cfg.groups : 1) * 2 * 4);
+    f.emb_all = emb_all;
+    size_t cur_elems = 0;
+    for (int l = 0; l <= L; ++l) {   // every tensor handed from one stage to the next
+        const int rd = l < L ? l : L - 1;                 // down-path / bottleneck outputs
+        const int ru = l > 0 ? l - 1 : 0;                 // up-path outputs (dims[l] at one level finer)
+        const size_t e1 = (size_t)n_hyp * (HW >> (2 * rd)) * dims[l];
+        const size_t e2 = l < L ? (size_t)n_hyp * (HW >> (2 * ru)) * dims[l] : 0;
+        if (e1 > cur_elems) cur_elems = e1;
+        if (e2 > cur_elems) cur_elems = e2;
+    }
+    void* curbuf[2] = {f.alloc_act(cur_elems), f.alloc_act(cur_elems)};
+    void* hbuf[16];
+    for (int l = 0; l < L; ++l) {
+        const size_t e = (size_t)n_hyp * (HW >> (2 * l)) * dims[l];
+        hbuf[2 * l] = f.alloc_act(e);
+        hbuf[2 * l + 1] = f.alloc_act(e);
+    }
+    if (!dry && (!c0 || !c1 || !emb_all || !f.gn_partial)) f.chk(NOPE_ERR_WORKSPACE);
+    if (f.err) return f.err;
+
+    // ---- input + pose embedding ----------------------------------------------------------------
+    if (f.live()) {
+        f.chk(launch_nchw_to_nhwc(net->dt, x, x_in, n_src, cfg.channels, HW, s));
+        f.chk(launch_linear_naive(pose, net->pose_w0, net->pose_b0, c0, n_hyp, net->classes, cfg.pose_dim, 0, net->classes, s));
+        const float* c = c0;
+        if (cfg.pose_mlp_layers == 2) {
+            f.chk(launch_linear_naive(c0, net->pose_w2, net->pose_b2, c1, n_hyp, net->classes, net->classes, 2, net->classes, s));
+            c = c1;
+        }
+        float* sc = (c == c0) ? c1 : c0;
+        f.chk(launch_silu_f32(c, sc, (size_t)n_hyp * net->classes, s));
+        ConvArgs ea;   // emb_all[n_hyp][emb_total] = SiLU(c) @ W_all^T + b_all, exact-f32 MFMA
+        ea.src1 = sc; ea.C1 = net->classes; ea.w = net->emb_w; ea.bias = net->emb_b; ea.out = emb_all;
+        ea.Cout = net->emb_total; ea.nhyp = n_hyp;
+        f.chk(launch_conv(NOPE_F32, ea, s));
+    }
+    Act xin{x_in, cfg.channels, H, W, 1};
+    {
+        Fwd g = f;   // init_conv runs over the n_src reference samples only
+        g.nhyp = n_src;
+        g.conv(net->init_conv, xin, nullptr, x0, H, W, n_src, 1, 1);
+        f.chk(g.err);
+    }
+    Act r0{x0, dims[0], H, W, x_rep};
+    Act cur = r0;
+    int slot = 0;
+
+    // ---- down path ---------------------------------------------------------------------------------
+    for (int l = 0; l < L; ++l) {
+        const Level& D = net->downs[l];
+        Act h1{hbuf[2 * l], dims[l], cur.H, cur.W, 1};
+        Act h2{hbuf[2 * l + 1], dims[l], cur.H, cur.W, 1};
+        f.resnet(D.r0, cur, nullptr, true, h1.p);
+        {
+            const size_t mark = f.ar.off;
+            Act t{f.alloc_act((size_t)n_hyp * cur.H * cur.W * dims[l]), dims[l], cur.H, cur.W, 1};
+            f.resnet(D.r1, h1, nullptr, true, t.p);
+            f.linattn(D.attn, t, h2.p);
+            f.ar.off = mark;
+        }
+        Act nxt{curbuf[slot], dims[l + 1], cur.H, cur.W, 1};
+        if (l < L - 1) { nxt.H = cur.H / 2; nxt.W = cur.W / 2; }
+        f.conv(D.resample, h2, nullptr, nxt.p, nxt.H, nxt.W, n_hyp, 1, 1);
+        cur = nxt;
+        slot ^= 1;
+    }
+    // ---- bottleneck, applied twice with the same weights (u_net.py:177-183) ---------------------------
+    for (int it = 0; it < 2; ++it) {
+        const size_t mark = f.ar.off;
+        const size_t e = (size_t)n_hyp * cur.H * cur.W * cur.C;
+        Act a{f.alloc_act(e), cur.C, cur.H, cur.W, 1};
+        Act b{f.alloc_act(e), cur.C, cur.H, cur.W, 1};
+        f.resnet(net->mid1, cur, nullptr, true, a.p);
+        f.attn(net->mid_attn, a, b.p);
+        Act c{curbuf[slot], cur.C, cur.H, cur.W, 1};
+        f.resnet(net->mid2, b, nullptr, true, c.p);
+        f.ar.off = mark;
+        cur = c;
+        slot ^= 1;
+    }
+    // ---- up path --------------------------------------------------------------------------------------
+    for (int l = 0; l < L; ++l) {
+        const Level& U = net->ups[l];
+        const int r = L - 1 - l;
+        Act h2{hbuf[2 * r + 1], dims[r], cur.H, cur.W, 1};
+        Act h1{hbuf[2 * r], dims[r], cur.H, cur.W, 1};
+        const size_t mark = f.ar.off;
+        const size_t e = (size_t)n_hyp * cur.H * cur.W * dims[r + 1];
+        Act a{f.alloc_act(e), dims[r + 1], cur.H, cur.W, 1};
+        Act b{f.alloc_act(e), dims[r + 1], cur.H, cur.W, 1};
+        f.resnet(U.r0, cur, &h2, true, a.p);
+        f.resnet(U.r1, a, &h1, true, b.p);
+        f.linattn(U.attn, b, a.p);
+        Act nxt{curbuf[slot], dims[r], cur.H, cur.W, 1};
+        if (l < L - 1) { nxt.H = cur.H * 2; nxt.W = cur.W * 2; }
+        f.conv(U.resample, a, nullptr, nxt.p, nxt.H, nxt.W, n_hyp, 1, 1);
+        f.ar.off = mark;
+        cur = nxt;
+        slot ^= 1;
+    }
+    // ---- head --------------------------------------------------------------------------------------------
+    {
+        const size_t mark = f.ar.off;
+        const size_t e = (size_t)n_hyp * HW * cfg.u_net_dim;
+        Act a{f.alloc_act(e), cfg.u_net_dim, H, W, 1};
+        Act b{f.alloc_act(e), cfg.u_net_dim, H, W, 1};
+        f.resnet(net->final_res, cur, &r0, true, a.p);
+        f.resnet(net->final_conv0, a, nullptr, false, b.p);
+        f.conv(net->final_conv1, b, nullptr, out, H, W, n_hyp, 1, 1, nullptr, /*out_nchw=*/1, out_dtype);
+        f.ar.off = mark;
+    }
+    if (peak) *peak = f.ar.peak;
+    return f.err;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensors, int n_tensors, nope_stream_t stream,
+                     nope_unet** out) {
+    if (!cfg || !tensors || !out || n_tensors <= 0) return NOPE_ERR_ARG;
+    if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->groups < 1 || cfg->heads < 1 || cfg->dim_head != 32) return NOPE_ERR_UNSUPPORTED;
+    if (cfg->compute_dtype != NOPE_F32 && cfg->compute_dtype != NOPE_BF16) return NOPE_ERR_UNSUPPORTED;
+    if (cfg->pose_mlp_layers != 1 && cfg->pose_mlp_layers != 2) return NOPE_ERR_UNSUPPORTED;
+    if (cfg->u_net_dim % 8 || cfg->channels % 8 || cfg->u_net_dim % cfg->groups) return NOPE_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    nope_unet* net = new nope_unet();
+    net->cfg = *cfg;
+    net->dt = cfg->compute_dtype;
+    const int L = cfg->n_levels;
+    net->dims[0] = cfg->u_net_dim;
+    for (int l = 0; l < L; ++l) net->dims[l + 1] = cfg->u_net_dim * cfg->dim_mults[l];
+    net->classes = cfg->u_net_dim * 4;
+    const int* dims = net->dims;
+    const int HD = cfg->heads * cfg->dim_head;
+
+    Loader ld;
+    ld.net = net; ld.s = s;
+    for (int i = 0; i < n_tensors; ++i)
+        if (tensors[i].name) ld.tab[tensors[i].name] = &tensors[i];
+    std::vector<std::pair<std::string, int>> embs;
+
+    net->pose_w0 = ld.copy_f32("pose_mlp.0.weight", {net->classes, cfg->pose_dim});
+    net->pose_b0 = ld.copy_f32("pose_mlp.0.bias", {net->classes});
+    if (cfg->pose_mlp_layers == 2) {
+        net->pose_w2 = ld.copy_f32("pose_mlp.2.weight", {net->classes, net->classes});
+        net->pose_b2 = ld.copy_f32("pose_mlp.2.bias", {net->classes});
+    }
+    net->init_conv = ld.conv("init_conv.", cfg->channels, dims[0], 3, NOPE_CONV_PLAIN, true);
+    auto linattn = [&](const std::string& p, int C) {
+        LinAttn a;
+        a.pre = ld.norm(p + "fn.norm.", C);
+        a.qkv = ld.conv(p + "fn.fn.to_qkv.", C, 3 * HD, 1, NOPE_CONV_PLAIN, false);
+        a.out = ld.conv(p + "fn.fn.to_out.0.", HD, C, 1, NOPE_CONV_PLAIN, true);
+        a.post = ld.norm(p + "fn.fn.to_out.1.", C);
+        return a;
+    };
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "downs." + std::to_string(l) + ".";
+        Level& D = net->downs[l];
+        D.r0 = ld.res(p + "0.", dims[l], dims[l], true, embs);
+        D.r1 = ld.res(p + "1.", dims[l], dims[l], true, embs);
+        D.attn = linattn(p + "2.", dims[l]);
+        if (l < L - 1) D.resample = ld.conv(p + "3.1.", dims[l], dims[l + 1], 1, NOPE_CONV_DOWN2, true);
+        else D.resample = ld.conv(p + "3.", dims[l], dims[l + 1], 3, NOPE_CONV_PLAIN, true);
+    }
+    net->mid1 = ld.res("mid_block1.", dims[L], dims[L], true, embs);
+    net->mid_attn.pre = ld.norm("mid_attn.fn.norm.", dims[L]);
+    net->mid_attn.qkv = ld.conv("mid_attn.fn.fn.to_qkv.", dims[L], 3 * HD, 1, NOPE_CONV_PLAIN, false);
+    net->mid_attn.out = ld.conv("mid_attn.fn.fn.to_out.", HD, dims[L], 1, NOPE_CONV_PLAIN, true);
+    net->mid2 = ld.res("mid_block2.", dims[L], dims[L], true, embs);
+    for (int l = 0; l < L; ++l) {
+        const int r = L - 1 - l;
+        const std::string p = "ups." + std::to_string(l) + ".";
+        Level& U = net->ups[l];
+        U.r0 = ld.res(p + "0.", dims[r + 1] + dims[r], dims[r + 1], true, embs);
+        U.r1 = ld.res(p + "1.", dims[r + 1] + dims[r], dims[r + 1], true, embs);
+        U.attn = linattn(p + "2.", dims[r + 1]);
+        if (l < L - 1) U.resample = ld.conv(p + "3.1.", dims[r + 1], dims[r], 3, NOPE_CONV_UP2, true);
+        else U.resample = ld.conv(p + "3.", dims[r + 1], dims[r], 3, NOPE_CONV_PLAIN, true);
+    }
+    net->final_res = ld.res("final_res_block.", cfg->u_net_dim * 2, cfg->u_net_dim, true, embs);
+    net->final_conv0 = ld.res("final_conv.0.", cfg->u_net_dim, cfg->u_net_dim, false, embs);
+    net->final_conv1 = ld.conv("final_conv.1.", cfg->u_net_dim, cfg->out_dim, 1, NOPE_CONV_PLAIN, true);
+    if (dims[0] != cfg->u_net_dim) ld.fail("init_dim");
+
+    // row-concatenated embedding linears
+    net->emb_w = (float*)ld.dmalloc((size_t)net->emb_total * net->classes * 4);
+    net->emb_b = (float*)ld.dmalloc((size_t)net->emb_total * 4);
+    int off = 0;
+    for (auto& e : embs) {
+        const nope_tensor_desc* w = ld.get(e.first + "weight", {e.second, net->classes});
+        const nope_tensor_desc* b = ld.get(e.first + "bias", {e.second});
+        if (w && b && net->emb_w && net->emb_b) {
+            hipMemcpyAsync(net->emb_w + (size_t)off * net->classes, w->data, (size_t)e.second * net->classes * 4, hipMemcpyDeviceToDevice, s);
+            hipMemcpyAsync(net->emb_b + off, b->data, (size_t)e.second * 4, hipMemcpyDeviceToDevice, s);
+        }
+        off += e.second;
+    }
+    if (ld.err == NOPE_OK && hipStreamSynchronize(s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
+    if (ld.err != NOPE_OK) {
+        if (!ld.missing.empty()) fprintf(stderr, "nope_unet_create: missing or mis-shaped tensor '%s'\n", ld.missing.c_str());
+        nope_unet_destroy(net);
+        return ld.err;
+    }
+    *out = net;
+    return NOPE_OK;
+}
+
+void nope_unet_destroy(nope_unet* net) {
+    if (!net) return;
+    for (void* p : net->allocs) hipFree(p);
+    delete net;
+}
+
+static int check_shape(const nope_unet* net, int n_hyp, int n_src, int x_rep, int H, int W) {
+    if (!net || n_hyp <= 0 || n_src <= 0 || x_rep <= 0 || (long long)n_src * x_rep != n_hyp || H <= 0 || W <= 0) return NOPE_ERR_ARG;
+    const int f = 1 << (net->cfg.n_levels - 1);
+    if (H % f || W % f) return NOPE_ERR_UNSUPPORTED;
+    if ((H / f) * (W / f) > 64) return NOPE_ERR_UNSUPPORTED;   // bottleneck attention tile
+    return NOPE_OK;
+}
+
+size_t nope_unet_workspace_bytes(const nope_unet* net, int n_hyp, int n_src, int H, int W) {
+    if (!net || n_src <= 0 || n_hyp % n_src) return 0;
+    if (check_shape(net, n_hyp, n_src, n_hyp / n_src, H, W) != NOPE_OK) return 0;
+    size_t peak = 0;
+    run_forward(net, nullptr, n_src, n_hyp / n_src, nullptr, n_hyp, H, W, nullptr, NOPE_F32, nullptr, 0, nullptr, true, &peak);
+    return align_up(peak, 256) + 256;
+}
+
+int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep, const float* pose, int n_hyp, int H, int W,
+                      void* out, int out_dtype, void* workspace, size_t workspace_bytes, nope_stream_t stream) {
+    int e = check_shape(net, n_hyp, n_src, x_rep, H, W);
+    if (e) return e;
+    if (!x || !pose || !out || !workspace) return NOPE_ERR_ARG;
+    if (out_dtype != NOPE_F32 && out_dtype != NOPE_BF16) return NOPE_ERR_UNSUPPORTED;
+    unsigned char* base = (unsigned char*)(((uintptr_t)workspace + 255) / 256 * 256);
+    const size_t lost = (size_t)(base - (unsigned char*)workspace);
+    if (workspace_bytes < lost) return NOPE_ERR_WORKSPACE;
+    return run_forward(net, x, n_src, x_rep, pose, n_hyp, H, W, out, out_dtype, base, workspace_bytes - lost,
+                       (hipStream_t)stream, false, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+"""`FeatureExtractor` -- the "template" encoder on the input side of the hot path
+(src/model/encoder/template.py:24-53; ResNet-50 trunk src/model/encoder/resnet.py:55-152).
+
+ResNet-50 without max-pool / avg-pool / fc, strides (2,1,2,2,1) -> /8, then
+ReLU -> 1x1(2048->256) -> ReLU -> 1x1(256->descriptor_size); optional channel L2-normalise.
+Same constructor kwargs, attributes (`latent_dim`, `name`, `normalize`) and state-dict keys
+as the reference (including its aliased `encoder.0.* / encoder.1.*` entries and the unused
+`backbone.fc`), so `resnet50_template_pose.pth` loads unchanged.
+
+Round-1 status: this runs ONCE per query and once per reference image
+(the reference re-runs it N times, model.py:115) and is executed with stock PyTorch-ROCm
+convolutions; it is the first "next" row to move onto the implicit-GEMM kernel (needs
+stride-2 / 7x7 taps and a folded-BN + ReLU epilogue).  It is not part of the U-Net/scoring
+kernels the north star names and is <1 % of a 512-template step.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+_LAYERS = (3, 4, 6, 3)
+_STRIDES = (1, 2, 2, 1)      # resnet.py:102-105
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, cin, planes, stride, project):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = None
+        if project:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, planes * 4, 1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(planes * 4))
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = F.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return F.relu(y + x)
+
+
+class _Trunk(nn.Module):
+    def __init__(self, features=64):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, features, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(features)
+        cin = features
+        for i, (n, s) in enumerate(zip(_LAYERS, _STRIDES), start=1):
+            planes = features * 2 ** (i - 1)
+            blocks = []
+            for b in range(n):
+                blocks.append(_Bottleneck(cin, planes, s if b == 0 else 1, b == 0))
+                cin = planes * 4
+            setattr(self, f"layer{i}", nn.Sequential(*blocks))
+        self.fc = nn.Linear(cin, 1)          # present (unused) in the reference: resnet.py:107, num_classes=1
+        for m in self.modules():             # resnet.py:110-116
+            if isinstance(m, nn.Conv2d):
+                n_ = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / n_))
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)))
+        for i in range(1, 5):
+            x = getattr(self, f"layer{i}")(x)
+        return x
+
+
+class FeatureExtractor(nn.Module):
+    def __init__(self, descriptor_size, threshold=0.2, normalize=False, **kwargs):
+        super().__init__()
+        self.latent_dim = descriptor_size
+        self.normalize = normalize
+        self.threshold = threshold
+        self.name = "template"
+        self.backbone = _Trunk()
+        self.projector = nn.Sequential(nn.ReLU(), nn.Conv2d(2048, 256, 1, bias=False), nn.ReLU(),
+                                       nn.Conv2d(256, descriptor_size, 1, bias=False))
+        self.encoder = nn.Sequential(self.backbone, self.projector)   # aliased, as in template.py:40
+        self.eval()
+
+    @torch.no_grad()
+    def encode_image(self, image, mode=None):
+        feat = self.projector(self.backbone(image))
+        if self.normalize:
+            feat = F.normalize(feat, dim=1)
+        return feat

@@ -1,0 +1,323 @@
+"""ctypes binding of libnope_hip.so (include/nope_hip.h) for torch tensors.
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation below is
+a hand-written gfx950 kernel behind the C ABI.  There is NO fallback: if the library is
+missing (not built) the import of anything that computes fails with a clear error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+
+F32, BF16 = 0, 1
+CONV_PLAIN, CONV_UP2, CONV_DOWN2 = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnope_hip.so")
+
+_vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", _vp), ("ndim", _i), ("shape", _i64 * 4)]
+
+
+class UNetConfig(C.Structure):
+    _fields_ = [("u_net_dim", _i), ("channels", _i), ("out_dim", _i), ("pose_dim", _i), ("n_levels", _i),
+                ("dim_mults", _i * 8), ("groups", _i), ("heads", _i), ("dim_head", _i), ("pose_mlp_layers", _i),
+                ("compute_dtype", _i)]
+
+
+_PROTOS = {
+    "nope_strerror": (C.c_char_p, [_i]),
+    "nope_abi_version": (_i, []),
+    "nope_similarity": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp]),
+    "nope_topk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "nope_unet_create": (_i, [C.POINTER(UNetConfig), C.POINTER(TensorDesc), _i, _vp, C.POINTER(_vp)]),
+    "nope_unet_destroy": (None, [_vp]),
+    "nope_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "nope_unet_forward": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "nope_op_nchw_to_nhwc": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
+    "nope_op_nhwc_to_nchw": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
+    "nope_op_pack_conv_weight": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "nope_op_conv": (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "nope_op_gn_chunks": (_i, [_i, _i, _i]),
+    "nope_op_group_norm": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "nope_op_linear_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "nope_op_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "nope_op_linear": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+class NopeError(RuntimeError):
+    pass
+
+
+class NopeLib:
+    """A loaded C-ABI library with typed prototypes."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise NopeError(
+                f"{path} not found: the gfx950 library is not built. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (needs hipcc). nope_amd has no CPU fallback.")
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(self.dll, name)
+            fn.restype = res
+            fn.argtypes = args
+
+    def check(self, code: int, what: str):
+        if code != 0:
+            raise NopeError(f"{what}: {self.dll.nope_strerror(code).decode()} ({code})")
+
+
+_lib: Optional[NopeLib] = None
+
+
+def lib() -> NopeLib:
+    global _lib
+    if _lib is None:
+        _lib = NopeLib(LIB_PATH)
+    return _lib
+
+
+def _set_library_for_testing(l: Optional[NopeLib]):
+    """tests/ only: lets the CPU test-suite run the same host code over tests/hipemu."""
+    global _lib
+    _lib = l
+
+
+def _stream(t: torch.Tensor) -> int:
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return 0
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def torch_dtype(dt: int) -> torch.dtype:
+    return torch.float32 if dt == F32 else torch.bfloat16
+
+
+def dtype_code(dt) -> int:
+    if dt in (F32, "f32", "fp32", "float32", torch.float32):
+        return F32
+    if dt in (BF16, "bf16", "bfloat16", torch.bfloat16):
+        return BF16
+    raise NopeError(f"unsupported dtype {dt!r}")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# scoring
+# --------------------------------------------------------------------------------------------
+def similarity(q: torch.Tensor, bank: torch.Tensor, out: Optional[torch.Tensor] = None,
+               col_offset: int = 0) -> torch.Tensor:
+    """score[b,n] of model.py:257-262.  q (B,C,H,W) f32; bank (B|1,N,C,H,W) f32|bf16.
+    With `out` (B, Ntotal) given, writes columns [col_offset, col_offset+N)."""
+    q = _f32c(q)
+    B, Cc, H, W = q.shape
+    if bank.dim() != 5 or tuple(bank.shape[2:]) != (Cc, H, W) or bank.shape[0] not in (1, B):
+        raise NopeError(f"bank shape {tuple(bank.shape)} does not match query {tuple(q.shape)}")
+    if bank.dtype not in (torch.float32, torch.bfloat16):
+        bank = bank.float()
+    bank = bank.contiguous()
+    N = bank.shape[1]
+    stride_b = 0 if (bank.shape[0] == 1 and B > 1) else N * Cc * H * W
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=q.device)
+        col_offset = 0
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == B
+    ld = out.shape[1]
+    assert col_offset + N <= ld
+    l = lib()
+    l.check(l.dll.nope_similarity(_ptr(q), _ptr(bank), dtype_code(bank.dtype), out.data_ptr() + 4 * col_offset, B, N, Cc,
+                                  H, W, stride_b, ld, _stream(q)), "nope_similarity")
+    return out
+
+
+def topk(scores: torch.Tensor, k: int = 5) -> Tuple[torch.Tensor, torch.Tensor]:
+    scores = _f32c(scores)
+    B, N = scores.shape
+    idx = torch.empty((B, k), dtype=torch.int64, device=scores.device)
+    vals = torch.empty((B, k), dtype=torch.float32, device=scores.device)
+    l = lib()
+    l.check(l.dll.nope_topk(_ptr(scores), _ptr(idx), _ptr(vals), B, N, k, N, _stream(scores)), "nope_topk")
+    return vals, idx
+
+
+# --------------------------------------------------------------------------------------------
+# U-Net handle
+# --------------------------------------------------------------------------------------------
+class UNetHandle:
+    """Owns a `nope_unet*` built from a reference-keyed state dict."""
+
+    def __init__(self, cfg: dict, state_dict: Dict[str, torch.Tensor], compute_dtype=F32):
+        l = lib()
+        self._l = l
+        c = UNetConfig()
+        c.u_net_dim = cfg["u_net_dim"]; c.channels = cfg["channels"]; c.out_dim = cfg.get("out_dim", cfg["channels"])
+        c.pose_dim = cfg.get("pose_dim", 6)
+        mults = tuple(cfg.get("dim_mults", (1, 2, 4, 8)))
+        c.n_levels = len(mults)
+        for i, m in enumerate(mults):
+            c.dim_mults[i] = m
+        c.groups = cfg.get("groups", 8); c.heads = 4; c.dim_head = 32
+        c.pose_mlp_layers = cfg.get("pose_mlp_layers", 1)
+        c.compute_dtype = dtype_code(compute_dtype)
+        self.cfg = dict(cfg)
+        self.compute_dtype = c.compute_dtype
+        self.channels, self.out_dim, self.pose_dim = c.channels, c.out_dim, c.pose_dim
+        keep = []
+        descs = (TensorDesc * len(state_dict))()
+        dev = None
+        for i, (k, v) in enumerate(state_dict.items()):
+            t = _f32c(v.detach())
+            keep.append(t)
+            dev = t.device
+            descs[i].name = k.encode()
+            descs[i].data = t.data_ptr()
+            descs[i].ndim = t.dim()
+            for j, s in enumerate(t.shape[:4]):
+                descs[i].shape[j] = s
+        self.device = dev
+        h = _vp()
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev is not None and dev.type == "cuda" else 0
+        l.check(l.dll.nope_unet_create(C.byref(c), descs, len(state_dict), stream, C.byref(h)), "nope_unet_create")
+        self._h = h
+        self._ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._l.dll.nope_unet_destroy(h)
+            self._h = None
+
+    def workspace_bytes(self, n_hyp: int, n_src: int, H: int, W: int) -> int:
+        return int(self._l.dll.nope_unet_workspace_bytes(self._h, n_hyp, n_src, H, W))
+
+    def forward(self, x: torch.Tensor, pose: torch.Tensor, x_rep: int = 1, out: Optional[torch.Tensor] = None,
+                out_dtype=F32) -> torch.Tensor:
+        """out[j] = UNet(x[j // x_rep], pose[j]); x (n_src,C,H,W) f32, pose (n_src*x_rep, pose_dim)."""
+        x = _f32c(x)
+        pose = _f32c(pose)
+        n_src, Cc, H, W = x.shape
+        n_hyp = pose.shape[0]
+        if Cc != self.channels or pose.shape[1] != self.pose_dim or n_src * x_rep != n_hyp:
+            raise NopeError(f"shape mismatch: x {tuple(x.shape)}, pose {tuple(pose.shape)}, x_rep {x_rep}")
+        odt = dtype_code(out_dtype)
+        if out is None:
+            out = torch.empty((n_hyp, self.out_dim, H, W), dtype=torch_dtype(odt), device=x.device)
+        assert out.is_contiguous() and out.numel() == n_hyp * self.out_dim * H * W and out.dtype == torch_dtype(odt)
+        need = self.workspace_bytes(n_hyp, n_src, H, W)
+        if need == 0:
+            raise NopeError(f"unsupported U-Net problem size n_hyp={n_hyp} H={H} W={W}")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        self._l.check(self._l.dll.nope_unet_forward(self._h, _ptr(x), n_src, x_rep, _ptr(pose), n_hyp, H, W, _ptr(out), odt,
+                                                    _ptr(self._ws), self._ws.numel(), _stream(x)), "nope_unet_forward")
+        return out
+
+
+# --------------------------------------------------------------------------------------------
+# operator-level wrappers (parity tests of single blocks; NCHW f32 in/out at the boundary)
+# --------------------------------------------------------------------------------------------
+def to_nhwc(x: torch.Tensor, dt: int) -> torch.Tensor:
+    x = _f32c(x)
+    n, c, h, w = x.shape
+    y = torch.empty((n, h, w, c), dtype=torch_dtype(dt), device=x.device)
+    l = lib()
+    l.check(l.dll.nope_op_nchw_to_nhwc(dt, _ptr(x), _ptr(y), n, c, h * w, _stream(x)), "nchw_to_nhwc")
+    return y
+
+
+def to_nchw(y: torch.Tensor, dt: int) -> torch.Tensor:
+    n, h, w, c = y.shape
+    x = torch.empty((n, c, h, w), dtype=torch.float32, device=y.device)
+    l = lib()
+    l.check(l.dll.nope_op_nhwc_to_nchw(dt, _ptr(y), _ptr(x), n, c, h * w, _stream(y)), "nhwc_to_nchw")
+    return x
+
+
+def pack_conv_weight(w: torch.Tensor, dt: int, mode: int = CONV_PLAIN) -> Tuple[torch.Tensor, int, int]:
+    w = _f32c(w)
+    cout = w.shape[0]
+    if mode == CONV_DOWN2:
+        cin, ntaps = w.shape[1] // 4, 4
+    else:
+        cin, ntaps = w.shape[1], w.shape[2] * w.shape[3]
+    out = torch.empty((cout, ntaps, cin), dtype=torch_dtype(dt), device=w.device)
+    l = lib()
+    l.check(l.dll.nope_op_pack_conv_weight(dt, _ptr(w), _ptr(out), cout, cin, ntaps, mode, _stream(w)), "pack_conv_weight")
+    return out, cin, ntaps
+
+
+def op_conv(dt: int, src1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+            src2: Optional[torch.Tensor] = None, mode: int = CONV_PLAIN, rep1: int = 1, rep2: int = 1,
+            resid: Optional[torch.Tensor] = None, n_hyp: Optional[int] = None, out_nchw: bool = False,
+            out_dtype: int = F32) -> torch.Tensor:
+    """src* NHWC tensors of dtype dt; w torch Conv2d weight (f32).  Returns NHWC (or NCHW)."""
+    pw, cin, ntaps = pack_conv_weight(w, dt, mode)
+    n1, hs, ws, c1 = src1.shape
+    c2 = 0 if src2 is None else src2.shape[3]
+    assert c1 + c2 == cin
+    n_hyp = n_hyp if n_hyp is not None else n1 * rep1
+    ho, wo = (2 * hs, 2 * ws) if mode == CONV_UP2 else ((hs // 2, ws // 2) if mode == CONV_DOWN2 else (hs, ws))
+    cout = w.shape[0]
+    if out_nchw:
+        out = torch.empty((n_hyp, cout, ho, wo), dtype=torch_dtype(out_dtype), device=src1.device)
+    else:
+        out = torch.empty((n_hyp, ho, wo, cout), dtype=torch_dtype(dt), device=src1.device)
+    b = None if bias is None else _f32c(bias)
+    l = lib()
+    l.check(l.dll.nope_op_conv(dt, _ptr(src1), c1, rep1, _ptr(src2), c2, rep2, hs, ws, mode, ntaps, _ptr(pw), _ptr(b),
+                               _ptr(resid), _ptr(out), cout, n_hyp, int(out_nchw), out_dtype, _stream(src1)), "nope_op_conv")
+    return out
+
+
+def op_group_norm(dt: int, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, act_silu: bool = False,
+                  emb: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, h, w, c = x.shape
+    l = lib()
+    nch = l.dll.nope_op_gn_chunks(dt, h * w, c)
+    partial = torch.empty((n, nch, groups, 2), dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    g, b = _f32c(gamma), _f32c(beta)
+    e = None if emb is None else _f32c(emb)
+    l.check(l.dll.nope_op_group_norm(dt, _ptr(x), _ptr(y), _ptr(partial), _ptr(g), _ptr(b), n, h * w, c, groups,
+                                     int(act_silu), _ptr(e), 0 if e is None else e.shape[1], _ptr(resid), _stream(x)),
+            "nope_op_group_norm")
+    return y
+
+
+def op_linear_attention(dt: int, qkv: torch.Tensor, heads: int = 4, dim_head: int = 32, full: bool = False) -> torch.Tensor:
+    n, h, w, c3 = qkv.shape
+    out = torch.empty((n, h, w, heads * dim_head), dtype=qkv.dtype, device=qkv.device)
+    l = lib()
+    fn = l.dll.nope_op_attention if full else l.dll.nope_op_linear_attention
+    l.check(fn(dt, _ptr(qkv), _ptr(out), n, h * w, heads, dim_head, _stream(qkv)), "nope_op_attention")
+    return out
+
+
+def op_linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act_in: int = 0) -> torch.Tensor:
+    x, w = _f32c(x), _f32c(w)
+    b = None if bias is None else _f32c(bias)
+    out = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+    l = lib()
+    l.check(l.dll.nope_op_linear(_ptr(x), _ptr(w), _ptr(b), _ptr(out), x.shape[0], w.shape[0], x.shape[1], act_in,
+                                 _stream(x)), "nope_op_linear")
+    return out

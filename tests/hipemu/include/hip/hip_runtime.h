@@ -1,0 +1,341 @@
+// hipemu -- a tiny CPU interpreter for the subset of HIP used by nope_amd/csrc.
+//
+// TEST INFRASTRUCTURE ONLY.  It lives under tests/, is never built by
+// `__graft_entry__.build()` into the product library and nothing under `nope_amd/`
+// can load it.  Its single purpose: the GPU-less build container can execute the
+// *unmodified* kernel sources (index math, tap geometry, LDS swizzles, masks,
+// epilogues, the C++ U-Net schedule) against the oracle before a GPU-minute is spent.
+// It is NOT a fallback: `nope_amd.hip` loads only the gfx950 library and fails loudly
+// without it.
+//
+// Model: a workgroup is a set of fibers (ucontext) on one OS thread; `__syncthreads`
+// and every wave-collective (shuffles, MFMA) are rendezvous points.  Workgroups are
+// distributed over OS threads; `__shared__` is `static thread_local`, so concurrently
+// running workgroups never share LDS.  MFMA fragment layouts follow
+// /opt/skills/guides/cdna_hip_programming.md §3 (what the real kernels assume, too --
+// the first GPU run has a dedicated fragment-layout test because the emulator cannot
+// validate that assumption).
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+#define HIPEMU 1
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct hipemu_uint3 { unsigned x, y, z; };
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+
+namespace hipemu {
+
+constexpr int kWave = 64;
+constexpr size_t kStack = 96 * 1024;
+
+struct WaveSync {
+    int arrived = 0;
+    unsigned gen = 0;
+    int nlanes = 0;
+    alignas(16) unsigned char slot[2][kWave][64];
+};
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool done = false;
+    hipemu_uint3 tid;
+    int flat = 0;
+};
+
+struct BlockCtx {
+    ucontext_t sched;
+    std::vector<Fiber> fibers;
+    std::vector<WaveSync> waves;
+    int nthreads = 0;
+    int barrier_arrived = 0;
+    unsigned barrier_gen = 0;
+    int cur = -1;
+    std::function<void()> body;
+    hipemu_uint3 bid, bdim, gdim;
+};
+
+inline thread_local BlockCtx* g_blk = nullptr;
+inline thread_local hipemu_uint3 g_tid, g_bid, g_bdim, g_gdim;
+
+inline void yield_to_sched() {
+    BlockCtx* b = g_blk;
+    int me = b->cur;
+    swapcontext(&b->fibers[me].ctx, &b->sched);
+    // resumed
+    g_tid = b->fibers[me].tid;
+}
+
+inline void fiber_entry() {
+    BlockCtx* b = g_blk;
+    int me = b->cur;
+    g_tid = b->fibers[me].tid;
+    b->body();
+    b->fibers[me].done = true;
+    swapcontext(&b->fibers[me].ctx, &b->sched);
+}
+
+inline void run_block(BlockCtx& b) {
+    g_blk = &b;
+    g_bid = b.bid; g_bdim = b.bdim; g_gdim = b.gdim;
+    int n = b.nthreads;
+    for (int i = 0; i < n; ++i) {
+        Fiber& f = b.fibers[i];
+        f.done = false;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = &b.sched;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+    }
+    for (auto& w : b.waves) { w.arrived = 0; w.gen = 0; }
+    int nw = (n + kWave - 1) / kWave;
+    for (int w = 0; w < nw; ++w) b.waves[w].nlanes = std::min(kWave, n - w * kWave);
+    b.barrier_arrived = 0; b.barrier_gen = 0;
+    int remaining = n;
+    long spins = 0;
+    while (remaining > 0) {
+        int progressed = 0;
+        for (int i = 0; i < n; ++i) {
+            if (b.fibers[i].done) continue;
+            b.cur = i;
+            swapcontext(&b.sched, &b.fibers[i].ctx);
+            if (b.fibers[i].done) { --remaining; }
+            ++progressed;
+        }
+        if (++spins > 100000000L) { fprintf(stderr, "hipemu: deadlock?\n"); abort(); }
+        (void)progressed;
+    }
+    g_blk = nullptr;
+}
+
+inline void syncthreads() {
+    BlockCtx* b = g_blk;
+    unsigned gen = b->barrier_gen;
+    if (++b->barrier_arrived == b->nthreads) { b->barrier_arrived = 0; ++b->barrier_gen; return; }
+    while (b->barrier_gen == gen) yield_to_sched();
+}
+
+// wave rendezvous: publish `bytes` of payload, wait for the whole wave, return slot table
+inline const unsigned char (*wave_exchange(const void* payload, size_t bytes))[64] {
+    BlockCtx* b = g_blk;
+    int flat = b->fibers[b->cur].flat;
+    WaveSync& w = b->waves[flat / kWave];
+    unsigned gen = w.gen;
+    int lane = flat % kWave;
+    memcpy(w.slot[gen & 1][lane], payload, bytes);
+    if (++w.arrived == w.nlanes) { w.arrived = 0; ++w.gen; }
+    else while (w.gen == gen) yield_to_sched();
+    return w.slot[gen & 1];
+}
+inline int lane_id() { BlockCtx* b = g_blk; return b->fibers[b->cur].flat % kWave; }
+
+template <class F>
+void launch(dim3 grid, dim3 block, F&& body) {
+    size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    int nthreads = block.x * block.y * block.z;
+    unsigned hw = std::thread::hardware_concurrency();
+    const char* env = getenv("HIPEMU_THREADS");
+    if (env) hw = (unsigned)atoi(env);
+    size_t nos = std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, nblocks));
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        BlockCtx b;
+        b.nthreads = nthreads;
+        b.fibers.resize(nthreads);
+        b.waves.resize((nthreads + kWave - 1) / kWave);
+        for (int i = 0; i < nthreads; ++i) {
+            b.fibers[i].stack = (char*)malloc(kStack);
+            b.fibers[i].flat = i;
+            b.fibers[i].tid = {unsigned(i % block.x), unsigned((i / block.x) % block.y), unsigned(i / (block.x * block.y))};
+        }
+        b.body = body;
+        b.bdim = {block.x, block.y, block.z};
+        b.gdim = {grid.x, grid.y, grid.z};
+        for (;;) {
+            size_t i = next.fetch_add(1);
+            if (i >= nblocks) break;
+            b.bid = {unsigned(i % grid.x), unsigned((i / grid.x) % grid.y), unsigned(i / ((size_t)grid.x * grid.y))};
+            run_block(b);
+        }
+        for (auto& f : b.fibers) free(f.stack);
+    };
+    if (nos == 1) { worker(); return; }
+    std::vector<std::thread> ts;
+    for (size_t t = 0; t < nos; ++t) ts.emplace_back(worker);
+    for (auto& t : ts) t.join();
+}
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::g_tid)
+#define blockIdx (hipemu::g_bid)
+#define blockDim (hipemu::g_bdim)
+#define gridDim (hipemu::g_gdim)
+#define warpSize 64
+
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
+    hipemu::launch((grid), (block), [=]() { kern(__VA_ARGS__); })
+
+inline void __syncthreads() { hipemu::syncthreads(); }
+
+template <class T>
+inline T __shfl(T v, int src, int width = 64) {
+    auto s = hipemu::wave_exchange(&v, sizeof(T));
+    int lane = hipemu::lane_id();
+    int base = lane & ~(width - 1);
+    T r; memcpy(&r, s[base + (src & (width - 1))], sizeof(T)); return r;
+}
+template <class T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+    auto s = hipemu::wave_exchange(&v, sizeof(T));
+    int lane = hipemu::lane_id();
+    int src = lane ^ mask;
+    if ((src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
+    T r; memcpy(&r, s[src], sizeof(T)); return r;
+}
+template <class T>
+inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    auto s = hipemu::wave_exchange(&v, sizeof(T));
+    int lane = hipemu::lane_id();
+    int src = lane + (int)delta;
+    if ((src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
+    T r; memcpy(&r, s[src], sizeof(T)); return r;
+}
+inline unsigned long long __ballot(int pred) {
+    auto s = hipemu::wave_exchange(&pred, sizeof(int));
+    unsigned long long m = 0;
+    hipemu::BlockCtx* b = hipemu::g_blk;
+    int n = b->waves[b->fibers[b->cur].flat / 64].nlanes;
+    for (int i = 0; i < n; ++i) { int p; memcpy(&p, s[i], 4); if (p) m |= 1ull << i; }
+    return m;
+}
+inline int __all(int pred) {
+    hipemu::BlockCtx* b = hipemu::g_blk;
+    int n = b->waves[b->fibers[b->cur].flat / 64].nlanes;
+    unsigned long long full = n == 64 ? ~0ull : ((1ull << n) - 1);
+    return __ballot(pred) == full;
+}
+inline int __any(int pred) { return __ballot(pred) != 0; }
+
+// ---- MFMA (fragment maps: cdna_hip_programming.md §3) ---------------------------------
+typedef __attribute__((ext_vector_type(8))) short hipemu_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float hipemu_f32x4;
+typedef __attribute__((ext_vector_type(16))) float hipemu_f32x16;
+
+inline float hipemu_bf16_to_f32(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// v_mfma_f32_16x16x32_bf16: A[i=l&15][k=(l>>4)*8+e], B[k=(l>>4)*8+e][j=l&15]; D: col=l&15,row=(l>>4)*4+r
+inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x4 c, int, int, int) {
+    struct P { hipemu_bf16x8 a, b; } p{a, b};
+    auto s = hipemu::wave_exchange(&p, sizeof(P));
+    int lane = hipemu::lane_id();
+    int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (lane >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            P pa, pb;
+            memcpy(&pa, s[row + 16 * (k >> 3)], sizeof(P));
+            memcpy(&pb, s[col + 16 * (k >> 3)], sizeof(P));
+            acc = fmaf(hipemu_bf16_to_f32((unsigned short)pa.a[k & 7]), hipemu_bf16_to_f32((unsigned short)pb.b[k & 7]), acc);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+// v_mfma_f32_16x16x4_f32: A[l&15][k=l>>4], B[k=l>>4][l&15]; exact fmaf chain over k
+inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+    struct P { float a, b; } p{a, b};
+    auto s = hipemu::wave_exchange(&p, sizeof(P));
+    int lane = hipemu::lane_id();
+    int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (lane >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            P pa, pb;
+            memcpy(&pa, s[row + 16 * k], sizeof(P));
+            memcpy(&pb, s[col + 16 * k], sizeof(P));
+            acc = fmaf(pa.a, pb.b, acc);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+// v_mfma_f32_32x32x16_bf16: A[i=l&31][k=(l>>5)*8+e], B[k][j=l&31]; D: col=l&31,row=(r&3)+8*(r>>2)+4*(l>>5)
+inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c, int, int, int) {
+    struct P { hipemu_bf16x8 a, b; } p{a, b};
+    auto s = hipemu::wave_exchange(&p, sizeof(P));
+    int lane = hipemu::lane_id();
+    int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            P pa, pb;
+            memcpy(&pa, s[row + 32 * (k >> 3)], sizeof(P));
+            memcpy(&pb, s[col + 32 * (k >> 3)], sizeof(P));
+            acc = fmaf(hipemu_bf16_to_f32((unsigned short)pa.a[k & 7]), hipemu_bf16_to_f32((unsigned short)pb.b[k & 7]), acc);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_f32_16x16x32_bf16
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_barrier() __syncthreads()
+inline int hipemu_readfirstlane(int v) { return __shfl(v, 0); }
+#define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
+
+inline float __expf(float x) { return expf(x); }
+inline float __fdividef(float a, float b) { return a / b; }
+inline float __frcp_rn(float a) { return 1.0f / a; }
+inline float __fsqrt_rn(float a) { return sqrtf(a); }
+
+inline float atomicAdd(float* p, float v) {
+    float old = *p, neu;
+    do { neu = old + v; } while (!__atomic_compare_exchange(p, &old, &neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    return old;
+}
+
+// ---- runtime API shims --------------------------------------------------------------------
+inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
