@@ -1,0 +1,189 @@
+"""bench.py -- pose-hypotheses/sec of the NOPE hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch, inputs resident in HBM:
+    generate_templates(reference, all_relativeR)   encoder(reference) once + U-Net for every pose hypothesis
+    retrieval(query, bank)                         encoder(query) + scoring + top-5
+Workload at N=1: BASELINE.json configs[1] -- one 256x256 query against 512 viewpoint templates,
+bf16 (bf16 U-Net compute with f32 accumulation/statistics, bf16 bank).  For N>1 the template
+axis is sharded (weak scaling: 512 templates per GPU, N_total = 512*N) and the per-rank scores
+are all-gathered over RCCL before the top-5, as BASELINE configs[3]/[4] describe.
+
+Extra legs on rank 0 at N=1 (outside the timed region):
+  roofline      the dominant kernel of the step, conv_gemm_kernel<bf16> (94 % of the flops):
+                algorithmic flops of all its launches / their summed duration, measured with HIP
+                events around every launch on the launch stream, vs the 2.5 PFLOP/s dense bf16 peak;
+  scoring       the similarity kernel on a 1.07 GB resident bank, vs 8 TB/s HBM;
+  cpu_baseline  the oracle (CPU restatement, kind "port") on the host cores, bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(model, size: int, n_templates: int, hyp_sample: int = 16, chunk: int = 8):
+    """Oracle timed on the host cores: U-Net on `hyp_sample` hypotheses (the reference's loop is
+    linear in N, model.py:212-222), scoring on a 64-template bank slice, the encoder once;
+    extrapolated to one full step (hoisted-encoder schedule = the faster CPU schedule)."""
+    from oracle import nope_ref as R
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = {k: v.detach().float().cpu() for k, v in model.u_net.own_state_dict().items()}
+    enc_sd = {k: v.detach().float().cpu() for k, v in model.u_net.encoder.state_dict().items()}
+    h = size // 8
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(1, 3, size, size, generator=g) * 2 - 1
+    x = torch.randn(1, 8, h, h, generator=g)
+    poses = torch.randn(1, hyp_sample, 6, generator=g)
+    with torch.no_grad():
+        R.unet_forward(sd, x.expand(2, -1, -1, -1), poses[0, :2])          # warm-up
+        t0 = time.perf_counter()
+        R.generate_templates(sd, x, poses, chunk=chunk)
+        t_unet = (time.perf_counter() - t0) / hyp_sample
+        t0 = time.perf_counter()
+        R.encode_image(enc_sd, img)
+        t_enc = time.perf_counter() - t0
+        bank = torch.randn(1, 64, 8, h, h, generator=g)
+        q = torch.randn(1, 8, h, h, generator=g)
+        R.retrieval(q, bank)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            R.retrieval(q, bank)
+        t_score = (time.perf_counter() - t0) / 3 / 64
+    step = n_templates * (t_unet + t_score) + 2 * t_enc
+    return {"value": n_templates / step, "unit": "pose-hypotheses/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32: U-Net on {hyp_sample} hypotheses (batches of {chunk}) at {h}x{h} latent = {t_unet * 1e3:.0f} ms/hyp, "
+                      f"scoring 64 templates = {t_score * 1e6:.0f} us/hyp, encoder {t_enc * 1e3:.0f} ms/image; extrapolated linearly "
+                      f"to {n_templates} templates + 2 encoder passes"}
+
+
+def scoring_roofline(dtype: torch.dtype):
+    from nope_amd import hip
+    B, C, h = 32, 8, 32
+    N = 512 if dtype == torch.float32 else 2048                 # 1.07 GB either way (> 256 MB Infinity Cache)
+    bank = torch.randn(B, N, C, h, h, device="cuda", dtype=torch.float16).to(dtype)
+    q = torch.randn(B, C, h, h, device="cuda")
+    out = torch.empty(B, N, device="cuda")
+    for _ in range(3):
+        hip.similarity(q, bank, out=out)
+    reps = 20
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]   # kernels run on torch's current stream
+    ev[0].record()
+    for i in range(reps):
+        hip.similarity(q, bank, out=out)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
+    med = ms[len(ms) // 2]
+    byts = B * N * (C * h * h * bank.element_size() + 4)
+    gbs = byts / med / 1e6
+    return {"kernel": "sim_reg_kernel", "bank_dtype": str(dtype).split(".")[-1], "B": B, "N": N, "bytes_per_launch": byts,
+            "ms_per_launch": med, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+            "hyp_per_s": B * N / med * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--templates", type=int, default=512, help="templates per GPU")
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--skip-extras", action="store_true", help="skip roofline / cpu_baseline legs")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from nope_amd.harness import build_model, synthetic_batch
+    model = build_model(seed=2022, compute_dtype=a.dtype, bank_dtype=a.dtype, device=dev, template_parallel=world > 1)
+    n_total = a.templates * world
+    batch = synthetic_batch(a.batch, n_total, a.size, seed=2022, device=dev)
+    query, reference, poses = batch["query"], batch["reference"], batch["all_relativeR"]
+
+    def step():
+        bank, _, _ = model.generate_templates(reference, poses, None)
+        return model.retrieval(query, bank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        sim, idx = step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sim, idx = step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    hyp = a.batch * n_total
+    res = {
+        "metric": "pose-hypotheses/sec (queries x templates), generate_templates + retrieval",
+        "value": hyp * a.steps / dt, "unit": "pose-hypotheses/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"{a.batch} query {a.size}x{a.size} x {a.templates} viewpoint templates per GPU "
+                               f"(BASELINE configs[1]); U-Net u_net_dim=192 (305.8M params, random init) at "
+                               f"{a.size // 8}x{a.size // 8} latent + ResNet-50 template encoder + l2 scoring + top-5",
+                   "batch": a.batch, "templates_total": n_total, "templates_per_gpu": a.templates, "image": a.size,
+                   "parallelism": f"template-shard x{world} + score all-gather" if world > 1 else "single GPU",
+                   "bank_dtype": a.dtype, "top5": idx[0].tolist()},
+    }
+    if rank == 0 and world == 1 and not a.skip_extras:
+        h = model.u_net._get_handle(dev)
+        torch.cuda.synchronize()
+        h.profile(True)
+        step()
+        torch.cuda.synchronize()
+        n_launch, ms, flops = h.profile_read()
+        h.profile(False)
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        tf = flops / ms / 1e9
+        res["roofline"] = {"bound": "mfma", "kernel": f"conv_gemm_kernel<{a.dtype}>", "achieved": tf, "peak": peak,
+                           "unit": "TFLOP/s", "frac": tf / peak, "traffic": None, "launches_per_step": n_launch,
+                           "avg_launch_ms": ms / max(n_launch, 1), "kernel_ms_per_step": ms, "flops_per_step": flops}
+        res["scoring_roofline"] = [scoring_roofline(torch.bfloat16), scoring_roofline(torch.float32)]
+        res["cpu_baseline"] = cpu_baseline(model, a.size, a.templates)
+        res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,10 @@ struct nope_unet {
     float *pose_w0 = nullptr, *pose_b0 = nullptr, *pose_w2 = nullptr, *pose_b2 = nullptr;
     float *emb_w = nullptr, *emb_b = nullptr;
     int emb_total = 0;
+    // optional per-launch timing of the implicit-GEMM kernel (bench.py roofline leg)
+    struct Ev { hipEvent_t a, b; double flops; };
+    mutable bool profile = false;
+    mutable std::vector<Ev> evs;
 };
 
 namespace {
@@ -165,7 +169,17 @@ struct Fwd {
         ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.bias = c.bias; ca.resid = resid;
         ca.out = out; ca.Cout = c.Cout; ca.nhyp = n; ca.out_nchw = out_nchw; ca.out_dt = out_dt;
         if (a.C + (b ? b->C : 0) != c.Cin) { chk(NOPE_ERR_ARG); return; }
-        chk(launch_conv(net->dt, ca, s));
+        if (net->profile) {
+            nope_unet::Ev ev;
+            hipEventCreate(&ev.a); hipEventCreate(&ev.b);
+            ev.flops = 2.0 * (double)n * Ho * Wo * c.Cout * c.ntaps * c.Cin;
+            hipEventRecord(ev.a, s);
+            chk(launch_conv(net->dt, ca, s));
+            hipEventRecord(ev.b, s);
+            net->evs.push_back(ev);
+        } else {
+            chk(launch_conv(net->dt, ca, s));
+        }
     }
     // y = act(GN(x)) [+emb] [+resid]; x holds n_x = nhyp / x_rep samples
     void gn(const Norm& nm, int G, const void* x, int x_rep, void* y, int HW, int act, int emb_off, const void* resid,
@@ -476,8 +490,30 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
     return NOPE_OK;
 }
 
+int nope_unet_profile(nope_unet* net, int enable) {
+    if (!net) return NOPE_ERR_ARG;
+    for (auto& e : net->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    net->evs.clear();
+    net->profile = enable != 0;
+    return NOPE_OK;
+}
+
+int nope_unet_profile_read(nope_unet* net, int* n_launches, double* total_ms, double* total_flops) {
+    if (!net || !n_launches || !total_ms || !total_flops) return NOPE_ERR_ARG;
+    double ms = 0.0, fl = 0.0;
+    for (auto& e : net->evs) {
+        if (hipEventSynchronize(e.b) != hipSuccess) return NOPE_ERR_LAUNCH;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) return NOPE_ERR_LAUNCH;
+        ms += t; fl += e.flops;
+    }
+    *n_launches = (int)net->evs.size(); *total_ms = ms; *total_flops = fl;
+    return NOPE_OK;
+}
+
 void nope_unet_destroy(nope_unet* net) {
     if (!net) return;
+    for (auto& e : net->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (void* p : net->allocs) hipFree(p);
     delete net;
 }

@@ -1,0 +1,139 @@
+"""Evaluation harness -- counterpart of the reference's `test_shapeNet.py`, which the README
+names (README.md:82) but the tree does not contain.
+
+Builds the model from the values of configs/model/template_base.yaml, feeds batches shaped
+like `ShapeNet.__getitem__` on the test split (src/dataloader/shapeNet.py:348-357, keyed
+"shapeNet_<category>" as model.py:551-552 expects) and runs the hot path:
+`generate_templates -> retrieval -> template_poses[0][nearest_idx]` (model.py:313,323,352),
+then the geodesic angle / Acc@{15,30} (loss.py:76-115; non-symmetric branch only).  There is
+no dataset and no checkpoint in the tree or on the box, so images, poses and weights are
+synthetic and seeded; the numbers are plumbing checks, not accuracy claims.  It does not
+replicate the reference's `vis_imgs` UnboundLocalError (model.py:367): predictions are saved
+with `query_pose` and `similarity` only.
+
+    python -m nope_amd.harness --batch 1 --templates 64 --size 128     # BASELINE config 1 shape
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+TEMPLATE_BASE = dict(          # configs/model/template_base.yaml
+    u_net=dict(u_net_dim=192, rot_representation_dim=6, pose_mlp_name="single_layer",
+               encoder=dict(descriptor_size=8, threshold=0.2, normalize=False)),
+    optim_config=dict(loss_type="l1", lr=5e-5, weight_decay=0.0005, warm_up_steps=500, use_inv_deltaR=True),
+    testing_config=dict(similarity_metric="l2"),
+)
+
+
+def random_rotations(n: int, gen: torch.Generator) -> torch.Tensor:
+    """Haar-distributed rotations, float64 (n,3,3): QR of a Gaussian with sign fix."""
+    a = torch.randn(n, 3, 3, generator=gen, dtype=torch.float64)
+    q, r = torch.linalg.qr(a)
+    q = q * torch.sign(torch.diagonal(r, dim1=-2, dim2=-1)).unsqueeze(-2)
+    det = torch.linalg.det(q)
+    q[:, :, 0] = q[:, :, 0] * det.unsqueeze(-1)
+    return q
+
+
+def rotation_6d(m: torch.Tensor) -> torch.Tensor:
+    """6D representation = first two rows, flattened (src/poses/rotation_conversions.py:490-503)."""
+    return m[..., :2, :].clone().reshape(*m.shape[:-2], 6)
+
+
+def synthetic_batch(batch: int, n_templates: int, size: int, seed: int = 2022, device="cpu") -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    query = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
+    reference = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
+    R_tpl = random_rotations(n_templates, g)
+    R_ref = random_rotations(batch, g)
+    R_query = random_rotations(batch, g)
+    rel = lambda a, b: a @ torch.linalg.inv(b)          # shapeNet.py:243-245
+    all_rel = rotation_6d(rel(R_tpl[None], R_ref[:, None])).float()
+    gt_rel = rotation_6d(rel(R_query, R_ref)).float()
+    out = dict(query=query, reference=reference, gt_relativeR=gt_rel, all_relativeR=all_rel,
+               symmetry=torch.zeros(batch, 1), query_pose=R_query,
+               template_poses=R_tpl[None].expand(batch, -1, -1, -1).contiguous())
+    return {k: v.to(device) for k, v in out.items()}
+
+
+def build_model(seed: int = 2022, compute_dtype="f32", bank_dtype="f32", device="cuda", u_net_dim: Optional[int] = None,
+                save_dir: Optional[str] = None, template_parallel: bool = False, max_hypotheses_per_launch: int = 512):
+    from .encoder import FeatureExtractor
+    from .model import PoseConditional
+    from .u_net import UNet
+    from .weights import synth_init_
+    cfg = TEMPLATE_BASE
+    enc = FeatureExtractor(**cfg["u_net"]["encoder"])
+    synth_init_(enc, seed, prefix="encoder.")
+    unet = UNet(u_net_dim=u_net_dim or cfg["u_net"]["u_net_dim"], rot_representation_dim=6, encoder=enc,
+                pose_mlp_name=cfg["u_net"]["pose_mlp_name"], compute_dtype=compute_dtype)
+    # U-Net tensors are keyed without the "encoder." prefix; the encoder was initialised above
+    from .weights import synth_tensor
+    with torch.no_grad():
+        for k, v in unet.state_dict().items():
+            if not k.startswith("encoder."):
+                v.copy_(synth_tensor(seed, k, tuple(v.shape)))
+    model = PoseConditional(unet, cfg["optim_config"], cfg["testing_config"], save_dir, bank_dtype=bank_dtype,
+                            template_parallel=template_parallel, max_hypotheses_per_launch=max_hypotheses_per_launch)
+    return model.to(device).eval()
+
+
+def geodesic_deg(predR: torch.Tensor, gtR: torch.Tensor) -> torch.Tensor:
+    rel = predR.double() @ gtR.double().transpose(-1, -2)
+    cos = (rel.diagonal(dim1=-2, dim2=-1).sum(-1) - 1.0) / 2.0
+    return torch.rad2deg(torch.acos(cos.clamp(-1.0, 1.0)))
+
+
+@torch.no_grad()
+def eval_geodesic(model, batch: Dict[str, torch.Tensor], thresholds=(15, 30), save_path: Optional[str] = None):
+    """The body of PoseConditional.eval_geodesic (model.py:268-376) without visualisation."""
+    loss = model.forward(batch["query"], batch["reference"], batch["gt_relativeR"])
+    pred_feat, _, _ = model.generate_templates(batch["reference"], batch["all_relativeR"], None, visualize=False)
+    similarity, nearest_idx = model.retrieval(batch["query"], pred_feat)
+    template_poses = batch["template_poses"][0]                 # model.py:352
+    predR = template_poses[nearest_idx]                         # (B,5,3,3)
+    err = torch.stack([geodesic_deg(predR[:, k], batch["query_pose"]) for k in range(predR.shape[1])], 1)
+    res = {"loss": float(loss)}
+    for k in (1, 3, 5):                                         # loss.py:104-114
+        top = err[:, :k].min(dim=1).values
+        for t in thresholds:
+            res[f"top{k}, accuracy_{t}"] = float((top <= t).float().mean() * 100)
+        res[f"top{k}, median"] = float(top.median())
+    if save_path:
+        np.savez(save_path, query_pose=batch["query_pose"].cpu().numpy(), similarity=similarity.cpu().numpy())
+    return similarity, nearest_idx, res
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--templates", type=int, default=64)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--bank-dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--seed", type=int, default=2022)
+    ap.add_argument("--category", default="synthetic")
+    ap.add_argument("--save-dir", default=None)
+    a = ap.parse_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("nope_amd.harness needs an MI355X (no CPU fallback)")
+    model = build_model(a.seed, a.dtype, a.bank_dtype, "cuda", save_dir=a.save_dir)
+    batches = {f"shapeNet_{a.category}": synthetic_batch(a.batch, a.templates, a.size, a.seed, "cuda")}
+    for name, batch in batches.items():                         # test_step, model.py:550-565
+        t0 = time.time()
+        save = os.path.join(a.save_dir, "predictions", f"pred_step0_rank{model.global_rank}") if a.save_dir else None
+        sim, idx, res = eval_geodesic(model, batch, save_path=save)
+        torch.cuda.synchronize()
+        res.update(dataloader=name, seconds=time.time() - t0, nearest_idx=idx.tolist())
+        print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

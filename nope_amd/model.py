@@ -1,0 +1,134 @@
+"""`PoseConditional` -- the task module of the hot path, mirroring the reference's call
+surface (src/model/model.py:32-266): `forward`, `sample`, `generate_templates`, `retrieval`
+with the same arguments and return tuples, on top of the HIP U-Net and scoring kernels.
+
+Differences in *schedule*, none in arithmetic:
+  * `generate_templates` encodes the reference image once (the reference re-encodes it for
+    every template, model.py:115 via :219) and evaluates all N pose hypotheses as batched
+    U-Net launches writing straight into the (B,N,C,h,w) bank;
+  * `retrieval` never materialises the N-fold repeated query (model.py:258);
+  * top-k uses "descending score, ties -> lowest index" (torch.topk leaves tie order
+    unspecified);
+  * with `template_parallel=True` under torch.distributed each rank generates and scores only
+    its slice of the template axis and the scores are all-gathered (nope_amd/dist.py).
+Lightning-specific members (optimizers, wandb logging, VSD/pyrender evaluation) are out of
+scope and are not provided.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import dist as ndist
+from . import hip
+
+
+def _cfg_get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+class PoseConditional(nn.Module):
+    def __init__(self, u_net, optim_config=None, testing_config=None, save_dir=None, bank_dtype="f32",
+                 max_hypotheses_per_launch=512, template_parallel=False, **kwargs):
+        super().__init__()
+        self.u_net = u_net
+        self.save_dir = save_dir
+        self.lr = _cfg_get(optim_config, "lr", 5e-5)
+        self.weight_decay = _cfg_get(optim_config, "weight_decay", 0.0005)
+        self.warm_up_steps = _cfg_get(optim_config, "warm_up_steps", 500)
+        self.use_inv_deltaR = _cfg_get(optim_config, "use_inv_deltaR", True)
+        self.loss_type = _cfg_get(optim_config, "loss_type", "l1")
+        self.testing_config = testing_config
+        self.similarity_metric = _cfg_get(testing_config, "similarity_metric", "l2")
+        self.bank_dtype = bank_dtype
+        self.max_hyp = int(max_hypotheses_per_launch)
+        self.template_parallel = bool(template_parallel)
+        self._slice = None          # (lo, hi, N) of the last sharded generate_templates
+        self.global_step = 0
+        self.global_rank = ndist.world()[0]
+        if save_dir is not None:    # model.py:63-66
+            os.makedirs(os.path.join(save_dir, "media"), exist_ok=True)
+            os.makedirs(os.path.join(save_dir, "predictions"), exist_ok=True)
+            self.log_dir = os.path.join(save_dir, "predictions")
+
+    # ---- model.py:96-111 ------------------------------------------------------------------
+    def compute_loss(self, pred, gt):
+        d = (pred - gt).abs() if self.loss_type == "l1" else (pred - gt) ** 2
+        return d.flatten(1).mean(dim=1).mean()
+
+    @torch.no_grad()
+    def forward(self, query, reference, relativeR):
+        enc = self.u_net.encoder
+        query_feat = enc.encode_image(query)
+        reference_feat = enc.encode_image(reference, mode="mode")
+        pred_query_feat = self.u_net(reference_feat, relativeR)
+        return self.compute_loss(pred_query_feat, query_feat)
+
+    # ---- model.py:113-124 -------------------------------------------------------------------
+    @torch.no_grad()
+    def sample(self, reference, relativeR):
+        reference_feat = self.u_net.encoder.encode_image(reference, mode="mode")
+        pred_query_feat = self.u_net(reference_feat, relativeR)
+        return pred_query_feat, None      # template encoder has no decode_latent (model.py:117-123)
+
+    # ---- model.py:193-252 -----------------------------------------------------------------------
+    @torch.no_grad()
+    def generate_templates(self, reference, all_relativeR, gt_templates=None, visualize=False):
+        """reference (B,3,S,S); all_relativeR (B,N,6) -> (pred_feat_templates (B,N',C,S/8,S/8),
+        None, None).  N' = N, or this rank's slice of N under `template_parallel`."""
+        reference_feat = self.u_net.encoder.encode_image(reference, mode="mode")   # hoisted: once, not N times
+        return self.generate_templates_from_feat(reference_feat, all_relativeR), None, None
+
+    @torch.no_grad()
+    def generate_templates_from_feat(self, reference_feat, all_relativeR):
+        B, N = all_relativeR.shape[:2]
+        lo, hi = 0, N
+        if self.template_parallel:
+            rank, ws = ndist.world()
+            lo, hi = ndist.shard_range(N, rank, ws)
+        self._slice = (lo, hi, N)
+        poses = all_relativeR[:, lo:hi].contiguous().float()
+        n = hi - lo
+        C, h, w = self.u_net.out_dim, reference_feat.shape[2], reference_feat.shape[3]
+        bank = torch.empty((B, n, C, h, w), dtype=hip.torch_dtype(hip.dtype_code(self.bank_dtype)),
+                           device=reference_feat.device)
+        if n == 0:
+            return bank
+        if n <= self.max_hyp:
+            bs = max(1, self.max_hyp // n)
+            for b0 in range(0, B, bs):
+                self.u_net.forward_hypotheses(reference_feat[b0:b0 + bs], poses[b0:b0 + bs], out=bank[b0:b0 + bs],
+                                              out_dtype=self.bank_dtype)
+        else:
+            for b in range(B):
+                for s in range(0, n, self.max_hyp):
+                    e = min(n, s + self.max_hyp)
+                    self.u_net.forward_hypotheses(reference_feat[b:b + 1], poses[b:b + 1, s:e],
+                                                  out=bank[b:b + 1, s:e], out_dtype=self.bank_dtype)
+        return bank
+
+    # ---- model.py:254-266 ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def retrieval(self, query, template_feat):
+        if self.similarity_metric != "l2":
+            return None                   # the reference implements only "l2" (model.py:256,266)
+        query_feat = self.u_net.encoder.encode_image(query, mode="mode")
+        return self.retrieval_from_feat(query_feat, template_feat)
+
+    @torch.no_grad()
+    def retrieval_from_feat(self, query_feat, template_feat, k=5):
+        local = hip.similarity(query_feat, template_feat)
+        sl = self._slice
+        if self.template_parallel and sl is not None and (sl[1] - sl[0]) == template_feat.shape[1] and sl[2] != template_feat.shape[1]:
+            similarity = ndist.all_gather_scores(local, sl[2])
+        else:
+            similarity = local
+        _, nearest_idx = hip.topk(similarity, k)
+        return similarity, nearest_idx

@@ -336,6 +336,12 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { m
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+typedef void* hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }

@@ -1,0 +1,70 @@
+"""CPU, world_size 2, gloo: the template-sharded path (SURVEY.md §8 e).  Each rank scores its
+slice of the bank (kernels interpreted by tests/hipemu) and the score all-gather must
+reproduce the unsharded oracle on every rank, including an uneven split."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, ws, port, emu_path, q, bank, poses, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HIPEMU_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        from nope_amd import hip
+        from nope_amd.dist import all_gather_scores, shard_range
+        from nope_amd.model import PoseConditional
+        from nope_amd.u_net import UNet
+        from nope_amd.weights import synth_init_
+        from tests.util import StubEncoder
+        hip._set_library_for_testing(hip.NopeLib(emu_path))
+        N = bank.shape[1]
+        lo, hi = shard_range(N, rank, ws)
+        local = hip.similarity(q, bank[:, lo:hi].contiguous())
+        full = all_gather_scores(local, N)
+        # full PoseConditional path: sharded template generation + scoring + gather
+        u = UNet(u_net_dim=8, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer")
+        synth_init_(u, 2022)
+        m = PoseConditional(u, None, {"similarity_metric": "l2"}, None, template_parallel=True)
+        ref_feat = q[:1, :, :8, :8].contiguous()
+        b_local, _, _ = m.generate_templates(ref_feat, poses)
+        sim, idx = m.retrieval(ref_feat * 0.5, b_local)
+        ret[rank] = (full, tuple(b_local.shape), sim, idx)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_scoring_matches_unsharded(emu):
+    from oracle import nope_ref as R
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    from tests.util import StubEncoder, rel
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(2, 8, 16, 16, generator=g)
+    bank = torch.randn(2, 7, 8, 16, 16, generator=g)          # 7 templates over 2 ranks: 4 + 3
+    poses = torch.randn(1, 5, 6, generator=g)
+    emu_path = emu.lib().path
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, emu_path, q, bank, poses, ret), nprocs=2, join=True)
+    want = R.similarity_scores(q, bank)
+    u = UNet(u_net_dim=8, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer")
+    synth_init_(u, 2022)
+    ref_feat = q[:1, :, :8, :8]
+    bank2 = R.generate_templates(u.own_state_dict(), ref_feat, poses)
+    sim_want, idx_want = R.retrieval(ref_feat * 0.5, bank2)
+    for r in range(2):
+        full, bshape, sim, idx = ret[r]
+        assert rel(full, want) < 1e-5
+        assert bshape[1] == (3 if r == 0 else 2)
+        assert rel(sim, sim_want) < 1e-4 and torch.equal(idx, idx_want)
+    assert torch.equal(ret[0][0], ret[1][0]) and torch.equal(ret[0][2], ret[1][2])

@@ -1,0 +1,121 @@
+"""CPU: host-side logic, C-ABI surface, weight determinism, sharding helpers."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "nope_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nope_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_capi_exports_every_declared_symbol():
+    """libnope_hip.so (gfx950 build) loads and exports exactly what include/nope_hip.h declares.
+    No compute call is made here (no GPU in this suite)."""
+    from nope_amd import hip
+    from nope_amd.csrc import build
+    lib = build.build()
+    declared = _header_functions()
+    assert set(declared) == set(hip.EXPORTED_SYMBOLS)
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (nope_[a-z0-9_]+)", out))
+    assert set(declared) <= exported, set(declared) - exported
+    dll = ctypes.CDLL(lib)
+    assert dll.nope_abi_version() == 1
+    dll.nope_strerror.restype = ctypes.c_char_p
+    assert dll.nope_strerror(-3) == b"workspace too small"
+
+
+def test_code_object_is_gfx950():
+    from nope_amd.csrc import build
+    lib = build.build()
+    data = open(lib, "rb").read()
+    assert b"gfx950" in data and b"gfx942" not in data and b"sm_" not in data
+
+
+def test_missing_library_error_message(tmp_path):
+    from nope_amd import hip
+    with pytest.raises(hip.NopeError, match="no CPU fallback"):
+        hip.NopeLib(str(tmp_path / "nope.so"))
+
+
+def test_package_never_imports_oracle_or_emulator():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "nope_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                s = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in s and "from oracle" not in s, f
+                assert "hipemu" not in s.replace("tests/hipemu", ""), f
+
+
+def test_synth_weights_are_a_pure_function():
+    from nope_amd.weights import sha256_of, synth_tensor
+    a = synth_tensor(2022, "downs.0.0.block1.proj.weight", (192, 192, 3, 3))
+    b = synth_tensor(2022, "downs.0.0.block1.proj.weight", (192, 192, 3, 3))
+    c = synth_tensor(2023, "downs.0.0.block1.proj.weight", (192, 192, 3, 3))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert float(a.abs().max()) <= 1 / (192 * 9) ** 0.5 + 1e-7
+    assert sha256_of(a) == sha256_of(b)
+
+
+def test_state_dict_contract():
+    """Key names/shapes the reference checkpoints use (SURVEY.md §8 'State-dict keys')."""
+    from nope_amd.u_net import UNet
+    from tests.util import StubEncoder
+    m = UNet(u_net_dim=192, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", pretrained_path=None)
+    sd = m.state_dict()
+    assert sum(v.numel() for v in sd.values()) == 305_771_144
+    want = {
+        "pose_mlp.0.weight": (768, 6), "init_conv.weight": (192, 8, 3, 3),
+        "downs.0.0.mlp.1.weight": (192, 768), "downs.0.0.block1.proj.weight": (192, 192, 3, 3),
+        "downs.0.2.fn.norm.weight": (192,), "downs.0.2.fn.fn.to_qkv.weight": (384, 192, 1, 1),
+        "downs.0.2.fn.fn.to_out.1.bias": (192,), "downs.0.3.1.weight": (192, 768, 1, 1),
+        "downs.3.3.weight": (1536, 768, 3, 3), "mid_attn.fn.fn.to_out.weight": (1536, 128, 1, 1),
+        "ups.0.0.block1.proj.weight": (1536, 2304, 3, 3), "ups.0.0.res_conv.weight": (1536, 2304, 1, 1),
+        "ups.0.3.1.weight": (768, 1536, 3, 3), "ups.3.3.weight": (192, 192, 3, 3),
+        "final_res_block.res_conv.weight": (192, 384, 1, 1), "final_conv.0.mlp.1.weight": (192, 768),
+        "final_conv.1.weight": (8, 192, 1, 1),
+    }
+    for k, s in want.items():
+        assert tuple(sd[k].shape) == s, k
+    assert m.channels == 8 and m.out_dim == 8 and m.name == "template" and m.rot_representation_dim == 6
+
+
+def test_shard_range_partitions():
+    from nope_amd.dist import shard_range
+    for n in (0, 1, 5, 64, 341, 512, 8192):
+        for ws in (1, 2, 3, 8):
+            spans = [shard_range(n, r, ws) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_harness_batch_shapes():
+    from nope_amd.harness import geodesic_deg, random_rotations, rotation_6d, synthetic_batch
+    b = synthetic_batch(2, 7, 64, seed=1)
+    assert b["query"].shape == (2, 3, 64, 64) and b["all_relativeR"].shape == (2, 7, 6)
+    assert b["template_poses"].shape == (2, 7, 3, 3) and b["query_pose"].dtype == torch.float64
+    assert float(b["query"].min()) >= -1 and float(b["query"].max()) <= 1
+    R_ = random_rotations(5, torch.Generator().manual_seed(0))
+    assert torch.allclose(R_ @ R_.transpose(-1, -2), torch.eye(3, dtype=torch.float64).expand(5, 3, 3), atol=1e-12)
+    assert torch.allclose(torch.linalg.det(R_), torch.ones(5, dtype=torch.float64))
+    assert rotation_6d(R_).shape == (5, 6) and torch.equal(rotation_6d(R_)[:, :3], R_[:, 0])
+    assert float(geodesic_deg(R_, R_).abs().max()) < 1e-5
+
+
+def test_unsupported_metric_returns_none():
+    """model.py:256,266: any metric other than "l2" silently returns None."""
+    from nope_amd.model import PoseConditional
+    from nope_amd.u_net import UNet
+    from tests.util import StubEncoder
+    u = UNet(u_net_dim=8, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer")
+    m = PoseConditional(u, None, {"similarity_metric": "cosine"}, None)
+    assert m.retrieval(torch.zeros(1, 8, 8, 8), torch.zeros(1, 2, 8, 8, 8)) is None

@@ -1,0 +1,209 @@
+"""Parity of the HIP path against the oracle and the reference-generated golden fixtures,
+through the C ABI (nope_amd.hip -> libnope_hip.so).
+
+Every test here runs twice:
+  * backend "gpu"  (marked `gpu`): the real gfx950 library on cuda:0 -- the parity tests proper;
+  * backend "emu"  (CPU suite):    the same kernel sources interpreted by tests/hipemu, so index
+    math / masks / schedules are checked in the GPU-less build container too.
+Tolerances: f32 compute 1e-4 relative to max|ref| on scores and U-Net outputs (north_star;
+relative), observed ~1e-6; bf16 compute/storage is a throughput configuration with
+no reference counterpart: bounded loosely and checked on arg-top indices.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import nope_ref as R
+from tests.util import StubEncoder, rel
+
+BACKENDS = [pytest.param("emu"), pytest.param("gpu", marks=pytest.mark.gpu)]
+F32_TOL = 1e-4
+BF16_TOL = 4e-2
+
+
+@pytest.fixture(params=BACKENDS)
+def be(request):
+    hip = request.getfixturevalue(request.param)
+    dev = "cuda" if request.param == "gpu" else "cpu"
+    return hip, dev, request.param
+
+
+def sub(d, tag):
+    return {k[len(tag) + 3:]: v for k, v in d.items() if k.startswith(tag + "/w/")}
+
+
+def _q(x, dt, hip):
+    return x.to(hip.torch_dtype(dt)).float()
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_conv_variants(be, dt):
+    """Implicit-GEMM conv: 3x3 over a virtual concat with a broadcast source, 1x1 + residual,
+    nearest-x2 + 3x3, space-to-depth + 1x1, NCHW epilogue, multi-tile M/N, Cin < BK, ragged M."""
+    hip, dev, _ = be
+    tol = 2e-5 if dt == 0 else BF16_TOL
+    g = torch.Generator().manual_seed(0)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    q = lambda x: _q(x, dt, hip)
+    d = lambda x: x.to(dev)
+    x1, x2, w, b = rn(2, 16, 6, 6), rn(4, 8, 6, 6), rn(24, 24, 3, 3) / 15, rn(24)
+    y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(w), d(b), src2=hip.to_nhwc(d(x2), dt), rep1=2, rep2=1, n_hyp=4)
+    ref = F.conv2d(torch.cat((q(x1).repeat_interleave(2, 0), q(x2)), 1), q(w), b, padding=1)
+    assert rel(hip.to_nchw(y, dt).cpu(), ref) < tol
+    w1, rs = rn(40, 16, 1, 1) / 4, rn(2, 40, 6, 6)
+    y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(w1), None, resid=hip.to_nhwc(d(rs), dt))
+    assert rel(hip.to_nchw(y, dt).cpu(), F.conv2d(q(x1), q(w1)) + q(rs)) < tol
+    wu, bu = rn(8, 16, 3, 3) / 12, rn(8)
+    y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(wu), d(bu), mode=hip.CONV_UP2)
+    assert rel(hip.to_nchw(y, dt).cpu(), R.hard_upsample(q(x1), {"1.weight": q(wu), "1.bias": bu}, "")) < tol
+    wd, bd = rn(32, 64, 1, 1) / 8, rn(32)
+    y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(wd), d(bd), mode=hip.CONV_DOWN2)
+    assert rel(hip.to_nchw(y, dt).cpu(), R.hard_downsample(q(x1), {"1.weight": q(wd), "1.bias": bd}, "")) < tol
+    y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(w1), None, out_nchw=True, out_dtype=hip.F32)
+    assert rel(y.cpu(), F.conv2d(q(x1), q(w1))) < (2e-5 if dt == 0 else 1e-2)
+    xb, wb = rn(3, 72, 8, 8), rn(200, 72, 3, 3) / 25          # 192 rows -> 2 M tiles (ragged), 2 N tiles
+    y = hip.op_conv(dt, hip.to_nhwc(d(xb), dt), d(wb), None)
+    assert rel(hip.to_nchw(y, dt).cpu(), F.conv2d(q(xb), q(wb), padding=1)) < tol
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_group_norm_variants(be, dt):
+    hip, dev, _ = be
+    tol = 2e-5 if dt == 0 else BF16_TOL
+    g = torch.Generator().manual_seed(1)
+    for (C, G) in ((16, 8), (48, 8), (64, 1), (8, 8), (24, 8), (192, 8), (1536, 8), (1536, 1)):
+        hw = (5, 4) if C < 1000 else (2, 2)
+        x = torch.randn(3, C, *hw, generator=g) * 2 + 0.5
+        ga, be_, emb, rs = torch.randn(C, generator=g), torch.randn(C, generator=g), torch.randn(3, C, generator=g), torch.randn(3, C, *hw, generator=g)
+        y = hip.op_group_norm(dt, hip.to_nhwc(x.to(dev), dt), ga.to(dev), be_.to(dev), G, act_silu=True, emb=emb.to(dev),
+                              resid=hip.to_nhwc(rs.to(dev), dt))
+        ref = F.silu(F.group_norm(_q(x, dt, hip), G, ga, be_)) + emb[:, :, None, None] + _q(rs, dt, hip)
+        assert rel(hip.to_nchw(y, dt).cpu(), ref) < tol, (C, G)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_attention_cores(be, dt):
+    hip, dev, _ = be
+    tol = 2e-5 if dt == 0 else BF16_TOL
+    g = torch.Generator().manual_seed(2)
+    for (h, w) in ((6, 5), (4, 4), (1, 1), (9, 8)):
+        qkv = torch.randn(2, 384, h, w, generator=g)
+        b_ = 2
+        qq, kk, vv = (t.reshape(b_, 4, 32, h * w) for t in _q(qkv, dt, hip).chunk(3, 1))
+        lq = qq.softmax(-2) * 32 ** -0.5
+        lk = kk.softmax(-1)
+        ctx = torch.einsum("bhdn,bhen->bhde", lk, vv)
+        o = torch.einsum("bhde,bhdn->bhen", ctx, lq).reshape(b_, 128, h, w)
+        y = hip.op_linear_attention(dt, hip.to_nhwc(qkv.to(dev), dt))
+        assert rel(hip.to_nchw(y, dt).cpu(), o) < tol
+        if h * w <= 64:
+            sim = torch.einsum("bhdi,bhdj->bhij", qq * 32 ** -0.5, kk).softmax(-1)
+            o = torch.einsum("bhij,bhdj->bhid", sim, vv).permute(0, 1, 3, 2).reshape(b_, 128, h, w)
+            y = hip.op_linear_attention(dt, hip.to_nhwc(qkv.to(dev), dt), full=True)
+            assert rel(hip.to_nchw(y, dt).cpu(), o) < tol
+
+
+def test_linear(be):
+    hip, dev, _ = be
+    g = torch.Generator().manual_seed(3)
+    x, w, b = torch.randn(5, 6, generator=g), torch.randn(32, 6, generator=g), torch.randn(32, generator=g)
+    for act, f in ((0, lambda t: t), (1, F.silu), (2, F.gelu)):
+        assert rel(hip.op_linear(x.to(dev), w.to(dev), b.to(dev), act).cpu(), F.linear(f(x), w, b)) < 1e-5
+
+
+def test_blocks_vs_reference_golden(be, golden):
+    """ResnetBlock / attention / resampling blocks assembled from the operator entry points,
+    against outputs recorded from the reference's own modules (f32)."""
+    hip, dev, _ = be
+    g = golden("blocks.npz")
+    dt = hip.F32
+    d = lambda t: t.to(dev)
+
+    def resnet(tag):
+        w = sub(g, tag)
+        x, emb = g[f"{tag}/in0"], g[f"{tag}/in1"]
+        xn = hip.to_nhwc(d(x), dt)
+        e = hip.op_linear(d(emb), d(w["mlp.1.weight"]), d(w["mlp.1.bias"]), 1)
+        h = hip.op_conv(dt, xn, d(w["block1.proj.weight"]), d(w["block1.proj.bias"]))
+        h = hip.op_group_norm(dt, h, d(w["block1.norm.weight"]), d(w["block1.norm.bias"]), 8, act_silu=True, emb=e)
+        h = hip.op_conv(dt, h, d(w["block2.proj.weight"]), d(w["block2.proj.bias"]))
+        res = hip.op_conv(dt, xn, d(w["res_conv.weight"]), d(w["res_conv.bias"])) if "res_conv.weight" in w else xn
+        h = hip.op_group_norm(dt, h, d(w["block2.norm.weight"]), d(w["block2.norm.bias"]), 8, act_silu=True, resid=res)
+        return hip.to_nchw(h, dt).cpu()
+
+    assert rel(resnet("resnet_proj"), g["resnet_proj/out"]) < F32_TOL
+    assert rel(resnet("resnet_id"), g["resnet_id/out"]) < F32_TOL
+
+    for tag, full in (("linattn", False), ("attn", True)):
+        w = sub(g, tag)
+        xn = hip.to_nhwc(d(g[f"{tag}/in0"]), dt)
+        y = hip.op_group_norm(dt, xn, d(w["fn.norm.weight"]), d(w["fn.norm.bias"]), 1)
+        qkv = hip.op_conv(dt, y, d(w["fn.fn.to_qkv.weight"]), None)
+        a = hip.op_linear_attention(dt, qkv, full=full)
+        if full:
+            o = hip.op_conv(dt, a, d(w["fn.fn.to_out.weight"]), d(w["fn.fn.to_out.bias"]), resid=xn)
+        else:
+            o = hip.op_conv(dt, a, d(w["fn.fn.to_out.0.weight"]), d(w["fn.fn.to_out.0.bias"]))
+            o = hip.op_group_norm(dt, o, d(w["fn.fn.to_out.1.weight"]), d(w["fn.fn.to_out.1.bias"]), 1, resid=xn)
+        assert rel(hip.to_nchw(o, dt).cpu(), g[f"{tag}/out"]) < F32_TOL
+
+    for tag, mode in (("down", hip.CONV_DOWN2), ("up", hip.CONV_UP2)):
+        w = sub(g, tag)
+        y = hip.op_conv(dt, hip.to_nhwc(d(g[f"{tag}/in0"]), dt), d(w["1.weight"]), d(w["1.bias"]), mode=mode)
+        assert rel(hip.to_nchw(y, dt).cpu(), g[f"{tag}/out"]) < F32_TOL
+
+
+@pytest.mark.parametrize("tag,dim,mlp", [("d8", 8, "single_layer"), ("d16two", 16, "two_layers")])
+def test_tiny_unet_vs_reference_golden(be, golden, tag, dim, mlp):
+    """Whole U-Net schedule (C++ runtime + all kernels) vs the reference module's output."""
+    hip, dev, name = be
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    g = golden("unet_tiny.npz")
+    x, pose, ref = g[f"{tag}/x"], g[f"{tag}/pose"], g[f"{tag}/out"]
+    for cdt, tol in (("f32", F32_TOL), ("bf16", 6e-2)):
+        if name == "emu" and cdt == "bf16" and tag != "d8":
+            continue      # keep the CPU suite short
+        m = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name=mlp, compute_dtype=cdt)
+        synth_init_(m, 2022)
+        m = m.to(dev)
+        y = m(x.to(dev), pose.to(dev)).cpu()
+        assert rel(y, ref) < tol, (cdt, rel(y, ref))
+        if cdt == "f32":
+            # batched-hypothesis form == per-pose form (x shared by 3 poses, exercises rep / hoisting)
+            yh = m.forward_hypotheses(x[:1].to(dev), pose[None].to(dev)).cpu()[0]
+            want = R.unet_forward(m.cpu().own_state_dict(), x[:1].expand(3, -1, -1, -1), pose)
+            assert rel(yh, want) < tol
+
+
+def test_retrieval_vs_reference_golden(be, golden):
+    hip, dev, _ = be
+    g = golden("retrieval.npz")
+    for tag in "abc":
+        q, bank = g[f"{tag}/q"], g[f"{tag}/bank"]
+        s = hip.similarity(q.to(dev), bank.to(dev))
+        assert rel(s.cpu(), g[f"{tag}/sim"]) < 1e-5
+        _, idx = hip.topk(s, 5)
+        assert torch.equal(idx.cpu(), g[f"{tag}/idx"])
+        B, N = s.shape
+        assert float(s[B - 1, N // 2]) == 0.0 and int(idx[B - 1, 0]) == N // 2      # exact-match KAT
+        sb = hip.similarity(q.to(dev), bank.to(dev).to(torch.bfloat16))
+        if bank.shape[-1] * bank.shape[-2] % 8 == 0:
+            assert rel(sb.cpu(), R.similarity_scores(q, bank.to(torch.bfloat16).float())) < 1e-5
+
+
+def test_topk_ties_nan_and_shared_bank(be):
+    hip, dev, _ = be
+    s = torch.tensor([[1, 3, 3, 2, 3, 0, 3, 3.0], [float("nan"), 1, 2, 3, 4, 5, 6, 7]])
+    _, idx = hip.topk(s.to(dev), 5)
+    assert idx.cpu().tolist() == [[1, 2, 4, 6, 7], [0, 7, 6, 5, 4]]
+    assert torch.equal(idx.cpu(), R.topk_desc_lowest_index(s, 5))
+    g = torch.Generator().manual_seed(5)
+    q, bank = torch.randn(3, 8, 16, 16, generator=g), torch.randn(1, 9, 8, 16, 16, generator=g)
+    s = hip.similarity(q.to(dev), bank.to(dev))                      # stride-0 shared bank
+    assert rel(s.cpu(), R.similarity_scores(q, bank.expand(3, -1, -1, -1, -1))) < 1e-5
+    out = torch.full((3, 20), 7.0, device=dev)
+    hip.similarity(q.to(dev), bank.to(dev), out=out, col_offset=4)   # in-place slice of a gathered matrix
+    assert torch.equal(out[:, 4:13], s) and float(out[:, :4].min()) == 7.0 and float(out[:, 13:].min()) == 7.0
+    with pytest.raises(hip.NopeError):
+        hip.topk(torch.zeros(1, 3, device=dev), 5)                   # k > N is an error, as in torch
