@@ -18,18 +18,33 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int D = 32;      // dim_head (fixed by the reference, model_utils.py:368,394)
-constexpr int PT = 64;     // pixels per LDS tile
 
+// 4 consecutive channels as one 8-byte (bf16) / 16-byte (f32) store
+template <class T> __device__ __forceinline__ void store4(T* p, const f32x4& v);
+template <> __device__ __forceinline__ void store4<float>(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const f32x4& v) {
+    const unsigned long long lo = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    const unsigned long long hi = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<unsigned long long*>(p) = lo | (hi << 32);
+}
+
+template <bool FAST> __device__ __forceinline__ float fexp(float x) { return FAST ? __expf(x) : expf(x); }
+
+// All global traffic is 16-byte vectors: a head row is 32 channels = CG = 32/VEC vectors.
 template <class T>
-__global__ __launch_bounds__(NT) void linattn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n, int heads) {
-    __shared__ float s_red[NT];
-    __shared__ float s_kmax[D];
-    __shared__ float s_ek[PT][D + 1];
+__global__ __launch_bounds__(NT, 4) void linattn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n, int heads) {
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr bool FASTM = sizeof(T) == 2;   // bf16 storage: hardware exp2 is far inside the format's precision
+    constexpr int CG = D / VEC;            // channel vectors per head row (4 bf16 / 8 f32)
+    constexpr int PT = NT / CG;            // pixels staged per pass (64 bf16 / 32 f32)
+    __shared__ __attribute__((aligned(16))) float s_a[PT][D];       // exp(k - kmax) tile; also the sweep-1 scratch
     __shared__ __attribute__((aligned(16))) float s_v[PT][D];
-    __shared__ float s_ctx[D][D + 1];
-    __shared__ float s_z[D];
+    __shared__ __attribute__((aligned(16))) float s_part[NT / 64][D][D];
+    __shared__ __attribute__((aligned(16))) float s_ctx[D][D];
+    __shared__ float s_kmax[D];
+    __shared__ float s_zp[NT / 64][D];
     const int hyp = blockIdx.x / heads, head = blockIdx.x % heads;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int HD = heads * D;
     const int ldq = 3 * HD;
     const T* base = qkv + (size_t)hyp * n * ldq;
@@ -37,81 +52,135 @@ __global__ __launch_bounds__(NT) void linattn_kernel(const T* __restrict__ qkv, 
     const T* kp = base + HD + head * D;
     const T* vp = base + 2 * HD + head * D;
     const float scale = 0.17677669529663687f;   // 32^-0.5
+    const int cg = tid % CG, pp = tid / CG;     // staging role: (pixel-in-pass, channel vector)
 
     // ---- sweep 1: kmax[d] = max_n k[n][d] --------------------------------------------------
     {
-        const int d = tid & (D - 1), pg = tid >> 5;   // 8 pixel groups
-        float m = -3.0e38f;
-        for (int p = pg; p < n; p += NT / D) m = fmaxf(m, Elt<T>::ld(kp + (size_t)p * ldq + d));
-        s_red[tid] = m;
+        float m[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) m[e] = -3.0e38f;
+        for (int p = pp; p < n; p += PT) {
+            float kv[VEC];
+            Elt<T>::unpack(ld16(kp + (size_t)p * ldq + cg * VEC), kv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], kv[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s_a[pp][cg * VEC + e] = m[e];
         __syncthreads();
         if (tid < D) {
-            float mm = s_red[tid];
-#pragma unroll
-            for (int g = 1; g < NT / D; ++g) mm = fmaxf(mm, s_red[g * D + tid]);
+            float mm = s_a[0][tid];
+            for (int j = 1; j < PT; ++j) mm = fmaxf(mm, s_a[j][tid]);
             s_kmax[tid] = mm;
         }
         __syncthreads();
     }
 
     // ---- sweep 2: ctx[d][e] = sum_n exp(k[n][d]-kmax[d]) v[n][e],  z[d] = sum_n exp(...) -----
-    const int cd = tid >> 3;          // 0..31
-    const int ce = (tid & 7) * 4;     // 0,4,..,28
-    float cacc[4] = {0.f, 0.f, 0.f, 0.f};
-    float zacc = 0.f;
+    // each wave takes a quarter of every staged tile; lane -> 4x4 block of ctx
+    const int d0 = (lane >> 3) * 4, e0 = (lane & 7) * 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    float zacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float kmx[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) kmx[e] = s_kmax[cg * VEC + e];
     for (int t0 = 0; t0 < n; t0 += PT) {
-        for (int i = tid; i < PT * D; i += NT) {
-            const int pp = i >> 5, d = i & (D - 1);
-            const int p = t0 + pp;
-            float ek = 0.f, vv = 0.f;
-            if (p < n) {
-                ek = expf(Elt<T>::ld(kp + (size_t)p * ldq + d) - s_kmax[d]);
-                vv = Elt<T>::ld(vp + (size_t)p * ldq + d);
-            }
-            s_ek[pp][d] = ek;
-            s_v[pp][d] = vv;
+        const int p = t0 + pp;
+        float ek[VEC], vv[VEC];
+        if (p < n) {
+            Elt<T>::unpack(ld16(kp + (size_t)p * ldq + cg * VEC), ek);
+            Elt<T>::unpack(ld16(vp + (size_t)p * ldq + cg * VEC), vv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) ek[e] = fexp<FASTM>(ek[e] - kmx[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { ek[e] = 0.f; vv[e] = 0.f; }
         }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s_a[pp][cg * VEC + e] = ek[e]; s_v[pp][cg * VEC + e] = vv[e]; }
         __syncthreads();
-#pragma unroll 8
-        for (int pp = 0; pp < PT; ++pp) {
-            const float ek = s_ek[pp][cd];
-            const f32x4 v4 = *reinterpret_cast<const f32x4*>(&s_v[pp][ce]);
-            cacc[0] += ek * v4[0]; cacc[1] += ek * v4[1]; cacc[2] += ek * v4[2]; cacc[3] += ek * v4[3];
-            zacc += ek;
+#pragma unroll 4
+        for (int i = 0; i < PT / 4; ++i) {
+            const int r = wave * (PT / 4) + i;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&s_a[r][d0]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&s_v[r][e0]);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                zacc[x] += a[x];
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
+            }
         }
         __syncthreads();
     }
-    if ((tid & 7) == 0) s_z[cd] = zacc;
-    __syncthreads();
-    {
-        const float inv = 1.0f / s_z[cd];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s_ctx[cd][ce + j] = cacc[j] * inv;
+    for (int x = 0; x < 4; ++x) {
+#pragma unroll
+        for (int y = 0; y < 4; ++y) s_part[wave][d0 + x][e0 + y] = acc[x][y];
+        if ((lane & 7) == 0) s_zp[wave][d0 + x] = zacc[x];
+    }
+    __syncthreads();
+    for (int i = tid; i < D * D; i += NT) {
+        const int d = i >> 5, e = i & (D - 1);
+        float c = 0.f, z = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { c += s_part[w][d][e]; z += s_zp[w][d]; }
+        s_ctx[d][e] = c / z;
     }
     __syncthreads();
 
     // ---- sweep 3: out[n][e] = sum_d ctx[d][e] * softmax_d(q[n])[d] * scale ----------------------
-    // 4 threads per pixel, 8 output channels each
-    const int sub = tid & 3;
-    for (int p = tid >> 2; p < n; p += NT / 4) {
-        float qv[D];
-        float m = -3.0e38f;
+    // out^T tile = ctx^T (32 x 32, loop-invariant: 16 A-fragments in registers) x qs (32 x 16 pixels)
+    // on the exact-f32 MFMA 16x16x4.  Lane (pixel = lane & 15, kg = lane >> 4) owns channels
+    // d = kg*8 .. kg*8+7 of its pixel -- one 16-byte load for bf16 -- and MFMA step j contracts
+    // d = kg*8 + j on both operands (any K permutation is valid when A and B agree).
+    {
+        const int pr = lane & 15, kg = lane >> 4;
+        float cf[2][8];
 #pragma unroll
-        for (int d = 0; d < D; ++d) { qv[d] = Elt<T>::ld(qp + (size_t)p * ldq + d); m = fmaxf(m, qv[d]); }
-        float z = 0.f;
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int d = 0; d < D; ++d) { qv[d] = expf(qv[d] - m); z += qv[d]; }
-        const float qs = scale / z;
-        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 8; ++j) cf[mt][j] = s_ctx[kg * 8 + j][mt * 16 + pr];
+        const int groups = (n + 15) >> 4;
+        for (int g = wave; g < groups; g += NT / 64) {
+            const int p = g * 16 + pr;
+            float qv[8];
+            if (p < n) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float qd = qv[d] * qs;
+                for (int c = 0; c < 8 / VEC; ++c) Elt<T>::unpack(ld16(qp + (size_t)p * ldq + kg * 8 + c * VEC), &qv[c * VEC]);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += s_ctx[d][sub * 8 + j] * qd;
+                for (int j = 0; j < 8; ++j) qv[j] = 0.f;
+            }
+            float m = qv[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) m = fmaxf(m, qv[j]);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float z = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { qv[j] = fexp<FASTM>(qv[j] - m); z += qv[j]; }
+            z += __shfl_xor(z, 16, 64);
+            z += __shfl_xor(z, 32, 64);
+            const float qs = scale / z;
+            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float bq = qv[j] * qs;
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cf[0][j], bq, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cf[1][j], bq, o1, 0, 0, 0);
+            }
+            // D map: col = lane & 15 -> pixel, row = kg*4 + r -> e (4 consecutive channels per tile)
+            if (p < n) {
+                T* op = out + ((size_t)hyp * n + p) * HD + head * D + kg * 4;
+                store4<T>(op, o0);
+                store4<T>(op + 16, o1);
+            }
         }
-        T* op = out + ((size_t)hyp * n + p) * HD + head * D + sub * 8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) Elt<T>::st(op + j, o[j]);
     }
 }
 

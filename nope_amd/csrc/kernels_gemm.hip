@@ -54,6 +54,7 @@ struct ConvParams {
     int Cout, M;
     int out_nchw, out_dt;
     int tiles_m, tiles_n, xcd_map;
+    unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
 };
 
 template <class T> struct Mma;
@@ -72,6 +73,89 @@ template <> struct Mma<float> {
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
 
+__device__ __forceinline__ void tile_coords(const ConvParams& p, int& tile_m, int& tile_n) {
+    const int g = blockIdx.x;
+    if (p.xcd_map) {   // tiles_n in {1,2,4,8}, tiles_m % (8 / tiles_n) == 0
+        const int x = g & 7, j = g >> 3;
+        const int per = 8 / p.tiles_n;
+        tile_n = x % p.tiles_n;
+        tile_m = j * per + x / p.tiles_n;
+    } else {
+        tile_n = g % p.tiles_n;
+        tile_m = g / p.tiles_n;
+    }
+}
+
+// One K step (128 bytes of K per row) of the 64x96 wave tile from swizzled LDS tiles.
+template <class T>
+__device__ __forceinline__ void mma_step(const unsigned char* ldsA, const unsigned char* ldsB, int wm, int wn, int lane,
+                                         f32x4 (&acc)[MT][NTL]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        u32x4 af[MT], bfr[NTL];
+        const int s = kk * 4 + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = ld16(ldsA + lds_off(wm * 64 + i * 16 + (lane & 15), s));
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) bfr[j] = ld16(ldsB + lds_off(wn * 96 + j * 16 + (lane & 15), s));
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+    }
+}
+
+// C/D map of the 16x16 MFMA tiles: col = lane & 15, row = (lane >> 4) * 4 + r
+template <class T>
+__device__ __forceinline__ void epilogue(const ConvParams& p, const f32x4 (&acc)[MT][NTL], int m0, int n0, int wm, int wn, int lane) {
+    const int HWo = p.Ho * p.Wo;
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* resid = reinterpret_cast<const T*>(p.resid);
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+        const int n = n0 + wn * 96 + j * 16 + (lane & 15);
+        if (n >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (resid) v += Elt<T>::ld(resid + (size_t)m * p.Cout + n);
+                if (p.out_nchw) {
+                    const int b = m / HWo;
+                    const int pix = m - b * HWo;
+                    const size_t o = ((size_t)b * p.Cout + n) * HWo + pix;
+                    if (p.out_dt == NOPE_F32) reinterpret_cast<float*>(p.out)[o] = v;
+                    else reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(v);
+                } else {
+                    Elt<T>::st(out + (size_t)m * p.Cout + n, v);
+                }
+            }
+        }
+    }
+}
+
+// Source pixel of output pixel (oy, ox) under tap (dy, dx); false = zero padding / beyond M.
+__device__ __forceinline__ bool tap_pixel(const ConvParams& p, int oy, int ox, int dy, int dx, int& iy, int& ix) {
+    if (p.mode == NOPE_CONV_DOWN2) { iy = 2 * oy + dy; ix = 2 * ox + dx; return oy >= 0; }
+    if (p.mode == NOPE_CONV_UP2) {
+        const int uy = oy + dy, ux = ox + dx;
+        iy = uy >> 1; ix = ux >> 1;
+        return uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
+    }
+    iy = oy + dy; ix = ox + dx;
+    return iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+}
+__device__ __forceinline__ void tap_delta(const ConvParams& p, int tap, int& dy, int& dx) {
+    dy = 0; dx = 0;
+    if (p.mode == NOPE_CONV_DOWN2) { dy = tap >> 1; dx = tap & 1; }
+    else if (p.ntaps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+}
+
+// ---- generic kernel: global -> VGPR -> LDS staging, any channel counts ----------------------------
 template <class T>
 __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
     constexpr int VEC = Elt<T>::VEC;
@@ -85,20 +169,8 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-
     int tile_m, tile_n;
-    {
-        const int g = blockIdx.x;
-        if (p.xcd_map) {   // tiles_n in {1,2,4,8}, tiles_m % (8 / tiles_n) == 0
-            const int x = g & 7, j = g >> 3;
-            const int per = 8 / p.tiles_n;
-            tile_n = x % p.tiles_n;
-            tile_m = j * per + x / p.tiles_n;
-        } else {
-            tile_n = g % p.tiles_n;
-            tile_m = g / p.tiles_n;
-        }
-    }
+    tile_coords(p, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int slot = tid & 7;
@@ -129,9 +201,8 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
 
     auto load_step = [&]() {
         const int c = ld_kc * BK + slot * VEC;
-        int dy = 0, dx = 0;
-        if (p.mode == NOPE_CONV_DOWN2) { dy = ld_tap >> 1; dx = ld_tap & 1; }
-        else if (p.ntaps == 9) { dy = ld_tap / 3 - 1; dx = ld_tap - (ld_tap / 3) * 3 - 1; }
+        int dy, dx;
+        tap_delta(p, ld_tap, dy, dx);
         const bool c_ok = c < Cin;
         const bool first = c < p.C1;
         const unsigned char* sbase = first ? p.src1 : p.src2;
@@ -140,19 +211,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
             int iy, ix;
-            bool ok;
-            if (p.mode == NOPE_CONV_DOWN2) {
-                iy = 2 * a_oy[i] + dy; ix = 2 * a_ox[i] + dx;
-                ok = a_oy[i] >= 0;
-            } else if (p.mode == NOPE_CONV_UP2) {
-                const int uy = a_oy[i] + dy, ux = a_ox[i] + dx;
-                ok = uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
-                iy = uy >> 1; ix = ux >> 1;
-            } else {
-                iy = a_oy[i] + dy; ix = a_ox[i] + dx;
-                ok = iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
-            }
-            ok = ok && c_ok;
+            const bool ok = tap_pixel(p, a_oy[i], a_ox[i], dy, dx, iy, ix) && c_ok;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (ok) {
                 const int sb = first ? a_s1[i] : a_s2[i];
@@ -185,50 +244,162 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
         for (int j = 0; j < B_ITERS; ++j) st16(ldsB + lds_off(rbase + 32 * j, slot), rb[j]);
         __syncthreads();
         if (ks + 1 < nk) load_step();   // global loads for step ks+1 fly under the MFMAs below
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            u32x4 af[MT], bfr[NTL];
-            const int s = kk * 4 + (lane >> 4);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = ld16(ldsA + lds_off(wm * 64 + i * 16 + (lane & 15), s));
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) bfr[j] = ld16(ldsB + lds_off(wn * 96 + j * 16 + (lane & 15), s));
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NTL; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
-        }
+        mma_step<T>(ldsA, ldsB, wm, wn, lane, acc);
         __syncthreads();
     }
+    epilogue<T>(p, acc, m0, n0, wm, wn, lane);
+}
 
-    // epilogue: C/D map col = lane & 15, row = (lane >> 4) * 4 + r
-    T* out = reinterpret_cast<T*>(p.out);
-    const T* resid = reinterpret_cast<const T*>(p.resid);
+// ---- fast kernel: LDS-DMA staging (buffer_load ... lds, 16 B per lane), double-buffered ------------
+// Preconditions (checked by the launcher): Cin % BK == 0, C1 % BK == 0 when there is a second
+// source (so a K step never straddles the two sources), every tensor < 2 GiB (32-bit buffer
+// offsets).  Each wave instruction fills 8 consecutive 128-byte LDS rows (lane -> row l>>3, slot
+// l&7, destination = wave-uniform base + lane*16); the XOR swizzle is applied to the SOURCE
+// channel chunk, (l&7) ^ swz(row), so the LDS image is the same swizzled tile the MFMA reads expect
+// (cdna_hip_programming.md rule 21).  Zero padding / masked rows use an out-of-range buffer offset:
+// the hardware range check returns 0 and the DMA writes it.  One barrier per K step: the loads of
+// step k+1 fly under the MFMAs of step k, and nothing passes through VGPRs or ds_write.
+typedef __attribute__((address_space(3))) void lds_void_t;
+constexpr unsigned OOB = 0x80000000u;   // >= any num_records (tensors < 2 GiB); stays out of range after adding a K offset
+
+template <class T, int MODE>
+__global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr int BK = 8 * VEC;
+    constexpr unsigned ES = (unsigned)sizeof(T);
+    constexpr int STAGE = (BM + BN) * ROWB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    tile_coords(p, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int HWo = p.Ho * p.Wo;
+    const int Cin = p.C1 + p.C2;
+
+    const auto r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src1, (short)0, (int)p.bytes1, 0x00020000);
+    const auto r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src2 ? p.src2 : p.src1), (short)0, (int)(p.src2 ? p.bytes2 : p.bytes1), 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)p.bytesw, 0x00020000);
+
+    // This lane's rows: A chunk i of wave w covers tile rows 8*(4w+i) .. +7, B chunk j rows 8*(6w+j) .. +7.
+    // Everything that does not depend on the K step is folded into per-row byte offsets + a tap-validity mask.
+    const int rsub = lane >> 3, lslot = lane & 7;
+    unsigned a_b1[A_ITERS], a_b2[A_ITERS], a_mask[A_ITERS];
+    unsigned a_y[MODE == NOPE_CONV_UP2 ? A_ITERS : 1][3], a_x[MODE == NOPE_CONV_UP2 ? A_ITERS : 1][3];
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) {
-        const int n = n0 + wn * 96 + j * 16 + (lane & 15);
-        if (n >= p.Cout) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int i = 0; i < A_ITERS; ++i) {
+        const int row = 8 * (A_ITERS * wave + i) + rsub;
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / HWo;
+        const int r = mm - b * HWo;
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        const unsigned cs = (unsigned)((lslot ^ ((row >> 1) & 7)) * VEC);   // source channel chunk of this LDS slot
+        const unsigned s1 = (unsigned)(b / p.rep1), s2 = (unsigned)(b / p.rep2);
+        unsigned mask = 0;
+        if (MODE == NOPE_CONV_PLAIN) {
+            a_b1[i] = (((s1 * p.Hs + oy) * p.Ws + ox) * p.C1 + cs) * ES;
+            a_b2[i] = (((s2 * p.Hs + oy) * p.Ws + ox) * p.C2 + cs) * ES;
+            if (p.ntaps == 9) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (resid) v += Elt<T>::ld(resid + (size_t)m * p.Cout + n);
-                if (p.out_nchw) {
-                    const int b = m / HWo;
-                    const int pix = m - b * HWo;
-                    const size_t o = ((size_t)b * p.Cout + n) * HWo + pix;
-                    if (p.out_dt == NOPE_F32) reinterpret_cast<float*>(p.out)[o] = v;
-                    else reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(v);
-                } else {
-                    Elt<T>::st(out + (size_t)m * p.Cout + n, v);
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+                    if (iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws) mask |= 1u << t;
                 }
+            } else mask = 1u;
+        } else if (MODE == NOPE_CONV_DOWN2) {
+            a_b1[i] = (((s1 * p.Hs + 2 * oy) * p.Ws + 2 * ox) * p.C1 + cs) * ES;
+            a_b2[i] = 0;
+            mask = 0xfu;
+        } else {   // UP2: source row/col of the 3 vertical / horizontal taps in the upsampled image
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int uy = oy + d - 1, ux = ox + d - 1;
+                a_y[i][d] = (s1 * p.Hs + (unsigned)((uy < 0 ? 0 : uy) >> 1)) * p.Ws * p.C1 * ES;
+                a_x[i][d] = ((unsigned)((ux < 0 ? 0 : ux) >> 1) * p.C1 + cs) * ES;
             }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int uy = oy + t / 3 - 1, ux = ox + t % 3 - 1;
+                if (uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo) mask |= 1u << t;
+            }
+            a_b1[i] = 0; a_b2[i] = 0;
         }
+        a_mask[i] = ok ? mask : 0u;
     }
+    unsigned b_off[B_ITERS];
+#pragma unroll
+    for (int j = 0; j < B_ITERS; ++j) {
+        const int row = 8 * (B_ITERS * wave + j) + rsub;
+        const int n = n0 + row;
+        const unsigned cs = (unsigned)((lslot ^ ((row >> 1) & 7)) * VEC);
+        b_off[j] = n < p.Cout ? ((unsigned)n * p.ntaps * Cin + cs) * ES : OOB;
+    }
+
+    const int kc_per_tap = Cin / BK;
+    const int nk = p.ntaps * kc_per_tap;
+    int ld_tap = 0, ld_kc = 0;
+
+    auto issue = [&](int buf) {
+        unsigned char* dA = lds + buf * STAGE + (A_ITERS * wave) * 8 * ROWB;
+        unsigned char* dB = lds + buf * STAGE + BM * ROWB + (B_ITERS * wave) * 8 * ROWB;
+        const int c0 = ld_kc * BK;
+        const bool first = c0 < p.C1;          // wave-uniform: a K step lies inside one source
+        const auto ra = first ? r1 : r2;
+        const int Cs = first ? p.C1 : p.C2;
+        unsigned kadd = (unsigned)(first ? c0 : c0 - p.C1) * ES;     // scalar part of the A offset
+        int dyi = 1, dxi = 1;
+        if (MODE == NOPE_CONV_PLAIN) {
+            if (p.ntaps == 9) {
+                dyi = ld_tap / 3; dxi = ld_tap - dyi * 3;
+                kadd += (unsigned)(((dyi - 1) * p.Ws + (dxi - 1)) * Cs) * ES;
+            }
+        } else if (MODE == NOPE_CONV_DOWN2) {
+            kadd += (unsigned)(((ld_tap >> 1) * p.Ws + (ld_tap & 1)) * Cs) * ES;
+        } else {
+            dyi = ld_tap / 3; dxi = ld_tap - dyi * 3;
+        }
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            unsigned base;
+            if (MODE == NOPE_CONV_UP2) base = (dyi == 0 ? a_y[i][0] : dyi == 1 ? a_y[i][1] : a_y[i][2]) +
+                                              (dxi == 0 ? a_x[i][0] : dxi == 1 ? a_x[i][1] : a_x[i][2]);
+            else base = first ? a_b1[i] : a_b2[i];
+            const unsigned off = (((a_mask[i] >> ld_tap) & 1u) ? base : OOB) + kadd;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(dA + i * 8 * ROWB), 16, off, 0, 0, 0);
+        }
+        const unsigned kofs = (unsigned)(ld_tap * Cin + c0) * ES;
+#pragma unroll
+        for (int j = 0; j < B_ITERS; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(dB + j * 8 * ROWB), 16, b_off[j] + kofs, 0, 0, 0);
+        if (++ld_kc == kc_per_tap) { ld_kc = 0; ++ld_tap; }
+    };
+
+    f32x4 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        __syncthreads();                       // stage ks landed (vmcnt drain) + everyone left stage ks-1
+        if (ks + 1 < nk) issue(buf ^ 1);
+        mma_step<T>(lds + buf * STAGE, lds + buf * STAGE + BM * ROWB, wm, wn, lane, acc);
+    }
+    epilogue<T>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <class T>
+void launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
+    if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN>), grid, dim3(NT), 0, s, p);
+    else if (p.mode == NOPE_CONV_UP2) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2>), grid, dim3(NT), 0, s, p);
+    else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_DOWN2>), grid, dim3(NT), 0, s, p);
 }
 
 }  // namespace
@@ -263,8 +434,25 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.xcd_map = (tn == 1 || tn == 2 || tn == 4 || tn == 8) && (p.tiles_m % (8 / tn) == 0) ? 1 : 0;
     const long long nblocks = (long long)p.tiles_m * p.tiles_n;
     if (nblocks > 0x7fffffffLL) return NOPE_ERR_UNSUPPORTED;
-    if (dt == NOPE_F32) hipLaunchKernelGGL((conv_gemm_kernel<float>), dim3((unsigned)nblocks), dim3(NT), 0, s, p);
-    else hipLaunchKernelGGL((conv_gemm_kernel<bf16_t>), dim3((unsigned)nblocks), dim3(NT), 0, s, p);
+    // LDS-DMA kernel when a K step (128 B of channels) never straddles sources and 32-bit offsets suffice
+    const int es = dt == NOPE_F32 ? 4 : 2;
+    const int bk = 8 * vec;
+    const int Cin = a.C1 + a.C2;
+    const unsigned long long lim = 0x7fffffffULL;
+    const unsigned long long b1 = (unsigned long long)cdiv(a.nhyp, a.rep1) * a.Hs * a.Ws * a.C1 * es;
+    const unsigned long long b2 = a.C2 ? (unsigned long long)cdiv(a.nhyp, a.rep2) * a.Hs * a.Ws * a.C2 * es : 0;
+    const unsigned long long bw = (unsigned long long)a.Cout * a.ntaps * Cin * es;
+    const bool dma = !a.force_generic && Cin % bk == 0 && (a.C2 == 0 || (a.C1 % bk == 0 && a.mode == NOPE_CONV_PLAIN)) &&
+                     b1 < lim && b2 < lim && bw < lim;
+    p.bytes1 = (unsigned)(dma ? b1 : 0); p.bytes2 = (unsigned)(dma ? b2 : 0); p.bytesw = (unsigned)(dma ? bw : 0);
+    const dim3 grid((unsigned)nblocks), block(NT);
+    if (dt == NOPE_F32) {
+        if (dma) launch_dma<float>(p, grid, s);
+        else hipLaunchKernelGGL((conv_gemm_kernel<float>), grid, block, 0, s, p);
+    } else {
+        if (dma) launch_dma<bf16_t>(p, grid, s);
+        else hipLaunchKernelGGL((conv_gemm_kernel<bf16_t>), grid, block, 0, s, p);
+    }
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

@@ -117,31 +117,70 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
         s_rstd[g] = 1.0f / sqrtf(var + eps);
     }
     __syncthreads();
-    const size_t nvec = (size_t)HW * C / VEC;
-    const size_t per = (nvec + blocks_per_hyp - 1) / blocks_per_hyp;
-    const size_t v0 = (size_t)blk * per;
-    const size_t v1 = v0 + per < nvec ? v0 + per : nvec;
+    // Pure streaming body: a thread owns ONE 16-byte channel vector for its whole pixel walk, so
+    // the per-channel affine (rstd*gamma, beta - mean*rstd*gamma) and the embedding live in
+    // registers and the inner loop is load -> fma -> SiLU -> adds -> store.
+    const int pper = (HW + blocks_per_hyp - 1) / blocks_per_hyp;
+    const int p0 = blk * pper;
+    const int p1 = p0 + pper < HW ? p0 + pper : HW;
     const T* xb = x + (size_t)xs * HW * C;
     T* yb = y + (size_t)hyp * HW * C;
     const T* rb = resid ? resid + (size_t)(hyp / resid_rep) * HW * C : nullptr;
     const float* eb = emb ? emb + (size_t)hyp * emb_stride : nullptr;
     const int cvecs = C / VEC;
-    for (size_t i = v0 + tid; i < v1; i += NT) {
-        const int c0 = (int)(i % cvecs) * VEC;
-        float v[VEC], r[VEC];
-        Elt<T>::unpack(ld16(xb + i * VEC), v);
-        if (rb) Elt<T>::unpack(ld16(rb + i * VEC), r);
+    const int tpr = cvecs < NT ? cvecs : NT;
+    const int rows = NT / tpr;
+    const int row = tid / tpr, lc = tid - row * tpr;
+    if (row >= rows) return;
+    for (int cv = lc; cv < cvecs; cv += tpr) {
+        float sc[VEC], sh[VEC], ev[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const int c = c0 + e;
+            const int c = cv * VEC + e;
             const int g = c / cpg;
-            float t = (v[e] - s_mean[g]) * s_rstd[g] * gamma[c] + beta[c];
-            if (act) t = silu_f<FAST>(t);
-            if (eb) t += eb[c];
-            if (rb) t += r[e];
-            v[e] = t;
+            const float a = s_rstd[g] * gamma[c];
+            sc[e] = a;
+            sh[e] = beta[c] - s_mean[g] * a;
+            ev[e] = eb ? eb[c] : 0.f;
         }
-        st16(yb + i * VEC, Elt<T>::pack(v));
+        const size_t coff = (size_t)cv * VEC;
+        int pix = p0 + row;
+        for (; pix + rows < p1; pix += 2 * rows) {       // two pixels in flight per thread
+            const size_t o0 = (size_t)pix * C + coff, o1 = (size_t)(pix + rows) * C + coff;
+            float v0[VEC], v1[VEC], r0[VEC], r1[VEC];
+            const u32x4 a0 = ld16(xb + o0), a1 = ld16(xb + o1);
+            u32x4 b0 = a0, b1 = a1;
+            if (rb) { b0 = ld16(rb + o0); b1 = ld16(rb + o1); }
+            Elt<T>::unpack(a0, v0); Elt<T>::unpack(a1, v1);
+            Elt<T>::unpack(b0, r0); Elt<T>::unpack(b1, r1);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float t0 = v0[e] * sc[e] + sh[e], t1 = v1[e] * sc[e] + sh[e];
+                if (act) { t0 = silu_f<FAST>(t0); t1 = silu_f<FAST>(t1); }
+                t0 += ev[e]; t1 += ev[e];
+                if (rb) { t0 += r0[e]; t1 += r1[e]; }
+                v0[e] = t0; v1[e] = t1;
+            }
+            st16(yb + o0, Elt<T>::pack(v0));
+            st16(yb + o1, Elt<T>::pack(v1));
+        }
+        for (; pix < p1; pix += rows) {
+            const size_t o0 = (size_t)pix * C + coff;
+            float v0[VEC], r0[VEC];
+            const u32x4 a0 = ld16(xb + o0);
+            u32x4 b0 = a0;
+            if (rb) b0 = ld16(rb + o0);
+            Elt<T>::unpack(a0, v0); Elt<T>::unpack(b0, r0);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float t0 = v0[e] * sc[e] + sh[e];
+                if (act) t0 = silu_f<FAST>(t0);
+                t0 += ev[e];
+                if (rb) t0 += r0[e];
+                v0[e] = t0;
+            }
+            st16(yb + o0, Elt<T>::pack(v0));
+        }
     }
 }
 

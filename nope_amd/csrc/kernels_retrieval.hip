@@ -66,21 +66,25 @@ __global__ __launch_bounds__(NT) void sim_reg_kernel(const float* __restrict__ q
     const T* bb = bank + (size_t)b * bank_stride_b;
     const size_t hyp_elems = (size_t)C * HW;
     int buf = 0;
-    for (int g = g0; g < g1; ++g) {
+    // Software pipeline, depth 1: the C plane loads of group g+1 are issued before group g is
+    // reduced, so every workgroup keeps C x 16 B per lane in flight across the reduction + barrier
+    // (without it the memory pipe of a workgroup drains once per hypothesis).
+    u32x4 rawA[CMAX], rawB[CMAX];
+    auto fetch = [&](u32x4 (&raw)[CMAX], int g) {
+        const int n = g * hpi + sub;
+        const T* tp = bb + (size_t)(n < N ? n : 0) * hyp_elems + (size_t)pv * VEC;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) raw[c] = ld16(tp + (size_t)c * HW);
+    };
+    auto reduce = [&](const u32x4 (&raw)[CMAX], int g) {
         const int n = g * hpi + sub;
         float acc[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-        if (n < N) {
-            const T* tp = bb + (size_t)n * hyp_elems + (size_t)pv * VEC;
-            u32x4 raw[CMAX];
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c)
-                if (c < C) raw[c] = ld16(tp + (size_t)c * HW);
-#pragma unroll
-            for (int c = 0; c < CMAX; ++c)
-                if (c < C) accum_quartic<T>(raw[c], qr[c], acc);
-        }
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) accum_quartic<T>(raw[c], qr[c], acc);
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) s += sqrtf(acc[e]);
@@ -99,6 +103,15 @@ __global__ __launch_bounds__(NT) void sim_reg_kernel(const float* __restrict__ q
         } else {
             for (int o = P >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
             if (pv == 0 && n < N) scores[(size_t)b * score_ld + n] = -s;
+        }
+    };
+    if (g0 < g1) fetch(rawA, g0);
+    for (int g = g0; g < g1; g += 2) {
+        if (g + 1 < g1) fetch(rawB, g + 1);
+        reduce(rawA, g);
+        if (g + 1 < g1) {
+            if (g + 2 < g1) fetch(rawA, g + 2);
+            reduce(rawB, g + 1);
         }
     }
 }

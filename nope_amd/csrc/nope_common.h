@@ -119,6 +119,7 @@ struct ConvArgs {
     int nhyp = 0;                // M = nhyp * Ho * Wo
     int out_nchw = 0;            // 1: write (nhyp, Cout, Ho, Wo) with dtype out_dt
     int out_dt = NOPE_F32;       // only for out_nchw
+    int force_generic = 0;       // tests: take the register-staged kernel even when the LDS-DMA one applies
 };
 int launch_conv(int dt, const ConvArgs& a, hipStream_t s);
 

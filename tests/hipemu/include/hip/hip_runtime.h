@@ -317,6 +317,25 @@ inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x
 inline int hipemu_readfirstlane(int v) { return __shfl(v, 0); }
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
 
+// ---- buffer resources + LDS-DMA (buffer_load ... lds): destination = wave-uniform base + lane*size,
+// out-of-range lanes write zeros (the raw-buffer range check).  The hardware lands the data
+// asynchronously; the interpreter copies immediately, so it checks addressing, not wait placement.
+struct hipemu_rsrc { const unsigned char* base; unsigned num; };
+inline hipemu_rsrc hipemu_make_rsrc(void* p, short, int num, int) { return hipemu_rsrc{(const unsigned char*)p, (unsigned)num}; }
+template <class P>
+inline void hipemu_buffer_load_lds(hipemu_rsrc r, P ldsptr, unsigned size, unsigned voffset, unsigned soffset, unsigned imm, int) {
+    uintptr_t base = (uintptr_t)ldsptr;
+    auto s = hipemu::wave_exchange(&base, sizeof(base));
+    uintptr_t b0; memcpy(&b0, s[0], sizeof(b0));
+    if (b0 != base) { fprintf(stderr, "hipemu: LDS-DMA base is not wave-uniform\n"); abort(); }
+    unsigned char* dst = (unsigned char*)base + imm + (size_t)hipemu::lane_id() * size;
+    unsigned long long off = (unsigned long long)voffset + soffset + imm;
+    if (off + size > r.num) memset(dst, 0, size);
+    else memcpy(dst, r.base + off, size);
+}
+#define __builtin_amdgcn_make_buffer_rsrc hipemu_make_rsrc
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds hipemu_buffer_load_lds
+
 inline float __expf(float x) { return expf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline float __frcp_rn(float a) { return 1.0f / a; }

@@ -17,6 +17,25 @@ def model_f32(gpu):
     return build_model(compute_dtype="f32", bank_dtype="f32", device="cuda")
 
 
+@pytest.mark.parametrize("cdt,tol", [("f32", 1e-4), ("bf16", 6e-2)])
+def test_mid_unet_dma_path_vs_oracle(gpu, cdt, tol):
+    """u_net_dim=64: every conv's channel count is a multiple of the 128-byte K step, so the whole
+    network runs on the LDS-DMA implicit-GEMM kernel in both dtypes; checked against the oracle."""
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    from tests.util import StubEncoder
+    m = UNet(u_net_dim=64, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype=cdt)
+    synth_init_(m, 2022)
+    sd = {k: v.clone() for k, v in m.own_state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    x, poses = torch.randn(2, 8, 16, 16, generator=g), torch.randn(2, 5, 6, generator=g)
+    y = m.cuda().forward_hypotheses(x.cuda(), poses.cuda()).cpu()
+    want = R.generate_templates(sd, x, poses)
+    e = rel(y, want)
+    print(f"u_net_dim=64 {cdt} rel err", e)
+    assert e < tol
+
+
 def test_full_unet_f32_vs_reference(model_f32, golden):
     g = golden("unet_full_32.npz")
     y = model_f32.u_net.forward_hypotheses(g["x"].cuda(), g["pose"][None].cuda())[0].cpu()

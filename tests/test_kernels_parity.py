@@ -67,6 +67,38 @@ def test_conv_variants(be, dt):
 
 
 @pytest.mark.parametrize("dt", [0, 1])
+def test_conv_lds_dma_path(be, dt):
+    """Channel counts that are multiples of the 128-byte K step take the LDS-DMA kernel
+    (buffer_load ... lds, double-buffered): zero padding through out-of-range buffer offsets,
+    source-side swizzle, concat switching sources between K steps, broadcast source, ragged M,
+    two N tiles, all three tap geometries."""
+    hip, dev, _ = be
+    tol = 2e-5 if dt == 0 else BF16_TOL
+    g = torch.Generator().manual_seed(7)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    q = lambda x: _q(x, dt, hip)
+    d = lambda x: x.to(dev)
+    C = 64
+    x1, x2 = rn(1, C, 5, 6), rn(3, C, 5, 6)
+    w, b = rn(200, 2 * C, 3, 3) / 30, rn(200)
+    y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(w), d(b), src2=hip.to_nhwc(d(x2), dt), rep1=3, rep2=1, n_hyp=3)
+    ref = F.conv2d(torch.cat((q(x1).expand(3, -1, -1, -1), q(x2)), 1), q(w), b, padding=1)
+    assert rel(hip.to_nchw(y, dt).cpu(), ref) < tol
+    w1, rs = rn(24, C, 1, 1) / 8, rn(3, 24, 5, 6)
+    y = hip.op_conv(dt, hip.to_nhwc(d(x2), dt), d(w1), None, resid=hip.to_nhwc(d(rs), dt))
+    assert rel(hip.to_nchw(y, dt).cpu(), F.conv2d(q(x2), q(w1)) + q(rs)) < tol
+    wu, bu = rn(40, C, 3, 3) / 24, rn(40)
+    y = hip.op_conv(dt, hip.to_nhwc(d(x2), dt), d(wu), d(bu), mode=hip.CONV_UP2)
+    assert rel(hip.to_nchw(y, dt).cpu(), R.hard_upsample(q(x2), {"1.weight": q(wu), "1.bias": bu}, "")) < tol
+    x4 = rn(2, C, 6, 4)
+    wd, bd = rn(72, 4 * C, 1, 1) / 16, rn(72)
+    y = hip.op_conv(dt, hip.to_nhwc(d(x4), dt), d(wd), d(bd), mode=hip.CONV_DOWN2)
+    assert rel(hip.to_nchw(y, dt).cpu(), R.hard_downsample(q(x4), {"1.weight": q(wd), "1.bias": bd}, "")) < tol
+    y = hip.op_conv(dt, hip.to_nhwc(d(x2), dt), d(w1), None, out_nchw=True, out_dtype=hip.BF16)
+    assert rel(y.float().cpu(), F.conv2d(q(x2), q(w1))) < 1e-2
+
+
+@pytest.mark.parametrize("dt", [0, 1])
 def test_group_norm_variants(be, dt):
     hip, dev, _ = be
     tol = 2e-5 if dt == 0 else BF16_TOL
