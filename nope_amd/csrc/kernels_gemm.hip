@@ -53,7 +53,7 @@ struct ConvParams {
     unsigned char* out;
     int Cout, M;
     int out_nchw, out_dt;
-    int tiles_m, tiles_n, xcd_map;
+    int tiles_m, tiles_n, xcd_map, wide_out;
     unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
 };
 
@@ -76,10 +76,12 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + 
 __device__ __forceinline__ void tile_coords(const ConvParams& p, int& tile_m, int& tile_n) {
     const int g = blockIdx.x;
     if (p.xcd_map) {   // tiles_n in {1,2,4,8}, tiles_m % (8 / tiles_n) == 0
+        // XCD x = g & 7 keeps one weight panel (tile_n) and a CONTIGUOUS run of M tiles, so the
+        // 3x3 halo rows shared by neighbouring tiles hit the same XCD's L2.
         const int x = g & 7, j = g >> 3;
         const int per = 8 / p.tiles_n;
         tile_n = x % p.tiles_n;
-        tile_m = j * per + x / p.tiles_n;
+        tile_m = (x / p.tiles_n) * (p.tiles_m / per) + j;
     } else {
         tile_n = g % p.tiles_n;
         tile_m = g / p.tiles_n;
@@ -138,6 +140,62 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const f32x4 (&acc)
     }
 }
 
+// Wide-store epilogue (NHWC output, Cout % VEC == 0).  The MFMA C/D layout gives a lane one
+// column x 4 rows per 16x16 tile, i.e. 2-byte scattered stores; instead each wave stages its 64x96
+// f32 accumulators (+bias) through its private 64 x 52-word LDS panel, 48 columns at a time, and
+// writes rows back as 16-byte vectors (residual added in f32 before the single rounding to T).
+// Row stride 52 words: the two 16-lane row segments of a ds_write_b32 half-wave land 16 banks apart.
+constexpr int EP_LD = 52;
+constexpr int EP_WAVE_BYTES = 64 * EP_LD * 4;
+
+template <class T>
+__device__ __forceinline__ void epilogue_wide(const ConvParams& p, const f32x4 (&acc)[MT][NTL], int m0, int n0, int wm, int wn,
+                                              int lane, unsigned char* lds_wave) {
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr int CH = 48 / VEC;                // 16-byte output chunks per 48-column row (6 bf16 / 12 f32)
+    float* pan = reinterpret_cast<float*>(lds_wave);
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* resid = reinterpret_cast<const T*>(p.resid);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const int j = half * 3 + jj;
+            const int n = n0 + wn * 96 + j * 16 + (lane & 15);
+            const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pan[(i * 16 + (lane >> 4) * 4 + r) * EP_LD + jj * 16 + (lane & 15)] = acc[i][j][r] + bv;
+        }
+        // same-wave LDS write -> read: the LDS queue of a wave is in order, so no s_barrier; the wave
+        // barrier only pins the compiler's ordering (and is the rendezvous point of tests/hipemu)
+        __builtin_amdgcn_wave_barrier();
+        for (int idx = lane; idx < 64 * CH; idx += 64) {
+            const int row = idx / CH, ch = idx - row * CH;
+            const int m = m0 + wm * 64 + row;
+            const int n = n0 + wn * 96 + half * 48 + ch * VEC;
+            if (m >= p.M || n >= p.Cout) continue;
+            float v[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&pan[row * EP_LD + ch * VEC + q * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[q * 4 + e] = t[e];
+            }
+            const size_t o = (size_t)m * p.Cout + n;
+            if (resid) {
+                float rv[VEC];
+                Elt<T>::unpack(ld16(resid + o), rv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] += rv[e];
+            }
+            st16(out + o, Elt<T>::pack(v));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Source pixel of output pixel (oy, ox) under tap (dy, dx); false = zero padding / beyond M.
 __device__ __forceinline__ bool tap_pixel(const ConvParams& p, int oy, int ox, int dy, int dx, int& iy, int& ix) {
     if (p.mode == NOPE_CONV_DOWN2) { iy = 2 * oy + dy; ix = 2 * ox + dx; return oy >= 0; }
@@ -161,7 +219,8 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
     constexpr int VEC = Elt<T>::VEC;
     constexpr int BK = 8 * VEC;
     constexpr int ES = (int)sizeof(T);
-    __shared__ __attribute__((aligned(16))) unsigned char lds[(BM + BN) * ROWB];
+    constexpr int LDS_BYTES = (BM + BN) * ROWB > 4 * EP_WAVE_BYTES ? (BM + BN) * ROWB : 4 * EP_WAVE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];   // K-step tile, then the epilogue panels
     unsigned char* ldsA = lds;
     unsigned char* ldsB = lds + BM * ROWB;
 
@@ -247,7 +306,8 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
         mma_step<T>(ldsA, ldsB, wm, wn, lane, acc);
         __syncthreads();
     }
-    epilogue<T>(p, acc, m0, n0, wm, wn, lane);
+    if (p.wide_out) epilogue_wide<T>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
+    else epilogue<T>(p, acc, m0, n0, wm, wn, lane);
 }
 
 // ---- fast kernel: LDS-DMA staging (buffer_load ... lds, 16 B per lane), double-buffered ------------
@@ -376,7 +436,10 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < B_ITERS; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(dB + j * 8 * ROWB), 16, b_off[j] + kofs, 0, 0, 0);
-        if (++ld_kc == kc_per_tap) { ld_kc = 0; ++ld_tap; }
+        // K order: channel chunk outer, tap inner -- the 9 taps of one 128-byte channel chunk re-read
+        // the same few image rows back to back, so a workgroup's live footprint in L2 is
+        // rows x BK instead of rows x Cin (the sum order is a free choice as long as A and W agree).
+        if (++ld_tap == p.ntaps) { ld_tap = 0; ++ld_kc; }
     };
 
     f32x4 acc[MT][NTL];
@@ -392,7 +455,12 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
         if (ks + 1 < nk) issue(buf ^ 1);
         mma_step<T>(lds + buf * STAGE, lds + buf * STAGE + BM * ROWB, wm, wn, lane, acc);
     }
-    epilogue<T>(p, acc, m0, n0, wm, wn, lane);
+    if (p.wide_out) {
+        __syncthreads();                       // every wave is done reading the last stage
+        epilogue_wide<T>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
+    } else {
+        epilogue<T>(p, acc, m0, n0, wm, wn, lane);
+    }
 }
 
 template <class T>
@@ -432,6 +500,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.tiles_m = cdiv((int)M, BM); p.tiles_n = cdiv(a.Cout, BN);
     const int tn = p.tiles_n;
     p.xcd_map = (tn == 1 || tn == 2 || tn == 4 || tn == 8) && (p.tiles_m % (8 / tn) == 0) ? 1 : 0;
+    p.wide_out = (!a.out_nchw && a.Cout % vec == 0) ? 1 : 0;
     const long long nblocks = (long long)p.tiles_m * p.tiles_n;
     if (nblocks > 0x7fffffffLL) return NOPE_ERR_UNSUPPORTED;
     // LDS-DMA kernel when a K step (128 B of channels) never straddles sources and 32-bit offsets suffice

@@ -314,6 +314,8 @@ inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() __syncthreads()
+inline void hipemu_wave_barrier() { int z = 0; hipemu::wave_exchange(&z, sizeof(z)); }
+#define __builtin_amdgcn_wave_barrier() hipemu_wave_barrier()
 inline int hipemu_readfirstlane(int v) { return __shfl(v, 0); }
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
 
