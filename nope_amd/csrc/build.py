@@ -57,6 +57,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs = list(ex.map(compile_one, SOURCES))
     if force or not _newer(LIB, objs):
         subprocess.run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs, check=True)
+    import ctypes
+    ctypes.CDLL(LIB, mode=os.RTLD_NOW)     # every symbol must resolve (catches a silently dropped kernel stub)
     return LIB
 
 

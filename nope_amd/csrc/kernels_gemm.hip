@@ -27,6 +27,8 @@
 // Workgroup -> tile map is XCD-aware: blocks that land on one XCD (blockIdx % 8) share the
 // weight panel (tile_n), so at the deep levels (8 N-tiles of 8 MB each) every XCD's L2
 // streams one panel instead of all eight.
+#include <cstdlib>
+
 #include "nope_common.h"
 
 namespace nope {
@@ -322,13 +324,49 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr unsigned OOB = 0x80000000u;   // >= any num_records (tensors < 2 GiB); stays out of range after adding a K offset
 
-template <class T, int MODE>
+// Row geometry of a staged tile: RB bytes of K per row (128 or 64), 16-byte slots XOR-swizzled so that
+// the 16 rows x one slot of a ds_read_b128 lane group hit 16 different bank positions.
+template <int RB> __device__ __forceinline__ int swz_of(int row) { return RB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+template <int RB> __device__ __forceinline__ int lds_off_rb(int row, int slot) { return row * RB + ((slot ^ swz_of<RB>(row)) << 4); }
+
+template <class T, int RB>
+__device__ __forceinline__ void mma_stage(const unsigned char* ldsA, const unsigned char* ldsB, int wm, int wn, int lane,
+                                          f32x4 (&acc)[MT][NTL]) {
+#pragma unroll
+    for (int kk = 0; kk < RB / 64; ++kk) {
+        u32x4 af[MT], bfr[NTL];
+        const int s = kk * 4 + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = ld16(ldsA + lds_off_rb<RB>(wm * 64 + i * 16 + (lane & 15), s));
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) bfr[j] = ld16(ldsB + lds_off_rb<RB>(wn * 96 + j * 16 + (lane & 15), s));
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+    }
+}
+
+// s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
+template <int N> __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt((N & 15) | 0x0F70 | ((N >> 4) << 14)); }
+
+// RB = bytes of K per row per stage, NS = stages in the LDS ring (NS - 1 of them in flight).
+//   <128, 2>: two 40 KiB stages, one plain barrier per stage.
+//   < 64, 4>: four 20 KiB stages; loads run three stages ahead behind COUNTED vmcnt + a raw s_barrier, so
+//             60 of the 80 KiB are in flight instead of 40 (same LDS, 1.5x the bytes in flight).
+template <class T, int MODE, int RB, int NS, bool IL>
 __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
     constexpr int VEC = Elt<T>::VEC;
-    constexpr int BK = 8 * VEC;
     constexpr unsigned ES = (unsigned)sizeof(T);
-    constexpr int STAGE = (BM + BN) * ROWB;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    constexpr int BK = RB / (int)ES;
+    constexpr int STAGE = (BM + BN) * RB;
+    constexpr int RPI = 1024 / RB;              // tile rows filled by one wave instruction
+    constexpr int SPR = RB / 16;                // 16-byte slots per row
+    constexpr int AI = BM / RPI / 4, BI = BN / RPI / 4;   // DMA instructions per wave per stage
+    constexpr int L = AI + BI;
+    static_assert(NS * STAGE >= 4 * EP_WAVE_BYTES, "epilogue panels must fit in the ring");
+    static_assert(AI <= 4 && BI <= 6, "row bookkeeping arrays");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NS * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -344,21 +382,23 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
     const auto r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src2 ? p.src2 : p.src1), (short)0, (int)(p.src2 ? p.bytes2 : p.bytes1), 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)p.bytesw, 0x00020000);
 
-    // This lane's rows: A chunk i of wave w covers tile rows 8*(4w+i) .. +7, B chunk j rows 8*(6w+j) .. +7.
+    // This lane's rows: A chunk i of wave w covers tile rows RPI*(AI*w+i) .. +RPI-1, B chunk j likewise.
     // Everything that does not depend on the K step is folded into per-row byte offsets + a tap-validity mask.
-    const int rsub = lane >> 3, lslot = lane & 7;
-    unsigned a_b1[A_ITERS], a_b2[A_ITERS], a_mask[A_ITERS];
-    unsigned a_y[MODE == NOPE_CONV_UP2 ? A_ITERS : 1][3], a_x[MODE == NOPE_CONV_UP2 ? A_ITERS : 1][3];
+    const int rsub = lane / SPR, lslot = lane % SPR;
+    // NB: fixed-size arrays on purpose -- with arrays whose size depends on a template parameter captured by
+    // the `issue` lambda, hipcc (ROCm 7.2) silently drops the kernel's HOST stub (undefined symbol at load).
+    unsigned a_b1[4], a_b2[4], a_mask[4];     // AI <= 4
+    unsigned a_y[4][3], a_x[4][3];            // UP2 only
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-        const int row = 8 * (A_ITERS * wave + i) + rsub;
+    for (int i = 0; i < AI; ++i) {
+        const int row = RPI * (AI * wave + i) + rsub;
         const int m = m0 + row;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         const int b = mm / HWo;
         const int r = mm - b * HWo;
         const int oy = r / p.Wo, ox = r - oy * p.Wo;
-        const unsigned cs = (unsigned)((lslot ^ ((row >> 1) & 7)) * VEC);   // source channel chunk of this LDS slot
+        const unsigned cs = (unsigned)((lslot ^ swz_of<RB>(row)) * VEC);   // source channel chunk of this LDS slot
         const unsigned s1 = (unsigned)(b / p.rep1), s2 = (unsigned)(b / p.rep2);
         unsigned mask = 0;
         if (MODE == NOPE_CONV_PLAIN) {
@@ -391,12 +431,12 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
         }
         a_mask[i] = ok ? mask : 0u;
     }
-    unsigned b_off[B_ITERS];
+    unsigned b_off[6];                        // BI <= 6
 #pragma unroll
-    for (int j = 0; j < B_ITERS; ++j) {
-        const int row = 8 * (B_ITERS * wave + j) + rsub;
+    for (int j = 0; j < BI; ++j) {
+        const int row = RPI * (BI * wave + j) + rsub;
         const int n = n0 + row;
-        const unsigned cs = (unsigned)((lslot ^ ((row >> 1) & 7)) * VEC);
+        const unsigned cs = (unsigned)((lslot ^ swz_of<RB>(row)) * VEC);
         b_off[j] = n < p.Cout ? ((unsigned)n * p.ntaps * Cin + cs) * ES : OOB;
     }
 
@@ -404,42 +444,54 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
     const int nk = p.ntaps * kc_per_tap;
     int ld_tap = 0, ld_kc = 0;
 
-    auto issue = [&](int buf) {
-        unsigned char* dA = lds + buf * STAGE + (A_ITERS * wave) * 8 * ROWB;
-        unsigned char* dB = lds + buf * STAGE + BM * ROWB + (B_ITERS * wave) * 8 * ROWB;
+    // One stage's loads, split so they can be interleaved with MFMA groups: begin -> A pieces -> B pieces -> end.
+    unsigned char* st_dA = nullptr; unsigned char* st_dB = nullptr;
+    bool st_first = true;
+    unsigned st_kadd = 0, st_kofs = 0;
+    int st_dyi = 1, st_dxi = 1;
+    auto step_begin = [&](int buf) {
+        st_dA = lds + buf * STAGE + (AI * wave) * 1024;
+        st_dB = lds + buf * STAGE + BM * RB + (BI * wave) * 1024;
         const int c0 = ld_kc * BK;
-        const bool first = c0 < p.C1;          // wave-uniform: a K step lies inside one source
-        const auto ra = first ? r1 : r2;
-        const int Cs = first ? p.C1 : p.C2;
-        unsigned kadd = (unsigned)(first ? c0 : c0 - p.C1) * ES;     // scalar part of the A offset
-        int dyi = 1, dxi = 1;
+        st_first = c0 < p.C1;                  // wave-uniform: a K step lies inside one source
+        const int Cs = st_first ? p.C1 : p.C2;
+        st_kadd = (unsigned)(st_first ? c0 : c0 - p.C1) * ES;     // scalar part of the A offset
+        st_dyi = 1; st_dxi = 1;
         if (MODE == NOPE_CONV_PLAIN) {
             if (p.ntaps == 9) {
-                dyi = ld_tap / 3; dxi = ld_tap - dyi * 3;
-                kadd += (unsigned)(((dyi - 1) * p.Ws + (dxi - 1)) * Cs) * ES;
+                st_dyi = ld_tap / 3; st_dxi = ld_tap - st_dyi * 3;
+                st_kadd += (unsigned)(((st_dyi - 1) * p.Ws + (st_dxi - 1)) * Cs) * ES;
             }
         } else if (MODE == NOPE_CONV_DOWN2) {
-            kadd += (unsigned)(((ld_tap >> 1) * p.Ws + (ld_tap & 1)) * Cs) * ES;
+            st_kadd += (unsigned)(((ld_tap >> 1) * p.Ws + (ld_tap & 1)) * Cs) * ES;
         } else {
-            dyi = ld_tap / 3; dxi = ld_tap - dyi * 3;
+            st_dyi = ld_tap / 3; st_dxi = ld_tap - st_dyi * 3;
         }
+        st_kofs = (unsigned)(ld_tap * Cin + c0) * ES;
+    };
+    auto step_a = [&](int i) {
+        unsigned base;
+        if (MODE == NOPE_CONV_UP2) base = (st_dyi == 0 ? a_y[i][0] : st_dyi == 1 ? a_y[i][1] : a_y[i][2]) +
+                                          (st_dxi == 0 ? a_x[i][0] : st_dxi == 1 ? a_x[i][1] : a_x[i][2]);
+        else base = st_first ? a_b1[i] : a_b2[i];
+        const unsigned off = (((a_mask[i] >> ld_tap) & 1u) ? base : OOB) + st_kadd;
+        const auto ra = st_first ? r1 : r2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(st_dA + i * 1024), 16, off, 0, 0, 0);
+    };
+    auto step_b = [&](int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(st_dB + j * 1024), 16, b_off[j] + st_kofs, 0, 0, 0);
+    };
+    // K order: channel chunk outer, tap inner -- the 9 taps of one channel chunk re-read the same few image
+    // rows back to back, so a workgroup's live footprint in L2 is rows x BK instead of rows x Cin (the sum
+    // order is a free choice as long as A and W agree).
+    auto step_end = [&]() { if (++ld_tap == p.ntaps) { ld_tap = 0; ++ld_kc; } };
+    auto issue = [&](int buf) {
+        step_begin(buf);
 #pragma unroll
-        for (int i = 0; i < A_ITERS; ++i) {
-            unsigned base;
-            if (MODE == NOPE_CONV_UP2) base = (dyi == 0 ? a_y[i][0] : dyi == 1 ? a_y[i][1] : a_y[i][2]) +
-                                              (dxi == 0 ? a_x[i][0] : dxi == 1 ? a_x[i][1] : a_x[i][2]);
-            else base = first ? a_b1[i] : a_b2[i];
-            const unsigned off = (((a_mask[i] >> ld_tap) & 1u) ? base : OOB) + kadd;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(dA + i * 8 * ROWB), 16, off, 0, 0, 0);
-        }
-        const unsigned kofs = (unsigned)(ld_tap * Cin + c0) * ES;
+        for (int i = 0; i < AI; ++i) step_a(i);
 #pragma unroll
-        for (int j = 0; j < B_ITERS; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(dB + j * 8 * ROWB), 16, b_off[j] + kofs, 0, 0, 0);
-        // K order: channel chunk outer, tap inner -- the 9 taps of one 128-byte channel chunk re-read
-        // the same few image rows back to back, so a workgroup's live footprint in L2 is
-        // rows x BK instead of rows x Cin (the sum order is a free choice as long as A and W agree).
-        if (++ld_tap == p.ntaps) { ld_tap = 0; ++ld_kc; }
+        for (int j = 0; j < BI; ++j) step_b(j);
+        step_end();
     };
 
     f32x4 acc[MT][NTL];
@@ -448,12 +500,80 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue(0);
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        __syncthreads();                       // stage ks landed (vmcnt drain) + everyone left stage ks-1
-        if (ks + 1 < nk) issue(buf ^ 1);
-        mma_step<T>(lds + buf * STAGE, lds + buf * STAGE + BM * ROWB, wm, wn, lane, acc);
+    if (NS == 2 && IL && RB == 128) {
+        // Interleaved schedule: the next stage's 10 LDS-DMA instructions are spread between four groups of 12
+        // MFMAs (pinned with sched_barrier), so a wave's address math + DMA issue runs under its OWN MFMAs
+        // instead of in front of them.
+        issue(0);
+        for (int ks = 0; ks < nk; ++ks) {
+            const int buf = ks & 1;
+            __syncthreads();
+            const bool more = ks + 1 < nk;
+            const unsigned char* tA = lds + buf * STAGE;
+            const unsigned char* tB = tA + BM * RB;
+            u32x4 af0[MT], bf0[NTL], af1[MT], bf1[NTL];
+            const int s0 = lane >> 4, s1 = 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af0[i] = ld16(tA + lds_off_rb<RB>(wm * 64 + i * 16 + (lane & 15), s0));
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) bf0[j] = ld16(tB + lds_off_rb<RB>(wn * 96 + j * 16 + (lane & 15), s0));
+            if (more) { step_begin(buf ^ 1); step_a(0); step_a(1); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) Mma<T>::run(af0[i], bf0[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) { step_a(2); step_a(3); }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af1[i] = ld16(tA + lds_off_rb<RB>(wm * 64 + i * 16 + (lane & 15), s1));
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) bf1[j] = ld16(tB + lds_off_rb<RB>(wn * 96 + j * 16 + (lane & 15), s1));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 2; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) Mma<T>::run(af0[i], bf0[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) { step_b(0); step_b(1); step_b(2); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) Mma<T>::run(af1[i], bf1[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) { step_b(3); step_b(4); step_b(5); step_end(); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 2; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) Mma<T>::run(af1[i], bf1[j], acc[i][j]);
+        }
+    } else if (NS == 2) {
+        issue(0);
+        for (int ks = 0; ks < nk; ++ks) {
+            const int buf = ks & 1;
+            __syncthreads();                       // stage ks landed (vmcnt drain) + everyone left stage ks-1
+            if (ks + 1 < nk) issue(buf ^ 1);
+            mma_stage<T, RB>(lds + buf * STAGE, lds + buf * STAGE + BM * RB, wm, wn, lane, acc);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nk) issue(s);
+        int buf = 0;
+        for (int ks = 0; ks < nk; ++ks) {
+            // this wave's loads of stage ks have landed once at most L * (stages issued after ks) remain
+            const int after = nk - 1 - ks;
+            if (after >= NS - 2) wait_vmcnt<L * (NS - 2)>();
+            else if (after == 1) wait_vmcnt<L>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();          // ... and every wave's have; everyone also left stage ks-1
+            const int nxt = buf == 0 ? NS - 1 : buf - 1;   // ring slot of stage ks-1 == slot of stage ks+NS-1
+            if (ks + NS - 1 < nk) issue(nxt);
+            mma_stage<T, RB>(lds + buf * STAGE, lds + buf * STAGE + BM * RB, wm, wn, lane, acc);
+            buf = buf == NS - 1 ? 0 : buf + 1;
+        }
     }
     if (p.wide_out) {
         __syncthreads();                       // every wave is done reading the last stage
@@ -463,11 +583,11 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
     }
 }
 
-template <class T>
+template <class T, int RB, int NS, bool IL>
 void launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
-    if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN>), grid, dim3(NT), 0, s, p);
-    else if (p.mode == NOPE_CONV_UP2) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2>), grid, dim3(NT), 0, s, p);
-    else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_DOWN2>), grid, dim3(NT), 0, s, p);
+    if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, IL>), grid, dim3(NT), 0, s, p);
+    else if (p.mode == NOPE_CONV_UP2) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2, RB, NS, IL>), grid, dim3(NT), 0, s, p);
+    else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_DOWN2, RB, NS, IL>), grid, dim3(NT), 0, s, p);
 }
 
 }  // namespace
@@ -514,12 +634,18 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     const bool dma = !a.force_generic && Cin % bk == 0 && (a.C2 == 0 || (a.C1 % bk == 0 && a.mode == NOPE_CONV_PLAIN)) &&
                      b1 < lim && b2 < lim && bw < lim;
     p.bytes1 = (unsigned)(dma ? b1 : 0); p.bytes2 = (unsigned)(dma ? b2 : 0); p.bytesw = (unsigned)(dma ? bw : 0);
+    static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
+    const bool deep = variant == 1;   // 64-byte rows x 4-stage ring (experimental)
     const dim3 grid((unsigned)nblocks), block(NT);
     if (dt == NOPE_F32) {
-        if (dma) launch_dma<float>(p, grid, s);
+        if (dma && deep) launch_dma<float, 64, 4, false>(p, grid, s);
+        else if (dma && variant == 2) launch_dma<float, 128, 2, true>(p, grid, s);
+        else if (dma) launch_dma<float, 128, 2, false>(p, grid, s);
         else hipLaunchKernelGGL((conv_gemm_kernel<float>), grid, block, 0, s, p);
     } else {
-        if (dma) launch_dma<bf16_t>(p, grid, s);
+        if (dma && deep) launch_dma<bf16_t, 64, 4, false>(p, grid, s);
+        else if (dma && variant == 2) launch_dma<bf16_t, 128, 2, true>(p, grid, s);
+        else if (dma) launch_dma<bf16_t, 128, 2, false>(p, grid, s);
         else hipLaunchKernelGGL((conv_gemm_kernel<bf16_t>), grid, block, 0, s, p);
     }
     NOPE_CHECK_LAUNCH();

@@ -31,12 +31,15 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--nhyp", type=int, default=512)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--only", default="", help="comma-separated shape indices")
     a = ap.parse_args()
     dt = hip.dtype_code(a.dtype)
     tdt = hip.torch_dtype(dt)
     l = hip.lib()
     tot_ms = tot_fl = 0.0
     for name, c1, c2, cout, hs, mode, ks, calls in SHAPES:
+        if a.only and str(SHAPES.index((name, c1, c2, cout, hs, mode, ks, calls))) not in a.only.split(','):
+            continue
         cin = c1 + c2
         ntaps = 4 if mode == hip.CONV_DOWN2 else ks * ks
         wshape = (cout, cin * 4, 1, 1) if mode == hip.CONV_DOWN2 else (cout, cin, ks, ks)
