@@ -24,7 +24,10 @@ extern "C" {
 #endif
 
 enum { NOPE_F32 = 0, NOPE_BF16 = 1 };
-enum { NOPE_CONV_PLAIN = 0, NOPE_CONV_UP2 = 1, NOPE_CONV_DOWN2 = 2 };
+/* Tap geometries of nope_op_conv.  UP2P is UP2 (nearest-x2 upsample + 3x3, pad 1) rewritten as four
+ * 2x2 convolutions over the un-upsampled input, one per output-pixel parity, with the 3x3 weights that
+ * fall on the same source pixel pre-summed at pack time: same function, 4/9 of the multiply-adds. */
+enum { NOPE_CONV_PLAIN = 0, NOPE_CONV_UP2 = 1, NOPE_CONV_DOWN2 = 2, NOPE_CONV_UP2P = 3 };
 enum {
     NOPE_OK = 0,
     NOPE_ERR_ARG = -1,        /* bad argument (null pointer, unsupported size/dtype) */

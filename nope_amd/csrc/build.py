@@ -35,6 +35,28 @@ def _newer(target: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+def _record_usage(src: str, remarks: str, objdir: str) -> None:
+    """Keep per-kernel VGPR/LDS/scratch from hipcc's remarks and refuse a build whose hot kernels spill:
+    one runtime-indexed accumulator silently moves a whole GEMM to scratch (a 5x slowdown, still correct)."""
+    import re
+    rows, name = [], None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            rows.append({"kernel": name})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and rows:
+            rows[-1][m.group(1).split(" ")[0]] = int(m.group(2))
+    with open(os.path.join(objdir, src + ".usage.txt"), "w") as f:
+        for r in rows:
+            f.write(" ".join(f"{k}={v}" for k, v in r.items()) + "\n")
+    bad = [r["kernel"] for r in rows if r.get("ScratchSize", 0) > 0 and any(t in r["kernel"] for t in ("conv_gemm", "sim_reg", "gn_", "linattn"))]
+    if bad:
+        raise RuntimeError(f"{src}: kernels use scratch memory (register spill / runtime-indexed array): {bad}")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(ROOT, "build", "hip")
@@ -47,10 +69,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
         path = os.path.join(HERE, src)
         if not force and _newer(obj, [path] + headers):
             return obj
-        cmd = [hipcc] + flags + ["-c", path, "-o", obj]
+        cmd = [hipcc] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr)
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        _record_usage(src, r.stderr, objdir)
         return obj
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:

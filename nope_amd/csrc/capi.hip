@@ -47,8 +47,9 @@ int nope_op_conv(int dtype, const void* src1, int C1, int rep1, const void* src2
     ConvArgs a;
     a.src1 = src1; a.C1 = C1; a.rep1 = rep1; a.src2 = src2; a.C2 = C2; a.rep2 = rep2 > 0 ? rep2 : 1;
     a.Hs = Hs; a.Ws = Ws; a.mode = mode; a.ntaps = ntaps;
-    a.Ho = mode == NOPE_CONV_UP2 ? 2 * Hs : (mode == NOPE_CONV_DOWN2 ? Hs / 2 : Hs);
-    a.Wo = mode == NOPE_CONV_UP2 ? 2 * Ws : (mode == NOPE_CONV_DOWN2 ? Ws / 2 : Ws);
+    const bool up = mode == NOPE_CONV_UP2 || mode == NOPE_CONV_UP2P;
+    a.Ho = up ? 2 * Hs : (mode == NOPE_CONV_DOWN2 ? Hs / 2 : Hs);
+    a.Wo = up ? 2 * Ws : (mode == NOPE_CONV_DOWN2 ? Ws / 2 : Ws);
     if (mode == NOPE_CONV_DOWN2 && ((Hs | Ws) & 1)) return NOPE_ERR_ARG;
     a.w = w_packed; a.bias = bias; a.resid = resid; a.out = out; a.Cout = Cout; a.nhyp = n_hyp;
     a.out_nchw = out_nchw; a.out_dt = out_dtype;

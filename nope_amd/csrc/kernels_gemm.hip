@@ -56,6 +56,8 @@ struct ConvParams {
     int Cout, M;
     int out_nchw, out_dt;
     int tiles_m, tiles_n, xcd_map, wide_out;
+    int Hm, Wm;                        // grid the GEMM rows enumerate: output grid, or the SOURCE grid for UP2P
+    unsigned w_phase_bytes;            // UP2P: byte stride between the 4 phase weight sets
     unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
 };
 
@@ -109,33 +111,59 @@ __device__ __forceinline__ void mma_step(const unsigned char* ldsA, const unsign
     }
 }
 
+// Output pixel row of GEMM row m.  Identity except for UP2P, whose rows walk the source grid and land on
+// output pixel (2y + py, 2x + px) of phase blockIdx.y.
+__device__ __forceinline__ size_t out_row(const ConvParams& p, int m) {
+    if (p.mode != NOPE_CONV_UP2P) return (size_t)m;
+    const int hw = p.Hm * p.Wm;
+    const int b = m / hw;
+    const int r = m - b * hw;
+    const int y = r / p.Wm, x = r - y * p.Wm;
+    const int py = (int)blockIdx.y >> 1, px = (int)blockIdx.y & 1;
+    return ((size_t)b * p.Ho + 2 * y + py) * p.Wo + 2 * x + px;
+}
+
 // C/D map of the 16x16 MFMA tiles: col = lane & 15, row = (lane >> 4) * 4 + r
 template <class T>
 __device__ __forceinline__ void epilogue(const ConvParams& p, const f32x4 (&acc)[MT][NTL], int m0, int n0, int wm, int wn, int lane) {
+    // Every index into acc must stay a compile-time constant (full unroll): a runtime index would move the
+    // accumulators to scratch for the WHOLE kernel.  Row bookkeeping (incl. the divisions) is hoisted to
+    // once per (i, r).
     const int HWo = p.Ho * p.Wo;
     T* out = reinterpret_cast<T*>(p.out);
     const T* resid = reinterpret_cast<const T*>(p.resid);
+    float bv[NTL];
+    int ncol[NTL];
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
-        const int n = n0 + wn * 96 + j * 16 + (lane & 15);
-        if (n >= p.Cout) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+        ncol[j] = n0 + wn * 96 + j * 16 + (lane & 15);
+        bv[j] = (p.bias && ncol[j] < p.Cout) ? p.bias[ncol[j]] : 0.f;
+    }
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < MT; ++i) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (resid) v += Elt<T>::ld(resid + (size_t)m * p.Cout + n);
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+            const bool row_ok = m < p.M;
+            const size_t mo = out_row(p, row_ok ? m : 0);
+            size_t nchw_base = 0;
+            if (p.out_nchw) {
+                const int mm = row_ok ? m : 0;
+                const int b = mm / HWo;
+                nchw_base = (size_t)b * p.Cout * HWo + (mm - b * HWo);
+            }
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int n = ncol[j];
+                if (!row_ok || n >= p.Cout) continue;
+                float v = acc[i][j][r] + bv[j];
+                if (resid) v += Elt<T>::ld(resid + mo * p.Cout + n);
                 if (p.out_nchw) {
-                    const int b = m / HWo;
-                    const int pix = m - b * HWo;
-                    const size_t o = ((size_t)b * p.Cout + n) * HWo + pix;
+                    const size_t o = nchw_base + (size_t)n * HWo;
                     if (p.out_dt == NOPE_F32) reinterpret_cast<float*>(p.out)[o] = v;
                     else reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(v);
                 } else {
-                    Elt<T>::st(out + (size_t)m * p.Cout + n, v);
+                    Elt<T>::st(out + mo * p.Cout + n, v);
                 }
             }
         }
@@ -185,7 +213,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const f32x4 (
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[q * 4 + e] = t[e];
             }
-            const size_t o = (size_t)m * p.Cout + n;
+            const size_t o = out_row(p, m) * p.Cout + n;
             if (resid) {
                 float rv[VEC];
                 Elt<T>::unpack(ld16(resid + o), rv);
@@ -201,6 +229,10 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const f32x4 (
 // Source pixel of output pixel (oy, ox) under tap (dy, dx); false = zero padding / beyond M.
 __device__ __forceinline__ bool tap_pixel(const ConvParams& p, int oy, int ox, int dy, int dx, int& iy, int& ix) {
     if (p.mode == NOPE_CONV_DOWN2) { iy = 2 * oy + dy; ix = 2 * ox + dx; return oy >= 0; }
+    if (p.mode == NOPE_CONV_UP2P) {   // rows are source pixels; (dy, dx) already include the phase shift
+        iy = oy + dy; ix = ox + dx;
+        return iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+    }
     if (p.mode == NOPE_CONV_UP2) {
         const int uy = oy + dy, ux = ox + dx;
         iy = uy >> 1; ix = ux >> 1;
@@ -212,6 +244,7 @@ __device__ __forceinline__ bool tap_pixel(const ConvParams& p, int oy, int ox, i
 __device__ __forceinline__ void tap_delta(const ConvParams& p, int tap, int& dy, int& dx) {
     dy = 0; dx = 0;
     if (p.mode == NOPE_CONV_DOWN2) { dy = tap >> 1; dx = tap & 1; }
+    else if (p.mode == NOPE_CONV_UP2P) { dy = (tap >> 1) + ((int)blockIdx.y >> 1) - 1; dx = (tap & 1) + ((int)blockIdx.y & 1) - 1; }
     else if (p.ntaps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
 }
 
@@ -236,8 +269,9 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
 
     const int slot = tid & 7;
     const int rbase = tid >> 3;
-    const int HWo = p.Ho * p.Wo;
+    const int HWo = p.Hm * p.Wm;
     const int Cin = p.C1 + p.C2;
+    const unsigned char* wbase = p.w + (size_t)blockIdx.y * p.w_phase_bytes;
 
     int a_s1[A_ITERS], a_s2[A_ITERS], a_oy[A_ITERS], a_ox[A_ITERS];
 #pragma unroll
@@ -247,9 +281,9 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
         const int mm = ok ? m : 0;
         const int b = mm / HWo;
         const int r = mm - b * HWo;
-        const int oy = r / p.Wo;
+        const int oy = r / p.Wm;
         a_oy[i] = ok ? oy : -100000;   // poisons the bounds test for rows beyond M
-        a_ox[i] = r - oy * p.Wo;
+        a_ox[i] = r - oy * p.Wm;
         a_s1[i] = b / p.rep1;
         a_s2[i] = b / p.rep2;
     }
@@ -285,7 +319,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
         for (int j = 0; j < B_ITERS; ++j) {
             const int n = n0 + rbase + 32 * j;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (n < p.Cout && c_ok) v = ld16(p.w + (((size_t)n * p.ntaps + ld_tap) * Cin + c) * ES);
+            if (n < p.Cout && c_ok) v = ld16(wbase + (((size_t)n * p.ntaps + ld_tap) * Cin + c) * ES);
             rb[j] = v;
         }
         if (++ld_kc == kc_per_tap) { ld_kc = 0; ++ld_tap; }
@@ -375,12 +409,13 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
     int tile_m, tile_n;
     tile_coords(p, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int HWo = p.Ho * p.Wo;
+    const int HWo = p.Hm * p.Wm;
     const int Cin = p.C1 + p.C2;
+    const int ph_y = MODE == NOPE_CONV_UP2P ? ((int)blockIdx.y >> 1) : 0, ph_x = MODE == NOPE_CONV_UP2P ? ((int)blockIdx.y & 1) : 0;
 
     const auto r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src1, (short)0, (int)p.bytes1, 0x00020000);
     const auto r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src2 ? p.src2 : p.src1), (short)0, (int)(p.src2 ? p.bytes2 : p.bytes1), 0x00020000);
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)p.bytesw, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (size_t)blockIdx.y * p.w_phase_bytes), (short)0, (int)p.bytesw, 0x00020000);
 
     // This lane's rows: A chunk i of wave w covers tile rows RPI*(AI*w+i) .. +RPI-1, B chunk j likewise.
     // Everything that does not depend on the K step is folded into per-row byte offsets + a tap-validity mask.
@@ -397,11 +432,19 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
         const int mm = ok ? m : 0;
         const int b = mm / HWo;
         const int r = mm - b * HWo;
-        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        const int oy = r / p.Wm, ox = r - oy * p.Wm;
         const unsigned cs = (unsigned)((lslot ^ swz_of<RB>(row)) * VEC);   // source channel chunk of this LDS slot
         const unsigned s1 = (unsigned)(b / p.rep1), s2 = (unsigned)(b / p.rep2);
         unsigned mask = 0;
-        if (MODE == NOPE_CONV_PLAIN) {
+        if (MODE == NOPE_CONV_UP2P) {
+            a_b1[i] = (((s1 * p.Hs + oy) * p.Ws + ox) * p.C1 + cs) * ES;
+            a_b2[i] = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int iy = oy + (t >> 1) + ph_y - 1, ix = ox + (t & 1) + ph_x - 1;
+                if (iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws) mask |= 1u << t;
+            }
+        } else if (MODE == NOPE_CONV_PLAIN) {
             a_b1[i] = (((s1 * p.Hs + oy) * p.Ws + ox) * p.C1 + cs) * ES;
             a_b2[i] = (((s2 * p.Hs + oy) * p.Ws + ox) * p.C2 + cs) * ES;
             if (p.ntaps == 9) {
@@ -464,6 +507,8 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
             }
         } else if (MODE == NOPE_CONV_DOWN2) {
             st_kadd += (unsigned)(((ld_tap >> 1) * p.Ws + (ld_tap & 1)) * Cs) * ES;
+        } else if (MODE == NOPE_CONV_UP2P) {
+            st_kadd += (unsigned)((((ld_tap >> 1) + ph_y - 1) * p.Ws + ((ld_tap & 1) + ph_x - 1)) * Cs) * ES;
         } else {
             st_dyi = ld_tap / 3; st_dxi = ld_tap - st_dyi * 3;
         }
@@ -587,6 +632,7 @@ template <class T, int RB, int NS, bool IL>
 void launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
     if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, IL>), grid, dim3(NT), 0, s, p);
     else if (p.mode == NOPE_CONV_UP2) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2, RB, NS, IL>), grid, dim3(NT), 0, s, p);
+    else if (p.mode == NOPE_CONV_UP2P) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2P, RB, NS, IL>), grid, dim3(NT), 0, s, p);
     else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_DOWN2, RB, NS, IL>), grid, dim3(NT), 0, s, p);
 }
 
@@ -605,14 +651,18 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         if (a.ntaps != 9 || a.Ho != 2 * a.Hs || a.Wo != 2 * a.Ws) return NOPE_ERR_ARG;
     } else if (a.mode == NOPE_CONV_DOWN2) {
         if (a.ntaps != 4 || a.Hs != 2 * a.Ho || a.Ws != 2 * a.Wo) return NOPE_ERR_ARG;
+    } else if (a.mode == NOPE_CONV_UP2P) {
+        if (a.ntaps != 4 || a.Ho != 2 * a.Hs || a.Wo != 2 * a.Ws || a.C2 != 0 || a.out_nchw) return NOPE_ERR_ARG;
     } else return NOPE_ERR_ARG;
-    const long long M = (long long)a.nhyp * a.Ho * a.Wo;
+    const bool phased = a.mode == NOPE_CONV_UP2P;
+    const long long M = phased ? (long long)a.nhyp * a.Hs * a.Ws : (long long)a.nhyp * a.Ho * a.Wo;
     if (M > 0x7fffffffLL) return NOPE_ERR_UNSUPPORTED;
 
     ConvParams p;
     p.src1 = (const unsigned char*)a.src1; p.src2 = (const unsigned char*)a.src2;
     p.C1 = a.C1; p.C2 = a.C2; p.rep1 = a.rep1; p.rep2 = a.rep2;
     p.Hs = a.Hs; p.Ws = a.Ws; p.Ho = a.Ho; p.Wo = a.Wo;
+    p.Hm = phased ? a.Hs : a.Ho; p.Wm = phased ? a.Ws : a.Wo;
     p.mode = a.mode; p.ntaps = a.ntaps;
     p.w = (const unsigned char*)a.w; p.bias = a.bias; p.resid = (const unsigned char*)a.resid;
     p.out = (unsigned char*)a.out; p.Cout = a.Cout; p.M = (int)M;
@@ -630,13 +680,14 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     const unsigned long long lim = 0x7fffffffULL;
     const unsigned long long b1 = (unsigned long long)cdiv(a.nhyp, a.rep1) * a.Hs * a.Ws * a.C1 * es;
     const unsigned long long b2 = a.C2 ? (unsigned long long)cdiv(a.nhyp, a.rep2) * a.Hs * a.Ws * a.C2 * es : 0;
-    const unsigned long long bw = (unsigned long long)a.Cout * a.ntaps * Cin * es;
+    const unsigned long long bw = (unsigned long long)a.Cout * a.ntaps * Cin * es;     // one phase's weights
+    p.w_phase_bytes = phased ? (unsigned)bw : 0u;
     const bool dma = !a.force_generic && Cin % bk == 0 && (a.C2 == 0 || (a.C1 % bk == 0 && a.mode == NOPE_CONV_PLAIN)) &&
                      b1 < lim && b2 < lim && bw < lim;
     p.bytes1 = (unsigned)(dma ? b1 : 0); p.bytes2 = (unsigned)(dma ? b2 : 0); p.bytesw = (unsigned)(dma ? bw : 0);
     static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
     const bool deep = variant == 1;   // 64-byte rows x 4-stage ring (experimental)
-    const dim3 grid((unsigned)nblocks), block(NT);
+    const dim3 grid((unsigned)nblocks, phased ? 4u : 1u), block(NT);
     if (dt == NOPE_F32) {
         if (dma && deep) launch_dma<float, 64, 4, false>(p, grid, s);
         else if (dma && variant == 2) launch_dma<float, 128, 2, true>(p, grid, s);

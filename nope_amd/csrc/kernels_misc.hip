@@ -50,6 +50,27 @@ __global__ __launch_bounds__(NT) void pack_conv_w_kernel(const float* __restrict
     }
 }
 
+// HardUpsample 3x3 weight [Cout][Cin][3][3] -> four phase sets [py*2+px][Cout][ty*2+tx][Cin]:
+// tap (ty, tx) of phase (py, px) reads source pixel (y + ty + py - 1, x + tx + px - 1) and carries the sum of
+// the 3x3 taps that land on it: rows {0} | {1,2} for py = 0, {0,1} | {2} for py = 1 (same for columns).
+template <class T>
+__global__ __launch_bounds__(NT) void pack_up2p_w_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % Cin);
+        size_t t = i / Cin;
+        const int tap = (int)(t % 4); t /= 4;
+        const int co = (int)(t % Cout);
+        const int ph = (int)(t / Cout);
+        const int py = ph >> 1, px = ph & 1, ty = tap >> 1, tx = tap & 1;
+        const int y0 = py == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), y1 = py == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+        const int x0 = px == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), x1 = px == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+        float a = 0.f;
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) a += w[(((size_t)co * Cin + c) * 3 + yy) * 3 + xx];
+        Elt<T>::st(out + i, a);
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(NT) void cast_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) Elt<T>::st(out + i, in[i]);
@@ -116,6 +137,15 @@ int launch_nhwc_to_nchw_f32(int dt, const void* x, float* y, int n, int C, int H
 int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s) {
     if (!w || !out || Cout <= 0 || Cin <= 0 || ntaps <= 0) return NOPE_ERR_ARG;
     if (mode == NOPE_CONV_DOWN2 && ntaps != 4) return NOPE_ERR_ARG;
+    if (mode == NOPE_CONV_UP2P) {
+        if (ntaps != 4) return NOPE_ERR_ARG;
+        const size_t tot = (size_t)4 * Cout * 4 * Cin;
+        if (dt == NOPE_F32) hipLaunchKernelGGL((pack_up2p_w_kernel<float>), dim3(grid_for(tot)), dim3(NT), 0, s, w, (float*)out, Cout, Cin, tot);
+        else if (dt == NOPE_BF16) hipLaunchKernelGGL((pack_up2p_w_kernel<bf16_t>), dim3(grid_for(tot)), dim3(NT), 0, s, w, (bf16_t*)out, Cout, Cin, tot);
+        else return NOPE_ERR_UNSUPPORTED;
+        NOPE_CHECK_LAUNCH();
+        return NOPE_OK;
+    }
     const size_t total = (size_t)Cout * ntaps * Cin;
     if (dt == NOPE_F32) hipLaunchKernelGGL((pack_conv_w_kernel<float>), dim3(grid_for(total)), dim3(NT), 0, s, w, (float*)out, Cin, ntaps, mode, total);
     else if (dt == NOPE_BF16) hipLaunchKernelGGL((pack_conv_w_kernel<bf16_t>), dim3(grid_for(total)), dim3(NT), 0, s, w, (bf16_t*)out, Cin, ntaps, mode, total);

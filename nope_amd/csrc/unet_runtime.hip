@@ -95,12 +95,12 @@ struct Loader {
     Conv conv(const std::string& pfx, int Cin, int Cout, int ksz, int mode, bool has_bias) {
         Conv c;
         c.Cin = Cin; c.Cout = Cout; c.mode = mode;
-        c.ntaps = mode == NOPE_CONV_DOWN2 ? 4 : ksz * ksz;
+        c.ntaps = (mode == NOPE_CONV_DOWN2 || mode == NOPE_CONV_UP2P) ? 4 : ksz * ksz;
         const nope_tensor_desc* d = mode == NOPE_CONV_DOWN2 ? get(pfx + "weight", {Cout, (int64_t)Cin * 4, 1, 1})
                                                             : get(pfx + "weight", {Cout, Cin, ksz, ksz});
         if (d) {
             const size_t es = net->dt == NOPE_F32 ? 4 : 2;
-            c.w = dmalloc((size_t)Cout * c.ntaps * Cin * es);
+            c.w = dmalloc((size_t)Cout * c.ntaps * Cin * es * (mode == NOPE_CONV_UP2P ? 4 : 1));
             if (c.w) { int e = launch_pack_conv_w(net->dt, d->data, c.w, Cout, Cin, c.ntaps, mode, s); if (e && err == NOPE_OK) err = e; }
         }
         if (has_bias) c.bias = copy_f32(pfx + "bias", {Cout});
@@ -172,7 +172,7 @@ struct Fwd {
         if (net->profile) {
             nope_unet::Ev ev;
             hipEventCreate(&ev.a); hipEventCreate(&ev.b);
-            ev.flops = 2.0 * (double)n * Ho * Wo * c.Cout * c.ntaps * c.Cin;
+            ev.flops = 2.0 * (double)n * Ho * Wo * c.Cout * c.ntaps * c.Cin;   // executed MACs (UP2P: 4 taps per output pixel)
             hipEventRecord(ev.a, s);
             chk(launch_conv(net->dt, ca, s));
             hipEventRecord(ev.b, s);
@@ -459,7 +459,7 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
         U.r0 = ld.res(p + "0.", dims[r + 1] + dims[r], dims[r + 1], true, embs);
         U.r1 = ld.res(p + "1.", dims[r + 1] + dims[r], dims[r + 1], true, embs);
         U.attn = linattn(p + "2.", dims[r + 1]);
-        if (l < L - 1) U.resample = ld.conv(p + "3.1.", dims[r + 1], dims[r], 3, NOPE_CONV_UP2, true);
+        if (l < L - 1) U.resample = ld.conv(p + "3.1.", dims[r + 1], dims[r], 3, NOPE_CONV_UP2P, true);   // 4 phase 2x2 convs
         else U.resample = ld.conv(p + "3.", dims[r + 1], dims[r], 3, NOPE_CONV_PLAIN, true);
     }
     net->final_res = ld.res("final_res_block.", cfg->u_net_dim * 2, cfg->u_net_dim, true, embs);

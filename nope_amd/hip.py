@@ -13,7 +13,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 F32, BF16 = 0, 1
-CONV_PLAIN, CONV_UP2, CONV_DOWN2 = 0, 1, 2
+CONV_PLAIN, CONV_UP2, CONV_DOWN2, CONV_UP2P = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libnope_hip.so")
@@ -269,9 +269,11 @@ def pack_conv_weight(w: torch.Tensor, dt: int, mode: int = CONV_PLAIN) -> Tuple[
     cout = w.shape[0]
     if mode == CONV_DOWN2:
         cin, ntaps = w.shape[1] // 4, 4
+    elif mode == CONV_UP2P:
+        cin, ntaps = w.shape[1], 4
     else:
         cin, ntaps = w.shape[1], w.shape[2] * w.shape[3]
-    out = torch.empty((cout, ntaps, cin), dtype=torch_dtype(dt), device=w.device)
+    out = torch.empty((4 if mode == CONV_UP2P else 1, cout, ntaps, cin), dtype=torch_dtype(dt), device=w.device)
     l = lib()
     l.check(l.dll.nope_op_pack_conv_weight(dt, _ptr(w), _ptr(out), cout, cin, ntaps, mode, _stream(w)), "pack_conv_weight")
     return out, cin, ntaps
@@ -287,7 +289,7 @@ def op_conv(dt: int, src1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.T
     c2 = 0 if src2 is None else src2.shape[3]
     assert c1 + c2 == cin
     n_hyp = n_hyp if n_hyp is not None else n1 * rep1
-    ho, wo = (2 * hs, 2 * ws) if mode == CONV_UP2 else ((hs // 2, ws // 2) if mode == CONV_DOWN2 else (hs, ws))
+    ho, wo = (2 * hs, 2 * ws) if mode in (CONV_UP2, CONV_UP2P) else ((hs // 2, ws // 2) if mode == CONV_DOWN2 else (hs, ws))
     cout = w.shape[0]
     if out_nchw:
         out = torch.empty((n_hyp, cout, ho, wo), dtype=torch_dtype(out_dtype), device=src1.device)

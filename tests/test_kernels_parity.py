@@ -56,6 +56,9 @@ def test_conv_variants(be, dt):
     wu, bu = rn(8, 16, 3, 3) / 12, rn(8)
     y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(wu), d(bu), mode=hip.CONV_UP2)
     assert rel(hip.to_nchw(y, dt).cpu(), R.hard_upsample(q(x1), {"1.weight": q(wu), "1.bias": bu}, "")) < tol
+    # same op as four 2x2 phase convolutions with pre-summed weights (what the U-Net runtime launches)
+    y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(wu), d(bu), mode=hip.CONV_UP2P)
+    assert rel(hip.to_nchw(y, dt).cpu(), R.hard_upsample(q(x1), {"1.weight": wu, "1.bias": bu}, "")) < (tol if dt == 0 else 6e-2)
     wd, bd = rn(32, 64, 1, 1) / 8, rn(32)
     y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(wd), d(bd), mode=hip.CONV_DOWN2)
     assert rel(hip.to_nchw(y, dt).cpu(), R.hard_downsample(q(x1), {"1.weight": q(wd), "1.bias": bd}, "")) < tol
@@ -90,6 +93,8 @@ def test_conv_lds_dma_path(be, dt):
     wu, bu = rn(40, C, 3, 3) / 24, rn(40)
     y = hip.op_conv(dt, hip.to_nhwc(d(x2), dt), d(wu), d(bu), mode=hip.CONV_UP2)
     assert rel(hip.to_nchw(y, dt).cpu(), R.hard_upsample(q(x2), {"1.weight": q(wu), "1.bias": bu}, "")) < tol
+    y = hip.op_conv(dt, hip.to_nhwc(d(x2), dt), d(wu), d(bu), mode=hip.CONV_UP2P)
+    assert rel(hip.to_nchw(y, dt).cpu(), R.hard_upsample(q(x2), {"1.weight": wu, "1.bias": bu}, "")) < (tol if dt == 0 else 6e-2)
     x4 = rn(2, C, 6, 4)
     wd, bd = rn(72, 4 * C, 1, 1) / 16, rn(72)
     y = hip.op_conv(dt, hip.to_nhwc(d(x4), dt), d(wd), d(bd), mode=hip.CONV_DOWN2)
