@@ -58,6 +58,7 @@ struct ConvParams {
     int tiles_m, tiles_n, xcd_map, wide_out;
     int Hm, Wm;                        // grid the GEMM rows enumerate: output grid, or the SOURCE grid for UP2P
     unsigned w_phase_bytes;            // UP2P: byte stride between the 4 phase weight sets
+    float* colstats;                   // optional [M/64][Cout][2]: per 64-row block column sum / sum of squares
     unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
 };
 
@@ -201,6 +202,19 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const f32x4 (
         // same-wave LDS write -> read: the LDS queue of a wave is in order, so no s_barrier; the wave
         // barrier only pins the compiler's ordering (and is the rendezvous point of tests/hipemu)
         __builtin_amdgcn_wave_barrier();
+        if (p.colstats && lane < 48) {
+            // GroupNorm statistics of the conv output, fused: this wave's 64 rows x one column per lane
+            // (f32, before the rounding to T); every [row block][column] entry has exactly one writer, so the
+            // later fold is deterministic.  Requires M % 64 == 0 (checked by the launcher).
+            const int n = n0 + wn * 96 + half * 48 + lane;
+            if (n < p.Cout) {
+                float s = 0.f, q = 0.f;
+#pragma unroll 8
+                for (int row = 0; row < 64; ++row) { const float v = pan[row * EP_LD + lane]; s += v; q += v * v; }
+                float* cs = p.colstats + ((size_t)((m0 + wm * 64) >> 6) * p.Cout + n) * 2;
+                cs[0] = s; cs[1] = q;
+            }
+        }
         for (int idx = lane; idx < 64 * CH; idx += 64) {
             const int row = idx / CH, ch = idx - row * CH;
             const int m = m0 + wm * 64 + row;
@@ -671,6 +685,8 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     const int tn = p.tiles_n;
     p.xcd_map = (tn == 1 || tn == 2 || tn == 4 || tn == 8) && (p.tiles_m % (8 / tn) == 0) ? 1 : 0;
     p.wide_out = (!a.out_nchw && a.Cout % vec == 0) ? 1 : 0;
+    p.colstats = a.colstats;
+    if (a.colstats && (!p.wide_out || M % 64 != 0 || phased || a.resid)) return NOPE_ERR_ARG;
     const long long nblocks = (long long)p.tiles_m * p.tiles_n;
     if (nblocks > 0x7fffffffLL) return NOPE_ERR_UNSUPPORTED;
     // LDS-DMA kernel when a K step (128 B of channels) never straddles sources and 32-bit offsets suffice

@@ -91,6 +91,31 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, f
     }
 }
 
+// Fold [HW/64 row blocks][C][2] column statistics (written by the conv epilogue) of one hypothesis into
+// [G][2] group sums.  Fixed summation order -> deterministic.
+__global__ __launch_bounds__(NT) void gn_fold_kernel(const float* __restrict__ colstats, float* __restrict__ partial, int nb, int C, int G) {
+    __shared__ float ch_s[2048];
+    __shared__ float ch_q[2048];
+    const int hyp = blockIdx.x, tid = threadIdx.x;
+    const float* base = colstats + (size_t)hyp * nb * C * 2;
+    for (int c = tid; c < C; c += NT) {
+        float s = 0.f, q = 0.f;
+        for (int b = 0; b < nb; ++b) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(base + ((size_t)b * C + c) * 2);
+            s += v[0]; q += v[1];
+        }
+        ch_s[c] = s; ch_q[c] = q;
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int g = tid; g < G; g += NT) {
+        float S = 0.f, Q = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { S += ch_s[c]; Q += ch_q[c]; }
+        partial[((size_t)hyp * G + g) * 2] = S;
+        partial[((size_t)hyp * G + g) * 2 + 1] = Q;
+    }
+}
+
 template <class T, bool FAST>
 __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ partial,
                                                       int nchunk, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -213,6 +238,13 @@ int launch_gn_stats(int dt, const void* x, float* partial, int nhyp, int HW, int
         if (fast) hipLaunchKernelGGL((gn_stats_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)x, partial, HW, C, G, nchunk);
         else hipLaunchKernelGGL((gn_stats_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)x, partial, HW, C, G, nchunk);
     } else return NOPE_ERR_UNSUPPORTED;
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_gn_fold(const float* colstats, float* partial, int nhyp, int HW, int C, int G, hipStream_t s) {
+    if (!colstats || !partial || nhyp <= 0 || HW % 64 || C % G || C > 2048 || G > 64) return NOPE_ERR_ARG;
+    hipLaunchKernelGGL(gn_fold_kernel, dim3((unsigned)nhyp), dim3(NT), 0, s, colstats, partial, HW / 64, C, G);
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

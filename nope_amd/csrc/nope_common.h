@@ -120,6 +120,7 @@ struct ConvArgs {
     int out_nchw = 0;            // 1: write (nhyp, Cout, Ho, Wo) with dtype out_dt
     int out_dt = NOPE_F32;       // only for out_nchw
     int force_generic = 0;       // tests: take the register-staged kernel even when the LDS-DMA one applies
+    float* colstats = nullptr;   // optional fused GroupNorm statistics: [M/64][Cout][2] (needs M % 64 == 0, NHWC out)
 };
 int launch_conv(int dt, const ConvArgs& a, hipStream_t s);
 
@@ -138,6 +139,8 @@ struct GnApplyArgs {
 };
 int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s);
 int gn_stats_chunks(int HW, int C, int dt);
+// fold the conv epilogue's per-64-row-block column statistics into per-(hypothesis, group) partials (nchunk = 1)
+int launch_gn_fold(const float* colstats, float* partial, int nhyp, int HW, int C, int G, hipStream_t s);
 
 int launch_linattn(int dt, const void* qkv, void* out, int nhyp, int HW, int heads, int dim_head, hipStream_t s);
 int launch_attn(int dt, const void* qkv, void* out, int nhyp, int HW, int heads, int dim_head, hipStream_t s);

@@ -160,9 +160,10 @@ struct Fwd {
 
     // out = conv(a [cat b]) (+bias) (+resid);  n = number of samples computed (nhyp or fewer)
     void conv(const Conv& c, const Act& a, const Act* b, void* out, int Ho, int Wo, int n, int rep1, int rep2,
-              const void* resid = nullptr, int out_nchw = 0, int out_dt = NOPE_F32) {
+              const void* resid = nullptr, int out_nchw = 0, int out_dt = NOPE_F32, float* colstats = nullptr) {
         if (!live()) return;
         ConvArgs ca;
+        ca.colstats = colstats;
         ca.src1 = a.p; ca.C1 = a.C; ca.rep1 = rep1;
         if (b) { ca.src2 = b->p; ca.C2 = b->C; ca.rep2 = rep2; }
         ca.Hs = a.H; ca.Ws = a.W; ca.Ho = Ho; ca.Wo = Wo;
@@ -181,13 +182,25 @@ struct Fwd {
             chk(launch_conv(net->dt, ca, s));
         }
     }
-    // y = act(GN(x)) [+emb] [+resid]; x holds n_x = nhyp / x_rep samples
+    // Can the conv that produces a [n][HW][C] tensor also emit its GroupNorm statistics?  (64-row blocks
+    // must not straddle samples; the wide epilogue needs C % VEC == 0.)  Returns the scratch it needs.
+    float* colstats_for(int n, int HW, int C) {
+        if (HW % 64 || C % 8 || C > 2048) return nullptr;
+        return (float*)ar.alloc((size_t)n * (HW / 64) * C * 2 * sizeof(float));
+    }
+    // y = act(GN(x)) [+emb] [+resid]; x holds n_x = nhyp / x_rep samples; `colstats` != null: statistics were
+    // produced by the conv epilogue and only need folding.
     void gn(const Norm& nm, int G, const void* x, int x_rep, void* y, int HW, int act, int emb_off, const void* resid,
-            int resid_rep) {
+            int resid_rep, const float* colstats = nullptr) {
         if (!live()) return;
         const int nx = nhyp / x_rep;
-        const int nch = gn_stats_chunks(HW, nm.C, net->dt);
-        chk(launch_gn_stats(net->dt, x, gn_partial, nx, HW, nm.C, G, nch, s));
+        int nch = 1;
+        if (colstats) {
+            chk(launch_gn_fold(colstats, gn_partial, nx, HW, nm.C, G, s));
+        } else {
+            nch = gn_stats_chunks(HW, nm.C, net->dt);
+            chk(launch_gn_stats(net->dt, x, gn_partial, nx, HW, nm.C, G, nch, s));
+        }
         GnApplyArgs ga;
         ga.x = x; ga.y = y; ga.partial = gn_partial; ga.nchunk = nch; ga.gamma = nm.gamma; ga.beta = nm.beta;
         ga.nhyp = nhyp; ga.HW = HW; ga.C = nm.C; ga.G = G; ga.act = act;
@@ -208,14 +221,17 @@ struct Fwd {
             // pose-independent prefix: conv + GN statistics once per reference sample
             const int ns = nhyp / a.rep;
             void* t1s = alloc_act((size_t)ns * HW * R.c1.Cout);
-            conv(R.c1, a, nullptr, t1s, a.H, a.W, ns, 1, 1);
-            gn(R.n1, G, t1s, a.rep, t1, HW, 1, emb_off, nullptr, 1);
+            float* cs = colstats_for(ns, HW, R.c1.Cout);
+            conv(R.c1, a, nullptr, t1s, a.H, a.W, ns, 1, 1, nullptr, 0, NOPE_F32, cs);
+            gn(R.n1, G, t1s, a.rep, t1, HW, 1, emb_off, nullptr, 1, cs);
         } else {
-            conv(R.c1, a, b, t1, a.H, a.W, nhyp, a.rep, b ? b->rep : 1);
-            gn(R.n1, G, t1, 1, t1, HW, 1, emb_off, nullptr, 1);
+            float* cs = colstats_for(nhyp, HW, R.c1.Cout);
+            conv(R.c1, a, b, t1, a.H, a.W, nhyp, a.rep, b ? b->rep : 1, nullptr, 0, NOPE_F32, cs);
+            gn(R.n1, G, t1, 1, t1, HW, 1, emb_off, nullptr, 1, cs);
         }
         Act h{t1, R.c1.Cout, a.H, a.W, 1};
-        conv(R.c2, h, nullptr, out, a.H, a.W, nhyp, 1, 1);
+        float* cs2 = colstats_for(nhyp, HW, R.c2.Cout);
+        conv(R.c2, h, nullptr, out, a.H, a.W, nhyp, 1, 1, nullptr, 0, NOPE_F32, cs2);
         const void* resid = a.p;
         int resid_rep = a.rep;
         if (R.has_res) {
@@ -223,7 +239,7 @@ struct Fwd {
             conv(R.res, a, b, t3, a.H, a.W, nhyp, a.rep, b ? b->rep : 1);
             resid = t3; resid_rep = 1;
         } else if (b) { chk(NOPE_ERR_ARG); }
-        gn(R.n2, G, out, 1, out, HW, 1, -1, resid, resid_rep);
+        gn(R.n2, G, out, 1, out, HW, 1, -1, resid, resid_rep, cs2);
         ar.off = mark;
     }
 
@@ -240,8 +256,9 @@ struct Fwd {
         conv(L.qkv, ya, nullptr, qkv, x.H, x.W, nhyp, 1, 1);
         if (live()) chk(launch_linattn(net->dt, qkv, a, nhyp, HW, heads, dh, s));
         Act aa{a, heads * dh, x.H, x.W, 1};
-        conv(L.out, aa, nullptr, y, x.H, x.W, nhyp, 1, 1);
-        gn(L.post, 1, y, 1, out, HW, 0, -1, x.p, 1);
+        float* cs = colstats_for(nhyp, HW, L.out.Cout);
+        conv(L.out, aa, nullptr, y, x.H, x.W, nhyp, 1, 1, nullptr, 0, NOPE_F32, cs);
+        gn(L.post, 1, y, 1, out, HW, 0, -1, x.p, 1, cs);
         ar.off = mark;
     }
 
