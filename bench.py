@@ -212,13 +212,26 @@ def main():
         h.profile(True)
         step()
         torch.cuda.synchronize()
-        n_launch, ms, flops = h.profile_read()
+        n_launch, ms, flops, abytes = h.profile_read()
         h.profile(False)
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
         tf = flops / ms / 1e9
-        res["roofline"] = {"bound": "mfma", "kernel": f"conv_gemm_kernel<{a.dtype}>", "achieved": tf, "peak": peak,
-                           "unit": "TFLOP/s", "frac": tf / peak, "traffic": None, "launches_per_step": n_launch,
-                           "avg_launch_ms": ms / max(n_launch, 1), "kernel_ms_per_step": ms, "flops_per_step": flops}
+        # HBM traffic of the same kernel from rocprofv3 PMC passes over this command (FETCH_SIZE / WRITE_SIZE in
+        # their own runs, tools/gpu_pmc.sh); PMC cannot be read from inside the process, so the figure is loaded
+        # from the committed measurement and is null when the workload differs from the one it was taken on.
+        traffic = None
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if rec.get("dtype") == a.dtype and rec.get("templates") == a.templates and rec.get("size") == a.size:
+                traffic = rec["bytes_per_launch"]
+        except Exception:
+            rec = None
+        res["roofline"] = {"bound": "mfma", "kernel": f"conv_gemm_dma_kernel<{a.dtype}>", "achieved": tf, "peak": peak,
+                           "unit": "TFLOP/s", "frac": tf / peak, "traffic": traffic,
+                           "algorithmic_bytes_per_launch": abytes / max(n_launch, 1), "launches_per_step": n_launch,
+                           "avg_launch_ms": ms / max(n_launch, 1), "kernel_ms_per_step": ms, "flops_per_step": flops,
+                           "note": "flops = executed MACs x2 of all implicit-GEMM launches of one step (the nearest-x2 convs run "
+                                   "as four 2x2 phase convs = 4/9 of the reference MACs); time = HIP events around each launch"}
         res["scoring_roofline"] = [scoring_roofline(torch.bfloat16), scoring_roofline(torch.float32)]
         res["cpu_baseline"] = cpu_baseline(model, a.size, a.templates)
         res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]

@@ -113,10 +113,11 @@ int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep
 /* Measurement aid (bench.py roofline leg, no reference counterpart): while enabled, every
  * launch of the implicit-GEMM conv kernel made by nope_unet_forward is bracketed by HIP events on
  * the caller's stream; _read synchronises them and returns the launch count, the summed kernel
- * time and the summed algorithmic flops (2*M*Cout*taps*Cin).  Adds two event records per launch:
+ * time, the summed executed flops (2*M*Cout*taps*Cin) and the summed algorithmic HBM bytes (each input,
+ * weight and output element once).  Adds two event records per launch:
  * keep it off in timed regions. */
 int nope_unet_profile(nope_unet* net, int enable);
-int nope_unet_profile_read(nope_unet* net, int* n_launches, double* total_ms, double* total_flops);
+int nope_unet_profile_read(nope_unet* net, int* n_launches, double* total_ms, double* total_flops, double* total_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * Operator-level entry points (NHWC activations of `dtype`), exported so that each block of

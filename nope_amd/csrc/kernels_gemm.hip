@@ -59,6 +59,7 @@ struct ConvParams {
     int Hm, Wm;                        // grid the GEMM rows enumerate: output grid, or the SOURCE grid for UP2P
     unsigned w_phase_bytes;            // UP2P: byte stride between the 4 phase weight sets
     float* colstats;                   // optional [M/64][Cout][2]: per 64-row block column sum / sum of squares
+    int ablate;                        // timing experiments only (NOPE_CONV_ABLATE): 1 no DMA, 2 no MFMA, 4 no epilogue
     unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
 };
 
@@ -613,8 +614,8 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
         for (int ks = 0; ks < nk; ++ks) {
             const int buf = ks & 1;
             __syncthreads();                       // stage ks landed (vmcnt drain) + everyone left stage ks-1
-            if (ks + 1 < nk) issue(buf ^ 1);
-            mma_stage<T, RB>(lds + buf * STAGE, lds + buf * STAGE + BM * RB, wm, wn, lane, acc);
+            if (ks + 1 < nk && !(p.ablate & 1)) issue(buf ^ 1);
+            if (!(p.ablate & 2)) mma_stage<T, RB>(lds + buf * STAGE, lds + buf * STAGE + BM * RB, wm, wn, lane, acc);
         }
     } else {
 #pragma unroll
@@ -634,7 +635,9 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
             buf = buf == NS - 1 ? 0 : buf + 1;
         }
     }
-    if (p.wide_out) {
+    if (p.ablate & 4) {
+        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;   // keep the accumulators live
+    } else if (p.wide_out) {
         __syncthreads();                       // every wave is done reading the last stage
         epilogue_wide<T>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
     } else {
@@ -701,6 +704,8 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     const bool dma = !a.force_generic && Cin % bk == 0 && (a.C2 == 0 || (a.C1 % bk == 0 && a.mode == NOPE_CONV_PLAIN)) &&
                      b1 < lim && b2 < lim && bw < lim;
     p.bytes1 = (unsigned)(dma ? b1 : 0); p.bytes2 = (unsigned)(dma ? b2 : 0); p.bytesw = (unsigned)(dma ? bw : 0);
+    static const int ablate = getenv("NOPE_CONV_ABLATE") ? atoi(getenv("NOPE_CONV_ABLATE")) : 0;
+    p.ablate = ablate;
     static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
     const bool deep = variant == 1;   // 64-byte rows x 4-stage ring (experimental)
     const dim3 grid((unsigned)nblocks, phased ? 4u : 1u), block(NT);

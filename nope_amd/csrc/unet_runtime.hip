@@ -53,7 +53,7 @@ struct nope_unet {
     float *emb_w = nullptr, *emb_b = nullptr;
     int emb_total = 0;
     // optional per-launch timing of the implicit-GEMM kernel (bench.py roofline leg)
-    struct Ev { hipEvent_t a, b; double flops; };
+    struct Ev { hipEvent_t a, b; double flops, bytes; };
     mutable bool profile = false;
     mutable std::vector<Ev> evs;
 };
@@ -174,6 +174,9 @@ struct Fwd {
             nope_unet::Ev ev;
             hipEventCreate(&ev.a); hipEventCreate(&ev.b);
             ev.flops = 2.0 * (double)n * Ho * Wo * c.Cout * c.ntaps * c.Cin;   // executed MACs (UP2P: 4 taps per output pixel)
+            // algorithmic HBM bytes: every input, weight and output element exactly once
+            ev.bytes = ((double)(n / rep1) * a.H * a.W * a.C + (b ? (double)(n / rep2) * a.H * a.W * b->C : 0.0) +
+                        (double)c.Cout * c.ntaps * c.Cin * (c.mode == NOPE_CONV_UP2P ? 4 : 1) + (double)n * Ho * Wo * c.Cout) * (double)es;
             hipEventRecord(ev.a, s);
             chk(launch_conv(net->dt, ca, s));
             hipEventRecord(ev.b, s);
@@ -515,16 +518,16 @@ int nope_unet_profile(nope_unet* net, int enable) {
     return NOPE_OK;
 }
 
-int nope_unet_profile_read(nope_unet* net, int* n_launches, double* total_ms, double* total_flops) {
-    if (!net || !n_launches || !total_ms || !total_flops) return NOPE_ERR_ARG;
-    double ms = 0.0, fl = 0.0;
+int nope_unet_profile_read(nope_unet* net, int* n_launches, double* total_ms, double* total_flops, double* total_bytes) {
+    if (!net || !n_launches || !total_ms || !total_flops || !total_bytes) return NOPE_ERR_ARG;
+    double ms = 0.0, fl = 0.0, by = 0.0;
     for (auto& e : net->evs) {
         if (hipEventSynchronize(e.b) != hipSuccess) return NOPE_ERR_LAUNCH;
         float t = 0.f;
         if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) return NOPE_ERR_LAUNCH;
-        ms += t; fl += e.flops;
+        ms += t; fl += e.flops; by += e.bytes;
     }
-    *n_launches = (int)net->evs.size(); *total_ms = ms; *total_flops = fl;
+    *n_launches = (int)net->evs.size(); *total_ms = ms; *total_flops = fl; *total_bytes = by;
     return NOPE_OK;
 }
 

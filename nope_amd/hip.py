@@ -41,7 +41,7 @@ _PROTOS = {
     "nope_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "nope_unet_forward": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "nope_unet_profile": (_i, [_vp, _i]),
-    "nope_unet_profile_read": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "nope_unet_profile_read": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nope_op_nchw_to_nhwc": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
     "nope_op_nhwc_to_nchw": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
     "nope_op_pack_conv_weight": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -212,10 +212,10 @@ class UNetHandle:
         self._l.check(self._l.dll.nope_unet_profile(self._h, int(enable)), "nope_unet_profile")
 
     def profile_read(self):
-        """(n_launches, total_ms, total_flops) of the conv-GEMM launches since profile(True)."""
-        n, ms, fl = _i(0), C.c_double(0), C.c_double(0)
-        self._l.check(self._l.dll.nope_unet_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(fl)), "profile_read")
-        return n.value, ms.value, fl.value
+        """(n_launches, total_ms, total_flops, total_bytes) of the conv-GEMM launches since profile(True)."""
+        n, ms, fl, by = _i(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        self._l.check(self._l.dll.nope_unet_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "profile_read")
+        return n.value, ms.value, fl.value, by.value
 
     def workspace_bytes(self, n_hyp: int, n_src: int, H: int, W: int) -> int:
         return int(self._l.dll.nope_unet_workspace_bytes(self._h, n_hyp, n_src, H, W))
