@@ -13,11 +13,19 @@
 // Tiling (64-wide wavefronts): 128 x 192 output tile per 256-thread workgroup, 4 waves as
 // 2(M) x 2(N), each wave 64 x 96 = 4 x 6 MFMA 16x16 tiles (96 accumulator VGPRs).  192
 // divides every Cout of the network (192/384/768/1536 and the 384-wide qkv).  K step = 128
-// bytes per row (64 bf16 / 32 f32), staged global -> VGPR -> LDS with the next step's global
-// loads in flight under the current step's MFMAs.  LDS rows are 128 B = 8 x 16-B slots,
-// XOR-swizzled by (row >> 1) & 7 so both the ds_write_b128 staging writes (8 consecutive
-// lanes = one row) and the ds_read_b128 fragment reads (16 rows x one slot per lane group)
-// are bank-conflict free (MI355X_MICROARCH.md, LDS table).
+// bytes per row (64 bf16 / 32 f32).  LDS rows are 128 B = 8 x 16-B slots, XOR-swizzled by
+// (row >> 1) & 7 so the ds_read_b128 fragment reads (16 rows x one slot per lane group) are
+// bank-conflict free (MI355X_MICROARCH.md, LDS table).
+//
+// Two kernels share the MFMA stage / epilogues:
+//   conv_gemm_dma_kernel  the fast path: LDS-DMA staging (buffer_load ... lds), two 40 KiB stages,
+//                         one barrier per K step; needs Cin (and C1 of a concat) to be a multiple of
+//                         the K step.  Used by every conv of the real network.
+//   conv_gemm_kernel      any channel count (global -> VGPR -> LDS staging): init conv (Cin = 8) and
+//                         the tiny nets of the parity tests.
+// Epilogue: accumulators (+bias) are staged per wave through LDS in f32 and written as 16-byte rows
+// (epilogue_wide); on the way the per-64-row-block column sums needed by the following GroupNorm are
+// emitted (colstats), so no separate statistics pass reads the tensor again.
 //
 // MFMA: bf16 -> v_mfma_f32_16x16x32_bf16; f32 -> v_mfma_f32_16x16x4_f32 (exact f32 fma
 // chain; gfx950 has no xf32).  For f32 each lane's 16-byte fragment holds 4 consecutive
@@ -25,8 +33,7 @@
 // chunk is permuted identically for A and W, which only reorders the fp32 sum.
 //
 // Workgroup -> tile map is XCD-aware: blocks that land on one XCD (blockIdx % 8) share the
-// weight panel (tile_n), so at the deep levels (8 N-tiles of 8 MB each) every XCD's L2
-// streams one panel instead of all eight.
+// weight panel (tile_n) and a contiguous run of M tiles (shared 3x3 halo rows stay in that L2).
 #include <cstdlib>
 
 #include "nope_common.h"
@@ -396,24 +403,19 @@ __device__ __forceinline__ void mma_stage(const unsigned char* ldsA, const unsig
     }
 }
 
-// s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
-template <int N> __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt((N & 15) | 0x0F70 | ((N >> 4) << 14)); }
-
-// RB = bytes of K per row per stage, NS = stages in the LDS ring (NS - 1 of them in flight).
-//   <128, 2>: two 40 KiB stages, one plain barrier per stage.
-//   < 64, 4>: four 20 KiB stages; loads run three stages ahead behind COUNTED vmcnt + a raw s_barrier, so
-//             60 of the 80 KiB are in flight instead of 40 (same LDS, 1.5x the bytes in flight).
-template <class T, int MODE, int RB, int NS, bool IL>
-__global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
+// RB = bytes of K per row per stage (128), NS = LDS stages (2), BMT = tile rows (128: 4 waves, 256: 8 waves).
+template <class T, int MODE, int RB, int NS, int BMT>
+__global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p) {
     constexpr int VEC = Elt<T>::VEC;
     constexpr unsigned ES = (unsigned)sizeof(T);
     constexpr int BK = RB / (int)ES;
-    constexpr int STAGE = (BM + BN) * RB;
+    constexpr int STAGE = (BMT + BN) * RB;
     constexpr int RPI = 1024 / RB;              // tile rows filled by one wave instruction
     constexpr int SPR = RB / 16;                // 16-byte slots per row
-    constexpr int AI = BM / RPI / 4, BI = BN / RPI / 4;   // DMA instructions per wave per stage
+    constexpr int NW = BMT / 32;                  // waves: (BMT/64) along M x 2 along N, 64x96 each
+    constexpr int AI = BMT / RPI / NW, BI = BN / RPI / NW;   // DMA instructions per wave per stage
     constexpr int L = AI + BI;
-    static_assert(NS * STAGE >= 4 * EP_WAVE_BYTES, "epilogue panels must fit in the ring");
+    static_assert(NS * STAGE >= NW * EP_WAVE_BYTES, "epilogue panels must fit in the ring");
     static_assert(AI <= 4 && BI <= 6, "row bookkeeping arrays");
     __shared__ __attribute__((aligned(16))) unsigned char lds[NS * STAGE];
 
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     int tile_m, tile_n;
     tile_coords(p, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * BMT, n0 = tile_n * BN;
     const int HWo = p.Hm * p.Wm;
     const int Cin = p.C1 + p.C2;
     const int ph_y = MODE == NOPE_CONV_UP2P ? ((int)blockIdx.y >> 1) : 0, ph_x = MODE == NOPE_CONV_UP2P ? ((int)blockIdx.y & 1) : 0;
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
     int st_dyi = 1, st_dxi = 1;
     auto step_begin = [&](int buf) {
         st_dA = lds + buf * STAGE + (AI * wave) * 1024;
-        st_dB = lds + buf * STAGE + BM * RB + (BI * wave) * 1024;
+        st_dB = lds + buf * STAGE + BMT * RB + (BI * wave) * 1024;
         const int c0 = ld_kc * BK;
         st_first = c0 < p.C1;                  // wave-uniform: a K step lies inside one source
         const int Cs = st_first ? p.C1 : p.C2;
@@ -560,79 +562,13 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (NS == 2 && IL && RB == 128) {
-        // Interleaved schedule: the next stage's 10 LDS-DMA instructions are spread between four groups of 12
-        // MFMAs (pinned with sched_barrier), so a wave's address math + DMA issue runs under its OWN MFMAs
-        // instead of in front of them.
-        issue(0);
-        for (int ks = 0; ks < nk; ++ks) {
-            const int buf = ks & 1;
-            __syncthreads();
-            const bool more = ks + 1 < nk;
-            const unsigned char* tA = lds + buf * STAGE;
-            const unsigned char* tB = tA + BM * RB;
-            u32x4 af0[MT], bf0[NTL], af1[MT], bf1[NTL];
-            const int s0 = lane >> 4, s1 = 4 + (lane >> 4);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af0[i] = ld16(tA + lds_off_rb<RB>(wm * 64 + i * 16 + (lane & 15), s0));
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) bf0[j] = ld16(tB + lds_off_rb<RB>(wn * 96 + j * 16 + (lane & 15), s0));
-            if (more) { step_begin(buf ^ 1); step_a(0); step_a(1); }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NTL; ++j) Mma<T>::run(af0[i], bf0[j], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) { step_a(2); step_a(3); }
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af1[i] = ld16(tA + lds_off_rb<RB>(wm * 64 + i * 16 + (lane & 15), s1));
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) bf1[j] = ld16(tB + lds_off_rb<RB>(wn * 96 + j * 16 + (lane & 15), s1));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 2; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NTL; ++j) Mma<T>::run(af0[i], bf0[j], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) { step_b(0); step_b(1); step_b(2); }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NTL; ++j) Mma<T>::run(af1[i], bf1[j], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) { step_b(3); step_b(4); step_b(5); step_end(); }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 2; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NTL; ++j) Mma<T>::run(af1[i], bf1[j], acc[i][j]);
-        }
-    } else if (NS == 2) {
+    if (NS == 2) {
         issue(0);
         for (int ks = 0; ks < nk; ++ks) {
             const int buf = ks & 1;
             __syncthreads();                       // stage ks landed (vmcnt drain) + everyone left stage ks-1
             if (ks + 1 < nk && !(p.ablate & 1)) issue(buf ^ 1);
-            if (!(p.ablate & 2)) mma_stage<T, RB>(lds + buf * STAGE, lds + buf * STAGE + BM * RB, wm, wn, lane, acc);
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < NS - 1; ++s)
-            if (s < nk) issue(s);
-        int buf = 0;
-        for (int ks = 0; ks < nk; ++ks) {
-            // this wave's loads of stage ks have landed once at most L * (stages issued after ks) remain
-            const int after = nk - 1 - ks;
-            if (after >= NS - 2) wait_vmcnt<L * (NS - 2)>();
-            else if (after == 1) wait_vmcnt<L>();
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();          // ... and every wave's have; everyone also left stage ks-1
-            const int nxt = buf == 0 ? NS - 1 : buf - 1;   // ring slot of stage ks-1 == slot of stage ks+NS-1
-            if (ks + NS - 1 < nk) issue(nxt);
-            mma_stage<T, RB>(lds + buf * STAGE, lds + buf * STAGE + BM * RB, wm, wn, lane, acc);
-            buf = buf == NS - 1 ? 0 : buf + 1;
+            if (!(p.ablate & 2)) mma_stage<T, RB>(lds + buf * STAGE, lds + buf * STAGE + BMT * RB, wm, wn, lane, acc);
         }
     }
     if (p.ablate & 4) {
@@ -645,12 +581,12 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_dma_kernel(ConvParams p) {
     }
 }
 
-template <class T, int RB, int NS, bool IL>
+template <class T, int RB, int NS, int BMT>
 void launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
-    if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, IL>), grid, dim3(NT), 0, s, p);
-    else if (p.mode == NOPE_CONV_UP2) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2, RB, NS, IL>), grid, dim3(NT), 0, s, p);
-    else if (p.mode == NOPE_CONV_UP2P) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2P, RB, NS, IL>), grid, dim3(NT), 0, s, p);
-    else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_DOWN2, RB, NS, IL>), grid, dim3(NT), 0, s, p);
+    if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT>), grid, dim3(BMT * 2), 0, s, p);
+    else if (p.mode == NOPE_CONV_UP2) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2, RB, NS, BMT>), grid, dim3(BMT * 2), 0, s, p);
+    else if (p.mode == NOPE_CONV_UP2P) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2P, RB, NS, BMT>), grid, dim3(BMT * 2), 0, s, p);
+    else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_DOWN2, RB, NS, BMT>), grid, dim3(BMT * 2), 0, s, p);
 }
 
 }  // namespace
@@ -684,14 +620,9 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.w = (const unsigned char*)a.w; p.bias = a.bias; p.resid = (const unsigned char*)a.resid;
     p.out = (unsigned char*)a.out; p.Cout = a.Cout; p.M = (int)M;
     p.out_nchw = a.out_nchw; p.out_dt = a.out_dt;
-    p.tiles_m = cdiv((int)M, BM); p.tiles_n = cdiv(a.Cout, BN);
-    const int tn = p.tiles_n;
-    p.xcd_map = (tn == 1 || tn == 2 || tn == 4 || tn == 8) && (p.tiles_m % (8 / tn) == 0) ? 1 : 0;
     p.wide_out = (!a.out_nchw && a.Cout % vec == 0) ? 1 : 0;
     p.colstats = a.colstats;
     if (a.colstats && (!p.wide_out || M % 64 != 0 || phased || a.resid)) return NOPE_ERR_ARG;
-    const long long nblocks = (long long)p.tiles_m * p.tiles_n;
-    if (nblocks > 0x7fffffffLL) return NOPE_ERR_UNSUPPORTED;
     // LDS-DMA kernel when a K step (128 B of channels) never straddles sources and 32-bit offsets suffice
     const int es = dt == NOPE_F32 ? 4 : 2;
     const int bk = 8 * vec;
@@ -706,18 +637,23 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.bytes1 = (unsigned)(dma ? b1 : 0); p.bytes2 = (unsigned)(dma ? b2 : 0); p.bytesw = (unsigned)(dma ? bw : 0);
     static const int ablate = getenv("NOPE_CONV_ABLATE") ? atoi(getenv("NOPE_CONV_ABLATE")) : 0;
     p.ablate = ablate;
+    // NOPE_CONV_VARIANT=4 selects the 256x192 / 8-wave tile (measured on par with the default 128x192 / 4-wave
+    // tile in round 1; kept for tuning, see DESIGN.md section 4 for the other variants that were tried).
     static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
-    const bool deep = variant == 1;   // 64-byte rows x 4-stage ring (experimental)
+    const int bm = (dma && variant == 4 && M >= 256 * 256) ? 256 : BM;
+    p.tiles_m = cdiv((int)M, bm); p.tiles_n = cdiv(a.Cout, BN);
+    const int tn = p.tiles_n;
+    p.xcd_map = (tn == 1 || tn == 2 || tn == 4 || tn == 8) && (p.tiles_m % (8 / tn) == 0) ? 1 : 0;
+    const long long nblocks = (long long)p.tiles_m * p.tiles_n;
+    if (nblocks > 0x7fffffffLL) return NOPE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)nblocks, phased ? 4u : 1u), block(NT);
     if (dt == NOPE_F32) {
-        if (dma && deep) launch_dma<float, 64, 4, false>(p, grid, s);
-        else if (dma && variant == 2) launch_dma<float, 128, 2, true>(p, grid, s);
-        else if (dma) launch_dma<float, 128, 2, false>(p, grid, s);
+        if (dma && bm == 256) launch_dma<float, 128, 2, 256>(p, grid, s);
+        else if (dma) launch_dma<float, 128, 2, 128>(p, grid, s);
         else hipLaunchKernelGGL((conv_gemm_kernel<float>), grid, block, 0, s, p);
     } else {
-        if (dma && deep) launch_dma<bf16_t, 64, 4, false>(p, grid, s);
-        else if (dma && variant == 2) launch_dma<bf16_t, 128, 2, true>(p, grid, s);
-        else if (dma) launch_dma<bf16_t, 128, 2, false>(p, grid, s);
+        if (dma && bm == 256) launch_dma<bf16_t, 128, 2, 256>(p, grid, s);
+        else if (dma) launch_dma<bf16_t, 128, 2, 128>(p, grid, s);
         else hipLaunchKernelGGL((conv_gemm_kernel<bf16_t>), grid, block, 0, s, p);
     }
     NOPE_CHECK_LAUNCH();
