@@ -48,8 +48,6 @@ constexpr int NT = 256;
 constexpr int ROWB = 128;  // bytes per LDS row
 constexpr int A_ITERS = BM / 32;
 constexpr int B_ITERS = BN / 32;
-constexpr int MT = 4;  // 16-row tiles per wave (64 rows)
-constexpr int NTL = 6; // 16-col tiles per wave (96 cols)
 
 struct ConvParams {
     const unsigned char* src1; const unsigned char* src2;
@@ -70,21 +68,38 @@ struct ConvParams {
     unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
 };
 
-template <class T> struct Mma;
-template <> struct Mma<bf16_t> {
-    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
-        f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// MFMA tile of a wave's 64 x 96 output block, per element type.
+//   f32 : v_mfma_f32_16x16x4_f32  -- 4 x 6 tiles, a lane's 16-byte fragment = 4 channels = 4 chained steps
+//   bf16: v_mfma_f32_32x32x16_bf16 -- 2 x 3 tiles (the 32x32 form sustains ~15 % more than 16x16x32 on gfx950:
+//         2382 vs 2075 TFLOP/s, cdna_hip_programming.md section 3), a lane's fragment = 8 channels = 1 step
+// frag_row / frag_slot: which tile row and 16-byte K slot a lane feeds; out_row / out_col: the C/D map.
+template <class T> struct Tile;
+template <> struct Tile<float> {
+    static constexpr int TM = 16, MT = 4, NTL = 6, R = 4, KSLOTS = 4;
+    typedef f32x4 acc_t;
+    static __device__ __forceinline__ int frag_row(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int frag_slot(int lane) { return lane >> 4; }
+    static __device__ __forceinline__ int out_row(int lane, int r) { return (lane >> 4) * 4 + r; }
+    static __device__ __forceinline__ int out_col(int lane) { return lane & 15; }
+    static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, acc_t& c) {
+        const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], c, 0, 0, 0);
     }
 };
-
-__device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
+template <> struct Tile<bf16_t> {
+    static constexpr int TM = 32, MT = 2, NTL = 3, R = 16, KSLOTS = 2;
+    typedef f32x16 acc_t;
+    static __device__ __forceinline__ int frag_row(int lane) { return lane & 31; }
+    static __device__ __forceinline__ int frag_slot(int lane) { return lane >> 5; }
+    static __device__ __forceinline__ int out_row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+    static __device__ __forceinline__ int out_col(int lane) { return lane & 31; }
+    static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, acc_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
 
 __device__ __forceinline__ void tile_coords(const ConvParams& p, int& tile_m, int& tile_n) {
     const int g = blockIdx.x;
@@ -101,22 +116,28 @@ __device__ __forceinline__ void tile_coords(const ConvParams& p, int& tile_m, in
     }
 }
 
-// One K step (128 bytes of K per row) of the 64x96 wave tile from swizzled LDS tiles.
-template <class T>
-__device__ __forceinline__ void mma_step(const unsigned char* ldsA, const unsigned char* ldsB, int wm, int wn, int lane,
-                                         f32x4 (&acc)[MT][NTL]) {
+// Row geometry of a staged tile: RB bytes of K per row, 16-byte slots XOR-swizzled so that the rows x one slot
+// of a ds_read_b128 lane group hit different bank positions (for both the 16- and the 32-row fragment shapes).
+template <int RB> __device__ __forceinline__ int swz_of(int row) { return RB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+template <int RB> __device__ __forceinline__ int lds_off_rb(int row, int slot) { return row * RB + ((slot ^ swz_of<RB>(row)) << 4); }
+
+// One K stage (RB bytes of K per row) of the 64 x 96 wave tile from the swizzled LDS tiles.
+template <class T, int RB>
+__device__ __forceinline__ void mma_stage(const unsigned char* ldsA, const unsigned char* ldsB, int wm, int wn, int lane,
+                                          typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL]) {
+    typedef Tile<T> TL;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        u32x4 af[MT], bfr[NTL];
-        const int s = kk * 4 + (lane >> 4);
+    for (int kk = 0; kk < RB / 16 / TL::KSLOTS; ++kk) {
+        u32x4 af[TL::MT], bfr[TL::NTL];
+        const int s = kk * TL::KSLOTS + TL::frag_slot(lane);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = ld16(ldsA + lds_off(wm * 64 + i * 16 + (lane & 15), s));
+        for (int i = 0; i < TL::MT; ++i) af[i] = ld16(ldsA + lds_off_rb<RB>(wm * 64 + i * TL::TM + TL::frag_row(lane), s));
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) bfr[j] = ld16(ldsB + lds_off(wn * 96 + j * 16 + (lane & 15), s));
+        for (int j = 0; j < TL::NTL; ++j) bfr[j] = ld16(ldsB + lds_off_rb<RB>(wn * 96 + j * TL::TM + TL::frag_row(lane), s));
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+            for (int j = 0; j < TL::NTL; ++j) TL::mma(af[i], bfr[j], acc[i][j]);
     }
 }
 
@@ -134,25 +155,27 @@ __device__ __forceinline__ size_t out_row(const ConvParams& p, int m) {
 
 // C/D map of the 16x16 MFMA tiles: col = lane & 15, row = (lane >> 4) * 4 + r
 template <class T>
-__device__ __forceinline__ void epilogue(const ConvParams& p, const f32x4 (&acc)[MT][NTL], int m0, int n0, int wm, int wn, int lane) {
+__device__ __forceinline__ void epilogue(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL], int m0,
+                                         int n0, int wm, int wn, int lane) {
     // Every index into acc must stay a compile-time constant (full unroll): a runtime index would move the
     // accumulators to scratch for the WHOLE kernel.  Row bookkeeping (incl. the divisions) is hoisted to
     // once per (i, r).
+    typedef Tile<T> TL;
     const int HWo = p.Ho * p.Wo;
     T* out = reinterpret_cast<T*>(p.out);
     const T* resid = reinterpret_cast<const T*>(p.resid);
-    float bv[NTL];
-    int ncol[NTL];
+    float bv[TL::NTL];
+    int ncol[TL::NTL];
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) {
-        ncol[j] = n0 + wn * 96 + j * 16 + (lane & 15);
+    for (int j = 0; j < TL::NTL; ++j) {
+        ncol[j] = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
         bv[j] = (p.bias && ncol[j] < p.Cout) ? p.bias[ncol[j]] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < TL::MT; ++i) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        for (int r = 0; r < TL::R; ++r) {
+            const int m = m0 + wm * 64 + i * TL::TM + TL::out_row(lane, r);
             const bool row_ok = m < p.M;
             const size_t mo = out_row(p, row_ok ? m : 0);
             size_t nchw_base = 0;
@@ -162,7 +185,7 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const f32x4 (&acc)
                 nchw_base = (size_t)b * p.Cout * HWo + (mm - b * HWo);
             }
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) {
+            for (int j = 0; j < TL::NTL; ++j) {
                 const int n = ncol[j];
                 if (!row_ok || n >= p.Cout) continue;
                 float v = acc[i][j][r] + bv[j];
@@ -179,42 +202,46 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const f32x4 (&acc)
     }
 }
 
-// Wide-store epilogue (NHWC output, Cout % VEC == 0).  The MFMA C/D layout gives a lane one
-// column x 4 rows per 16x16 tile, i.e. 2-byte scattered stores; instead each wave stages its 64x96
-// f32 accumulators (+bias) through its private 64 x 52-word LDS panel, 48 columns at a time, and
-// writes rows back as 16-byte vectors (residual added in f32 before the single rounding to T).
-// Row stride 52 words: the two 16-lane row segments of a ds_write_b32 half-wave land 16 banks apart.
+// Wide-store epilogue (NHWC output, Cout % VEC == 0).  The MFMA C/D layout gives a lane one column x a few
+// rows per tile, i.e. 2-byte scattered stores; instead each wave stages its 64 x 96 f32 accumulators (+bias)
+// through its private 64 x 52-word LDS panel, PANW columns at a time (48 = three 16-wide tiles for f32, 32 =
+// one 32-wide tile for bf16), and writes rows back as 16-byte vectors (residual added in f32 before the
+// single rounding to T).  On the way it emits the per-column sums the following GroupNorm needs.
 constexpr int EP_LD = 52;
 constexpr int EP_WAVE_BYTES = 64 * EP_LD * 4;
 
 template <class T>
-__device__ __forceinline__ void epilogue_wide(const ConvParams& p, const f32x4 (&acc)[MT][NTL], int m0, int n0, int wm, int wn,
-                                              int lane, unsigned char* lds_wave) {
+__device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL],
+                                              int m0, int n0, int wm, int wn, int lane, unsigned char* lds_wave) {
+    typedef Tile<T> TL;
     constexpr int VEC = Elt<T>::VEC;
-    constexpr int CH = 48 / VEC;                // 16-byte output chunks per 48-column row (6 bf16 / 12 f32)
+    constexpr int PANW = TL::TM == 32 ? 32 : 48;   // panel width in columns
+    constexpr int TPP = PANW / TL::TM;             // MFMA tiles per panel pass
+    constexpr int CH = PANW / VEC;                 // 16-byte output chunks per panel row
     float* pan = reinterpret_cast<float*>(lds_wave);
     T* out = reinterpret_cast<T*>(p.out);
     const T* resid = reinterpret_cast<const T*>(p.resid);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int pass = 0; pass < 96 / PANW; ++pass) {
 #pragma unroll
-        for (int jj = 0; jj < 3; ++jj) {
-            const int j = half * 3 + jj;
-            const int n = n0 + wn * 96 + j * 16 + (lane & 15);
+        for (int jj = 0; jj < TPP; ++jj) {
+            const int j = pass * TPP + jj;
+            const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
             const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pan[(i * 16 + (lane >> 4) * 4 + r) * EP_LD + jj * 16 + (lane & 15)] = acc[i][j][r] + bv;
+                for (int r = 0; r < TL::R; ++r)
+                    pan[(i * TL::TM + TL::out_row(lane, r)) * EP_LD + jj * TL::TM + TL::out_col(lane)] = acc[i][j][r] + bv;
         }
         // same-wave LDS write -> read: the LDS queue of a wave is in order, so no s_barrier; the wave
         // barrier only pins the compiler's ordering (and is the rendezvous point of tests/hipemu)
         __builtin_amdgcn_wave_barrier();
-        if (p.colstats && lane < 48) {
+        if (p.colstats && lane < PANW) {
             // GroupNorm statistics of the conv output, fused: this wave's 64 rows x one column per lane
             // (f32, before the rounding to T); every [row block][column] entry has exactly one writer, so the
             // later fold is deterministic.  Requires M % 64 == 0 (checked by the launcher).
-            const int n = n0 + wn * 96 + half * 48 + lane;
+            const int n = n0 + wn * 96 + pass * PANW + lane;
             if (n < p.Cout) {
                 float s = 0.f, q = 0.f;
 #pragma unroll 8
@@ -226,7 +253,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const f32x4 (
         for (int idx = lane; idx < 64 * CH; idx += 64) {
             const int row = idx / CH, ch = idx - row * CH;
             const int m = m0 + wm * 64 + row;
-            const int n = n0 + wn * 96 + half * 48 + ch * VEC;
+            const int n = n0 + wn * 96 + pass * PANW + ch * VEC;
             if (m >= p.M || n >= p.Cout) continue;
             float v[VEC];
 #pragma unroll
@@ -347,21 +374,23 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
         if (++ld_kc == kc_per_tap) { ld_kc = 0; ++ld_tap; }
     };
 
-    f32x4 acc[MT][NTL];
+    typename Tile<T>::acc_t acc[Tile<T>::MT][Tile<T>::NTL];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < Tile<T>::MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < Tile<T>::NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < Tile<T>::R; ++r) acc[i][j][r] = 0.f;
 
     load_step();
     for (int ks = 0; ks < nk; ++ks) {
 #pragma unroll
-        for (int i = 0; i < A_ITERS; ++i) st16(ldsA + lds_off(rbase + 32 * i, slot), ra[i]);
+        for (int i = 0; i < A_ITERS; ++i) st16(ldsA + lds_off_rb<ROWB>(rbase + 32 * i, slot), ra[i]);
 #pragma unroll
-        for (int j = 0; j < B_ITERS; ++j) st16(ldsB + lds_off(rbase + 32 * j, slot), rb[j]);
+        for (int j = 0; j < B_ITERS; ++j) st16(ldsB + lds_off_rb<ROWB>(rbase + 32 * j, slot), rb[j]);
         __syncthreads();
         if (ks + 1 < nk) load_step();   // global loads for step ks+1 fly under the MFMAs below
-        mma_step<T>(ldsA, ldsB, wm, wn, lane, acc);
+        mma_stage<T, ROWB>(ldsA, ldsB, wm, wn, lane, acc);
         __syncthreads();
     }
     if (p.wide_out) epilogue_wide<T>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
@@ -379,29 +408,6 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
 // step k+1 fly under the MFMAs of step k, and nothing passes through VGPRs or ds_write.
 typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr unsigned OOB = 0x80000000u;   // >= any num_records (tensors < 2 GiB); stays out of range after adding a K offset
-
-// Row geometry of a staged tile: RB bytes of K per row (128 or 64), 16-byte slots XOR-swizzled so that
-// the 16 rows x one slot of a ds_read_b128 lane group hit 16 different bank positions.
-template <int RB> __device__ __forceinline__ int swz_of(int row) { return RB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
-template <int RB> __device__ __forceinline__ int lds_off_rb(int row, int slot) { return row * RB + ((slot ^ swz_of<RB>(row)) << 4); }
-
-template <class T, int RB>
-__device__ __forceinline__ void mma_stage(const unsigned char* ldsA, const unsigned char* ldsB, int wm, int wn, int lane,
-                                          f32x4 (&acc)[MT][NTL]) {
-#pragma unroll
-    for (int kk = 0; kk < RB / 64; ++kk) {
-        u32x4 af[MT], bfr[NTL];
-        const int s = kk * 4 + (lane >> 4);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = ld16(ldsA + lds_off_rb<RB>(wm * 64 + i * 16 + (lane & 15), s));
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) bfr[j] = ld16(ldsB + lds_off_rb<RB>(wn * 96 + j * 16 + (lane & 15), s));
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
-    }
-}
 
 // RB = bytes of K per row per stage (128), NS = LDS stages (2), BMT = tile rows (128: 4 waves, 256: 8 waves).
 template <class T, int MODE, int RB, int NS, int BMT>
@@ -556,11 +562,13 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
         step_end();
     };
 
-    f32x4 acc[MT][NTL];
+    typename Tile<T>::acc_t acc[Tile<T>::MT][Tile<T>::NTL];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < Tile<T>::MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < Tile<T>::NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < Tile<T>::R; ++r) acc[i][j][r] = 0.f;
 
     if (NS == 2) {
         issue(0);
