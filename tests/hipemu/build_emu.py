@@ -28,7 +28,7 @@ def build(force: bool = False) -> str:
             os.path.join(HERE, "include", "hip", "hip_runtime.h")]
     flags = ["-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-I", os.path.join(HERE, "include"),
              "-Wno-unused-value", "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-Wno-unknown-pragmas",
-             "-Wno-pass-failed"]
+             "-Wno-pass-failed", "-Wno-psabi"]
 
     def one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))

@@ -213,6 +213,31 @@ def test_tiny_unet_vs_reference_golden(be, golden, tag, dim, mlp):
             assert rel(yh, want) < tol
 
 
+def test_unet_ragged_shapes_and_chunked_templates(be):
+    """Non-square latent, a template count that is not a multiple of anything, several reference images,
+    and PoseConditional's chunking (max_hypotheses_per_launch smaller than N, and smaller than B*N)."""
+    hip, dev, name = be
+    from nope_amd.model import PoseConditional
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    u = UNet(u_net_dim=8, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer")
+    synth_init_(u, 2022)
+    sd = {k: v.clone() for k, v in u.own_state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    B, N, h, w = 2, 5, 8, 16
+    ref_feat, poses = torch.randn(B, 8, h, w, generator=g), torch.randn(B, N, 6, generator=g)
+    want = R.generate_templates(sd, ref_feat, poses)
+    for max_hyp in ((512, 7, 3) if name == "gpu" else (3,)):     # one launch / per-b launches / chunks along N
+        m = PoseConditional(u, None, {"similarity_metric": "l2"}, None, max_hypotheses_per_launch=max_hyp).to(dev)
+        bank = m.generate_templates_from_feat(ref_feat.to(dev), poses.to(dev))
+        assert bank.shape == (B, N, 8, h, w)
+        assert rel(bank.cpu(), want) < F32_TOL, max_hyp
+    q = torch.randn(B, 8, h, w, generator=g)
+    sim, idx = m.retrieval_from_feat(q.to(dev), bank)
+    ws, wi = R.retrieval(q, want)
+    assert rel(sim.cpu(), ws) < F32_TOL and torch.equal(idx.cpu(), wi)
+
+
 def test_retrieval_vs_reference_golden(be, golden):
     hip, dev, _ = be
     g = golden("retrieval.npz")
