@@ -64,6 +64,7 @@ struct ConvParams {
     int Hm, Wm;                        // grid the GEMM rows enumerate: output grid, or the SOURCE grid for UP2P
     unsigned w_phase_bytes;            // UP2P: byte stride between the 4 phase weight sets
     float* colstats;                   // optional [M/64][Cout][2]: per 64-row block column sum / sum of squares
+    const float* pn_ms; const float* pn_c0; const float* pn_c1;   // optional fused PreNorm (see ConvArgs)
     int ablate;                        // timing experiments only (NOPE_CONV_ABLATE): 1 no DMA, 2 no MFMA, 4 no epilogue
     unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
 };
@@ -154,7 +155,7 @@ __device__ __forceinline__ size_t out_row(const ConvParams& p, int m) {
 }
 
 // C/D map of the 16x16 MFMA tiles: col = lane & 15, row = (lane >> 4) * 4 + r
-template <class T>
+template <class T, bool PN>
 __device__ __forceinline__ void epilogue(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL], int m0,
                                          int n0, int wm, int wn, int lane) {
     // Every index into acc must stay a compile-time constant (full unroll): a runtime index would move the
@@ -178,6 +179,8 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const typename Til
             const int m = m0 + wm * 64 + i * TL::TM + TL::out_row(lane, r);
             const bool row_ok = m < p.M;
             const size_t mo = out_row(p, row_ok ? m : 0);
+            float pn_mean = 0.f, pn_rstd = 1.f;
+            if (PN) { const int b = (row_ok ? m : 0) / (p.Hm * p.Wm); pn_mean = p.pn_ms[2 * b]; pn_rstd = p.pn_ms[2 * b + 1]; }
             size_t nchw_base = 0;
             if (p.out_nchw) {
                 const int mm = row_ok ? m : 0;
@@ -189,6 +192,7 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const typename Til
                 const int n = ncol[j];
                 if (!row_ok || n >= p.Cout) continue;
                 float v = acc[i][j][r] + bv[j];
+                if (PN) v = pn_rstd * (acc[i][j][r] - pn_mean * p.pn_c1[n]) + p.pn_c0[n] + bv[j];
                 if (resid) v += Elt<T>::ld(resid + mo * p.Cout + n);
                 if (p.out_nchw) {
                     const size_t o = nchw_base + (size_t)n * HWo;
@@ -210,7 +214,7 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const typename Til
 constexpr int EP_LD = 52;
 constexpr int EP_WAVE_BYTES = 64 * EP_LD * 4;
 
-template <class T>
+template <class T, bool PN>
 __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL],
                                               int m0, int n0, int wm, int wn, int lane, unsigned char* lds_wave) {
     typedef Tile<T> TL;
@@ -250,6 +254,29 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                 cs[0] = s; cs[1] = q;
             }
         }
+        // Fused PreNorm operands, hoisted out of the chunk loop where they are loop-invariant: with 64 % CH == 0
+        // a lane keeps the same column chunk for the whole pass, and with HW % 64 == 0 the wave's 64 rows are
+        // one sample (one mean / rstd).
+        constexpr bool PN_COLS_FIXED = PN && (64 % CH == 0);
+        float pc0[VEC], pc1[VEC];
+        float pmean = 0.f, prstd = 1.f;
+        const bool pn_row_uniform = PN && ((p.Hm * p.Wm) % 64 == 0);
+        if (PN) {
+            if (PN_COLS_FIXED) {
+                const int nn = n0 + wn * 96 + pass * PANW + (lane % CH) * VEC;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const bool okc = nn + e < p.Cout;
+                    const float bias_e = (p.bias && okc) ? p.bias[nn + e] : 0.f;
+                    pc1[e] = okc ? p.pn_c1[nn + e] : 0.f;
+                    pc0[e] = (okc ? p.pn_c0[nn + e] : 0.f) + bias_e;     // v = rstd*(pan - bias - mean*c1) + c0 + bias
+                }
+            }
+            if (pn_row_uniform) {
+                const int b = (m0 + wm * 64 < p.M ? m0 + wm * 64 : 0) / (p.Hm * p.Wm);
+                pmean = p.pn_ms[2 * b]; prstd = p.pn_ms[2 * b + 1];
+            }
+        }
         for (int idx = lane; idx < 64 * CH; idx += 64) {
             const int row = idx / CH, ch = idx - row * CH;
             const int m = m0 + wm * 64 + row;
@@ -261,6 +288,20 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                 const f32x4 t = *reinterpret_cast<const f32x4*>(&pan[row * EP_LD + ch * VEC + q * 4]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[q * 4 + e] = t[e];
+            }
+            if (PN) {   // fused PreNorm: v = rstd_b * (acc - mean_b * c1[n]) + c0[n] (+ bias; the panel holds acc + bias)
+                float mean = pmean, rstd = prstd;
+                if (!pn_row_uniform) { const int b = m / (p.Hm * p.Wm); mean = p.pn_ms[2 * b]; rstd = p.pn_ms[2 * b + 1]; }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    if (PN_COLS_FIXED) {
+                        const float bias_e = p.bias ? p.bias[n + e] : 0.f;   // (qkv has no bias: folds away)
+                        v[e] = rstd * (v[e] - bias_e - mean * pc1[e]) + pc0[e];
+                    } else {
+                        const float bias_e = p.bias ? p.bias[n + e] : 0.f;
+                        v[e] = rstd * (v[e] - bias_e - mean * p.pn_c1[n + e]) + p.pn_c0[n + e] + bias_e;
+                    }
+                }
             }
             const size_t o = out_row(p, m) * p.Cout + n;
             if (resid) {
@@ -298,7 +339,7 @@ __device__ __forceinline__ void tap_delta(const ConvParams& p, int tap, int& dy,
 }
 
 // ---- generic kernel: global -> VGPR -> LDS staging, any channel counts ----------------------------
-template <class T>
+template <class T, bool PN>
 __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
     constexpr int VEC = Elt<T>::VEC;
     constexpr int BK = 8 * VEC;
@@ -393,8 +434,13 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
         mma_stage<T, ROWB>(ldsA, ldsB, wm, wn, lane, acc);
         __syncthreads();
     }
-    if (p.wide_out) epilogue_wide<T>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
-    else epilogue<T>(p, acc, m0, n0, wm, wn, lane);
+    if (PN) {
+        if (p.wide_out) epilogue_wide<T, true>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
+        else epilogue<T, true>(p, acc, m0, n0, wm, wn, lane);
+    } else {
+        if (p.wide_out) epilogue_wide<T, false>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
+        else epilogue<T, false>(p, acc, m0, n0, wm, wn, lane);
+    }
 }
 
 // ---- fast kernel: LDS-DMA staging (buffer_load ... lds, 16 B per lane), double-buffered ------------
@@ -410,7 +456,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr unsigned OOB = 0x80000000u;   // >= any num_records (tensors < 2 GiB); stays out of range after adding a K offset
 
 // RB = bytes of K per row per stage (128), NS = LDS stages (2), BMT = tile rows (128: 4 waves, 256: 8 waves).
-template <class T, int MODE, int RB, int NS, int BMT>
+template <class T, int MODE, int RB, int NS, int BMT, bool PN>
 __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p) {
     constexpr int VEC = Elt<T>::VEC;
     constexpr unsigned ES = (unsigned)sizeof(T);
@@ -583,18 +629,19 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;   // keep the accumulators live
     } else if (p.wide_out) {
         __syncthreads();                       // every wave is done reading the last stage
-        epilogue_wide<T>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
+        epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
     } else {
-        epilogue<T>(p, acc, m0, n0, wm, wn, lane);
+        epilogue<T, PN>(p, acc, m0, n0, wm, wn, lane);
     }
 }
 
 template <class T, int RB, int NS, int BMT>
 void launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
-    if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT>), grid, dim3(BMT * 2), 0, s, p);
-    else if (p.mode == NOPE_CONV_UP2) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2, RB, NS, BMT>), grid, dim3(BMT * 2), 0, s, p);
-    else if (p.mode == NOPE_CONV_UP2P) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2P, RB, NS, BMT>), grid, dim3(BMT * 2), 0, s, p);
-    else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_DOWN2, RB, NS, BMT>), grid, dim3(BMT * 2), 0, s, p);
+    if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT, true>), grid, dim3(BMT * 2), 0, s, p);   // 1x1 only
+    else if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT, false>), grid, dim3(BMT * 2), 0, s, p);
+    else if (p.mode == NOPE_CONV_UP2) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2, RB, NS, BMT, false>), grid, dim3(BMT * 2), 0, s, p);
+    else if (p.mode == NOPE_CONV_UP2P) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2P, RB, NS, BMT, false>), grid, dim3(BMT * 2), 0, s, p);
+    else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_DOWN2, RB, NS, BMT, false>), grid, dim3(BMT * 2), 0, s, p);
 }
 
 }  // namespace
@@ -630,6 +677,8 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.out_nchw = a.out_nchw; p.out_dt = a.out_dt;
     p.wide_out = (!a.out_nchw && a.Cout % vec == 0) ? 1 : 0;
     p.colstats = a.colstats;
+    p.pn_ms = a.pn_ms; p.pn_c0 = a.pn_c0; p.pn_c1 = a.pn_c1;
+    if (a.pn_ms && (!a.pn_c0 || !a.pn_c1 || a.mode != NOPE_CONV_PLAIN || a.ntaps != 1 || a.colstats)) return NOPE_ERR_ARG;
     if (a.colstats && (!p.wide_out || M % 64 != 0 || phased || a.resid)) return NOPE_ERR_ARG;
     // LDS-DMA kernel when a K step (128 B of channels) never straddles sources and 32-bit offsets suffice
     const int es = dt == NOPE_F32 ? 4 : 2;
@@ -658,11 +707,13 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     if (dt == NOPE_F32) {
         if (dma && bm == 256) launch_dma<float, 128, 2, 256>(p, grid, s);
         else if (dma) launch_dma<float, 128, 2, 128>(p, grid, s);
-        else hipLaunchKernelGGL((conv_gemm_kernel<float>), grid, block, 0, s, p);
+        else if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_kernel<float, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_gemm_kernel<float, false>), grid, block, 0, s, p);
     } else {
         if (dma && bm == 256) launch_dma<bf16_t, 128, 2, 256>(p, grid, s);
         else if (dma) launch_dma<bf16_t, 128, 2, 128>(p, grid, s);
-        else hipLaunchKernelGGL((conv_gemm_kernel<bf16_t>), grid, block, 0, s, p);
+        else if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_kernel<bf16_t, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_gemm_kernel<bf16_t, false>), grid, block, 0, s, p);
     }
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;

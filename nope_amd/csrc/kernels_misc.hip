@@ -37,7 +37,7 @@ __global__ __launch_bounds__(NT) void nhwc_to_nchw_kernel(const T* __restrict__ 
 //          c*4 + p1*2 + p2 (einops "b (c p1 p2) h w", model_utils.py:170); tap = p1*2 + p2.
 template <class T>
 __global__ __launch_bounds__(NT) void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ out, int Cin, int ntaps, int mode,
-                                                         size_t total) {
+                                                         size_t total, const float* __restrict__ cin_scale) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
         const int c = (int)(i % Cin);
         const size_t t = i / Cin;
@@ -46,8 +46,20 @@ __global__ __launch_bounds__(NT) void pack_conv_w_kernel(const float* __restrict
         size_t src;
         if (mode == NOPE_CONV_DOWN2) src = co * ((size_t)Cin * 4) + (size_t)c * 4 + tap;
         else src = (co * Cin + c) * ntaps + tap;
-        Elt<T>::st(out + i, w[src]);
+        Elt<T>::st(out + i, cin_scale ? w[src] * cin_scale[c] : w[src]);   // optional per-input-channel scale (PreNorm gamma)
     }
+}
+
+// out[r] = sum_k packed[r][k] (f32 sum of the values as the GEMM will see them)
+template <class T>
+__global__ __launch_bounds__(NT) void rowsum_kernel(const T* __restrict__ a, float* __restrict__ out, int rows, int K) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * NT + threadIdx.x) >> 6;
+    if (wave >= rows) return;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += Elt<T>::ld(a + (size_t)wave * K + k);
+    s = wave_sum(s);
+    if (lane == 0) out[wave] = s;
 }
 
 // HardUpsample 3x3 weight [Cout][Cin][3][3] -> four phase sets [py*2+px][Cout][ty*2+tx][Cin]:
@@ -134,7 +146,7 @@ int launch_nhwc_to_nchw_f32(int dt, const void* x, float* y, int n, int C, int H
     return NOPE_OK;
 }
 
-int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s) {
+int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s, const float* cin_scale) {
     if (!w || !out || Cout <= 0 || Cin <= 0 || ntaps <= 0) return NOPE_ERR_ARG;
     if (mode == NOPE_CONV_DOWN2 && ntaps != 4) return NOPE_ERR_ARG;
     if (mode == NOPE_CONV_UP2P) {
@@ -147,8 +159,18 @@ int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int
         return NOPE_OK;
     }
     const size_t total = (size_t)Cout * ntaps * Cin;
-    if (dt == NOPE_F32) hipLaunchKernelGGL((pack_conv_w_kernel<float>), dim3(grid_for(total)), dim3(NT), 0, s, w, (float*)out, Cin, ntaps, mode, total);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((pack_conv_w_kernel<bf16_t>), dim3(grid_for(total)), dim3(NT), 0, s, w, (bf16_t*)out, Cin, ntaps, mode, total);
+    if (dt == NOPE_F32) hipLaunchKernelGGL((pack_conv_w_kernel<float>), dim3(grid_for(total)), dim3(NT), 0, s, w, (float*)out, Cin, ntaps, mode, total, cin_scale);
+    else if (dt == NOPE_BF16) hipLaunchKernelGGL((pack_conv_w_kernel<bf16_t>), dim3(grid_for(total)), dim3(NT), 0, s, w, (bf16_t*)out, Cin, ntaps, mode, total, cin_scale);
+    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_rowsum(int dt, const void* packed, float* out, int rows, int K, hipStream_t s) {
+    if (!packed || !out || rows <= 0 || K <= 0) return NOPE_ERR_ARG;
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    if (dt == NOPE_F32) hipLaunchKernelGGL((rowsum_kernel<float>), dim3(blocks), dim3(NT), 0, s, (const float*)packed, out, rows, K);
+    else if (dt == NOPE_BF16) hipLaunchKernelGGL((rowsum_kernel<bf16_t>), dim3(blocks), dim3(NT), 0, s, (const bf16_t*)packed, out, rows, K);
     else return NOPE_ERR_UNSUPPORTED;
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;

@@ -120,10 +120,12 @@ template <class T, bool FAST>
 __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ partial,
                                                       int nchunk, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       int HW, int C, int G, int act, const float* __restrict__ emb, int emb_stride,
-                                                      const T* __restrict__ resid, float eps, int blocks_per_hyp, int x_rep, int resid_rep) {
+                                                      const T* __restrict__ resid, float eps, int blocks_per_hyp, int x_rep, int resid_rep,
+                                                      float* __restrict__ out_stats) {
     constexpr int VEC = Elt<T>::VEC;
     __shared__ float s_mean[64];
     __shared__ float s_rstd[64];
+    __shared__ float s_os[NT / 64], s_oq[NT / 64];
     const int hyp = blockIdx.x / blocks_per_hyp, blk = blockIdx.x % blocks_per_hyp;
     const int tid = threadIdx.x;
     const int cpg = C / G;
@@ -156,8 +158,8 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
     const int tpr = cvecs < NT ? cvecs : NT;
     const int rows = NT / tpr;
     const int row = tid / tpr, lc = tid - row * tpr;
-    if (row >= rows) return;
-    for (int cv = lc; cv < cvecs; cv += tpr) {
+    float os = 0.f, oq = 0.f;      // sum / sum of squares of this thread's OUTPUT values (optional out_stats)
+    for (int cv = lc; cv < cvecs && row < rows; cv += tpr) {
         float sc[VEC], sh[VEC], ev[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
                 t0 += ev[e]; t1 += ev[e];
                 if (rb) { t0 += r0[e]; t1 += r1[e]; }
                 v0[e] = t0; v1[e] = t1;
+                os += t0 + t1; oq += t0 * t0 + t1 * t1;
             }
             st16(yb + o0, Elt<T>::pack(v0));
             st16(yb + o1, Elt<T>::pack(v1));
@@ -203,10 +206,39 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
                 t0 += ev[e];
                 if (rb) t0 += r0[e];
                 v0[e] = t0;
+                os += t0; oq += t0 * t0;
             }
             st16(yb + o0, Elt<T>::pack(v0));
         }
     }
+    if (out_stats) {
+        // per-block (sum, sum of squares) of what was just written: the GroupNorm(1) statistics of the NEXT op
+        // (PreNorm of the attention that follows a ResnetBlock) without another pass over the tensor.
+        os = wave_sum(os); oq = wave_sum(oq);
+        if ((tid & 63) == 0) { s_os[tid >> 6] = os; s_oq[tid >> 6] = oq; }
+        __syncthreads();
+        if (tid == 0) {
+            float S = 0.f, Q = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) { S += s_os[w]; Q += s_oq[w]; }
+            out_stats[(size_t)blockIdx.x * 2] = S;
+            out_stats[(size_t)blockIdx.x * 2 + 1] = Q;
+        }
+    }
+}
+
+// (mean, rstd) per hypothesis from `nchunk` (sum, sum of squares) partials of a whole-sample GroupNorm(1).
+__global__ __launch_bounds__(NT) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ ms, int nhyp, int nchunk,
+                                                         float count, float eps) {
+    const int b = blockIdx.x * NT + threadIdx.x;
+    if (b >= nhyp) return;
+    float S = 0.f, Q = 0.f;
+    for (int k = 0; k < nchunk; ++k) { S += partial[((size_t)b * nchunk + k) * 2]; Q += partial[((size_t)b * nchunk + k) * 2 + 1]; }
+    const float mean = S / count;
+    float var = Q / count - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    ms[b * 2] = mean;
+    ms[b * 2 + 1] = 1.0f / sqrtf(var + eps);
 }
 
 }  // namespace
@@ -249,22 +281,34 @@ int launch_gn_fold(const float* colstats, float* partial, int nhyp, int HW, int 
     return NOPE_OK;
 }
 
+int gn_apply_blocks(int HW, int C, int dt) {
+    const size_t bytes = (size_t)HW * C * (dt == NOPE_F32 ? 4 : 2);
+    int bph = (int)(bytes / (32 * 1024));
+    if (bph < 1) bph = 1;
+    if (bph > 64) bph = 64;
+    return bph;
+}
+
+int launch_gn_finalize(const float* partial, float* ms, int nhyp, int nchunk, float count, float eps, hipStream_t s) {
+    if (!partial || !ms || nhyp <= 0 || nchunk < 1) return NOPE_ERR_ARG;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)cdiv(nhyp, NT)), dim3(NT), 0, s, partial, ms, nhyp, nchunk, count, eps);
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
 int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
     if (!a.x || !a.y || !a.partial || !a.gamma || !a.beta || a.nhyp <= 0 || a.C % a.G) return NOPE_ERR_ARG;
     const int vec = dt == NOPE_F32 ? 4 : 8;
     if (a.C % vec || a.G > 64) return NOPE_ERR_UNSUPPORTED;
     if (a.x_rep < 1 || a.resid_rep < 1) return NOPE_ERR_ARG;
-    const size_t bytes = (size_t)a.HW * a.C * (dt == NOPE_F32 ? 4 : 2);
-    int bph = (int)(bytes / (32 * 1024));
-    if (bph < 1) bph = 1;
-    if (bph > 64) bph = 64;
+    const int bph = gn_apply_blocks(a.HW, a.C, dt);
     dim3 grid((unsigned)(a.nhyp * bph)), block(NT);
     if (dt == NOPE_F32)
         hipLaunchKernelGGL((gn_apply_kernel<float, false>), grid, block, 0, s, (const float*)a.x, (float*)a.y, a.partial, a.nchunk,
-                           a.gamma, a.beta, a.HW, a.C, a.G, a.act, a.emb, a.emb_stride, (const float*)a.resid, a.eps, bph, a.x_rep, a.resid_rep);
+                           a.gamma, a.beta, a.HW, a.C, a.G, a.act, a.emb, a.emb_stride, (const float*)a.resid, a.eps, bph, a.x_rep, a.resid_rep, a.out_stats);
     else if (dt == NOPE_BF16)
         hipLaunchKernelGGL((gn_apply_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)a.x, (bf16_t*)a.y, a.partial, a.nchunk,
-                           a.gamma, a.beta, a.HW, a.C, a.G, a.act, a.emb, a.emb_stride, (const bf16_t*)a.resid, a.eps, bph, a.x_rep, a.resid_rep);
+                           a.gamma, a.beta, a.HW, a.C, a.G, a.act, a.emb, a.emb_stride, (const bf16_t*)a.resid, a.eps, bph, a.x_rep, a.resid_rep, a.out_stats);
     else return NOPE_ERR_UNSUPPORTED;
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;

@@ -121,6 +121,11 @@ struct ConvArgs {
     int out_dt = NOPE_F32;       // only for out_nchw
     int force_generic = 0;       // tests: take the register-staged kernel even when the LDS-DMA one applies
     float* colstats = nullptr;   // optional fused GroupNorm statistics: [M/64][Cout][2] (needs M % 64 == 0, NHWC out)
+    // optional fused PreNorm (GroupNorm(1) in front of a 1x1 conv whose weights already carry gamma):
+    //   out[m,n] = rstd[b] * (acc[m,n] - mean[b] * pn_c1[n]) + pn_c0[n],  b = sample of row m
+    const float* pn_ms = nullptr;   // [nhyp][2] (mean, rstd)
+    const float* pn_c0 = nullptr;   // [Cout]  sum_c W[n,c] * beta[c]
+    const float* pn_c1 = nullptr;   // [Cout]  sum_c W[n,c] * gamma[c]
 };
 int launch_conv(int dt, const ConvArgs& a, hipStream_t s);
 
@@ -135,9 +140,12 @@ struct GnApplyArgs {
     const void* resid = nullptr;       // optional NHWC tensor added last
     int x_rep = 1;                     // x (and its statistics) shared by x_rep consecutive hypotheses
     int resid_rep = 1;                 // resid shared by resid_rep consecutive hypotheses
+    float* out_stats = nullptr;        // optional [nhyp][gn_apply_blocks()][2]: (sum, sum sq) of the values written
     float eps = 1e-5f;
 };
 int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s);
+int gn_apply_blocks(int HW, int C, int dt);      // workgroups per hypothesis of launch_gn_apply (= chunks of out_stats)
+int launch_gn_finalize(const float* partial, float* ms, int nhyp, int nchunk, float count, float eps, hipStream_t s);
 int gn_stats_chunks(int HW, int C, int dt);
 // fold the conv epilogue's per-64-row-block column statistics into per-(hypothesis, group) partials (nchunk = 1)
 int launch_gn_fold(const float* colstats, float* partial, int nhyp, int HW, int C, int G, hipStream_t s);
@@ -147,7 +155,9 @@ int launch_attn(int dt, const void* qkv, void* out, int nhyp, int HW, int heads,
 
 int launch_nchw_to_nhwc(int dt, const float* x, void* y, int n, int C, int HW, hipStream_t s);
 int launch_nhwc_to_nchw_f32(int dt, const void* x, float* y, int n, int C, int HW, hipStream_t s);
-int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s);
+int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s,
+                       const float* cin_scale = nullptr);
+int launch_rowsum(int dt, const void* packed, float* out, int rows, int K, hipStream_t s);
 int launch_linear_naive(const float* in, const float* w, const float* bias, float* out, int M, int N, int K, int act_in,
                         int ldo, hipStream_t s);
 int launch_silu_f32(const float* in, float* out, size_t n, hipStream_t s);

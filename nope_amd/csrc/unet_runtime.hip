@@ -31,8 +31,10 @@ namespace {
 struct Conv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; };
 struct Norm { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct Res { Conv c1, c2, res; Norm n1, n2; bool has_res = false; int emb_off = -1; };
-struct LinAttn { Norm pre, post; Conv qkv, out; };
-struct Attn { Norm pre; Conv qkv, out; };
+// PreNorm's GroupNorm(1) is folded into the qkv conv: gamma into the packed weights, c0 = W beta, c1 = W gamma
+// (f32 [3*heads*dim_head]); mean / rstd enter in the conv epilogue.
+struct LinAttn { Norm pre, post; Conv qkv, out; float *c0 = nullptr, *c1 = nullptr; };
+struct Attn { Norm pre; Conv qkv, out; float *c0 = nullptr, *c1 = nullptr; };
 struct Level { Res r0, r1; LinAttn attn; Conv resample; };
 
 struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, rep = 1; };
@@ -92,7 +94,7 @@ struct Loader {
         if (p) hipMemcpyAsync(p, d->data, n * 4, hipMemcpyDeviceToDevice, s);
         return p;
     }
-    Conv conv(const std::string& pfx, int Cin, int Cout, int ksz, int mode, bool has_bias) {
+    Conv conv(const std::string& pfx, int Cin, int Cout, int ksz, int mode, bool has_bias, const float* cin_scale = nullptr) {
         Conv c;
         c.Cin = Cin; c.Cout = Cout; c.mode = mode;
         c.ntaps = (mode == NOPE_CONV_DOWN2 || mode == NOPE_CONV_UP2P) ? 4 : ksz * ksz;
@@ -101,7 +103,7 @@ struct Loader {
         if (d) {
             const size_t es = net->dt == NOPE_F32 ? 4 : 2;
             c.w = dmalloc((size_t)Cout * c.ntaps * Cin * es * (mode == NOPE_CONV_UP2P ? 4 : 1));
-            if (c.w) { int e = launch_pack_conv_w(net->dt, d->data, c.w, Cout, Cin, c.ntaps, mode, s); if (e && err == NOPE_OK) err = e; }
+            if (c.w) { int e = launch_pack_conv_w(net->dt, d->data, c.w, Cout, Cin, c.ntaps, mode, s, cin_scale); if (e && err == NOPE_OK) err = e; }
         }
         if (has_bias) c.bias = copy_f32(pfx + "bias", {Cout});
         return c;
@@ -112,6 +114,19 @@ struct Loader {
         n.gamma = copy_f32(pfx + "weight", {C});
         n.beta = copy_f32(pfx + "bias", {C});
         return n;
+    }
+    // qkv conv of an attention block with its PreNorm folded in (see LinAttn)
+    void prenorm_qkv(const std::string& p, int C, int N, Norm& pre, Conv& qkv, float*& c0, float*& c1) {
+        pre = norm(p + "fn.norm.", C);
+        qkv = conv(p + "fn.fn.to_qkv.", C, N, 1, NOPE_CONV_PLAIN, false, pre.gamma);
+        c0 = (float*)dmalloc((size_t)N * 4);
+        c1 = (float*)dmalloc((size_t)N * 4);
+        const nope_tensor_desc* w = get(p + "fn.fn.to_qkv.weight", {N, C, 1, 1});
+        if (w && c0 && c1 && pre.beta && qkv.w) {
+            int e = launch_linear_naive(pre.beta, w->data, nullptr, c0, 1, N, C, 0, N, s);
+            if (!e) e = launch_rowsum(net->dt, qkv.w, c1, N, C, s);
+            if (e && err == NOPE_OK) err = e;
+        }
     }
     Res res(const std::string& pfx, int Cin, int Cout, bool use_emb, std::vector<std::pair<std::string, int>>& embs) {
         Res r;
@@ -147,6 +162,8 @@ struct Fwd {
     int nhyp = 0, err = NOPE_OK;
     size_t es = 4;
     float* gn_partial = nullptr;
+    float* pn_partial = nullptr;   // (sum, sum sq) partials of the tensor that feeds the next attention block
+    float* pn_ms = nullptr;        // its per-hypothesis (mean, rstd)
     const float* emb_all = nullptr;
 
     bool dry() const { return ar.dry; }
@@ -160,10 +177,12 @@ struct Fwd {
 
     // out = conv(a [cat b]) (+bias) (+resid);  n = number of samples computed (nhyp or fewer)
     void conv(const Conv& c, const Act& a, const Act* b, void* out, int Ho, int Wo, int n, int rep1, int rep2,
-              const void* resid = nullptr, int out_nchw = 0, int out_dt = NOPE_F32, float* colstats = nullptr) {
+              const void* resid = nullptr, int out_nchw = 0, int out_dt = NOPE_F32, float* colstats = nullptr,
+              const float* pn_c0 = nullptr, const float* pn_c1 = nullptr) {
         if (!live()) return;
         ConvArgs ca;
         ca.colstats = colstats;
+        if (pn_c0) { ca.pn_ms = pn_ms; ca.pn_c0 = pn_c0; ca.pn_c1 = pn_c1; }
         ca.src1 = a.p; ca.C1 = a.C; ca.rep1 = rep1;
         if (b) { ca.src2 = b->p; ca.C2 = b->C; ca.rep2 = rep2; }
         ca.Hs = a.H; ca.Ws = a.W; ca.Ho = Ho; ca.Wo = Wo;
@@ -194,7 +213,7 @@ struct Fwd {
     // y = act(GN(x)) [+emb] [+resid]; x holds n_x = nhyp / x_rep samples; `colstats` != null: statistics were
     // produced by the conv epilogue and only need folding.
     void gn(const Norm& nm, int G, const void* x, int x_rep, void* y, int HW, int act, int emb_off, const void* resid,
-            int resid_rep, const float* colstats = nullptr) {
+            int resid_rep, const float* colstats = nullptr, float* out_stats = nullptr) {
         if (!live()) return;
         const int nx = nhyp / x_rep;
         int nch = 1;
@@ -208,13 +227,14 @@ struct Fwd {
         ga.x = x; ga.y = y; ga.partial = gn_partial; ga.nchunk = nch; ga.gamma = nm.gamma; ga.beta = nm.beta;
         ga.nhyp = nhyp; ga.HW = HW; ga.C = nm.C; ga.G = G; ga.act = act;
         if (emb_off >= 0) { ga.emb = emb_all + emb_off; ga.emb_stride = net->emb_total; }
-        ga.resid = resid; ga.x_rep = x_rep; ga.resid_rep = resid_rep;
+        ga.resid = resid; ga.x_rep = x_rep; ga.resid_rep = resid_rep; ga.out_stats = out_stats;
         chk(launch_gn_apply(net->dt, ga, s));
     }
 
     // ResnetBlock, model_utils.py:271-279.  `a` may be shared by a.rep hypotheses (rep > 1 only
     // for the very first block, where b == nullptr).
-    void resnet(const Res& R, const Act& a, const Act* b, bool use_emb, void* out) {
+    // `next_is_attention`: also emit the GroupNorm(1) partials of the block's output into pn_partial.
+    void resnet(const Res& R, const Act& a, const Act* b, bool use_emb, void* out, bool next_is_attention = false) {
         const int HW = a.H * a.W, G = net->cfg.groups;
         const size_t M = (size_t)nhyp * HW;
         const size_t mark = ar.off;
@@ -242,11 +262,21 @@ struct Fwd {
             conv(R.res, a, b, t3, a.H, a.W, nhyp, a.rep, b ? b->rep : 1);
             resid = t3; resid_rep = 1;
         } else if (b) { chk(NOPE_ERR_ARG); }
-        gn(R.n2, G, out, 1, out, HW, 1, -1, resid, resid_rep, cs2);
+        gn(R.n2, G, out, 1, out, HW, 1, -1, resid, resid_rep, cs2, next_is_attention ? pn_partial : nullptr);
         ar.off = mark;
     }
 
-    // Residual(PreNorm(LinearAttention)), model_utils.py:198-204,226-234,393-418
+    // PreNorm folded into the qkv conv: finalize (mean, rstd) of x from the producer's partials, then
+    // qkv = rstd * ((W gamma) x - mean * c1) + c0 in the conv epilogue -- x is read once, never re-written.
+    void qkv_prenorm(const Conv& qkvw, const float* c0, const float* c1, const Act& x, void* qkv) {
+        if (!live()) return;
+        const int HW = x.H * x.W;
+        chk(launch_gn_finalize(pn_partial, pn_ms, nhyp, gn_apply_blocks(HW, x.C, net->dt), (float)HW * (float)x.C, 1e-5f, s));
+        conv(qkvw, x, nullptr, qkv, x.H, x.W, nhyp, 1, 1, nullptr, 0, NOPE_F32, nullptr, c0, c1);
+    }
+
+    // Residual(PreNorm(LinearAttention)), model_utils.py:198-204,226-234,393-418.  x must come from
+    // resnet(..., next_is_attention = true).
     void linattn(const LinAttn& L, const Act& x, void* out) {
         const int HW = x.H * x.W, heads = net->cfg.heads, dh = net->cfg.dim_head;
         const size_t M = (size_t)nhyp * HW;
@@ -254,9 +284,7 @@ struct Fwd {
         void* y = alloc_act(M * x.C);
         void* qkv = alloc_act(M * 3 * heads * dh);
         void* a = alloc_act(M * heads * dh);
-        gn(L.pre, 1, x.p, 1, y, HW, 0, -1, nullptr, 1);
-        Act ya{y, x.C, x.H, x.W, 1};
-        conv(L.qkv, ya, nullptr, qkv, x.H, x.W, nhyp, 1, 1);
+        qkv_prenorm(L.qkv, L.c0, L.c1, x, qkv);
         if (live()) chk(launch_linattn(net->dt, qkv, a, nhyp, HW, heads, dh, s));
         Act aa{a, heads * dh, x.H, x.W, 1};
         float* cs = colstats_for(nhyp, HW, L.out.Cout);
@@ -270,12 +298,9 @@ struct Fwd {
         const int HW = x.H * x.W, heads = net->cfg.heads, dh = net->cfg.dim_head;
         const size_t M = (size_t)nhyp * HW;
         const size_t mark = ar.off;
-        void* y = alloc_act(M * x.C);
         void* qkv = alloc_act(M * 3 * heads * dh);
         void* a = alloc_act(M * heads * dh);
-        gn(A.pre, 1, x.p, 1, y, HW, 0, -1, nullptr, 1);
-        Act ya{y, x.C, x.H, x.W, 1};
-        conv(A.qkv, ya, nullptr, qkv, x.H, x.W, nhyp, 1, 1);
+        qkv_prenorm(A.qkv, A.c0, A.c1, x, qkv);
         if (live()) chk(launch_attn(net->dt, qkv, a, nhyp, HW, heads, dh, s));
         Act aa{a, heads * dh, x.H, x.W, 1};
         conv(A.out, aa, nullptr, out, x.H, x.W, nhyp, 1, 1, /*resid=*/x.p);
@@ -300,6 +325,8 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
     float* c1 = (float*)f.ar.alloc((size_t)n_hyp * net->classes * 4);
     float* emb_all = (float*)f.ar.alloc((size_t)n_hyp * net->emb_total * 4);
     f.gn_partial = (float*)f.ar.alloc((size_t)n_hyp * 16 * (cfg.groups > 1 ? cfg.groups : 1) * 2 * 4);
+    f.pn_partial = (float*)f.ar.alloc((size_t)n_hyp * 64 * 2 * 4);
+    f.pn_ms = (float*)f.ar.alloc((size_t)n_hyp * 2 * 4);
     f.emb_all = emb_all;
     size_t cur_elems = 0;
     for (int l = 0; l <= L; ++l) {   // every tensor handed from one stage to the next
@@ -317,7 +344,7 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
         hbuf[2 * l] = f.alloc_act(e);
         hbuf[2 * l + 1] = f.alloc_act(e);
     }
-    if (!dry && (!c0 || !c1 || !emb_all || !f.gn_partial)) f.chk(NOPE_ERR_WORKSPACE);
+    if (!dry && (!c0 || !c1 || !emb_all || !f.gn_partial || !f.pn_partial || !f.pn_ms)) f.chk(NOPE_ERR_WORKSPACE);
     if (f.err) return f.err;
 
     // ---- input + pose embedding ----------------------------------------------------------------
@@ -356,7 +383,7 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
         {
             const size_t mark = f.ar.off;
             Act t{f.alloc_act((size_t)n_hyp * cur.H * cur.W * dims[l]), dims[l], cur.H, cur.W, 1};
-            f.resnet(D.r1, h1, nullptr, true, t.p);
+            f.resnet(D.r1, h1, nullptr, true, t.p, /*next_is_attention=*/true);
             f.linattn(D.attn, t, h2.p);
             f.ar.off = mark;
         }
@@ -372,7 +399,7 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
         const size_t e = (size_t)n_hyp * cur.H * cur.W * cur.C;
         Act a{f.alloc_act(e), cur.C, cur.H, cur.W, 1};
         Act b{f.alloc_act(e), cur.C, cur.H, cur.W, 1};
-        f.resnet(net->mid1, cur, nullptr, true, a.p);
+        f.resnet(net->mid1, cur, nullptr, true, a.p, /*next_is_attention=*/true);
         f.attn(net->mid_attn, a, b.p);
         Act c{curbuf[slot], cur.C, cur.H, cur.W, 1};
         f.resnet(net->mid2, b, nullptr, true, c.p);
@@ -391,7 +418,7 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
         Act a{f.alloc_act(e), dims[r + 1], cur.H, cur.W, 1};
         Act b{f.alloc_act(e), dims[r + 1], cur.H, cur.W, 1};
         f.resnet(U.r0, cur, &h2, true, a.p);
-        f.resnet(U.r1, a, &h1, true, b.p);
+        f.resnet(U.r1, a, &h1, true, b.p, /*next_is_attention=*/true);
         f.linattn(U.attn, b, a.p);
         Act nxt{curbuf[slot], dims[r], cur.H, cur.W, 1};
         if (l < L - 1) { nxt.H = cur.H * 2; nxt.W = cur.W * 2; }
@@ -452,8 +479,7 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
     net->init_conv = ld.conv("init_conv.", cfg->channels, dims[0], 3, NOPE_CONV_PLAIN, true);
     auto linattn = [&](const std::string& p, int C) {
         LinAttn a;
-        a.pre = ld.norm(p + "fn.norm.", C);
-        a.qkv = ld.conv(p + "fn.fn.to_qkv.", C, 3 * HD, 1, NOPE_CONV_PLAIN, false);
+        ld.prenorm_qkv(p, C, 3 * HD, a.pre, a.qkv, a.c0, a.c1);
         a.out = ld.conv(p + "fn.fn.to_out.0.", HD, C, 1, NOPE_CONV_PLAIN, true);
         a.post = ld.norm(p + "fn.fn.to_out.1.", C);
         return a;
@@ -468,8 +494,7 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
         else D.resample = ld.conv(p + "3.", dims[l], dims[l + 1], 3, NOPE_CONV_PLAIN, true);
     }
     net->mid1 = ld.res("mid_block1.", dims[L], dims[L], true, embs);
-    net->mid_attn.pre = ld.norm("mid_attn.fn.norm.", dims[L]);
-    net->mid_attn.qkv = ld.conv("mid_attn.fn.fn.to_qkv.", dims[L], 3 * HD, 1, NOPE_CONV_PLAIN, false);
+    ld.prenorm_qkv("mid_attn.", dims[L], 3 * HD, net->mid_attn.pre, net->mid_attn.qkv, net->mid_attn.c0, net->mid_attn.c1);
     net->mid_attn.out = ld.conv("mid_attn.fn.fn.to_out.", HD, dims[L], 1, NOPE_CONV_PLAIN, true);
     net->mid2 = ld.res("mid_block2.", dims[L], dims[L], true, embs);
     for (int l = 0; l < L; ++l) {

@@ -16,7 +16,8 @@ F32, BF16 = 0, 1
 CONV_PLAIN, CONV_UP2, CONV_DOWN2, CONV_UP2P = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnope_hip.so")
+# NOPE_HIP_LIB: load another build of the SAME gfx950 library (A/B timing of kernel variants); default = in-tree build
+LIB_PATH = os.environ.get("NOPE_HIP_LIB") or os.path.join(_HERE, "csrc", "libnope_hip.so")
 
 _vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 
