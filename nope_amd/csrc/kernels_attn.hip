@@ -23,8 +23,8 @@ constexpr int D = 32;      // dim_head (fixed by the reference, model_utils.py:3
 template <class T> __device__ __forceinline__ void store4(T* p, const f32x4& v);
 template <> __device__ __forceinline__ void store4<float>(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const f32x4& v) {
-    const unsigned long long lo = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-    const unsigned long long hi = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    const unsigned long long lo = cvt_pk_bf16(v[0], v[1]);
+    const unsigned long long hi = cvt_pk_bf16(v[2], v[3]);
     *reinterpret_cast<unsigned long long*>(p) = lo | (hi << 32);
 }
 

@@ -61,6 +61,7 @@ struct ConvParams {
     int Cout, M;
     int out_nchw, out_dt;
     int tiles_m, tiles_n, xcd_map, wide_out;
+    int variant;                       // tuning switches (NOPE_CONV_VARIANT), 0 in production
     int Hm, Wm;                        // grid the GEMM rows enumerate: output grid, or the SOURCE grid for UP2P
     unsigned w_phase_bytes;            // UP2P: byte stride between the 4 phase weight sets
     float* colstats;                   // optional [M/64][Cout][2]: per 64-row block column sum / sum of squares
@@ -472,9 +473,9 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
     constexpr int NW = BMT / 32;                  // waves: (BMT/64) along M x 2 along N, 64x96 each
     constexpr int AI = BMT / RPI / NW, BI = BN / RPI / NW;   // DMA instructions per wave per stage
     constexpr int L = AI + BI;
-    static_assert(NS * STAGE >= NW * EP_WAVE_BYTES, "epilogue panels must fit in the ring");
+    constexpr int LDS_BYTES = NS * STAGE > NW * EP_WAVE_BYTES ? NS * STAGE : NW * EP_WAVE_BYTES;   // ring, reused by the epilogue panels
     static_assert(AI <= 4 && BI <= 6, "row bookkeeping arrays");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NS * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -626,8 +627,10 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
         for (int ks = 0; ks < nk; ++ks) {
             const int buf = ks & 1;
             __syncthreads();                       // stage ks landed (vmcnt drain) + everyone left stage ks-1
-            if (ks + 1 < nk) issue(buf ^ 1);
-            mma_stage<T, RB>(lds + buf * STAGE, lds + buf * STAGE + BMT * RB, wm, wn, lane, acc);
+            if (ks + 1 < nk && !(p.variant & 16)) issue(buf ^ 1);
+            if (p.variant & 1) __builtin_amdgcn_s_setprio(2);
+            if (!(p.variant & 32)) mma_stage<T, RB>(lds + buf * STAGE, lds + buf * STAGE + BMT * RB, wm, wn, lane, acc);
+            if (p.variant & 1) __builtin_amdgcn_s_setprio(0);
         }
     }
     if (p.wide_out) {
@@ -698,6 +701,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     // NOPE_CONV_VARIANT=4 selects the 256x192 / 8-wave tile (measured on par with the default 128x192 / 4-wave
     // tile in round 1; kept for tuning, see DESIGN.md section 4 for the other variants that were tried).
     static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
+    p.variant = variant;
     const int bm = (dma && variant == 4 && M >= 256 * 256) ? 256 : BM;
     p.tiles_m = cdiv((int)M, bm); p.tiles_n = cdiv(a.Cout, BN);
     const int tn = p.tiles_n;
@@ -712,6 +716,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((conv_gemm_kernel<float, false>), grid, block, 0, s, p);
     } else {
         if (dma && bm == 256) launch_dma<bf16_t, 128, 2, 256>(p, grid, s);
+        else if (dma && (variant & 2)) launch_dma<bf16_t, 64, 2, 128>(p, grid, s);
         else if (dma) launch_dma<bf16_t, 128, 2, 128>(p, grid, s);
         else if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_kernel<bf16_t, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((conv_gemm_kernel<bf16_t, false>), grid, block, 0, s, p);

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NT) void gn_fold_kernel(const float* __restrict__ c
     }
 }
 
-template <class T, bool FAST>
+template <class T, bool FAST, bool OS>
 __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ partial,
                                                       int nchunk, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       int HW, int C, int G, int act, const float* __restrict__ emb, int emb_stride,
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
                 t0 += ev[e]; t1 += ev[e];
                 if (rb) { t0 += r0[e]; t1 += r1[e]; }
                 v0[e] = t0; v1[e] = t1;
-                os += t0 + t1; oq += t0 * t0 + t1 * t1;
+                if (OS) { os += t0 + t1; oq += t0 * t0 + t1 * t1; }
             }
             st16(yb + o0, Elt<T>::pack(v0));
             st16(yb + o1, Elt<T>::pack(v1));
@@ -206,12 +206,12 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
                 t0 += ev[e];
                 if (rb) t0 += r0[e];
                 v0[e] = t0;
-                os += t0; oq += t0 * t0;
+                if (OS) { os += t0; oq += t0 * t0; }
             }
             st16(yb + o0, Elt<T>::pack(v0));
         }
     }
-    if (out_stats) {
+    if (OS) {
         // per-block (sum, sum of squares) of what was just written: the GroupNorm(1) statistics of the NEXT op
         // (PreNorm of the attention that follows a ResnetBlock) without another pass over the tensor.
         os = wave_sum(os); oq = wave_sum(oq);
@@ -303,13 +303,16 @@ int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
     if (a.x_rep < 1 || a.resid_rep < 1) return NOPE_ERR_ARG;
     const int bph = gn_apply_blocks(a.HW, a.C, dt);
     dim3 grid((unsigned)(a.nhyp * bph)), block(NT);
-    if (dt == NOPE_F32)
-        hipLaunchKernelGGL((gn_apply_kernel<float, false>), grid, block, 0, s, (const float*)a.x, (float*)a.y, a.partial, a.nchunk,
-                           a.gamma, a.beta, a.HW, a.C, a.G, a.act, a.emb, a.emb_stride, (const float*)a.resid, a.eps, bph, a.x_rep, a.resid_rep, a.out_stats);
-    else if (dt == NOPE_BF16)
-        hipLaunchKernelGGL((gn_apply_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)a.x, (bf16_t*)a.y, a.partial, a.nchunk,
-                           a.gamma, a.beta, a.HW, a.C, a.G, a.act, a.emb, a.emb_stride, (const bf16_t*)a.resid, a.eps, bph, a.x_rep, a.resid_rep, a.out_stats);
-    else return NOPE_ERR_UNSUPPORTED;
+#define NOPE_GN_APPLY(T, FAST, OS)                                                                                              \
+    hipLaunchKernelGGL((gn_apply_kernel<T, FAST, OS>), grid, block, 0, s, (const T*)a.x, (T*)a.y, a.partial, a.nchunk, a.gamma,  \
+                       a.beta, a.HW, a.C, a.G, a.act, a.emb, a.emb_stride, (const T*)a.resid, a.eps, bph, a.x_rep, a.resid_rep,   \
+                       a.out_stats)
+    if (dt == NOPE_F32) {
+        if (a.out_stats) NOPE_GN_APPLY(float, false, true); else NOPE_GN_APPLY(float, false, false);
+    } else if (dt == NOPE_BF16) {
+        if (a.out_stats) NOPE_GN_APPLY(bf16_t, true, true); else NOPE_GN_APPLY(bf16_t, true, false);
+    } else return NOPE_ERR_UNSUPPORTED;
+#undef NOPE_GN_APPLY
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

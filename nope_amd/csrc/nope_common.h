@@ -32,6 +32,16 @@ __device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// Two f32 -> packed bf16x2 in one v_cvt_pk_bf16_f32 (gfx950 hardware RNE; same results as f32_to_bf16).
+typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    const f32x2_hw_t v = {lo, hi};
+    union { bf16x2_hw_t h; unsigned u; } x;
+    x.h = __builtin_convertvector(v, bf16x2_hw_t);
+    return x.u;
+}
+
 // Element traits: VEC = elements per 16-byte vector.
 template <class T> struct Elt;
 template <> struct Elt<float> {
@@ -69,7 +79,7 @@ template <> struct Elt<bf16_t> {
     static __device__ __forceinline__ u32x4 pack(const float* o) {
         u32x4 v;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (unsigned)f32_to_bf16(o[2 * i]) | ((unsigned)f32_to_bf16(o[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) v[i] = cvt_pk_bf16(o[2 * i], o[2 * i + 1]);
         return v;
     }
 };
@@ -89,7 +99,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 template <bool FAST> __device__ __forceinline__ float silu_f(float x) {
-    if (FAST) return x * __frcp_rn(1.0f + __expf(-x));
+    if (FAST) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));   // v_exp_f32 + v_rcp_f32 (1 ulp each)
     return x / (1.0f + expf(-x));
 }
 

@@ -340,6 +340,8 @@ inline void hipemu_buffer_load_lds(hipemu_rsrc r, P ldsptr, unsigned size, unsig
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds hipemu_buffer_load_lds
 
 inline float __expf(float x) { return expf(x); }
+inline float hipemu_rcpf(float x) { return 1.0f / x; }
+#define __builtin_amdgcn_rcpf hipemu_rcpf
 inline float __fdividef(float a, float b) { return a / b; }
 inline float __frcp_rn(float a) { return 1.0f / a; }
 inline float __fsqrt_rn(float a) { return sqrtf(a); }
