@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--skip-extras", action="store_true", help="skip roofline / cpu_baseline legs")
+    ap.add_argument("--two-calls", action="store_true", help="generate_templates then retrieval as two calls (no stream overlap)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,8 +173,11 @@ def main():
     query, reference, poses = batch["query"], batch["reference"], batch["all_relativeR"]
 
     def step():
-        bank, _, _ = model.generate_templates(reference, poses, None)
-        return model.retrieval(query, bank)
+        if a.two_calls:                      # the reference's literal call sequence (model.py:313,323)
+            bank, _, _ = model.generate_templates(reference, poses, None)
+            return model.retrieval(query, bank)
+        sim, idx, _ = model.generate_and_retrieve(query, reference, poses)   # same values, query encoder on a side stream
+        return sim, idx
 
     def barrier():
         if world > 1:

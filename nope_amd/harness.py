@@ -95,8 +95,7 @@ def geodesic_deg(predR: torch.Tensor, gtR: torch.Tensor) -> torch.Tensor:
 def eval_geodesic(model, batch: Dict[str, torch.Tensor], thresholds=(15, 30), save_path: Optional[str] = None):
     """The body of PoseConditional.eval_geodesic (model.py:268-376) without visualisation."""
     loss = model.forward(batch["query"], batch["reference"], batch["gt_relativeR"])
-    pred_feat, _, _ = model.generate_templates(batch["reference"], batch["all_relativeR"], None, visualize=False)
-    similarity, nearest_idx = model.retrieval(batch["query"], pred_feat)
+    similarity, nearest_idx, _ = model.generate_and_retrieve(batch["query"], batch["reference"], batch["all_relativeR"])
     template_poses = batch["template_poses"][0]                 # model.py:352
     predR = template_poses[nearest_idx]                         # (B,5,3,3)
     err = torch.stack([geodesic_deg(predR[:, k], batch["query_pose"]) for k in range(predR.shape[1])], 1)

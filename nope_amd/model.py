@@ -51,6 +51,7 @@ class PoseConditional(nn.Module):
         self.max_hyp = int(max_hypotheses_per_launch)
         self.template_parallel = bool(template_parallel)
         self._slice = None          # (lo, hi, N) of the last sharded generate_templates
+        self._side_stream = None    # second HIP stream of generate_and_retrieve
         self.global_step = 0
         self.global_rank = ndist.world()[0]
         if save_dir is not None:    # model.py:63-66
@@ -121,6 +122,31 @@ class PoseConditional(nn.Module):
             return None                   # the reference implements only "l2" (model.py:256,266)
         query_feat = self.u_net.encoder.encode_image(query, mode="mode")
         return self.retrieval_from_feat(query_feat, template_feat)
+
+    # ---- model.py:313,323 (the two calls eval_geodesic makes back to back) --------------------------------
+    @torch.no_grad()
+    def generate_and_retrieve(self, query, reference, all_relativeR):
+        """`generate_templates(reference, all_relativeR)` followed by `retrieval(query, bank)` as one call,
+        returning (similarity, nearest_idx, bank) -- the same arithmetic in the same order.  The query does not depend on
+        the bank, so its encoder pass (launch-latency bound, a few CUs wide) is issued on a second HIP
+        stream and runs underneath the reference encoder and the first U-Net kernels."""
+        if self.similarity_metric != "l2":
+            return None
+        enc = self.u_net.encoder
+        if not query.is_cuda:
+            raise hip.NopeError("generate_and_retrieve needs device tensors (no CPU path)")
+        cur = torch.cuda.current_stream(query.device)
+        if self._side_stream is None or self._side_stream.device != query.device:
+            self._side_stream = torch.cuda.Stream(device=query.device)
+        side = self._side_stream
+        side.wait_stream(cur)                       # whatever produced `query` is ordered before the side work
+        with torch.cuda.stream(side):
+            query_feat = enc.encode_image(query, mode="mode")
+        bank, _, _ = self.generate_templates(reference, all_relativeR, None)
+        cur.wait_stream(side)
+        query_feat.record_stream(cur)
+        similarity, nearest_idx = self.retrieval_from_feat(query_feat, bank)
+        return similarity, nearest_idx, bank
 
     @torch.no_grad()
     def retrieval_from_feat(self, query_feat, template_feat, k=5):
