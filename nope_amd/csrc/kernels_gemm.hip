@@ -231,6 +231,29 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
     float* pan = reinterpret_cast<float*>(lds_wave);
     T* out = reinterpret_cast<T*>(p.out);
     const T* resid = reinterpret_cast<const T*>(p.resid);
+    if (p.colstats) {
+        // GroupNorm statistics of the conv output, fused: per column (sum, sum of squares) over this wave's 64
+        // rows, straight from the accumulators (f32, before the rounding to T): a lane adds up the rows it
+        // holds, the 64/TM lanes sharing a column are folded with cross-lane adds.  Fixed order and exactly one
+        // writer per [row block][column] entry -> the later fold is deterministic.  Requires M % 64 == 0
+        // (checked by the launcher).
+#pragma unroll
+        for (int j = 0; j < TL::NTL; ++j) {
+            const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
+            const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                for (int r = 0; r < TL::R; ++r) { const float v = acc[i][j][r] + bv; s += v; q += v * v; }
+#pragma unroll
+            for (int o = TL::TM; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+            if (lane < TL::TM && n < p.Cout) {
+                float* cs = p.colstats + ((size_t)((m0 + wm * 64) >> 6) * p.Cout + n) * 2;
+                cs[0] = s; cs[1] = q;
+            }
+        }
+    }
 #pragma unroll
     for (int pass = 0; pass < 96 / PANW; ++pass) {
 #pragma unroll
@@ -247,19 +270,6 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
         // same-wave LDS write -> read: the LDS queue of a wave is in order, so no s_barrier; the wave
         // barrier only pins the compiler's ordering (and is the rendezvous point of tests/hipemu)
         __builtin_amdgcn_wave_barrier();
-        if (p.colstats && lane < PANW) {
-            // GroupNorm statistics of the conv output, fused: this wave's 64 rows x one column per lane
-            // (f32, before the rounding to T); every [row block][column] entry has exactly one writer, so the
-            // later fold is deterministic.  Requires M % 64 == 0 (checked by the launcher).
-            const int n = n0 + wn * 96 + pass * PANW + lane;
-            if (n < p.Cout) {
-                float s = 0.f, q = 0.f;
-#pragma unroll 8
-                for (int row = 0; row < 64; ++row) { const float v = pan[row * EP_LD + lane]; s += v; q += v * v; }
-                float* cs = p.colstats + ((size_t)((m0 + wm * 64) >> 6) * p.Cout + n) * 2;
-                cs[0] = s; cs[1] = q;
-            }
-        }
         // Fused PreNorm operands, hoisted out of the chunk loop where they are loop-invariant: with 64 % CH == 0
         // a lane keeps the same column chunk for the whole pass, and with HW % 64 == 0 the wave's 64 rows are
         // one sample (one mean / rstd).
@@ -628,9 +638,10 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
             const int buf = ks & 1;
             __syncthreads();                       // stage ks landed (vmcnt drain) + everyone left stage ks-1
             if (ks + 1 < nk && !(p.variant & 16)) issue(buf ^ 1);
-            if (p.variant & 1) __builtin_amdgcn_s_setprio(2);
+            // the MFMA phase outranks the other workgroup's address arithmetic on this SIMD (-7 % cycles measured)
+            if (!(p.variant & 1)) __builtin_amdgcn_s_setprio(2);
             if (!(p.variant & 32)) mma_stage<T, RB>(lds + buf * STAGE, lds + buf * STAGE + BMT * RB, wm, wn, lane, acc);
-            if (p.variant & 1) __builtin_amdgcn_s_setprio(0);
+            if (!(p.variant & 1)) __builtin_amdgcn_s_setprio(0);
         }
     }
     if (p.wide_out) {
