@@ -49,6 +49,25 @@ constexpr int ROWB = 128;  // bytes per LDS row
 constexpr int A_ITERS = BM / 32;
 constexpr int B_ITERS = BN / 32;
 
+// Unsigned division by a launch-time constant, exact for n < 2^31: q = mulhi(n, M) >> sh with
+// M = floor(2^(32+sh) / d) + 1, sh = ceil(log2 d) - 1 (d >= 2); M == 0 encodes d == 1.  Replaces the ~35-instruction
+// integer-division sequences of the per-row index arithmetic in the conv prologue.
+struct FastDiv {
+    unsigned M, sh;
+    __device__ __forceinline__ unsigned div(unsigned n) const {
+        return M ? (unsigned)(((unsigned long long)n * M) >> 32) >> sh : n;
+    }
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f{0u, 0u};
+    if (d <= 1) return f;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;                       // s = ceil(log2 d) >= 1
+    f.sh = s - 1;
+    f.M = (unsigned)(((1ull << (31 + s)) / d) + 1);    // < 2^32 because d > 2^(s-1)
+    return f;
+}
+
 struct ConvParams {
     const unsigned char* src1; const unsigned char* src2;
     int C1, C2, rep1, rep2;
@@ -62,6 +81,7 @@ struct ConvParams {
     int out_nchw, out_dt;
     int tiles_m, tiles_n, xcd_map, wide_out;
     int variant;                       // tuning switches (NOPE_CONV_VARIANT), 0 in production
+    FastDiv d_hw, d_w, d_rep1, d_rep2; // / (Hm*Wm), / Wm, / rep1, / rep2
     int Hm, Wm;                        // grid the GEMM rows enumerate: output grid, or the SOURCE grid for UP2P
     unsigned w_phase_bytes;            // UP2P: byte stride between the 4 phase weight sets
     float* colstats;                   // optional [M/64][Cout][2]: per 64-row block column sum / sum of squares
@@ -488,6 +508,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int tid = threadIdx.x;
+    if (p.variant & 128) { if (tid == 9999) lds[0] = 1; return; }   // tuning only: launch cost of the grid
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -514,13 +535,18 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
         const int row = RPI * (AI * wave + i) + rsub;
         const int m = m0 + row;
         const bool ok = m < p.M;
-        const int mm = ok ? m : 0;
-        const int b = mm / HWo;
-        const int r = mm - b * HWo;
-        const int oy = r / p.Wm, ox = r - oy * p.Wm;
+        const unsigned mm = ok ? (unsigned)m : 0u;
+        const unsigned b = p.d_hw.div(mm);
+        const unsigned r = mm - b * (unsigned)HWo;
+        const int oy = (int)p.d_w.div(r), ox = (int)r - oy * p.Wm;
         const unsigned cs = (unsigned)((lslot ^ swz_of<RB>(row)) * VEC);   // source channel chunk of this LDS slot
-        const unsigned s1 = (unsigned)(b / p.rep1), s2 = (unsigned)(b / p.rep2);
+        const unsigned s1 = p.d_rep1.div(b), s2 = p.d_rep2.div(b);
         unsigned mask = 0;
+        // 3x3 validity as a 9-bit mask = (rows valid) x (columns valid) without nine separate bounds tests
+        auto mask3x3 = [](int y, int x, int H, int W) {
+            const unsigned vx = (x > 0 ? 1u : 0u) | (x >= 0 && x < W ? 2u : 0u) | (x + 1 < W ? 4u : 0u);
+            return (y > 0 ? vx : 0u) | (y >= 0 && y < H ? vx << 3 : 0u) | (y + 1 < H ? vx << 6 : 0u);
+        };
         if (MODE == NOPE_CONV_UP2P) {
             a_b1[i] = (((s1 * p.Hs + oy) * p.Ws + ox) * p.C1 + cs) * ES;
             a_b2[i] = 0;
@@ -532,13 +558,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
         } else if (MODE == NOPE_CONV_PLAIN) {
             a_b1[i] = (((s1 * p.Hs + oy) * p.Ws + ox) * p.C1 + cs) * ES;
             a_b2[i] = (((s2 * p.Hs + oy) * p.Ws + ox) * p.C2 + cs) * ES;
-            if (p.ntaps == 9) {
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
-                    if (iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws) mask |= 1u << t;
-                }
-            } else mask = 1u;
+            mask = p.ntaps == 9 ? mask3x3(oy, ox, p.Hs, p.Ws) : 1u;
         } else if (MODE == NOPE_CONV_DOWN2) {
             a_b1[i] = (((s1 * p.Hs + 2 * oy) * p.Ws + 2 * ox) * p.C1 + cs) * ES;
             a_b2[i] = 0;
@@ -550,11 +570,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
                 a_y[i][d] = (s1 * p.Hs + (unsigned)((uy < 0 ? 0 : uy) >> 1)) * p.Ws * p.C1 * ES;
                 a_x[i][d] = ((unsigned)((ux < 0 ? 0 : ux) >> 1) * p.C1 + cs) * ES;
             }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int uy = oy + t / 3 - 1, ux = ox + t % 3 - 1;
-                if (uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo) mask |= 1u << t;
-            }
+            mask = mask3x3(oy, ox, p.Ho, p.Wo);
             a_b1[i] = 0; a_b2[i] = 0;
         }
         a_mask[i] = ok ? mask : 0u;
@@ -644,7 +660,9 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
             if (!(p.variant & 1)) __builtin_amdgcn_s_setprio(0);
         }
     }
-    if (p.wide_out) {
+    if (p.variant & 64) {                      // tuning only: no epilogue (keeps the accumulators live)
+        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;
+    } else if (p.wide_out) {
         __syncthreads();                       // every wave is done reading the last stage
         epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
     } else {
@@ -713,6 +731,8 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     // tile in round 1; kept for tuning, see DESIGN.md section 4 for the other variants that were tried).
     static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
     p.variant = variant;
+    p.d_hw = make_fastdiv((unsigned)(p.Hm * p.Wm)); p.d_w = make_fastdiv((unsigned)p.Wm);
+    p.d_rep1 = make_fastdiv((unsigned)p.rep1); p.d_rep2 = make_fastdiv((unsigned)p.rep2);
     const int bm = (dma && variant == 4 && M >= 256 * 256) ? 256 : BM;
     p.tiles_m = cdiv((int)M, bm); p.tiles_n = cdiv(a.Cout, BN);
     const int tn = p.tiles_n;
