@@ -20,5 +20,5 @@ if [ "${SKIP_PROF:-0}" != "1" ]; then
   export TMPDIR=/tmp
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --gpus 1 --steps 3 --warmup 1 --skip-extras > "$OLDPWD/$OUT/prof.log" 2>&1 ); echo "rocprof rc=$?"
   find $OUT/prof -name "*stats*" | head; 
-  f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
+  f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then head -30 "$f"; fi; true
 fi
