@@ -27,7 +27,8 @@ enum { NOPE_F32 = 0, NOPE_BF16 = 1 };
 /* Tap geometries of nope_op_conv.  UP2P is UP2 (nearest-x2 upsample + 3x3, pad 1) rewritten as four
  * 2x2 convolutions over the un-upsampled input, one per output-pixel parity, with the 3x3 weights that
  * fall on the same source pixel pre-summed at pack time: same function, 4/9 of the multiply-adds. */
-enum { NOPE_CONV_PLAIN = 0, NOPE_CONV_UP2 = 1, NOPE_CONV_DOWN2 = 2, NOPE_CONV_UP2P = 3 };
+enum { NOPE_CONV_PLAIN = 0, NOPE_CONV_UP2 = 1, NOPE_CONV_DOWN2 = 2, NOPE_CONV_UP2P = 3,
+       NOPE_CONV_STRIDE2 = 4 /* stride 2: 3x3 pad 1 or 1x1 pad 0 (ResNet Bottleneck, encoder/resnet.py:64-65,122-123) */ };
 enum {
     NOPE_OK = 0,
     NOPE_ERR_ARG = -1,        /* bad argument (null pointer, unsupported size/dtype) */
@@ -120,6 +121,27 @@ int nope_unet_profile(nope_unet* net, int enable);
 int nope_unet_profile_read(nope_unet* net, int* n_launches, double* total_ms, double* total_flops, double* total_bytes);
 
 /* ------------------------------------------------------------------------------------------
+ * Template encoder.  Replaces FeatureExtractor.encode_image, src/model/encoder/template.py:47-53
+ * (ResNet-50 trunk src/model/encoder/resnet.py:92-152 with eval-mode BatchNorm, then the
+ * ReLU/1x1/ReLU/1x1 projector template.py:33-38).  Tensor names are the FeatureExtractor's own
+ * state-dict keys ("backbone.conv1.weight", "backbone.layer1.0.bn1.running_mean", "projector.1.weight", ...).
+ */
+typedef struct nope_encoder nope_encoder;
+typedef struct {
+    int descriptor_size;   /* 8 (configs/model/template_base.yaml:10) */
+    int compute_dtype;     /* NOPE_F32 | NOPE_BF16 storage of weights and activations (f32 accumulation) */
+    float bn_eps;          /* BatchNorm2d eps; <= 0 selects the torch default 1e-5 */
+} nope_encoder_config;
+
+int nope_encoder_create(const nope_encoder_config* cfg, const nope_tensor_desc* tensors, int n_tensors,
+                        nope_stream_t stream, nope_encoder** out);
+void nope_encoder_destroy(nope_encoder* enc);
+size_t nope_encoder_workspace_bytes(const nope_encoder* enc, int n_img, int H, int W);
+/* image (n_img, 3, H, W) f32 NCHW in [-1, 1], H and W multiples of 8 -> out (n_img, descriptor_size, H/8, W/8) f32 NCHW. */
+int nope_encoder_forward(const nope_encoder* enc, const float* image, int n_img, int H, int W, float* out,
+                         void* workspace, size_t workspace_bytes, nope_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Operator-level entry points (NHWC activations of `dtype`), exported so that each block of
  * model_utils.py can be parity-tested in isolation.  Weights for nope_op_conv are packed
  * [Cout][ntaps][Cin] by nope_op_pack_conv_weight.
@@ -129,11 +151,15 @@ int nope_op_nhwc_to_nchw(int dtype, const void* x_nhwc, float* y_nchw, int n, in
 int nope_op_pack_conv_weight(int dtype, const float* w, void* packed, int Cout, int Cin, int ntaps, int mode,
                              nope_stream_t s);
 /* conv3x3(pad1) / conv1x1 / nearest-x2+conv3x3 (HardUpsample, model_utils.py:161-165) /
- * space-to-depth+conv1x1 (HardDownsample, :168-172) over a virtual channel concat
+ * space-to-depth+conv1x1 (HardDownsample, :168-172) / stride-2 conv (encoder) over a virtual channel concat
  * (torch.cat((x, skip), dim=1), u_net.py:186,189,194) as one implicit GEMM. */
 int nope_op_conv(int dtype, const void* src1, int C1, int rep1, const void* src2, int C2, int rep2, int Hs, int Ws,
                  int mode, int ntaps, const void* w_packed, const float* bias, const void* resid, void* out,
-                 int Cout, int n_hyp, int out_nchw, int out_dtype, nope_stream_t s);
+                 int Cout, int n_hyp, int out_nchw, int out_dtype, int act_relu, nope_stream_t s);
+/* conv1 of the encoder trunk: 7x7 / stride 2 / pad 3 on an NCHW f32 image, + per-channel scale (folded into the
+ * weights) and shift + ReLU -> NHWC (n_img, H/2, W/2, 64).  w (64,3,7,7), scale/shift (64). */
+int nope_op_stem_conv(int dtype, const float* image, const float* w, const float* scale, const float* shift, float* w_scratch,
+                      void* out, int n_img, int H, int W, nope_stream_t s);
 /* GroupNorm(G, C) [+ SiLU] [+ emb[hyp, c]] [+ resid]: Block.norm/act (model_utils.py:241-252),
  * the conditioning add (:274-276), PreNorm (:226-234) and Residual (:198-204).
  * `partial` scratch: n_hyp * nope_op_gn_chunks() * G * 2 floats. */

@@ -43,17 +43,26 @@ int nope_op_pack_conv_weight(int dtype, const float* w, void* packed, int Cout, 
 
 int nope_op_conv(int dtype, const void* src1, int C1, int rep1, const void* src2, int C2, int rep2, int Hs, int Ws, int mode,
                  int ntaps, const void* w_packed, const float* bias, const void* resid, void* out, int Cout, int n_hyp,
-                 int out_nchw, int out_dtype, nope_stream_t s) {
+                 int out_nchw, int out_dtype, int act_relu, nope_stream_t s) {
     ConvArgs a;
     a.src1 = src1; a.C1 = C1; a.rep1 = rep1; a.src2 = src2; a.C2 = C2; a.rep2 = rep2 > 0 ? rep2 : 1;
     a.Hs = Hs; a.Ws = Ws; a.mode = mode; a.ntaps = ntaps;
     const bool up = mode == NOPE_CONV_UP2 || mode == NOPE_CONV_UP2P;
-    a.Ho = up ? 2 * Hs : (mode == NOPE_CONV_DOWN2 ? Hs / 2 : Hs);
-    a.Wo = up ? 2 * Ws : (mode == NOPE_CONV_DOWN2 ? Ws / 2 : Ws);
-    if (mode == NOPE_CONV_DOWN2 && ((Hs | Ws) & 1)) return NOPE_ERR_ARG;
+    const bool half = mode == NOPE_CONV_DOWN2 || mode == NOPE_CONV_STRIDE2;
+    a.Ho = up ? 2 * Hs : (half ? Hs / 2 : Hs);
+    a.Wo = up ? 2 * Ws : (half ? Ws / 2 : Ws);
+    if (half && ((Hs | Ws) & 1)) return NOPE_ERR_ARG;
+    a.act = act_relu ? 1 : 0;
     a.w = w_packed; a.bias = bias; a.resid = resid; a.out = out; a.Cout = Cout; a.nhyp = n_hyp;
     a.out_nchw = out_nchw; a.out_dt = out_dtype;
     return launch_conv(dtype, a, (hipStream_t)s);
+}
+
+int nope_op_stem_conv(int dtype, const float* image, const float* w, const float* scale, const float* shift, float* w_scratch,
+                      void* out, int n_img, int H, int W, nope_stream_t s) {
+    int e = launch_stem_pack(w, scale, w_scratch, (hipStream_t)s);      // w_scratch: 147 * 64 floats
+    if (e) return e;
+    return launch_stem_conv(dtype, image, w_scratch, shift, out, n_img, H, W, (hipStream_t)s);
 }
 
 int nope_op_gn_chunks(int dtype, int HW, int C) { return gn_stats_chunks(HW, C, dtype); }

@@ -1,0 +1,255 @@
+// Host-side runtime of the template encoder:
+//   FeatureExtractor.encode_image, src/model/encoder/template.py:47-53
+//   = projector(backbone(image)): ResNet-50 trunk resnet.py:92-152 (conv1 7x7/2 + bn + relu, no max-pool,
+//     Bottleneck layers [3,4,6,3] with strides (1,2,2,1), resnet.py:55-90,102-105,179-185) -> /8, 2048 channels ->
+//     ReLU, 1x1(2048->256), ReLU, 1x1(256->descriptor_size) (template.py:33-38).
+//
+// MI355X execution: NHWC activations; every eval-mode BatchNorm is folded into the preceding conv at
+// create time (scale into the packed weights, shift as the conv bias); ReLU and the residual add run in the
+// conv epilogue, so a Bottleneck is 3 (4 with a projection shortcut) launches of the implicit-GEMM kernel and
+// nothing else touches HBM.  conv1 (3 input channels) is a small direct kernel.  Activations live in five
+// ping-pong buffers of a caller-provided workspace: no allocation, no host sync, one stream.
+#include <cstdio>
+#include <initializer_list>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "nope_common.h"
+
+using namespace nope;
+
+namespace {
+
+struct EConv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; };
+struct Bottleneck { EConv c1, c2, c3, ds; bool has_ds = false; };
+
+constexpr int LAYERS[4] = {3, 4, 6, 3};       // resnet.py:179-185 (resnet50)
+constexpr int STRIDES[4] = {1, 2, 2, 1};      // resnet.py:102-105
+constexpr int FEATURES = 64;
+
+}  // namespace
+
+struct nope_encoder {
+    nope_encoder_config cfg;
+    int dt = NOPE_F32;
+    std::vector<void*> allocs;
+    float* stem_w = nullptr;      // [147][64] f32, bn1 scale folded
+    float* stem_shift = nullptr;  // [64]
+    std::vector<Bottleneck> blocks;
+    std::vector<int> block_stride;
+    EConv proj0, proj1;
+};
+
+namespace {
+
+struct ELoader {
+    nope_encoder* enc;
+    hipStream_t s;
+    std::map<std::string, const nope_tensor_desc*> tab;
+    int err = NOPE_OK;
+    std::string missing;
+
+    void fail(const std::string& n) { if (err == NOPE_OK) { err = NOPE_ERR_WEIGHT; missing = n; } }
+    const nope_tensor_desc* get(const std::string& name, std::initializer_list<int64_t> shape) {
+        auto it = tab.find(name);
+        if (it == tab.end() || !it->second->data) { fail(name); return nullptr; }
+        const nope_tensor_desc* d = it->second;
+        if (d->ndim != (int)shape.size()) { fail(name); return nullptr; }
+        int i = 0;
+        for (int64_t v : shape) if (d->shape[i++] != v) { fail(name); return nullptr; }
+        return d;
+    }
+    void* dmalloc(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { if (err == NOPE_OK) err = NOPE_ERR_ALLOC; return nullptr; }
+        enc->allocs.push_back(p);
+        return p;
+    }
+    void chk(int e) { if (e != NOPE_OK && err == NOPE_OK) err = e; }
+    // (scale, shift) of the eval-mode BatchNorm2d `pfx` over C channels
+    bool bn(const std::string& pfx, int C, float*& scale, float*& shift) {
+        const nope_tensor_desc* g = get(pfx + "weight", {C});
+        const nope_tensor_desc* b = get(pfx + "bias", {C});
+        const nope_tensor_desc* m = get(pfx + "running_mean", {C});
+        const nope_tensor_desc* v = get(pfx + "running_var", {C});
+        scale = (float*)dmalloc((size_t)C * 4);
+        shift = (float*)dmalloc((size_t)C * 4);
+        if (!g || !b || !m || !v || !scale || !shift) return false;
+        chk(launch_bn_fold(g->data, b->data, m->data, v->data, enc->cfg.bn_eps, scale, shift, C, s));
+        return true;
+    }
+    // conv `wname` (bias-free in the reference) followed by BatchNorm `bnpfx` -> packed weights * scale, bias = shift
+    EConv conv_bn(const std::string& wname, const std::string& bnpfx, int Cin, int Cout, int ksz, int stride) {
+        EConv c;
+        c.Cin = Cin; c.Cout = Cout; c.ntaps = ksz * ksz; c.mode = stride == 2 ? NOPE_CONV_STRIDE2 : NOPE_CONV_PLAIN;
+        const nope_tensor_desc* d = get(wname, {Cout, Cin, ksz, ksz});
+        float* scale = nullptr;
+        if (!bnpfx.empty()) { if (!bn(bnpfx, Cout, scale, c.bias)) return c; }
+        if (d) {
+            const size_t es = enc->dt == NOPE_F32 ? 4 : 2;
+            c.w = dmalloc((size_t)Cout * c.ntaps * Cin * es);
+            if (c.w) chk(launch_pack_conv_w(enc->dt, d->data, c.w, Cout, Cin, c.ntaps, NOPE_CONV_PLAIN, s, nullptr, scale));
+        }
+        return c;
+    }
+};
+
+struct EArena {
+    unsigned char* base = nullptr;
+    size_t cap = 0, off = 0;
+    bool dry = false;
+    void* alloc(size_t bytes) {
+        const size_t o = align_up(off, 256);
+        off = o + bytes;
+        if (dry) return (void*)(uintptr_t)(0x1000 + o);
+        if (off > cap) return nullptr;
+        return base + o;
+    }
+};
+
+// Buffer sizes (elements per image) of the five activation buffers for an H x W image.
+struct Plan { size_t x = 0, t1 = 0, t2 = 0; };
+Plan plan_for(int H, int W) {
+    Plan p;
+    int h = H / 2, w = W / 2, cin = FEATURES;
+    p.x = (size_t)h * w * cin;
+    for (int l = 0; l < 4; ++l) {
+        const int planes = FEATURES << l;
+        for (int b = 0; b < LAYERS[l]; ++b) {
+            const int st = b == 0 ? STRIDES[l] : 1;
+            const size_t e1 = (size_t)h * w * planes;                 // conv1 output at the input resolution
+            const int ho = h / st, wo = w / st;
+            const size_t e2 = (size_t)ho * wo * planes;
+            const size_t e3 = (size_t)ho * wo * planes * 4;
+            if (e1 > p.t1) p.t1 = e1;
+            if (e2 > p.t2) p.t2 = e2;
+            if (e3 > p.x) p.x = e3;
+            h = ho; w = wo; cin = planes * 4;
+        }
+    }
+    if ((size_t)h * w * 256 > p.t1) p.t1 = (size_t)h * w * 256;       // projector hidden
+    return p;
+}
+
+int run_encoder(const nope_encoder* enc, const float* image, int n_img, int H, int W, float* out, EArena& ar, hipStream_t s) {
+    const size_t es = enc->dt == NOPE_F32 ? 4 : 2;
+    const Plan pl = plan_for(H, W);
+    void* X[3];
+    for (int i = 0; i < 3; ++i) X[i] = ar.alloc(pl.x * n_img * es);
+    void* T1 = ar.alloc(pl.t1 * n_img * es);
+    void* T2 = ar.alloc(pl.t2 * n_img * es);
+    if (ar.dry) return NOPE_OK;
+    if (!X[0] || !X[1] || !X[2] || !T1 || !T2) return NOPE_ERR_WORKSPACE;
+
+    auto conv = [&](const EConv& c, const void* src, int Hs, int Ws, void* dst, int act, const void* resid, int out_nchw) -> int {
+        ConvArgs a;
+        a.src1 = src; a.C1 = c.Cin; a.Hs = Hs; a.Ws = Ws;
+        a.Ho = c.mode == NOPE_CONV_STRIDE2 ? Hs / 2 : Hs; a.Wo = c.mode == NOPE_CONV_STRIDE2 ? Ws / 2 : Ws;
+        a.mode = c.mode; a.ntaps = c.ntaps; a.w = c.w; a.bias = c.bias; a.resid = resid; a.out = dst; a.Cout = c.Cout;
+        a.nhyp = n_img; a.act = act; a.out_nchw = out_nchw; a.out_dt = NOPE_F32;
+        return launch_conv(enc->dt, a, s);
+    };
+
+    int e = launch_stem_conv(enc->dt, image, enc->stem_w, enc->stem_shift, X[0], n_img, H, W, s);   // resnet.py:136-138
+    if (e) return e;
+    int cur = 0, h = H / 2, w = W / 2;
+    for (size_t i = 0; i < enc->blocks.size(); ++i) {      // Bottleneck.forward, resnet.py:70-90
+        const Bottleneck& b = enc->blocks[i];
+        const int st = enc->block_stride[i];
+        const int ho = h / st, wo = w / st;
+        const void* identity = X[cur];
+        int nxt = (cur + 1) % 3;
+        if (b.has_ds) {
+            const int dsb = (cur + 2) % 3;
+            if ((e = conv(b.ds, X[cur], h, w, X[dsb], 0, nullptr, 0))) return e;
+            identity = X[dsb];
+        }
+        if ((e = conv(b.c1, X[cur], h, w, T1, 1, nullptr, 0))) return e;
+        if ((e = conv(b.c2, T1, h, w, T2, 1, nullptr, 0))) return e;
+        if ((e = conv(b.c3, T2, ho, wo, X[nxt], 1, identity, 0))) return e;       // relu(bn3(conv3) + identity)
+        cur = nxt; h = ho; w = wo;
+    }
+    // projector: ReLU (a no-op on the ReLU output above), 1x1 -> ReLU -> 1x1, NCHW f32 out (template.py:33-38)
+    if ((e = conv(enc->proj0, X[cur], h, w, T1, 1, nullptr, 0))) return e;
+    return conv(enc->proj1, T1, h, w, out, 0, nullptr, 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nope_encoder_create(const nope_encoder_config* cfg, const nope_tensor_desc* tensors, int n_tensors, nope_stream_t stream,
+                        nope_encoder** out) {
+    if (!cfg || !tensors || !out || n_tensors <= 0) return NOPE_ERR_ARG;
+    if (cfg->compute_dtype != NOPE_F32 && cfg->compute_dtype != NOPE_BF16) return NOPE_ERR_UNSUPPORTED;
+    const int D = cfg->descriptor_size;
+    if (D <= 0 || D > 2048) return NOPE_ERR_UNSUPPORTED;
+    nope_encoder* enc = new nope_encoder();
+    enc->cfg = *cfg;
+    if (enc->cfg.bn_eps <= 0.f) enc->cfg.bn_eps = 1e-5f;      // nn.BatchNorm2d default
+    enc->dt = cfg->compute_dtype;
+    ELoader L{enc, (hipStream_t)stream};
+    for (int i = 0; i < n_tensors; ++i) if (tensors[i].name) L.tab[tensors[i].name] = &tensors[i];
+
+    {   // conv1 + bn1 (resnet.py:98-99)
+        float* scale = nullptr;
+        const nope_tensor_desc* w = L.get("backbone.conv1.weight", {FEATURES, 3, 7, 7});
+        if (L.bn("backbone.bn1.", FEATURES, scale, enc->stem_shift) && w) {
+            enc->stem_w = (float*)L.dmalloc((size_t)147 * FEATURES * 4);
+            if (enc->stem_w) L.chk(launch_stem_pack(w->data, scale, enc->stem_w, L.s));
+        }
+    }
+    int cin = FEATURES;
+    for (int l = 0; l < 4; ++l) {
+        const int planes = FEATURES << l;
+        for (int b = 0; b < LAYERS[l]; ++b) {
+            const std::string p = "backbone.layer" + std::to_string(l + 1) + "." + std::to_string(b) + ".";
+            const int st = b == 0 ? STRIDES[l] : 1;
+            Bottleneck bk;
+            bk.c1 = L.conv_bn(p + "conv1.weight", p + "bn1.", cin, planes, 1, 1);
+            bk.c2 = L.conv_bn(p + "conv2.weight", p + "bn2.", planes, planes, 3, st);
+            bk.c3 = L.conv_bn(p + "conv3.weight", p + "bn3.", planes, planes * 4, 1, 1);
+            bk.has_ds = b == 0;                                  // resnet.py:119-128: stride != 1 or inplanes != planes * 4
+            if (bk.has_ds) bk.ds = L.conv_bn(p + "downsample.0.weight", p + "downsample.1.", cin, planes * 4, 1, st);
+            enc->blocks.push_back(bk);
+            enc->block_stride.push_back(st);
+            cin = planes * 4;
+        }
+    }
+    enc->proj0 = L.conv_bn("projector.1.weight", "", cin, 256, 1, 1);
+    enc->proj1 = L.conv_bn("projector.3.weight", "", 256, D, 1, 1);
+    if (hipStreamSynchronize(L.s) != hipSuccess && L.err == NOPE_OK) L.err = NOPE_ERR_LAUNCH;   // the sources may be freed by the caller
+    if (L.err != NOPE_OK) {
+        if (L.err == NOPE_ERR_WEIGHT) fprintf(stderr, "nope_encoder_create: missing or mis-shaped tensor '%s'\n", L.missing.c_str());
+        nope_encoder_destroy(enc);
+        return L.err;
+    }
+    *out = enc;
+    return NOPE_OK;
+}
+
+void nope_encoder_destroy(nope_encoder* enc) {
+    if (!enc) return;
+    for (void* p : enc->allocs) hipFree(p);
+    delete enc;
+}
+
+size_t nope_encoder_workspace_bytes(const nope_encoder* enc, int n_img, int H, int W) {
+    if (!enc || n_img <= 0 || H <= 0 || W <= 0 || H % 8 || W % 8) return 0;
+    EArena ar;
+    ar.dry = true;
+    if (run_encoder(enc, nullptr, n_img, H, W, nullptr, ar, nullptr) != NOPE_OK) return 0;
+    return align_up(ar.off, 256);
+}
+
+int nope_encoder_forward(const nope_encoder* enc, const float* image, int n_img, int H, int W, float* out, void* workspace,
+                         size_t workspace_bytes, nope_stream_t stream) {
+    if (!enc || !image || !out || !workspace || n_img <= 0) return NOPE_ERR_ARG;
+    if (H <= 0 || W <= 0 || H % 8 || W % 8) return NOPE_ERR_UNSUPPORTED;
+    EArena ar;
+    ar.base = (unsigned char*)workspace; ar.cap = workspace_bytes;
+    return run_encoder(enc, image, n_img, H, W, out, ar, (hipStream_t)stream);
+}
+
+}  // extern "C"

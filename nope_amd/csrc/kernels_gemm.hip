@@ -79,6 +79,7 @@ struct ConvParams {
     unsigned char* out;
     int Cout, M;
     int out_nchw, out_dt;
+    int act;                           // 0 none, 1 ReLU (after bias and residual)
     int tiles_m, tiles_n, xcd_map, wide_out;
     int variant;                       // tuning switches (NOPE_CONV_VARIANT), 0 in production
     FastDiv d_hw, d_w, d_rep1, d_rep2; // / (Hm*Wm), / Wm, / rep1, / rep2
@@ -220,6 +221,7 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const typename Til
                 float v = acc[i][j][r] + bv[j];
                 if (PN) v = pn_rstd * (acc[i][j][r] - pn_mean * p.pn_c1[n]) + p.pn_c0[n] + bv[j];
                 if (resid) v += Elt<T>::ld(resid + mo * p.Cout + n);
+                if (p.act) v = v > 0.f ? v : 0.f;
                 if (p.out_nchw) {
                     const size_t o = nchw_base + (size_t)n * HWo;
                     if (p.out_dt == NOPE_F32) reinterpret_cast<float*>(p.out)[o] = v;
@@ -346,6 +348,10 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] += rv[e];
             }
+            if (p.act) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
             st16(out + o, Elt<T>::pack(v));
         }
         __builtin_amdgcn_wave_barrier();
@@ -355,6 +361,10 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
 // Source pixel of output pixel (oy, ox) under tap (dy, dx); false = zero padding / beyond M.
 __device__ __forceinline__ bool tap_pixel(const ConvParams& p, int oy, int ox, int dy, int dx, int& iy, int& ix) {
     if (p.mode == NOPE_CONV_DOWN2) { iy = 2 * oy + dy; ix = 2 * ox + dx; return oy >= 0; }
+    if (p.mode == NOPE_CONV_STRIDE2) {   // stride 2, pad 1 (3x3) / pad 0 (1x1)
+        iy = 2 * oy + dy; ix = 2 * ox + dx;
+        return oy >= 0 && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+    }
     if (p.mode == NOPE_CONV_UP2P) {   // rows are source pixels; (dy, dx) already include the phase shift
         iy = oy + dy; ix = ox + dx;
         return iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
@@ -563,6 +573,10 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
             a_b1[i] = (((s1 * p.Hs + 2 * oy) * p.Ws + 2 * ox) * p.C1 + cs) * ES;
             a_b2[i] = 0;
             mask = 0xfu;
+        } else if (MODE == NOPE_CONV_STRIDE2) {   // centre tap at source pixel (2 oy, 2 ox)
+            a_b1[i] = (((s1 * p.Hs + 2 * oy) * p.Ws + 2 * ox) * p.C1 + cs) * ES;
+            a_b2[i] = 0;
+            mask = p.ntaps == 9 ? mask3x3(2 * oy, 2 * ox, p.Hs, p.Ws) : 1u;
         } else {   // UP2: source row/col of the 3 vertical / horizontal taps in the upsampled image
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
         const int Cs = st_first ? p.C1 : p.C2;
         st_kadd = (unsigned)(st_first ? c0 : c0 - p.C1) * ES;     // scalar part of the A offset
         st_dyi = 1; st_dxi = 1;
-        if (MODE == NOPE_CONV_PLAIN) {
+        if (MODE == NOPE_CONV_PLAIN || MODE == NOPE_CONV_STRIDE2) {
             if (p.ntaps == 9) {
                 st_dyi = ld_tap / 3; st_dxi = ld_tap - st_dyi * 3;
                 st_kadd += (unsigned)(((st_dyi - 1) * p.Ws + (st_dxi - 1)) * Cs) * ES;
@@ -676,6 +690,7 @@ void launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
     else if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT, false>), grid, dim3(BMT * 2), 0, s, p);
     else if (p.mode == NOPE_CONV_UP2) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2, RB, NS, BMT, false>), grid, dim3(BMT * 2), 0, s, p);
     else if (p.mode == NOPE_CONV_UP2P) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2P, RB, NS, BMT, false>), grid, dim3(BMT * 2), 0, s, p);
+    else if (p.mode == NOPE_CONV_STRIDE2) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_STRIDE2, RB, NS, BMT, false>), grid, dim3(BMT * 2), 0, s, p);
     else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_DOWN2, RB, NS, BMT, false>), grid, dim3(BMT * 2), 0, s, p);
 }
 
@@ -696,6 +711,8 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         if (a.ntaps != 4 || a.Hs != 2 * a.Ho || a.Ws != 2 * a.Wo) return NOPE_ERR_ARG;
     } else if (a.mode == NOPE_CONV_UP2P) {
         if (a.ntaps != 4 || a.Ho != 2 * a.Hs || a.Wo != 2 * a.Ws || a.C2 != 0 || a.out_nchw) return NOPE_ERR_ARG;
+    } else if (a.mode == NOPE_CONV_STRIDE2) {
+        if ((a.ntaps != 1 && a.ntaps != 9) || a.Hs != 2 * a.Ho || a.Ws != 2 * a.Wo || a.C2 != 0) return NOPE_ERR_ARG;
     } else return NOPE_ERR_ARG;
     const bool phased = a.mode == NOPE_CONV_UP2P;
     const long long M = phased ? (long long)a.nhyp * a.Hs * a.Ws : (long long)a.nhyp * a.Ho * a.Wo;
@@ -710,6 +727,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.w = (const unsigned char*)a.w; p.bias = a.bias; p.resid = (const unsigned char*)a.resid;
     p.out = (unsigned char*)a.out; p.Cout = a.Cout; p.M = (int)M;
     p.out_nchw = a.out_nchw; p.out_dt = a.out_dt;
+    p.act = a.act;
     p.wide_out = (!a.out_nchw && a.Cout % vec == 0) ? 1 : 0;
     p.colstats = a.colstats;
     p.pn_ms = a.pn_ms; p.pn_c0 = a.pn_c0; p.pn_c1 = a.pn_c1;

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(NT) void nhwc_to_nchw_kernel(const T* __restrict__ 
 //          c*4 + p1*2 + p2 (einops "b (c p1 p2) h w", model_utils.py:170); tap = p1*2 + p2.
 template <class T>
 __global__ __launch_bounds__(NT) void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ out, int Cin, int ntaps, int mode,
-                                                         size_t total, const float* __restrict__ cin_scale) {
+                                                         size_t total, const float* __restrict__ cin_scale,
+                                                         const float* __restrict__ cout_scale) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
         const int c = (int)(i % Cin);
         const size_t t = i / Cin;
@@ -46,7 +47,10 @@ __global__ __launch_bounds__(NT) void pack_conv_w_kernel(const float* __restrict
         size_t src;
         if (mode == NOPE_CONV_DOWN2) src = co * ((size_t)Cin * 4) + (size_t)c * 4 + tap;
         else src = (co * Cin + c) * ntaps + tap;
-        Elt<T>::st(out + i, cin_scale ? w[src] * cin_scale[c] : w[src]);   // optional per-input-channel scale (PreNorm gamma)
+        float v = w[src];
+        if (cin_scale) v *= cin_scale[c];      // per-input-channel scale (PreNorm gamma)
+        if (cout_scale) v *= cout_scale[co];   // per-output-channel scale (folded eval-mode BatchNorm)
+        Elt<T>::st(out + i, v);
     }
 }
 
@@ -146,11 +150,12 @@ int launch_nhwc_to_nchw_f32(int dt, const void* x, float* y, int n, int C, int H
     return NOPE_OK;
 }
 
-int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s, const float* cin_scale) {
+int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s, const float* cin_scale,
+                       const float* cout_scale) {
     if (!w || !out || Cout <= 0 || Cin <= 0 || ntaps <= 0) return NOPE_ERR_ARG;
     if (mode == NOPE_CONV_DOWN2 && ntaps != 4) return NOPE_ERR_ARG;
     if (mode == NOPE_CONV_UP2P) {
-        if (ntaps != 4) return NOPE_ERR_ARG;
+        if (ntaps != 4 || cin_scale || cout_scale) return NOPE_ERR_ARG;
         const size_t tot = (size_t)4 * Cout * 4 * Cin;
         if (dt == NOPE_F32) hipLaunchKernelGGL((pack_up2p_w_kernel<float>), dim3(grid_for(tot)), dim3(NT), 0, s, w, (float*)out, Cout, Cin, tot);
         else if (dt == NOPE_BF16) hipLaunchKernelGGL((pack_up2p_w_kernel<bf16_t>), dim3(grid_for(tot)), dim3(NT), 0, s, w, (bf16_t*)out, Cout, Cin, tot);
@@ -159,8 +164,8 @@ int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int
         return NOPE_OK;
     }
     const size_t total = (size_t)Cout * ntaps * Cin;
-    if (dt == NOPE_F32) hipLaunchKernelGGL((pack_conv_w_kernel<float>), dim3(grid_for(total)), dim3(NT), 0, s, w, (float*)out, Cin, ntaps, mode, total, cin_scale);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((pack_conv_w_kernel<bf16_t>), dim3(grid_for(total)), dim3(NT), 0, s, w, (bf16_t*)out, Cin, ntaps, mode, total, cin_scale);
+    if (dt == NOPE_F32) hipLaunchKernelGGL((pack_conv_w_kernel<float>), dim3(grid_for(total)), dim3(NT), 0, s, w, (float*)out, Cin, ntaps, mode, total, cin_scale, cout_scale);
+    else if (dt == NOPE_BF16) hipLaunchKernelGGL((pack_conv_w_kernel<bf16_t>), dim3(grid_for(total)), dim3(NT), 0, s, w, (bf16_t*)out, Cin, ntaps, mode, total, cin_scale, cout_scale);
     else return NOPE_ERR_UNSUPPORTED;
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;

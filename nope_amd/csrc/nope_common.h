@@ -119,8 +119,8 @@ struct ConvArgs {
     int rep1 = 1, rep2 = 1;      // source sample = hypothesis / rep  (broadcast of shared tensors)
     int Hs = 1, Ws = 1;          // source spatial size
     int Ho = 1, Wo = 1;          // output spatial size
-    int mode = NOPE_CONV_PLAIN;  // NOPE_CONV_PLAIN | NOPE_CONV_UP2 | NOPE_CONV_DOWN2
-    int ntaps = 1;               // 1 or 9 (PLAIN), 9 (UP2), 4 (DOWN2)
+    int mode = NOPE_CONV_PLAIN;  // NOPE_CONV_PLAIN | UP2 | DOWN2 | UP2P | STRIDE2
+    int ntaps = 1;               // 1 or 9 (PLAIN, STRIDE2), 9 (UP2), 4 (DOWN2, UP2P)
     const void* w = nullptr;     // packed [Cout][ntaps][Cin]
     const float* bias = nullptr; // [Cout] or null
     const void* resid = nullptr; // optional NHWC [M][Cout] added in the epilogue
@@ -129,6 +129,7 @@ struct ConvArgs {
     int nhyp = 0;                // M = nhyp * Ho * Wo
     int out_nchw = 0;            // 1: write (nhyp, Cout, Ho, Wo) with dtype out_dt
     int out_dt = NOPE_F32;       // only for out_nchw
+    int act = 0;                 // 0 none, 1 ReLU applied after bias (+ residual)
     int force_generic = 0;       // tests: take the register-staged kernel even when the LDS-DMA one applies
     float* colstats = nullptr;   // optional fused GroupNorm statistics: [M/64][Cout][2] (needs M % 64 == 0, NHWC out)
     // optional fused PreNorm (GroupNorm(1) in front of a 1x1 conv whose weights already carry gamma):
@@ -166,7 +167,13 @@ int launch_attn(int dt, const void* qkv, void* out, int nhyp, int HW, int heads,
 int launch_nchw_to_nhwc(int dt, const float* x, void* y, int n, int C, int HW, hipStream_t s);
 int launch_nhwc_to_nchw_f32(int dt, const void* x, float* y, int n, int C, int HW, hipStream_t s);
 int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s,
-                       const float* cin_scale = nullptr);
+                       const float* cin_scale = nullptr, const float* cout_scale = nullptr);
+// template encoder (kernels_encoder.hip)
+int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale, float* shift,
+                   int C, hipStream_t s);
+int launch_stem_pack(const float* w, const float* scale, float* out, hipStream_t s);
+int launch_stem_conv(int dt, const float* img, const float* w_packed, const float* shift, void* out, int n_img, int H, int W,
+                     hipStream_t s);
 int launch_rowsum(int dt, const void* packed, float* out, int rows, int K, hipStream_t s);
 int launch_linear_naive(const float* in, const float* w, const float* bias, float* out, int M, int N, int K, int act_in,
                         int ldo, hipStream_t s);

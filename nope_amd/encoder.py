@@ -7,11 +7,13 @@ Same constructor kwargs, attributes (`latent_dim`, `name`, `normalize`) and stat
 as the reference (including its aliased `encoder.0.* / encoder.1.*` entries and the unused
 `backbone.fc`), so `resnet50_template_pose.pth` loads unchanged.
 
-Round-1 status: this runs ONCE per query and once per reference image
-(the reference re-runs it N times, model.py:115) and is executed with stock PyTorch-ROCm
-convolutions; it is the first "next" row to move onto the implicit-GEMM kernel (needs
-stride-2 / 7x7 taps and a folded-BN + ReLU epilogue).  It is not part of the U-Net/scoring
-kernels the north star names and is <1 % of a 512-template step.
+Execution: device tensors go through the C ABI (`nope_encoder_*`,
+csrc/encoder_runtime.hip): eval-mode BatchNorm folded into the conv weights at handle creation, every
+1x1 / 3x3 / stride-2 conv on the implicit-GEMM MFMA kernel with bias + residual + ReLU in its epilogue,
+conv1 as a small direct kernel -- no PyTorch/MIOpen arithmetic, and no fallback when the library is
+missing.  The `nn.Module` tree below holds the parameters under the reference's keys; its torch
+`forward` is the host-side mirror used for CPU tensors only (CPU checks against the golden fixtures).
+It runs once per query and once per reference image (the reference re-runs it N times, model.py:115).
 """
 from __future__ import annotations
 
@@ -20,6 +22,8 @@ import math
 import torch
 import torch.nn.functional as F
 from torch import nn
+
+from . import hip
 
 _LAYERS = (3, 4, 6, 3)
 _STRIDES = (1, 2, 2, 1)      # resnet.py:102-105
@@ -75,8 +79,11 @@ class _Trunk(nn.Module):
 
 
 class FeatureExtractor(nn.Module):
-    def __init__(self, descriptor_size, threshold=0.2, normalize=False, **kwargs):
+    def __init__(self, descriptor_size, threshold=0.2, normalize=False, compute_dtype="f32", **kwargs):
         super().__init__()
+        self.compute_dtype = compute_dtype      # "f32": parity mode, "bf16": throughput mode (as UNet.compute_dtype)
+        self._handle = None
+        self._handle_key = None
         self.latent_dim = descriptor_size
         self.normalize = normalize
         self.threshold = threshold
@@ -87,9 +94,37 @@ class FeatureExtractor(nn.Module):
         self.encoder = nn.Sequential(self.backbone, self.projector)   # aliased, as in template.py:40
         self.eval()
 
+    def invalidate(self):
+        """Call after changing weights in place; the next device call refolds and repacks them."""
+        self._handle = None
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate()
+        return r
+
+    def _get_handle(self, device) -> "hip.EncoderHandle":
+        key = (str(device), self.compute_dtype)
+        if self._handle is None or self._handle_key != key:
+            sd = {k: v.to(device) for k, v in self.state_dict().items() if k.startswith(("backbone.", "projector."))}
+            self._handle = hip.EncoderHandle(self.latent_dim, sd, hip.dtype_code(self.compute_dtype),
+                                             bn_eps=self.backbone.bn1.eps)
+            self._handle_key = key
+        return self._handle
+
+    @torch.no_grad()
+    def encode_image_hip(self, image):
+        """template.py:47-53 through the C ABI (device tensors; CPU tensors only under tests/hipemu)."""
+        feat = self._get_handle(image.device).forward(image)
+        if self.normalize:
+            feat = F.normalize(feat, dim=1)
+        return feat
+
     @torch.no_grad()
     def encode_image(self, image, mode=None):
-        feat = self.projector(self.backbone(image))
+        if image.is_cuda:
+            return self.encode_image_hip(image)
+        feat = self.projector(self.backbone(image))     # host-side mirror, CPU tensors only
         if self.normalize:
             feat = F.normalize(feat, dim=1)
         return feat

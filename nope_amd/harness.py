@@ -70,7 +70,7 @@ def build_model(seed: int = 2022, compute_dtype="f32", bank_dtype="f32", device=
     from .u_net import UNet
     from .weights import synth_init_
     cfg = TEMPLATE_BASE
-    enc = FeatureExtractor(**cfg["u_net"]["encoder"])
+    enc = FeatureExtractor(**cfg["u_net"]["encoder"], compute_dtype=compute_dtype)
     synth_init_(enc, seed, prefix="encoder.")
     unet = UNet(u_net_dim=u_net_dim or cfg["u_net"]["u_net_dim"], rot_representation_dim=6, encoder=enc,
                 pose_mlp_name=cfg["u_net"]["pose_mlp_name"], compute_dtype=compute_dtype)

@@ -13,7 +13,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 F32, BF16 = 0, 1
-CONV_PLAIN, CONV_UP2, CONV_DOWN2, CONV_UP2P = 0, 1, 2, 3
+CONV_PLAIN, CONV_UP2, CONV_DOWN2, CONV_UP2P, CONV_STRIDE2 = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NOPE_HIP_LIB: load another build of the SAME gfx950 library (A/B timing of kernel variants); default = in-tree build
@@ -32,6 +32,10 @@ class UNetConfig(C.Structure):
                 ("compute_dtype", _i)]
 
 
+class EncoderConfig(C.Structure):
+    _fields_ = [("descriptor_size", _i), ("compute_dtype", _i), ("bn_eps", C.c_float)]
+
+
 _PROTOS = {
     "nope_strerror": (C.c_char_p, [_i]),
     "nope_abi_version": (_i, []),
@@ -46,7 +50,12 @@ _PROTOS = {
     "nope_op_nchw_to_nhwc": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
     "nope_op_nhwc_to_nchw": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
     "nope_op_pack_conv_weight": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "nope_op_conv": (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "nope_encoder_create": (_i, [C.POINTER(EncoderConfig), C.POINTER(TensorDesc), _i, _vp, C.POINTER(_vp)]),
+    "nope_encoder_destroy": (None, [_vp]),
+    "nope_encoder_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "nope_encoder_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "nope_op_conv": (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nope_op_stem_conv": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "nope_op_gn_chunks": (_i, [_i, _i, _i]),
     "nope_op_group_norm": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "nope_op_linear_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -162,6 +171,82 @@ def topk(scores: torch.Tensor, k: int = 5) -> Tuple[torch.Tensor, torch.Tensor]:
     return vals, idx
 
 
+def _tensor_descs(state_dict: Dict[str, torch.Tensor]):
+    keep, dev = [], None
+    descs = (TensorDesc * max(1, len(state_dict)))()
+    for i, (k, v) in enumerate(state_dict.items()):
+        t = _f32c(v.detach())
+        keep.append(t)
+        dev = t.device
+        descs[i].name = k.encode()
+        descs[i].data = t.data_ptr()
+        descs[i].ndim = t.dim()
+        for j, s in enumerate(t.shape[:4]):
+            descs[i].shape[j] = s
+    return descs, keep, dev
+
+
+# --------------------------------------------------------------------------------------------
+# Template-encoder handle
+# --------------------------------------------------------------------------------------------
+class EncoderHandle:
+    """Owns a `nope_encoder*` built from the FeatureExtractor's state dict (BatchNorm folded at create time)."""
+
+    def __init__(self, descriptor_size: int, state_dict: Dict[str, torch.Tensor], compute_dtype=F32, bn_eps: float = 1e-5):
+        l = lib()
+        self._l = l
+        c = EncoderConfig()
+        c.descriptor_size = int(descriptor_size)
+        c.compute_dtype = dtype_code(compute_dtype)
+        c.bn_eps = float(bn_eps)
+        self.descriptor_size, self.compute_dtype = c.descriptor_size, c.compute_dtype
+        sd = {k: v for k, v in state_dict.items() if k.startswith(("backbone.", "projector.")) and v.dtype.is_floating_point}
+        descs, keep, dev = _tensor_descs(sd)
+        self.device = dev
+        h = _vp()
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev is not None and dev.type == "cuda" else 0
+        l.check(l.dll.nope_encoder_create(C.byref(c), descs, len(sd), stream, C.byref(h)), "nope_encoder_create")
+        self._h = h
+        self._ws: Dict[tuple, torch.Tensor] = {}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._l.dll.nope_encoder_destroy(h)
+            self._h = None
+
+    def forward(self, image: torch.Tensor) -> torch.Tensor:
+        """image (B,3,H,W) f32 -> (B,descriptor_size,H/8,W/8) f32."""
+        image = _f32c(image)
+        B, Cc, H, W = image.shape
+        if Cc != 3:
+            raise NopeError(f"encoder expects 3-channel images, got {tuple(image.shape)}")
+        need = int(self._l.dll.nope_encoder_workspace_bytes(self._h, B, H, W))
+        if need == 0:
+            raise NopeError(f"unsupported encoder input size {H}x{W} (must be multiples of 8)")
+        # one workspace per stream: two encoder passes may be in flight on different streams (model.generate_and_retrieve)
+        key = (str(image.device), _stream(image))
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=image.device)
+        out = torch.empty((B, self.descriptor_size, H // 8, W // 8), dtype=torch.float32, device=image.device)
+        self._l.check(self._l.dll.nope_encoder_forward(self._h, _ptr(image), B, H, W, _ptr(out), _ptr(ws), need, _stream(image)),
+                      "nope_encoder_forward")
+        return out
+
+
+def op_stem_conv(dt: int, image: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    """conv1 7x7/2 pad 3 + per-channel affine + ReLU: image (B,3,H,W) f32 NCHW -> NHWC (B,H/2,W/2,64) of dtype dt."""
+    image = _f32c(image)
+    B, _, H, W = image.shape
+    out = torch.empty((B, H // 2, W // 2, 64), dtype=torch_dtype(dt), device=image.device)
+    scratch = torch.empty(147 * 64, dtype=torch.float32, device=image.device)
+    l = lib()
+    l.check(l.dll.nope_op_stem_conv(dt, _ptr(image), _ptr(_f32c(w)), _ptr(_f32c(scale)), _ptr(_f32c(shift)), _ptr(scratch),
+                                    _ptr(out), B, H, W, _stream(image)), "nope_op_stem_conv")
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # U-Net handle
 # --------------------------------------------------------------------------------------------
@@ -184,18 +269,7 @@ class UNetHandle:
         self.cfg = dict(cfg)
         self.compute_dtype = c.compute_dtype
         self.channels, self.out_dim, self.pose_dim = c.channels, c.out_dim, c.pose_dim
-        keep = []
-        descs = (TensorDesc * len(state_dict))()
-        dev = None
-        for i, (k, v) in enumerate(state_dict.items()):
-            t = _f32c(v.detach())
-            keep.append(t)
-            dev = t.device
-            descs[i].name = k.encode()
-            descs[i].data = t.data_ptr()
-            descs[i].ndim = t.dim()
-            for j, s in enumerate(t.shape[:4]):
-                descs[i].shape[j] = s
+        descs, keep, dev = _tensor_descs(state_dict)
         self.device = dev
         h = _vp()
         stream = torch.cuda.current_stream(dev).cuda_stream if dev is not None and dev.type == "cuda" else 0
@@ -283,14 +357,14 @@ def pack_conv_weight(w: torch.Tensor, dt: int, mode: int = CONV_PLAIN) -> Tuple[
 def op_conv(dt: int, src1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
             src2: Optional[torch.Tensor] = None, mode: int = CONV_PLAIN, rep1: int = 1, rep2: int = 1,
             resid: Optional[torch.Tensor] = None, n_hyp: Optional[int] = None, out_nchw: bool = False,
-            out_dtype: int = F32) -> torch.Tensor:
+            out_dtype: int = F32, act_relu: bool = False) -> torch.Tensor:
     """src* NHWC tensors of dtype dt; w torch Conv2d weight (f32).  Returns NHWC (or NCHW)."""
     pw, cin, ntaps = pack_conv_weight(w, dt, mode)
     n1, hs, ws, c1 = src1.shape
     c2 = 0 if src2 is None else src2.shape[3]
     assert c1 + c2 == cin
     n_hyp = n_hyp if n_hyp is not None else n1 * rep1
-    ho, wo = (2 * hs, 2 * ws) if mode in (CONV_UP2, CONV_UP2P) else ((hs // 2, ws // 2) if mode == CONV_DOWN2 else (hs, ws))
+    ho, wo = (2 * hs, 2 * ws) if mode in (CONV_UP2, CONV_UP2P) else ((hs // 2, ws // 2) if mode in (CONV_DOWN2, CONV_STRIDE2) else (hs, ws))
     cout = w.shape[0]
     if out_nchw:
         out = torch.empty((n_hyp, cout, ho, wo), dtype=torch_dtype(out_dtype), device=src1.device)
@@ -299,7 +373,8 @@ def op_conv(dt: int, src1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.T
     b = None if bias is None else _f32c(bias)
     l = lib()
     l.check(l.dll.nope_op_conv(dt, _ptr(src1), c1, rep1, _ptr(src2), c2, rep2, hs, ws, mode, ntaps, _ptr(pw), _ptr(b),
-                               _ptr(resid), _ptr(out), cout, n_hyp, int(out_nchw), out_dtype, _stream(src1)), "nope_op_conv")
+                               _ptr(resid), _ptr(out), cout, n_hyp, int(out_nchw), out_dtype, int(act_relu), _stream(src1)),
+            "nope_op_conv")
     return out
 
 

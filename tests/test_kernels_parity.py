@@ -269,3 +269,70 @@ def test_topk_ties_nan_and_shared_bank(be):
     assert torch.equal(out[:, 4:13], s) and float(out[:, :4].min()) == 7.0 and float(out[:, 13:].min()) == 7.0
     with pytest.raises(hip.NopeError):
         hip.topk(torch.zeros(1, 3, device=dev), 5)                   # k > N is an error, as in torch
+
+
+# ---- template encoder ---------------------------------------
+@pytest.mark.parametrize("dt", [0, 1])
+def test_encoder_conv_ops(be, dt):
+    """The conv forms only the encoder uses: stride-2 3x3 (pad 1) and 1x1 (pad 0) on both the LDS-DMA
+    kernel (Cin = 64) and the generic one (Cin = 24), ReLU after bias + residual in the epilogue, and the
+    7x7 / stride-2 stem on an NCHW image with a folded per-channel affine."""
+    hip, dev, _ = be
+    tol = 2e-5 if dt == 0 else BF16_TOL
+    g = torch.Generator().manual_seed(21)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    q = lambda x: _q(x, dt, hip)
+    d = lambda x: x.to(dev)
+    for cin in (64, 24):
+        x, w3, b3 = rn(3, cin, 12, 8), rn(40, cin, 3, 3) / (3 * cin ** 0.5), rn(40)
+        y = hip.op_conv(dt, hip.to_nhwc(d(x), dt), d(w3), d(b3), mode=hip.CONV_STRIDE2, act_relu=True)
+        assert rel(hip.to_nchw(y, dt).cpu(), F.relu(F.conv2d(q(x), q(w3), b3, stride=2, padding=1))) < tol
+        w1 = rn(48, cin, 1, 1) / cin ** 0.5
+        y = hip.op_conv(dt, hip.to_nhwc(d(x), dt), d(w1), None, mode=hip.CONV_STRIDE2)
+        assert rel(hip.to_nchw(y, dt).cpu(), F.conv2d(q(x), q(w1), stride=2)) < tol
+        rs = rn(3, 48, 12, 8)
+        y = hip.op_conv(dt, hip.to_nhwc(d(x), dt), d(w1), d(rn(48)) * 0, resid=hip.to_nhwc(d(rs), dt), act_relu=True)
+        assert rel(hip.to_nchw(y, dt).cpu(), F.relu(F.conv2d(q(x), q(w1)) + q(rs))) < tol
+    img, w7 = rn(2, 3, 24, 40), rn(64, 3, 7, 7) / 12
+    scale, shift = rn(64).abs() + 0.5, rn(64)
+    y = hip.op_stem_conv(dt, d(img), d(w7), d(scale), d(shift))
+    ref = F.relu(F.conv2d(img, w7, stride=2, padding=3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    assert rel(hip.to_nchw(y, dt).cpu(), ref) < (2e-5 if dt == 0 else 1e-2)
+
+
+def _encoder_pair(golden_seed=2022, compute_dtype="f32"):
+    from nope_amd.encoder import FeatureExtractor
+    from nope_amd.weights import synth_init_
+    enc = FeatureExtractor(8, 0.2, False, compute_dtype=compute_dtype)
+    synth_init_(enc, golden_seed, prefix="encoder.")
+    return enc
+
+
+def test_encoder_tiny_image_emu(emu):
+    """Whole encoder through the C ABI under the interpreter: 16x16 image -> 2x2 map, f32 mode, against the
+    CPU restatement (the same weights the golden fixtures use).  Covers BatchNorm folding, the ping-pong
+    buffers, both projection-shortcut forms and the NCHW f32 output."""
+    enc = _encoder_pair()
+    img = torch.rand(1, 3, 16, 16, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    got = enc.encode_image_hip(img)
+    ref = R.encode_image(enc.state_dict(), img)
+    assert got.shape == (1, 8, 2, 2)
+    assert rel(got, ref) < F32_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cdt,tol", [("f32", F32_TOL), ("bf16", 6e-2)])
+def test_encoder_golden_gpu(gpu, golden, cdt, tol):
+    """encode_image on the device against the feature map recorded from the reference FeatureExtractor
+    (tests/golden/encoder.npz: 2 x 3 x 64 x 64 -> 2 x 8 x 8 x 8)."""
+    g = golden("encoder.npz")
+    enc = _encoder_pair(compute_dtype=cdt).cuda()
+    got = enc.encode_image(g["img"].cuda())
+    e = rel(got.cpu(), g["feat"])
+    print(f"encoder {cdt} rel err {e}")
+    assert e < tol
+    # ragged sizes: non-square image, batch of 3 -> same values as image by image
+    img = torch.rand(3, 3, 64, 96, generator=torch.Generator().manual_seed(9)).cuda() * 2 - 1
+    allf = enc.encode_image(img)
+    one = torch.cat([enc.encode_image(img[i:i + 1]) for i in range(3)])
+    assert allf.shape == (3, 8, 8, 12) and torch.equal(allf, one)

@@ -54,7 +54,7 @@ def main():
 
         def run():
             rc = l.dll.nope_op_conv(dt, s1.data_ptr(), c1, 1, None if s2 is None else s2.data_ptr(), c2, 1, hs, hs, mode, ntaps,
-                                    pw.data_ptr(), bias.data_ptr(), None, out.data_ptr(), cout, a.nhyp, 0, 0, st)
+                                    pw.data_ptr(), bias.data_ptr(), None, out.data_ptr(), cout, a.nhyp, 0, 0, 0, st)
             assert rc == 0, rc
         for _ in range(2):
             run()
