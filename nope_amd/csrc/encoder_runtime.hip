@@ -7,8 +7,10 @@
 // MI355X execution: NHWC activations; every eval-mode BatchNorm is folded into the preceding conv at
 // create time (scale into the packed weights, shift as the conv bias); ReLU and the residual add run in the
 // conv epilogue, so a Bottleneck is 3 (4 with a projection shortcut) launches of the implicit-GEMM kernel and
-// nothing else touches HBM.  conv1 (3 input channels) is a small direct kernel.  Activations live in five
-// ping-pong buffers of a caller-provided workspace: no allocation, no host sync, one stream.
+// nothing else touches HBM.  conv1 (3 input channels) is a small direct kernel.  With one or two images the deep
+// layers have only 8-32 output tiles for 256 CUs, so those launches are split along K (deterministic: f32 partials +
+// a fixed-order reduce that also applies bias / residual / ReLU).  Activations live in five ping-pong buffers of a
+// caller-provided workspace: no allocation, no host sync, one stream.
 #include <cstdio>
 #include <initializer_list>
 #include <map>
@@ -135,44 +137,61 @@ Plan plan_for(int H, int W) {
 int run_encoder(const nope_encoder* enc, const float* image, int n_img, int H, int W, float* out, EArena& ar, hipStream_t s) {
     const size_t es = enc->dt == NOPE_F32 ? 4 : 2;
     const Plan pl = plan_for(H, W);
-    void* X[3];
-    for (int i = 0; i < 3; ++i) X[i] = ar.alloc(pl.x * n_img * es);
-    void* T1 = ar.alloc(pl.t1 * n_img * es);
-    void* T2 = ar.alloc(pl.t2 * n_img * es);
-    if (ar.dry) return NOPE_OK;
-    if (!X[0] || !X[1] || !X[2] || !T1 || !T2) return NOPE_ERR_WORKSPACE;
+    void* X[3] = {nullptr, nullptr, nullptr};
+    void *T1 = nullptr, *T2 = nullptr, *SK = nullptr;
+    size_t sk_bytes = 0;
+    bool measure = true;
 
+    // One conv launch; in the measuring pass it only records the split-K scratch the launch would like.
     auto conv = [&](const EConv& c, const void* src, int Hs, int Ws, void* dst, int act, const void* resid, int out_nchw) -> int {
         ConvArgs a;
         a.src1 = src; a.C1 = c.Cin; a.Hs = Hs; a.Ws = Ws;
         a.Ho = c.mode == NOPE_CONV_STRIDE2 ? Hs / 2 : Hs; a.Wo = c.mode == NOPE_CONV_STRIDE2 ? Ws / 2 : Ws;
         a.mode = c.mode; a.ntaps = c.ntaps; a.w = c.w; a.bias = c.bias; a.resid = resid; a.out = dst; a.Cout = c.Cout;
         a.nhyp = n_img; a.act = act; a.out_nchw = out_nchw; a.out_dt = NOPE_F32;
+        if (measure) {
+            const size_t need = (size_t)conv_splitk_factor(enc->dt, a) * n_img * a.Ho * a.Wo * c.Cout * 4;
+            if (need > sk_bytes) sk_bytes = need;
+            return NOPE_OK;
+        }
+        a.splitk_ws = SK; a.splitk_bytes = sk_bytes;
         return launch_conv(enc->dt, a, s);
     };
-
-    int e = launch_stem_conv(enc->dt, image, enc->stem_w, enc->stem_shift, X[0], n_img, H, W, s);   // resnet.py:136-138
-    if (e) return e;
-    int cur = 0, h = H / 2, w = W / 2;
-    for (size_t i = 0; i < enc->blocks.size(); ++i) {      // Bottleneck.forward, resnet.py:70-90
-        const Bottleneck& b = enc->blocks[i];
-        const int st = enc->block_stride[i];
-        const int ho = h / st, wo = w / st;
-        const void* identity = X[cur];
-        int nxt = (cur + 1) % 3;
-        if (b.has_ds) {
-            const int dsb = (cur + 2) % 3;
-            if ((e = conv(b.ds, X[cur], h, w, X[dsb], 0, nullptr, 0))) return e;
-            identity = X[dsb];
+    auto walk = [&]() -> int {
+        int e = NOPE_OK;
+        if (!measure && (e = launch_stem_conv(enc->dt, image, enc->stem_w, enc->stem_shift, X[0], n_img, H, W, s))) return e;   // resnet.py:136-138
+        int cur = 0, h = H / 2, w = W / 2;
+        for (size_t i = 0; i < enc->blocks.size(); ++i) {      // Bottleneck.forward, resnet.py:70-90
+            const Bottleneck& b = enc->blocks[i];
+            const int st = enc->block_stride[i];
+            const int ho = h / st, wo = w / st;
+            const void* identity = X[cur];
+            const int nxt = (cur + 1) % 3;
+            if (b.has_ds) {
+                const int dsb = (cur + 2) % 3;
+                if ((e = conv(b.ds, X[cur], h, w, X[dsb], 0, nullptr, 0))) return e;
+                identity = X[dsb];
+            }
+            if ((e = conv(b.c1, X[cur], h, w, T1, 1, nullptr, 0))) return e;
+            if ((e = conv(b.c2, T1, h, w, T2, 1, nullptr, 0))) return e;
+            if ((e = conv(b.c3, T2, ho, wo, X[nxt], 1, identity, 0))) return e;       // relu(bn3(conv3) + identity)
+            cur = nxt; h = ho; w = wo;
         }
-        if ((e = conv(b.c1, X[cur], h, w, T1, 1, nullptr, 0))) return e;
-        if ((e = conv(b.c2, T1, h, w, T2, 1, nullptr, 0))) return e;
-        if ((e = conv(b.c3, T2, ho, wo, X[nxt], 1, identity, 0))) return e;       // relu(bn3(conv3) + identity)
-        cur = nxt; h = ho; w = wo;
-    }
-    // projector: ReLU (a no-op on the ReLU output above), 1x1 -> ReLU -> 1x1, NCHW f32 out (template.py:33-38)
-    if ((e = conv(enc->proj0, X[cur], h, w, T1, 1, nullptr, 0))) return e;
-    return conv(enc->proj1, T1, h, w, out, 0, nullptr, 1);
+        // projector: ReLU (a no-op on the ReLU output above), 1x1 -> ReLU -> 1x1, NCHW f32 out (template.py:33-38)
+        if ((e = conv(enc->proj0, X[cur], h, w, T1, 1, nullptr, 0))) return e;
+        return conv(enc->proj1, T1, h, w, out, 0, nullptr, 1);
+    };
+
+    int e = walk();                       // measuring pass: no launches
+    if (e) return e;
+    for (int i = 0; i < 3; ++i) X[i] = ar.alloc(pl.x * n_img * es);
+    T1 = ar.alloc(pl.t1 * n_img * es);
+    T2 = ar.alloc(pl.t2 * n_img * es);
+    SK = ar.alloc(sk_bytes);
+    if (ar.dry) return NOPE_OK;
+    if (!X[0] || !X[1] || !X[2] || !T1 || !T2 || !SK) return NOPE_ERR_WORKSPACE;
+    measure = false;
+    return walk();
 }
 
 }  // namespace

@@ -83,6 +83,8 @@ struct ConvParams {
     int tiles_m, tiles_n, xcd_map, wide_out;
     int variant;                       // tuning switches (NOPE_CONV_VARIANT), 0 in production
     FastDiv d_hw, d_w, d_rep1, d_rep2; // / (Hm*Wm), / Wm, / rep1, / rep2
+    int splits;                        // > 1: blockIdx.z owns a K range and writes raw f32 partial sums
+    float* split_out;                  // [splits][M][Cout]
     int Hm, Wm;                        // grid the GEMM rows enumerate: output grid, or the SOURCE grid for UP2P
     unsigned w_phase_bytes;            // UP2P: byte stride between the 4 phase weight sets
     float* colstats;                   // optional [M/64][Cout][2]: per 64-row block column sum / sum of squares
@@ -358,6 +360,47 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
     }
 }
 
+// Split-K: this workgroup's raw partial sums, f32, to split_out[blockIdx.z][m][n].  Bias, residual and activation
+// are applied by splitk_reduce_kernel, which adds the partials in a fixed order (deterministic).
+template <class T>
+__device__ __forceinline__ void epilogue_split(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL],
+                                               int m0, int n0, int wm, int wn, int lane) {
+    typedef Tile<T> TL;
+    float* out = p.split_out + (size_t)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+    for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+        for (int r = 0; r < TL::R; ++r) {
+            const int m = m0 + wm * 64 + i * TL::TM + TL::out_row(lane, r);
+#pragma unroll
+            for (int j = 0; j < TL::NTL; ++j) {
+                const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
+                if (m < p.M && n < p.Cout) out[(size_t)m * p.Cout + n] = acc[i][j][r];
+            }
+        }
+}
+
+// out = act(sum_z part[z] + bias + resid): NHWC T, or NCHW f32 (out_nchw).
+template <class T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int Cout,
+                                                            const float* __restrict__ bias, const T* __restrict__ resid, int act,
+                                                            T* __restrict__ out, int out_nchw, int HWo) {
+    const size_t MN = (size_t)M * Cout;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < MN; i += (size_t)gridDim.x * 256) {
+        const int n = (int)(i % Cout);
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += part[(size_t)z * MN + i];
+        if (bias) v += bias[n];
+        if (resid) v += Elt<T>::ld(resid + i);
+        if (act) v = v > 0.f ? v : 0.f;
+        if (out_nchw) {
+            const size_t m = i / Cout;
+            const size_t b = m / HWo;
+            reinterpret_cast<float*>(out)[(b * Cout + n) * HWo + (m - b * HWo)] = v;
+        } else Elt<T>::st(out + i, v);
+    }
+}
+
 // Source pixel of output pixel (oy, ox) under tap (dy, dx); false = zero padding / beyond M.
 __device__ __forceinline__ bool tap_pixel(const ConvParams& p, int oy, int ox, int dy, int dx, int& iy, int& ix) {
     if (p.mode == NOPE_CONV_DOWN2) { iy = 2 * oy + dy; ix = 2 * ox + dx; return oy >= 0; }
@@ -599,8 +642,13 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
     }
 
     const int kc_per_tap = Cin / BK;
-    const int nk = p.ntaps * kc_per_tap;
-    int ld_tap = 0, ld_kc = 0;
+    int ks0 = 0, nk = p.ntaps * kc_per_tap;
+    if (p.splits > 1) {                       // split-K: blockIdx.z owns K steps [ks0, ks0 + nk)
+        const int tot = nk, z = (int)blockIdx.z;
+        ks0 = (int)((long long)z * tot / p.splits);
+        nk = (int)((long long)(z + 1) * tot / p.splits) - ks0;
+    }
+    int ld_kc = ks0 / p.ntaps, ld_tap = ks0 - (ks0 / p.ntaps) * p.ntaps;
 
     // One stage's loads, split so they can be interleaved with MFMA groups: begin -> A pieces -> B pieces -> end.
     unsigned char* st_dA = nullptr; unsigned char* st_dB = nullptr;
@@ -663,7 +711,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
             for (int r = 0; r < Tile<T>::R; ++r) acc[i][j][r] = 0.f;
 
     if (NS == 2) {
-        issue(0);
+        if (nk > 0) issue(0);
         for (int ks = 0; ks < nk; ++ks) {
             const int buf = ks & 1;
             __syncthreads();                       // stage ks landed (vmcnt drain) + everyone left stage ks-1
@@ -676,6 +724,8 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
     }
     if (p.variant & 64) {                      // tuning only: no epilogue (keeps the accumulators live)
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;
+    } else if (p.splits > 1) {
+        epilogue_split<T>(p, acc, m0, n0, wm, wn, lane);
     } else if (p.wide_out) {
         __syncthreads();                       // every wave is done reading the last stage
         epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
@@ -695,6 +745,23 @@ void launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
 }
 
 }  // namespace
+
+// Split-K factor for a conv that would otherwise leave most of the 256 CUs idle (few output tiles, long K):
+// enough K slices to reach ~2 workgroups per CU, at least 4 K steps each.  1 = do not split.
+int conv_splitk_factor(int dt, const ConvArgs& a) {
+    if (a.colstats || a.pn_ms || a.mode == NOPE_CONV_UP2P || a.mode == NOPE_CONV_UP2) return 1;
+    const int vec = dt == NOPE_F32 ? 4 : 8;
+    const int Cin = a.C1 + a.C2;
+    if (Cin % (8 * vec)) return 1;
+    const long long M = (long long)a.nhyp * a.Ho * a.Wo;
+    const long long tiles = (long long)cdiv((int)M, BM) * cdiv(a.Cout, BN);
+    const int nk = a.ntaps * (Cin / (8 * vec));
+    if (tiles >= 128 || nk < 8) return 1;
+    int S = (int)((512 + tiles - 1) / tiles);
+    if (S > nk / 4) S = nk / 4;
+    if (S > 16) S = 16;
+    return S < 2 ? 1 : S;
+}
 
 int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     if (!a.src1 || !a.w || !a.out || a.C1 <= 0 || a.Cout <= 0 || a.nhyp <= 0) return NOPE_ERR_ARG;
@@ -757,7 +824,13 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.xcd_map = (tn == 1 || tn == 2 || tn == 4 || tn == 8) && (p.tiles_m % (8 / tn) == 0) ? 1 : 0;
     const long long nblocks = (long long)p.tiles_m * p.tiles_n;
     if (nblocks > 0x7fffffffLL) return NOPE_ERR_UNSUPPORTED;
-    const dim3 grid((unsigned)nblocks, phased ? 4u : 1u), block(NT);
+    p.splits = 1; p.split_out = nullptr;
+    if (dma && a.splitk_ws) {
+        p.splits = conv_splitk_factor(dt, a);
+        if ((size_t)p.splits * (size_t)M * a.Cout * 4 > a.splitk_bytes) p.splits = 1;
+        if (p.splits > 1) p.split_out = (float*)a.splitk_ws;
+    }
+    const dim3 grid((unsigned)nblocks, phased ? 4u : 1u, (unsigned)p.splits), block(NT);
     if (dt == NOPE_F32) {
         if (dma && bm == 256) launch_dma<float, 128, 2, 256>(p, grid, s);
         else if (dma) launch_dma<float, 128, 2, 128>(p, grid, s);
@@ -771,6 +844,15 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((conv_gemm_kernel<bf16_t, false>), grid, block, 0, s, p);
     }
     NOPE_CHECK_LAUNCH();
+    if (p.splits > 1) {
+        const size_t MN = (size_t)M * a.Cout;
+        const unsigned rb = (unsigned)((MN + 255) / 256 < 4096 ? (MN + 255) / 256 : 4096);
+        if (dt == NOPE_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(rb), dim3(256), 0, s, p.split_out, p.splits, (int)M, a.Cout,
+                                               a.bias, (const float*)a.resid, a.act, (float*)a.out, a.out_nchw, a.Ho * a.Wo);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(rb), dim3(256), 0, s, p.split_out, p.splits, (int)M, a.Cout,
+                                a.bias, (const bf16_t*)a.resid, a.act, (bf16_t*)a.out, a.out_nchw, a.Ho * a.Wo);
+        NOPE_CHECK_LAUNCH();
+    }
     return NOPE_OK;
 }
 

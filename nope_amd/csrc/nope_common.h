@@ -130,6 +130,8 @@ struct ConvArgs {
     int out_nchw = 0;            // 1: write (nhyp, Cout, Ho, Wo) with dtype out_dt
     int out_dt = NOPE_F32;       // only for out_nchw
     int act = 0;                 // 0 none, 1 ReLU applied after bias (+ residual)
+    void* splitk_ws = nullptr;   // optional f32 scratch [splits][M][Cout]: allows a deterministic split-K launch for
+    size_t splitk_bytes = 0;     //   small-M / long-K problems (conv_splitk_factor); ignored when too small
     int force_generic = 0;       // tests: take the register-staged kernel even when the LDS-DMA one applies
     float* colstats = nullptr;   // optional fused GroupNorm statistics: [M/64][Cout][2] (needs M % 64 == 0, NHWC out)
     // optional fused PreNorm (GroupNorm(1) in front of a 1x1 conv whose weights already carry gamma):
@@ -139,6 +141,7 @@ struct ConvArgs {
     const float* pn_c1 = nullptr;   // [Cout]  sum_c W[n,c] * gamma[c]
 };
 int launch_conv(int dt, const ConvArgs& a, hipStream_t s);
+int conv_splitk_factor(int dt, const ConvArgs& a);
 
 int launch_gn_stats(int dt, const void* x, float* partial, int nhyp, int HW, int C, int G, int nchunk, hipStream_t s);
 struct GnApplyArgs {
