@@ -28,7 +28,7 @@ def main(path, out, dtype="bf16", templates=512, size=256):
            "launches": nf, "fetch_kib_per_launch_raw": fetch / nf, "write_kib_per_launch_raw": write / nw,
            "bytes_per_launch": (2.0 * fetch / nf + write / nw) * 1024.0,
            "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as reported; separate --pmc passes; "
-                   "command: bench.py --skip-extras --steps 1 --warmup 1"}
+                   "command: tools/unet_step.py (warm-up + one 512-hypothesis U-Net batch)"}
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec))
 
