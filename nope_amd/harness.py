@@ -85,6 +85,9 @@ def build_model(seed: int = 2022, compute_dtype="f32", bank_dtype="f32", device=
     return model.to(device).eval()
 
 
+from .metrics import GeodesicError  # noqa: E402
+
+
 def geodesic_deg(predR: torch.Tensor, gtR: torch.Tensor) -> torch.Tensor:
     rel = predR.double() @ gtR.double().transpose(-1, -2)
     cos = (rel.diagonal(dim1=-2, dim2=-1).sum(-1) - 1.0) / 2.0
@@ -98,13 +101,10 @@ def eval_geodesic(model, batch: Dict[str, torch.Tensor], thresholds=(15, 30), sa
     similarity, nearest_idx, _ = model.generate_and_retrieve(batch["query"], batch["reference"], batch["all_relativeR"])
     template_poses = batch["template_poses"][0]                 # model.py:352
     predR = template_poses[nearest_idx]                         # (B,5,3,3)
-    err = torch.stack([geodesic_deg(predR[:, k], batch["query_pose"]) for k in range(predR.shape[1])], 1)
+    sym = batch.get("symmetry", torch.zeros(predR.shape[0], 1, dtype=torch.long, device=predR.device))
+    _, metric = GeodesicError(list(thresholds))(predR, batch["query_pose"], sym)      # model.py:354-358, loss.py:78-115
     res = {"loss": float(loss)}
-    for k in (1, 3, 5):                                         # loss.py:104-114
-        top = err[:, :k].min(dim=1).values
-        for t in thresholds:
-            res[f"top{k}, accuracy_{t}"] = float((top <= t).float().mean() * 100)
-        res[f"top{k}, median"] = float(top.median())
+    res.update({k: float(v) for k, v in metric.items()})
     if save_path:
         np.savez(save_path, query_pose=batch["query_pose"].cpu().numpy(), similarity=similarity.cpu().numpy())
     return similarity, nearest_idx, res

@@ -119,3 +119,51 @@ def test_unsupported_metric_returns_none():
     u = UNet(u_net_dim=8, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer")
     m = PoseConditional(u, None, {"similarity_metric": "cosine"}, None)
     assert m.retrieval(torch.zeros(1, 8, 8, 8), torch.zeros(1, 2, 8, 8, 8)) is None
+
+
+def test_geodesic_error_metric():
+    """nope_amd.metrics (loss.py:14-115; pytorch3d restated, parity unpinned): known angles, the linear extrapolation
+    near 0 / 180 degrees, the three symmetry branches, top-k dictionary keys and dtypes."""
+    import math
+    from nope_amd.harness import random_rotations
+    from nope_amd.metrics import GeodesicError, acos_linear_extrapolation, so3_relative_angle, so3_relative_angle_with_symmetry
+
+    def rot(axis, deg):
+        a = math.radians(deg)
+        c, s = math.cos(a), math.sin(a)
+        m = {"x": [[1, 0, 0], [0, c, -s], [0, s, c]], "y": [[c, 0, s], [0, 1, 0], [-s, 0, c]], "z": [[c, -s, 0], [s, c, 0], [0, 0, 1]]}[axis]
+        return torch.tensor(m, dtype=torch.float64)
+
+    eye = torch.eye(3, dtype=torch.float64)
+    for deg in (5.0, 30.0, 90.0, 170.0):
+        ang = so3_relative_angle(rot("x", deg)[None], eye[None])
+        assert abs(math.degrees(float(ang)) - deg) < 1e-9
+    # identical rotations: cos = 1 is beyond the bound -> extrapolated value acos(b) - (1 - b) / sqrt(1 - b^2), not 0
+    b = 1.0 - 1e-4
+    z = float(so3_relative_angle(eye[None], eye[None]))
+    assert abs(z - (math.acos(b) - (1 - b) / math.sqrt(1 - b * b))) < 1e-12 and 0 < z < 0.01
+    x = torch.tensor([-1.0, -0.5, 0.0, 0.5, 1.0], dtype=torch.float64)
+    y = acos_linear_extrapolation(x)
+    assert torch.allclose(y[1:4], torch.acos(x[1:4])) and float(y[0]) > float(y[1]) > float(y[3]) > float(y[4])
+    with pytest.raises(ValueError):
+        so3_relative_angle(3.0 * eye[None], eye[None], eps=1e-2)
+    # symmetry 1: a prediction that is the ground truth turned by 180 degrees about Y scores (almost) zero
+    R = random_rotations(6, torch.Generator().manual_seed(4)).double()
+    flipped = rot("y", 180)[None] @ R
+    sym = torch.tensor([0, 1, 1, 0, 1, 0]).view(-1, 1)
+    e = so3_relative_angle_with_symmetry(flipped, R, sym)
+    assert bool((e[sym.view(-1) == 1] < 0.02).all()) and bool((e[sym.view(-1) == 0] > 3.0).all())
+    # symmetry 2 (circular): turning the object about its own symmetry (Z) axis does not change the error
+    spun = R @ rot("z", 77)[None]
+    e2 = so3_relative_angle_with_symmetry(spun, R, torch.full((6, 1), 2))
+    # (the reference takes acos of an unclamped cosine similarity, loss.py:71-73: exactly equal axes can give NaN)
+    assert float(torch.nan_to_num(e2, nan=0.0).abs().max()) < 1e-6
+    e3 = so3_relative_angle_with_symmetry(R @ rot("x", 40)[None], R, torch.full((6, 1), 2))
+    assert bool(((torch.rad2deg(e3) - 40.0).abs() < 1e-6).all())
+    # module: top-1 and top-k forms
+    err, res = GeodesicError([15, 30])(flipped, R, sym)
+    assert err.dtype == torch.float64 and set(res) == {"top1, accuracy_15", "top1, accuracy_30", "top1, median"}
+    predk = torch.stack([flipped, R, R, R, R], 1)
+    err, res = GeodesicError([15])(predk, R, torch.zeros(6, 1))
+    assert err.dtype == torch.float32 and float(res["top1, accuracy_15"]) == 0.0 and float(res["top3, accuracy_15"]) == 100.0
+    assert set(res) == {f"top{k}, {m}" for k in (1, 3, 5) for m in ("accuracy_15", "median")}
