@@ -133,8 +133,10 @@ class PoseConditional(nn.Module):
         if self.similarity_metric != "l2":
             return None
         enc = self.u_net.encoder
-        if not query.is_cuda:
-            raise hip.NopeError("generate_and_retrieve needs device tensors (no CPU path)")
+        if not query.is_cuda:          # host tensors exist only under tests/hipemu: same calls, one after the other
+            bank, _, _ = self.generate_templates(reference, all_relativeR, None)
+            similarity, nearest_idx = self.retrieval(query, bank)
+            return similarity, nearest_idx, bank
         cur = torch.cuda.current_stream(query.device)
         if self._side_stream is None or self._side_stream.device != query.device:
             self._side_stream = torch.cuda.Stream(device=query.device)

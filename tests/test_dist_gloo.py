@@ -37,6 +37,8 @@ def _worker(rank, ws, port, emu_path, q, bank, poses, ret):
         ref_feat = q[:1, :, :8, :8].contiguous()
         b_local, _, _ = m.generate_templates(ref_feat, poses)
         sim, idx = m.retrieval(ref_feat * 0.5, b_local)
+        sim2, idx2, _ = m.generate_and_retrieve(ref_feat * 0.5, ref_feat, poses)     # what bench.py --gpus N calls per step
+        assert torch.equal(sim2, sim) and torch.equal(idx2, idx)
         ret[rank] = (full, tuple(b_local.shape), sim, idx)
     finally:
         dist.destroy_process_group()
