@@ -137,7 +137,12 @@ int nope_encoder_create(const nope_encoder_config* cfg, const nope_tensor_desc* 
                         nope_stream_t stream, nope_encoder** out);
 void nope_encoder_destroy(nope_encoder* enc);
 size_t nope_encoder_workspace_bytes(const nope_encoder* enc, int n_img, int H, int W);
-/* image (n_img, 3, H, W) f32 NCHW in [-1, 1], H and W multiples of 8 -> out (n_img, descriptor_size, H/8, W/8) f32 NCHW. */
+/* image (n_img, 3, H, W) f32 NCHW in [-1, 1], H and W multiples of 8 -> out (n_img, descriptor_size, H/8, W/8) f32 NCHW.
+ * The launch sequence of a pass (~85 small kernels) is captured into a hipGraph the first time a
+ * (workspace, n_img, H, W) combination is seen and replayed afterwards (image / out are staged through the
+ * workspace, so they may change from call to call); if stream capture is unavailable the kernels are launched
+ * directly.  The graph cache lives in the handle: calls on ONE handle must come from one host thread at a time,
+ * and concurrent passes on different streams need different workspaces. */
 int nope_encoder_forward(const nope_encoder* enc, const float* image, int n_img, int H, int W, float* out,
                          void* workspace, size_t workspace_bytes, nope_stream_t stream);
 

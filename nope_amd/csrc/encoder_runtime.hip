@@ -32,10 +32,16 @@ constexpr int FEATURES = 64;
 
 }  // namespace
 
+// One captured launch sequence: valid for exactly this (workspace, batch, size); image and output are staged through
+// the workspace so that the caller's pointers stay out of the graph.
+struct EGraph { void* ws; size_t ws_bytes; int n_img, H, W; hipGraphExec_t exec; };
+
 struct nope_encoder {
     nope_encoder_config cfg;
     int dt = NOPE_F32;
     std::vector<void*> allocs;
+    mutable std::vector<EGraph> graphs;      // hipGraph cache (the ~85 launches of a pass are 5-15 us each at 1-2 images)
+    mutable bool graphs_ok = true;           // cleared when capture is unavailable: direct launches from then on
     float* stem_w = nullptr;      // [147][64] f32, bn1 scale folded
     float* stem_shift = nullptr;  // [64]
     std::vector<Bottleneck> blocks;
@@ -250,8 +256,16 @@ int nope_encoder_create(const nope_encoder_config* cfg, const nope_tensor_desc* 
 
 void nope_encoder_destroy(nope_encoder* enc) {
     if (!enc) return;
+    for (const EGraph& g : enc->graphs) hipGraphExecDestroy(g.exec);
     for (void* p : enc->allocs) hipFree(p);
     delete enc;
+}
+
+// Workspace = [staged image | staged output | activation arena].
+static size_t stage_bytes(const nope_encoder* enc, int n_img, int H, int W, size_t& img_b, size_t& out_b) {
+    img_b = align_up((size_t)n_img * 3 * H * W * 4, 256);
+    out_b = align_up((size_t)n_img * enc->cfg.descriptor_size * (H / 8) * (W / 8) * 4, 256);
+    return img_b + out_b;
 }
 
 size_t nope_encoder_workspace_bytes(const nope_encoder* enc, int n_img, int H, int W) {
@@ -259,16 +273,65 @@ size_t nope_encoder_workspace_bytes(const nope_encoder* enc, int n_img, int H, i
     EArena ar;
     ar.dry = true;
     if (run_encoder(enc, nullptr, n_img, H, W, nullptr, ar, nullptr) != NOPE_OK) return 0;
-    return align_up(ar.off, 256);
+    size_t ib, ob;
+    return stage_bytes(enc, n_img, H, W, ib, ob) + align_up(ar.off, 256);
 }
 
 int nope_encoder_forward(const nope_encoder* enc, const float* image, int n_img, int H, int W, float* out, void* workspace,
                          size_t workspace_bytes, nope_stream_t stream) {
     if (!enc || !image || !out || !workspace || n_img <= 0) return NOPE_ERR_ARG;
     if (H <= 0 || W <= 0 || H % 8 || W % 8) return NOPE_ERR_UNSUPPORTED;
-    EArena ar;
-    ar.base = (unsigned char*)workspace; ar.cap = workspace_bytes;
-    return run_encoder(enc, image, n_img, H, W, out, ar, (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    size_t ib, ob;
+    const size_t sb = stage_bytes(enc, n_img, H, W, ib, ob);
+    if (workspace_bytes < sb) return NOPE_ERR_WORKSPACE;
+    unsigned char* base = (unsigned char*)workspace;
+    float* img_s = (float*)base;
+    float* out_s = (float*)(base + ib);
+    auto direct = [&](const float* src, float* dst) {
+        EArena ar;
+        ar.base = base + sb; ar.cap = workspace_bytes - sb;
+        return run_encoder(enc, src, n_img, H, W, dst, ar, s);
+    };
+    if (!enc->graphs_ok) return direct(image, out);
+
+    const size_t in_bytes = (size_t)n_img * 3 * H * W * 4;
+    const size_t out_bytes = (size_t)n_img * enc->cfg.descriptor_size * (H / 8) * (W / 8) * 4;
+    const EGraph* hit = nullptr;
+    for (const EGraph& g : enc->graphs)
+        if (g.ws == workspace && g.ws_bytes == workspace_bytes && g.n_img == n_img && g.H == H && g.W == W) { hit = &g; break; }
+    if (!hit) {
+        // First call for this (workspace, shape): record the launch sequence once.
+        {   // dry pass: fail on a too-small arena BEFORE a capture is open
+            EArena chk; chk.dry = true;
+            int e = run_encoder(enc, nullptr, n_img, H, W, nullptr, chk, nullptr);
+            if (e) return e;
+            if (align_up(chk.off, 256) > workspace_bytes - sb) return NOPE_ERR_WORKSPACE;
+        }
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            enc->graphs_ok = false;
+            return direct(image, out);
+        }
+        const int e = direct(img_s, out_s);
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(s, &graph);
+        hipGraphExec_t exec = nullptr;
+        if (e != NOPE_OK || ce != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            enc->graphs_ok = false;
+            return e != NOPE_OK ? e : direct(image, out);
+        }
+        hipGraphDestroy(graph);
+        if (enc->graphs.size() >= 16) { hipGraphExecDestroy(enc->graphs.front().exec); enc->graphs.erase(enc->graphs.begin()); }
+        enc->graphs.push_back(EGraph{workspace, workspace_bytes, n_img, H, W, exec});
+        hit = &enc->graphs.back();
+    }
+    if (hipMemcpyAsync(img_s, image, in_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    if (hipGraphLaunch(hit->exec, s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    if (hipMemcpyAsync(out, out_s, out_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    return NOPE_OK;
 }
 
 }  // extern "C"
