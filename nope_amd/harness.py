@@ -47,11 +47,22 @@ def rotation_6d(m: torch.Tensor) -> torch.Tensor:
     return m[..., :2, :].clone().reshape(*m.shape[:-2], 6)
 
 
-def synthetic_batch(batch: int, n_templates: int, size: int, seed: int = 2022, device="cpu") -> Dict[str, torch.Tensor]:
+def synthetic_batch(batch: int, n_templates: int, size: int, seed: int = 2022, device="cpu",
+                    pose_level: Optional[int] = None, pose_root: Optional[str] = None) -> Dict[str, torch.Tensor]:
+    """A test-split batch shaped like ShapeNet.__getitem__ (dataloader/shapeNet.py:348-357).  Template poses are
+    Haar-random rotations, or -- `pose_level` 0..3 -- the upper-hemisphere icosphere grid the reference evaluates on
+    (nope_amd.poses: 26 / 91 / 341 / 1321 viewpoints; `pose_root` = the reference's predefined_poses directory to
+    read its own files); `n_templates` is ignored then."""
     g = torch.Generator().manual_seed(seed)
     query = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
     reference = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
-    R_tpl = random_rotations(n_templates, g)
+    if pose_level is not None:
+        from .poses import get_obj_poses_from_template_level
+        grid = get_obj_poses_from_template_level(pose_level, "upper", root=pose_root)
+        R_tpl = torch.from_numpy(grid[:, :3, :3].copy())
+        n_templates = R_tpl.shape[0]
+    else:
+        R_tpl = random_rotations(n_templates, g)
     R_ref = random_rotations(batch, g)
     R_query = random_rotations(batch, g)
     rel = lambda a, b: a @ torch.linalg.inv(b)          # shapeNet.py:243-245
@@ -120,11 +131,15 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=2022)
     ap.add_argument("--category", default="synthetic")
     ap.add_argument("--save-dir", default=None)
+    ap.add_argument("--pose-level", type=int, default=None, choices=[0, 1, 2, 3],
+                    help="use the upper-hemisphere icosphere grid (26/91/341/1321 templates) instead of --templates random poses")
+    ap.add_argument("--pose-root", default=None, help="directory with the reference's predefined_poses/*.npy")
     a = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("nope_amd.harness needs an MI355X (no CPU fallback)")
     model = build_model(a.seed, a.dtype, a.bank_dtype, "cuda", save_dir=a.save_dir)
-    batches = {f"shapeNet_{a.category}": synthetic_batch(a.batch, a.templates, a.size, a.seed, "cuda")}
+    batches = {f"shapeNet_{a.category}": synthetic_batch(a.batch, a.templates, a.size, a.seed, "cuda", pose_level=a.pose_level,
+                                                                  pose_root=a.pose_root)}
     for name, batch in batches.items():                         # test_step, model.py:550-565
         t0 = time.time()
         save = os.path.join(a.save_dir, "predictions", f"pred_step0_rank{model.global_rank}") if a.save_dir else None

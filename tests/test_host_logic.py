@@ -167,3 +167,47 @@ def test_geodesic_error_metric():
     err, res = GeodesicError([15])(predk, R, torch.zeros(6, 1))
     assert err.dtype == torch.float32 and float(res["top1, accuracy_15"]) == 0.0 and float(res["top3, accuracy_15"]) == 100.0
     assert set(res) == {f"top{k}, {m}" for k in (1, 3, 5) for m in ("accuracy_15", "median")}
+
+
+def test_pose_grids_and_relative_poses(tmp_path):
+    """nope_amd.poses (utils.py:72-125, shapeNet.py:243-251): synthesised icosphere grids have the reference's camera
+    positions (level-0 fixture, as a set) and its upper-hemisphere counts at every level; reading the reference's files
+    from a directory keeps its selection semantics; coarse grids index into fine ones; relative-pose identities."""
+    import os
+    import numpy as np
+    from nope_amd import poses as P
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "pose_grid_level0.npz"))
+    cams, objs = P.synthesize_grid(0)
+    ref_pos = fx["sphere_poses_level0"][:, :3, 3]
+    d = np.linalg.norm(cams[:, None, :3, 3] - ref_pos[None], axis=-1)
+    assert d.min(axis=1).max() < 2e-5 and len(set(d.argmin(axis=1))) == 42          # same 42 viewpoints
+    for c, o in zip(cams, objs):                                                    # proper look-at poses
+        assert np.allclose(c[:3, :3] @ c[:3, :3].T, np.eye(3), atol=1e-12) and abs(np.linalg.det(c[:3, :3]) - 1) < 1e-12
+        assert np.allclose(c[:3, :3].T @ (-c[:3, 3]), [0, 0, 1], atol=1e-12)          # +z looks at the object
+        assert np.allclose(o[:3, :3], c[:3, :3].T) and np.allclose(np.linalg.norm(o[:3, 3]), 0.5)
+    assert np.allclose(np.linalg.norm(fx["obj_poses_level0"][:, :3, 3], axis=1), 0.5, atol=1e-6)
+    for level, (n, up) in {0: (42, 26), 1: tuple(fx["count_level1"]), 2: tuple(fx["count_level2"]), 3: tuple(fx["count_level3"])}.items():
+        assert len(P.get_obj_poses_from_template_level(level, "all")) == n
+        idx, sel = P.get_obj_poses_from_template_level(level, "upper", return_index=True)
+        assert len(sel) == up and len(idx) == up
+    # the reference's own files, read from a directory
+    for k in ("sphere_poses_level0", "obj_poses_level0", "idx_upper_level0_in_level2"):
+        np.save(tmp_path / f"{k}.npy", fx[k])
+    idx, sel = P.get_obj_poses_from_template_level(0, "upper", return_index=True, root=str(tmp_path))
+    want = fx["sphere_poses_level0"][:, 2, 3] >= 0
+    assert np.array_equal(idx, np.arange(42)[want]) and np.array_equal(sel, fx["obj_poses_level0"][want])
+    assert np.array_equal(P.load_index_level0_in_level2("upper", root=str(tmp_path)), fx["idx_upper_level0_in_level2"])
+    assert P.load_mapping_id_templates_to_idx_pose_distribution(0, "upper", root=str(tmp_path))[int(idx[3])] == 3
+    # synthesised: level-0 viewpoints are found inside level 2
+    i02 = P.load_index_level0_in_level2("upper")
+    c0 = P.get_obj_poses_from_template_level(0, "upper", return_cam=True)
+    c2 = P.get_obj_poses_from_template_level(2, "upper", return_cam=True)
+    assert len(i02) == 26 and np.allclose(c2[i02][:, :3, 3], c0[:, :3, 3])
+    # relative poses
+    R = objs[:, :3, :3]
+    rel, inv = P.compute_relative_pose(objs[7], objs[3])
+    assert rel.dtype == torch.float32 and rel.shape == (6,)
+    assert np.allclose(rel.numpy(), (R[7] @ R[3].T)[:2].reshape(6), atol=1e-6) and np.allclose(inv.numpy(), (R[3] @ R[7].T)[:2].reshape(6), atol=1e-6)
+    allr = P.all_relative_poses(objs, objs[3])
+    assert allr.shape == (42, 6) and torch.allclose(allr[7], rel, atol=1e-6)
+    assert torch.allclose(allr[3], torch.tensor([1.0, 0, 0, 0, 1, 0]), atol=1e-6)
