@@ -83,6 +83,10 @@ struct ConvParams {
     int tiles_m, tiles_n, xcd_map, wide_out;
     int variant;                       // tuning switches (NOPE_CONV_VARIANT), 0 in production
     FastDiv d_hw, d_w, d_rep1, d_rep2; // / (Hm*Wm), / Wm, / rep1, / rep2
+    unsigned char pos_order[64];       // posmajor: pixel positions by descending number of valid taps
+    int posmajor;                      // 1: GEMM rows ordered (pixel position, sample) instead of (sample, pixel) -- see launch_conv
+    FastDiv d_n;                       // / nhyp (posmajor)
+    int nhyp;
     int splits;                        // > 1: blockIdx.z owns a K range and writes raw f32 partial sums
     float* split_out;                  // [splits][M][Cout]
     int Hm, Wm;                        // grid the GEMM rows enumerate: output grid, or the SOURCE grid for UP2P
@@ -174,6 +178,11 @@ __device__ __forceinline__ void mma_stage(const unsigned char* ldsA, const unsig
 // Output pixel row of GEMM row m.  Identity except for UP2P, whose rows walk the source grid and land on
 // output pixel (2y + py, 2x + px) of phase blockIdx.y.
 __device__ __forceinline__ size_t out_row(const ConvParams& p, int m) {
+    if (p.posmajor) {                  // row m = (position, sample) -> NHWC row (sample, position)
+        const unsigned pos = p.d_n.div((unsigned)m);
+        const unsigned b = (unsigned)m - pos * (unsigned)p.nhyp;
+        return (size_t)b * (size_t)(p.Hm * p.Wm) + pos;
+    }
     if (p.mode != NOPE_CONV_UP2P) return (size_t)m;
     const int hw = p.Hm * p.Wm;
     const int b = m / hw;
@@ -567,6 +576,16 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
     const int wm = wave >> 1, wn = wave & 1;
     int tile_m, tile_n;
     tile_coords(p, tile_m, tile_n);
+    if (MODE == NOPE_CONV_PLAIN && p.posmajor && !((p.Hm * p.Wm) & 1)) {     // (even pixel count: the pairing below is a bijection)
+        // Position-major tiles differ in length (4 / 6 / 9 valid taps).  The two workgroups that share a CU are
+        // (to first order) launch slots t and t + tiles/2 of an XCD: give slot t the k-th heaviest pixel position and
+        // slot t + tiles/2 the k-th lightest, so no CU is left with two 9-tap tiles while another holds two 4-tap ones.
+        const int G = p.nhyp / BMT, half = p.tiles_m >> 1, hw = p.Hm * p.Wm;
+        const int t = tile_m < half ? tile_m : tile_m - half;
+        const int k = t / G;
+        const int pos = p.pos_order[tile_m < half ? k : hw - 1 - k];
+        tile_m = pos * G + (t - k * G);
+    }
     const int m0 = tile_m * BMT, n0 = tile_n * BN;
     const int HWo = p.Hm * p.Wm;
     const int Cin = p.C1 + p.C2;
@@ -589,8 +608,9 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
         const int m = m0 + row;
         const bool ok = m < p.M;
         const unsigned mm = ok ? (unsigned)m : 0u;
-        const unsigned b = p.d_hw.div(mm);
-        const unsigned r = mm - b * (unsigned)HWo;
+        unsigned b, r;
+        if (MODE == NOPE_CONV_PLAIN && p.posmajor) { r = p.d_n.div(mm); b = mm - r * (unsigned)p.nhyp; }
+        else { b = p.d_hw.div(mm); r = mm - b * (unsigned)HWo; }
         const int oy = (int)p.d_w.div(r), ox = (int)r - oy * p.Wm;
         const unsigned cs = (unsigned)((lslot ^ swz_of<RB>(row)) * VEC);   // source channel chunk of this LDS slot
         const unsigned s1 = p.d_rep1.div(b), s2 = p.d_rep2.div(b);
@@ -642,13 +662,23 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
     }
 
     const int kc_per_tap = Cin / BK;
-    int ks0 = 0, nk = p.ntaps * kc_per_tap;
+    // Taps this tile has to visit.  Position-major tiles hold ONE pixel position of 128 samples, so the taps that fall
+    // into the zero padding are invalid for every row and their K steps are skipped altogether.
+    unsigned tile_taps = (1u << p.ntaps) - 1u;
+    if (MODE == NOPE_CONV_PLAIN && p.posmajor) {
+        const int pos = (int)p.d_n.div((unsigned)m0);
+        const int ty = (int)p.d_w.div((unsigned)pos), tx = pos - ty * p.Wm;
+        const unsigned vx = (tx > 0 ? 1u : 0u) | 2u | (tx + 1 < p.Ws ? 4u : 0u);
+        tile_taps = (ty > 0 ? vx : 0u) | (vx << 3) | (ty + 1 < p.Hs ? vx << 6 : 0u);
+    }
+    int ks0 = 0, nk = __builtin_popcount(tile_taps) * kc_per_tap;
     if (p.splits > 1) {                       // split-K: blockIdx.z owns K steps [ks0, ks0 + nk)
         const int tot = nk, z = (int)blockIdx.z;
         ks0 = (int)((long long)z * tot / p.splits);
         nk = (int)((long long)(z + 1) * tot / p.splits) - ks0;
     }
-    int ld_kc = ks0 / p.ntaps, ld_tap = ks0 - (ks0 / p.ntaps) * p.ntaps;
+    int ld_kc = ks0 / p.ntaps, ld_tap = ks0 - (ks0 / p.ntaps) * p.ntaps;      // (split-K is never combined with posmajor)
+    if (MODE == NOPE_CONV_PLAIN && p.posmajor) { ld_kc = 0; ld_tap = __builtin_ctz(tile_taps); }
 
     // One stage's loads, split so they can be interleaved with MFMA groups: begin -> A pieces -> B pieces -> end.
     unsigned char* st_dA = nullptr; unsigned char* st_dB = nullptr;
@@ -692,7 +722,13 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
     // K order: channel chunk outer, tap inner -- the 9 taps of one channel chunk re-read the same few image
     // rows back to back, so a workgroup's live footprint in L2 is rows x BK instead of rows x Cin (the sum
     // order is a free choice as long as A and W agree).
-    auto step_end = [&]() { if (++ld_tap == p.ntaps) { ld_tap = 0; ++ld_kc; } };
+    auto step_end = [&]() {
+        if (MODE == NOPE_CONV_PLAIN && p.posmajor) {       // next valid tap of this tile
+            const unsigned rest = tile_taps >> (ld_tap + 1);
+            if (rest) ld_tap += 1 + __builtin_ctz(rest);
+            else { ld_tap = __builtin_ctz(tile_taps); ++ld_kc; }
+        } else if (++ld_tap == p.ntaps) { ld_tap = 0; ++ld_kc; }
+    };
     auto issue = [&](int buf) {
         step_begin(buf);
 #pragma unroll
@@ -748,6 +784,25 @@ void launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
 
 // Split-K factor for a conv that would otherwise leave most of the 256 CUs idle (few output tiles, long K):
 // enough K slices to reach ~2 workgroups per CU, at least 4 K steps each.  1 = do not split.
+constexpr int POSMAJOR_MAX_HW = 64;
+
+// Would launch_conv run this conv in position-major row order (given that it takes the LDS-DMA kernel)?
+bool conv_is_posmajor(int dt, const ConvArgs& a) {
+    const int vec = dt == NOPE_F32 ? 4 : 8;
+    const int Cin = a.C1 + a.C2;
+    if (a.force_generic || Cin % (8 * vec) || (a.C2 && a.C1 % (8 * vec))) return false;
+    return a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && !a.colstats && !a.pn_ms && !a.out_nchw && !a.splitk_ws &&
+           a.nhyp % BM == 0 && a.Hs * a.Ws <= POSMAJOR_MAX_HW;
+}
+
+// Multiply-adds x2 the launch actually executes (position-major launches skip the taps that lie in the padding:
+// (3H-2)(3W-2) of the 9 H W tap instances remain).
+double conv_executed_flops(int dt, const ConvArgs& a) {
+    double taps = (double)a.ntaps;
+    if (conv_is_posmajor(dt, a)) taps = (double)(3 * a.Hs - 2) * (3 * a.Ws - 2) / ((double)a.Hs * a.Ws);
+    return 2.0 * (double)a.nhyp * a.Ho * a.Wo * a.Cout * taps * (a.C1 + a.C2);
+}
+
 int conv_splitk_factor(int dt, const ConvArgs& a) {
     if (a.colstats || a.pn_ms || a.mode == NOPE_CONV_UP2P || a.mode == NOPE_CONV_UP2) return 1;
     const int vec = dt == NOPE_F32 ? 4 : 8;
@@ -825,6 +880,22 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     const long long nblocks = (long long)p.tiles_m * p.tiles_n;
     if (nblocks > 0x7fffffffLL) return NOPE_ERR_UNSUPPORTED;
     p.splits = 1; p.split_out = nullptr;
+    // Position-major row order for small images: with 4x4 / 8x8 maps 31 % / 16 % of the 3x3 taps fall into the padding;
+    // grouping the rows of a tile by pixel position makes those taps invalid for whole tiles, whose K steps then vanish.
+    p.nhyp = a.nhyp; p.d_n = make_fastdiv((unsigned)a.nhyp);
+    p.posmajor = (dma && bm == BM && !(variant & 8) && conv_is_posmajor(dt, a)) ? 1 : 0;
+    if (p.posmajor) {       // positions sorted by descending valid-tap count (stable)
+        int cnt[64], n = a.Hs * a.Ws;
+        for (int i = 0; i < n; ++i) {
+            const int y = i / a.Ws, x = i % a.Ws;
+            cnt[i] = ((y > 0) + 1 + (y + 1 < a.Hs)) * ((x > 0) + 1 + (x + 1 < a.Ws));
+            p.pos_order[i] = (unsigned char)i;
+        }
+        for (int i = 1; i < n; ++i)      // insertion sort, n <= 64
+            for (int j = i; j > 0 && cnt[p.pos_order[j]] > cnt[p.pos_order[j - 1]]; --j) {
+                const unsigned char tmp = p.pos_order[j]; p.pos_order[j] = p.pos_order[j - 1]; p.pos_order[j - 1] = tmp;
+            }
+    }
     if (dma && a.splitk_ws) {
         p.splits = conv_splitk_factor(dt, a);
         if ((size_t)p.splits * (size_t)M * a.Cout * 4 > a.splitk_bytes) p.splits = 1;

@@ -17,6 +17,7 @@
 //     f32 GEMM against the row-concatenated weights;
 //   * a bump arena over caller-provided workspace: no allocation, no host sync, one stream.
 #include <cstdio>
+#include <cstdlib>
 #include <initializer_list>
 #include <map>
 #include <string>
@@ -192,7 +193,7 @@ struct Fwd {
         if (net->profile) {
             nope_unet::Ev ev;
             hipEventCreate(&ev.a); hipEventCreate(&ev.b);
-            ev.flops = 2.0 * (double)n * Ho * Wo * c.Cout * c.ntaps * c.Cin;   // executed MACs (UP2P: 4 taps per output pixel)
+            ev.flops = conv_executed_flops(net->dt, ca);   // executed MACs (UP2P: 4 taps per output pixel; padding taps of small maps skipped)
             // algorithmic HBM bytes: every input, weight and output element exactly once
             ev.bytes = ((double)(n / rep1) * a.H * a.W * a.C + (b ? (double)(n / rep2) * a.H * a.W * b->C : 0.0) +
                         (double)c.Cout * c.ntaps * c.Cin * (c.mode == NOPE_CONV_UP2P ? 4 : 1) + (double)n * Ho * Wo * c.Cout) * (double)es;
@@ -206,7 +207,12 @@ struct Fwd {
     }
     // Can the conv that produces a [n][HW][C] tensor also emit its GroupNorm statistics?  (64-row blocks
     // must not straddle samples; the wide epilogue needs C % VEC == 0.)  Returns the scratch it needs.
-    float* colstats_for(int n, int HW, int C) {
+    // `conv3x3`: the producer is a 3x3 conv; on maps of <= posmajor_hw pixels with a multiple of 128 samples it runs
+    // in position-major row order (padding taps skipped, kernels_gemm.hip), which cannot emit per-sample column
+    // statistics -- the GroupNorm then takes its own statistics pass over the (small) tensor.
+    float* colstats_for(int n, int HW, int C, bool conv3x3 = false) {
+        static const int posmajor_hw = getenv("NOPE_POSMAJOR_HW") ? atoi(getenv("NOPE_POSMAJOR_HW")) : 16;
+        if (conv3x3 && HW <= posmajor_hw && n % 128 == 0) return nullptr;
         if (HW % 64 || C % 8 || C > 2048) return nullptr;
         return (float*)ar.alloc((size_t)n * (HW / 64) * C * 2 * sizeof(float));
     }
@@ -244,16 +250,16 @@ struct Fwd {
             // pose-independent prefix: conv + GN statistics once per reference sample
             const int ns = nhyp / a.rep;
             void* t1s = alloc_act((size_t)ns * HW * R.c1.Cout);
-            float* cs = colstats_for(ns, HW, R.c1.Cout);
+            float* cs = colstats_for(ns, HW, R.c1.Cout, true);
             conv(R.c1, a, nullptr, t1s, a.H, a.W, ns, 1, 1, nullptr, 0, NOPE_F32, cs);
             gn(R.n1, G, t1s, a.rep, t1, HW, 1, emb_off, nullptr, 1, cs);
         } else {
-            float* cs = colstats_for(nhyp, HW, R.c1.Cout);
+            float* cs = colstats_for(nhyp, HW, R.c1.Cout, true);
             conv(R.c1, a, b, t1, a.H, a.W, nhyp, a.rep, b ? b->rep : 1, nullptr, 0, NOPE_F32, cs);
             gn(R.n1, G, t1, 1, t1, HW, 1, emb_off, nullptr, 1, cs);
         }
         Act h{t1, R.c1.Cout, a.H, a.W, 1};
-        float* cs2 = colstats_for(nhyp, HW, R.c2.Cout);
+        float* cs2 = colstats_for(nhyp, HW, R.c2.Cout, true);
         conv(R.c2, h, nullptr, out, a.H, a.W, nhyp, 1, 1, nullptr, 0, NOPE_F32, cs2);
         const void* resid = a.p;
         int resid_rep = a.rep;

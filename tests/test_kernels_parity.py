@@ -336,3 +336,26 @@ def test_encoder_golden_gpu(gpu, golden, cdt, tol):
     allf = enc.encode_image(img)
     one = torch.cat([enc.encode_image(img[i:i + 1]) for i in range(3)])
     assert allf.shape == (3, 8, 8, 12) and torch.equal(allf, one)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_conv_position_major(be, dt):
+    """3x3 convs on small maps with a multiple of 128 samples run with GEMM rows ordered (pixel position, sample), so
+    that tiles skip the taps lying in the zero padding: 2x2, 4x4 and a non-square 2x8 map, virtual concat with a
+    broadcast first source, residual, bias -- same values as the standard order."""
+    hip, dev, _ = be
+    tol = 2e-5 if dt == 0 else BF16_TOL
+    g = torch.Generator().manual_seed(33)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    q = lambda x: _q(x, dt, hip)
+    d = lambda x: x.to(dev)
+    cin = 32 if dt == 0 else 64          # one 128-byte K step per tap
+    for (h, w) in ((4, 4), (2, 2), (2, 8)):
+        x, wt, b = rn(128, cin, h, w), rn(24, cin, 3, 3) / (3 * cin ** 0.5), rn(24)
+        rs = rn(128, 24, h, w)
+        y = hip.op_conv(dt, hip.to_nhwc(d(x), dt), d(wt), d(b), resid=hip.to_nhwc(d(rs), dt))
+        assert rel(hip.to_nchw(y, dt).cpu(), F.conv2d(q(x), q(wt), b, padding=1) + q(rs)) < tol
+    x1, x2, wt = rn(2, cin, 4, 4), rn(128, cin, 4, 4), rn(40, 2 * cin, 3, 3) / (3 * (2 * cin) ** 0.5)
+    y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(wt), None, src2=hip.to_nhwc(d(x2), dt), rep1=64, rep2=1, n_hyp=128)
+    ref = F.conv2d(torch.cat((q(x1).repeat_interleave(64, 0), q(x2)), 1), q(wt), padding=1)
+    assert rel(hip.to_nchw(y, dt).cpu(), ref) < tol
