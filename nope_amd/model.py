@@ -127,7 +127,7 @@ class PoseConditional(nn.Module):
     @torch.no_grad()
     def generate_and_retrieve(self, query, reference, all_relativeR):
         """`generate_templates(reference, all_relativeR)` followed by `retrieval(query, bank)` as one call,
-        returning (similarity, nearest_idx, bank) -- the same arithmetic in the same order.  The query does not depend on
+        returning (similarity, nearest_idx, bank) -- the same arithmetic in the same order, bit-identical results.  The query does not depend on
         the bank, so its encoder pass (launch-latency bound, a few CUs wide) is issued on a second HIP
         stream and runs underneath the reference encoder and the first U-Net kernels."""
         if self.similarity_metric != "l2":
