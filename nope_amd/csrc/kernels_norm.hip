@@ -100,7 +100,15 @@ __global__ __launch_bounds__(NT) void gn_fold_kernel(const float* __restrict__ c
     const float* base = colstats + (size_t)hyp * nb * C * 2;
     for (int c = tid; c < C; c += NT) {
         float s = 0.f, q = 0.f;
-        for (int b = 0; b < nb; ++b) {
+        int b = 0;
+        for (; b + 8 <= nb; b += 8) {          // 8 independent loads in flight, then the adds in row-block order
+            f32x2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x2*>(base + ((size_t)(b + u) * C + c) * 2);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += v[u][0]; q += v[u][1]; }
+        }
+        for (; b < nb; ++b) {
             const f32x2 v = *reinterpret_cast<const f32x2*>(base + ((size_t)b * C + c) * 2);
             s += v[0]; q += v[1];
         }
