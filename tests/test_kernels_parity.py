@@ -359,3 +359,43 @@ def test_conv_position_major(be, dt):
     y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(wt), None, src2=hip.to_nhwc(d(x2), dt), rep1=64, rep2=1, n_hyp=128)
     ref = F.conv2d(torch.cat((q(x1).repeat_interleave(64, 0), q(x2)), 1), q(wt), padding=1)
     assert rel(hip.to_nchw(y, dt).cpu(), ref) < tol
+
+
+def test_c_abi_error_codes(be):
+    """The boundary never throws or crashes on bad input: null pointers, unsupported sizes / dtypes, too-small
+    workspaces and mis-shaped weights come back as negative NOPE_ERR_* codes (raised as NopeError by the binding)."""
+    import ctypes as C
+    hip, dev, _ = be
+    l = hip.lib()
+    d = l.dll
+    q = torch.randn(1, 8, 4, 4).to(dev)
+    bank = torch.randn(1, 3, 8, 4, 4).to(dev)
+    out = torch.empty(1, 3).to(dev)
+    assert d.nope_similarity(None, bank.data_ptr(), 0, out.data_ptr(), 1, 3, 8, 4, 4, 3 * 128, 3, None) == -1      # NOPE_ERR_ARG
+    assert d.nope_similarity(q.data_ptr(), bank.data_ptr(), 7, out.data_ptr(), 1, 3, 8, 4, 4, 3 * 128, 3, None) < 0   # dtype
+    idx = torch.empty(1, 5, dtype=torch.int64).to(dev)
+    assert d.nope_topk(out.data_ptr(), idx.data_ptr(), None, 1, 3, 5, 3, None) == -1                               # k > N
+    with pytest.raises(hip.NopeError):
+        hip.topk(out, 5)
+    assert d.nope_strerror(-3).decode() != "" and d.nope_strerror(-3) != d.nope_strerror(-1)
+    # conv: channel count that is not a multiple of the vector width, bad tap count
+    x = torch.randn(1, 4, 4, 6).to(dev)
+    w = torch.randn(8, 6, 3, 3).to(dev)
+    with pytest.raises(hip.NopeError):
+        hip.op_conv(hip.F32, x, w)
+    # encoder: wrong image size -> workspace query says 0 and the binding raises; missing tensor -> NOPE_ERR_WEIGHT
+    enc = _encoder_pair()
+    with pytest.raises(hip.NopeError, match="multiples of 8"):
+        enc.encode_image_hip(torch.zeros(1, 3, 20, 20).to(dev))
+    sd = {k: v.to(dev) for k, v in enc.state_dict().items() if k != "backbone.layer2.0.bn2.running_var"}
+    with pytest.raises(hip.NopeError, match="nope_encoder_create"):
+        hip.EncoderHandle(8, sd, hip.F32)
+    # encoder forward with a workspace that is too small
+    h = enc._get_handle(torch.device(dev))
+    need = d.nope_encoder_workspace_bytes(h._h, 1, 16, 16)
+    assert need > 0
+    small = torch.empty(1024, dtype=torch.uint8).to(dev)
+    img = torch.zeros(1, 3, 16, 16).to(dev)
+    o = torch.empty(1, 8, 2, 2).to(dev)
+    assert d.nope_encoder_forward(h._h, img.data_ptr(), 1, 16, 16, o.data_ptr(), small.data_ptr(), small.numel(), None) == -3   # NOPE_ERR_WORKSPACE
+    assert d.nope_encoder_forward(h._h, None, 1, 16, 16, o.data_ptr(), small.data_ptr(), small.numel(), None) == -1
