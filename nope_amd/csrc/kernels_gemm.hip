@@ -84,6 +84,8 @@ struct ConvParams {
     int variant;                       // tuning switches (NOPE_CONV_VARIANT), 0 in production
     FastDiv d_hw, d_w, d_rep1, d_rep2; // / (Hm*Wm), / Wm, / rep1, / rep2
     unsigned char pos_order[64];       // posmajor: pixel positions by descending number of valid taps
+    int persist_iters;                 // > 1: a workgroup walks this many tiles (tile_m advances by 64 each time)
+    unsigned persist_d1, persist_d2;   // byte advance of the A offsets per walked tile (src1 / src2)
     int posmajor;                      // 1: GEMM rows ordered (pixel position, sample) instead of (sample, pixel) -- see launch_conv
     FastDiv d_n;                       // / nhyp (posmajor)
     int nhyp;
@@ -250,8 +252,12 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const typename Til
 // through its private 64 x 52-word LDS panel, PANW columns at a time (48 = three 16-wide tiles for f32, 32 =
 // one 32-wide tile for bf16), and writes rows back as 16-byte vectors (residual added in f32 before the
 // single rounding to T).  On the way it emits the per-column sums the following GroupNorm needs.
-constexpr int EP_LD = 52;
-constexpr int EP_WAVE_BYTES = 64 * EP_LD * 4;
+// (panel row stride: 32 + 4 words for the bf16 tiles -- four 9 KiB panels then fit into ONE 40 KiB DMA stage, which
+// lets a persistent workgroup prefetch its next tile into the other stage during the epilogue -- 48 + 4 for f32)
+template <class T> struct Ep {
+    static constexpr int LD = Tile<T>::TM == 32 ? 36 : 52;
+    static constexpr int WAVE_BYTES = 64 * LD * 4;
+};
 
 template <class T, bool PN>
 __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL],
@@ -298,7 +304,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
             for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
                 for (int r = 0; r < TL::R; ++r)
-                    pan[(i * TL::TM + TL::out_row(lane, r)) * EP_LD + jj * TL::TM + TL::out_col(lane)] = acc[i][j][r] + bv;
+                    pan[(i * TL::TM + TL::out_row(lane, r)) * Ep<T>::LD + jj * TL::TM + TL::out_col(lane)] = acc[i][j][r] + bv;
         }
         // same-wave LDS write -> read: the LDS queue of a wave is in order, so no s_barrier; the wave
         // barrier only pins the compiler's ordering (and is the rendezvous point of tests/hipemu)
@@ -334,7 +340,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
             float v[VEC];
 #pragma unroll
             for (int q = 0; q < VEC / 4; ++q) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(&pan[row * EP_LD + ch * VEC + q * 4]);
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&pan[row * Ep<T>::LD + ch * VEC + q * 4]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[q * 4 + e] = t[e];
             }
@@ -442,7 +448,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
     constexpr int VEC = Elt<T>::VEC;
     constexpr int BK = 8 * VEC;
     constexpr int ES = (int)sizeof(T);
-    constexpr int LDS_BYTES = (BM + BN) * ROWB > 4 * EP_WAVE_BYTES ? (BM + BN) * ROWB : 4 * EP_WAVE_BYTES;
+    constexpr int LDS_BYTES = (BM + BN) * ROWB > 4 * Ep<T>::WAVE_BYTES ? (BM + BN) * ROWB : 4 * Ep<T>::WAVE_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];   // K-step tile, then the epilogue panels
     unsigned char* ldsA = lds;
     unsigned char* ldsB = lds + BM * ROWB;
@@ -533,10 +539,10 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
         __syncthreads();
     }
     if (PN) {
-        if (p.wide_out) epilogue_wide<T, true>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
+        if (p.wide_out) epilogue_wide<T, true>(p, acc, m0, n0, wm, wn, lane, lds + wave * Ep<T>::WAVE_BYTES);
         else epilogue<T, true>(p, acc, m0, n0, wm, wn, lane);
     } else {
-        if (p.wide_out) epilogue_wide<T, false>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
+        if (p.wide_out) epilogue_wide<T, false>(p, acc, m0, n0, wm, wn, lane, lds + wave * Ep<T>::WAVE_BYTES);
         else epilogue<T, false>(p, acc, m0, n0, wm, wn, lane);
     }
 }
@@ -565,7 +571,11 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
     constexpr int NW = BMT / 32;                  // waves: (BMT/64) along M x 2 along N, 64x96 each
     constexpr int AI = BMT / RPI / NW, BI = BN / RPI / NW;   // DMA instructions per wave per stage
     constexpr int L = AI + BI;
-    constexpr int LDS_BYTES = NS * STAGE > NW * EP_WAVE_BYTES ? NS * STAGE : NW * EP_WAVE_BYTES;   // ring, reused by the epilogue panels
+    // Epilogue panels reuse the ring.  When all of them fit into one stage they live in the LAST stage, so stage 0 is
+    // free for the next tile's first loads while the epilogue runs (persistent launches).
+    constexpr bool PANELS_IN_LAST = NW * Ep<T>::WAVE_BYTES <= STAGE;
+    constexpr int PANEL_BASE = PANELS_IN_LAST ? (NS - 1) * STAGE : 0;
+    constexpr int LDS_BYTES = NS * STAGE > PANEL_BASE + NW * Ep<T>::WAVE_BYTES ? NS * STAGE : PANEL_BASE + NW * Ep<T>::WAVE_BYTES;
     static_assert(AI <= 4 && BI <= 6, "row bookkeeping arrays");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -586,7 +596,8 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
         const int pos = p.pos_order[tile_m < half ? k : hw - 1 - k];
         tile_m = pos * G + (t - k * G);
     }
-    const int m0 = tile_m * BMT, n0 = tile_n * BN;
+    int m0 = tile_m * BMT;
+    const int n0 = tile_n * BN;
     const int HWo = p.Hm * p.Wm;
     const int Cin = p.C1 + p.C2;
     const int ph_y = MODE == NOPE_CONV_UP2P ? ((int)blockIdx.y >> 1) : 0, ph_x = MODE == NOPE_CONV_UP2P ? ((int)blockIdx.y & 1) : 0;
@@ -746,17 +757,42 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
 #pragma unroll
             for (int r = 0; r < Tile<T>::R; ++r) acc[i][j][r] = 0.f;
 
+    // Persistent launches (bf16 3x3 / 1x1 PLAIN convs with thousands of tiles): a workgroup walks `iters` tiles whose
+    // tile_m differ by 64 (same XCD, same weight panel, whole samples apart), so the per-row state only needs a constant
+    // added, and the first stage of the next tile is already in flight while the epilogue of this one runs.
+    const int iters = (MODE == NOPE_CONV_PLAIN && PANELS_IN_LAST && NS == 2 && p.persist_iters > 1) ? p.persist_iters : 1;
     if (NS == 2) {
         if (nk > 0) issue(0);
-        for (int ks = 0; ks < nk; ++ks) {
-            const int buf = ks & 1;
-            __syncthreads();                       // stage ks landed (vmcnt drain) + everyone left stage ks-1
-            if (ks + 1 < nk && !(p.variant & 16)) issue(buf ^ 1);
-            // the MFMA phase outranks the other workgroup's address arithmetic on this SIMD (-7 % cycles measured)
-            if (!(p.variant & 1)) __builtin_amdgcn_s_setprio(2);
-            if (!(p.variant & 32)) mma_stage<T, RB>(lds + buf * STAGE, lds + buf * STAGE + BMT * RB, wm, wn, lane, acc);
-            if (!(p.variant & 1)) __builtin_amdgcn_s_setprio(0);
+        for (int it = 0; it < iters; ++it) {
+            for (int ks = 0; ks < nk; ++ks) {
+                const int buf = ks & 1;
+                __syncthreads();                   // stage ks landed (vmcnt drain) + everyone left stage ks-1 (and its epilogue)
+                if (ks + 1 < nk && !(p.variant & 16)) issue(buf ^ 1);
+                // the MFMA phase outranks the other workgroup's address arithmetic on this SIMD (-7 % cycles measured)
+                if (!(p.variant & 1)) __builtin_amdgcn_s_setprio(2);
+                if (!(p.variant & 32)) mma_stage<T, RB>(lds + buf * STAGE, lds + buf * STAGE + BMT * RB, wm, wn, lane, acc);
+                if (!(p.variant & 1)) __builtin_amdgcn_s_setprio(0);
+            }
+            if (iters > 1) {                       // (the launcher guarantees wide_out, no split, no masked rows)
+                __syncthreads();                   // every wave is done reading the last stage
+                const int m0e = m0;
+                if (it + 1 < iters) {
+                    m0 += 64 * BMT;
+#pragma unroll
+                    for (int i = 0; i < AI; ++i) { a_b1[i] += p.persist_d1; a_b2[i] += p.persist_d2; }
+                    ld_tap = 0; ld_kc = 0;
+                    if (nk > 0) issue(0);          // stage 0 of the next tile; the panels below sit in stage 1
+                }
+                epilogue_wide<T, PN>(p, acc, m0e, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
+#pragma unroll
+                for (int i = 0; i < Tile<T>::MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < Tile<T>::NTL; ++j)
+#pragma unroll
+                        for (int r = 0; r < Tile<T>::R; ++r) acc[i][j][r] = 0.f;
+            }
         }
+        if (iters > 1) return;
     }
     if (p.variant & 64) {                      // tuning only: no epilogue (keeps the accumulators live)
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;
@@ -764,7 +800,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
         epilogue_split<T>(p, acc, m0, n0, wm, wn, lane);
     } else if (p.wide_out) {
         __syncthreads();                       // every wave is done reading the last stage
-        epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + wave * EP_WAVE_BYTES);
+        epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
     } else {
         epilogue<T, PN>(p, acc, m0, n0, wm, wn, lane);
     }
@@ -901,7 +937,22 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         if ((size_t)p.splits * (size_t)M * a.Cout * 4 > a.splitk_bytes) p.splits = 1;
         if (p.splits > 1) p.split_out = (float*)a.splitk_ws;
     }
-    const dim3 grid((unsigned)nblocks, phased ? 4u : 1u, (unsigned)p.splits), block(NT);
+    // Persistent walk: 512 workgroups (2 per CU), each `iters` tiles 64 tile_m apart (same XCD under xcd_map).
+    p.persist_iters = 1; p.persist_d1 = p.persist_d2 = 0;
+    unsigned gx = (unsigned)nblocks;
+    {
+        const long long hw = (long long)a.Hs * a.Ws;
+        static const int persist_on = getenv("NOPE_CONV_PERSIST") ? atoi(getenv("NOPE_CONV_PERSIST")) : 1;
+        if (persist_on && dma && bm == BM && dt == NOPE_BF16 && a.mode == NOPE_CONV_PLAIN && !p.posmajor && p.splits == 1 && p.xcd_map &&
+            p.wide_out && a.rep1 == 1 && a.rep2 == 1 && M % BM == 0 && nblocks > 512 && nblocks % 512 == 0 && (64ll * BM) % hw == 0 &&
+            !(variant & 2)) {
+            p.persist_iters = (int)(nblocks / 512);
+            p.persist_d1 = (unsigned)(64ll * BM * a.C1 * es);
+            p.persist_d2 = (unsigned)(64ll * BM * a.C2 * es);
+            gx = 512;
+        }
+    }
+    const dim3 grid(gx, phased ? 4u : 1u, (unsigned)p.splits), block(NT);
     if (dt == NOPE_F32) {
         if (dma && bm == 256) launch_dma<float, 128, 2, 256>(p, grid, s);
         else if (dma) launch_dma<float, 128, 2, 128>(p, grid, s);

@@ -57,6 +57,26 @@ def test_position_major_convs_inside_unet(gpu, cdt):
     assert rel(full[:, 60:66].cpu(), want) < (1e-4 if cdt == "f32" else 6e-2)
 
 
+def test_persistent_convs_inside_unet(gpu):
+    """256 hypotheses at a 32x32 latent in bf16: the level-0 convs (2048 tiles) run as persistent workgroups walking
+    4 tiles each, with fused GroupNorm statistics; 64 hypotheses at a time (512 tiles) do not.  Same arithmetic in the
+    same order -> bit-identical banks; a slice is checked against the oracle."""
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    from tests.util import StubEncoder
+    m = UNet(u_net_dim=64, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype="bf16")
+    synth_init_(m, 2022)
+    sd = {k: v.clone() for k, v in m.own_state_dict().items()}
+    g = torch.Generator().manual_seed(13)
+    x, poses = torch.randn(1, 8, 32, 32, generator=g), torch.randn(1, 256, 6, generator=g)
+    m = m.cuda()
+    full = m.forward_hypotheses(x.cuda(), poses.cuda())
+    parts = torch.cat([m.forward_hypotheses(x.cuda(), poses[:, i:i + 64].cuda()) for i in range(0, 256, 64)], 1)
+    assert torch.equal(full, parts)
+    want = R.generate_templates(sd, x, poses[:, 250:253])
+    assert rel(full[:, 250:253].cpu(), want) < 6e-2
+
+
 def test_full_unet_f32_vs_reference(model_f32, golden):
     g = golden("unet_full_32.npz")
     y = model_f32.u_net.forward_hypotheses(g["x"].cuda(), g["pose"][None].cuda())[0].cpu()

@@ -399,3 +399,21 @@ def test_c_abi_error_codes(be):
     o = torch.empty(1, 8, 2, 2).to(dev)
     assert d.nope_encoder_forward(h._h, img.data_ptr(), 1, 16, 16, o.data_ptr(), small.data_ptr(), small.numel(), None) == -3   # NOPE_ERR_WORKSPACE
     assert d.nope_encoder_forward(h._h, None, 1, 16, 16, o.data_ptr(), small.data_ptr(), small.numel(), None) == -1
+
+
+def test_conv_persistent_walk(be):
+    """bf16 PLAIN convs with more than 512 tiles run as 512 persistent workgroups that walk their tiles (next tile's
+    first stage prefetched under the epilogue).  1024 tiles of a 1x1 conv with residual; on the GPU also a 3x3."""
+    hip, dev, kind = be
+    dt = hip.BF16
+    g = torch.Generator().manual_seed(41)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    q = lambda x: _q(x, dt, hip)
+    d = lambda x: x.to(dev)
+    x, w1, b1, rs = rn(512, 64, 16, 16), rn(16, 64, 1, 1) / 8, rn(16), rn(512, 16, 16, 16)
+    y = hip.op_conv(dt, hip.to_nhwc(d(x), dt), d(w1), d(b1), resid=hip.to_nhwc(d(rs), dt))
+    assert rel(hip.to_nchw(y, dt).cpu(), F.conv2d(q(x), q(w1), b1) + q(rs)) < BF16_TOL
+    if kind == "gpu":
+        w3 = rn(200, 64, 3, 3) / 24
+        y = hip.op_conv(dt, hip.to_nhwc(d(x), dt), d(w3), None)
+        assert rel(hip.to_nchw(y, dt).cpu(), F.conv2d(q(x), q(w3), padding=1)) < BF16_TOL
