@@ -847,7 +847,7 @@ int conv_splitk_factor(int dt, const ConvArgs& a) {
     const long long M = (long long)a.nhyp * a.Ho * a.Wo;
     const long long tiles = (long long)cdiv((int)M, BM) * cdiv(a.Cout, BN);
     const int nk = a.ntaps * (Cin / (8 * vec));
-    if (tiles >= 128 || nk < 8) return 1;
+    if (tiles > 128 || nk < 8) return 1;
     int S = (int)((512 + tiles - 1) / tiles);
     if (S > nk / 4) S = nk / 4;
     if (S > 16) S = 16;

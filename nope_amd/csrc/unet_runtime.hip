@@ -180,7 +180,7 @@ struct Fwd {
     void conv(const Conv& c, const Act& a, const Act* b, void* out, int Ho, int Wo, int n, int rep1, int rep2,
               const void* resid = nullptr, int out_nchw = 0, int out_dt = NOPE_F32, float* colstats = nullptr,
               const float* pn_c0 = nullptr, const float* pn_c1 = nullptr) {
-        if (!live()) return;
+        if (err != NOPE_OK) return;
         ConvArgs ca;
         ca.colstats = colstats;
         if (pn_c0) { ca.pn_ms = pn_ms; ca.pn_c0 = pn_c0; ca.pn_c1 = pn_c1; }
@@ -190,6 +190,19 @@ struct Fwd {
         ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.bias = c.bias; ca.resid = resid;
         ca.out = out; ca.Cout = c.Cout; ca.nhyp = n; ca.out_nchw = out_nchw; ca.out_dt = out_dt;
         if (a.C + (b ? b->C : 0) != c.Cin) { chk(NOPE_ERR_ARG); return; }
+        // few output tiles + long K (small hypothesis batches at the 4x4 level): deterministic split-K through a
+        // scratch taken from the arena for the duration of the launch
+        const size_t sk_mark = ar.off;
+        if (!colstats && !pn_c0 && !out_nchw) {
+            const int S = conv_splitk_factor(net->dt, ca);
+            if (S > 1) {
+                ca.splitk_bytes = (size_t)S * n * Ho * Wo * c.Cout * 4;
+                ca.splitk_ws = ar.alloc(ca.splitk_bytes);
+                if (!ca.splitk_ws) { chk(NOPE_ERR_WORKSPACE); return; }
+            }
+        }
+        struct Release { Arena& a; size_t m; ~Release() { a.off = m; } } release{ar, sk_mark};
+        if (!live()) return;               // workspace-size query: only the arena bookkeeping above matters
         if (net->profile) {
             nope_unet::Ev ev;
             hipEventCreate(&ev.a); hipEventCreate(&ev.b);

@@ -39,8 +39,10 @@ def test_mid_unet_dma_path_vs_oracle(gpu, cdt, tol):
 @pytest.mark.parametrize("cdt", ["f32", "bf16"])
 def test_position_major_convs_inside_unet(gpu, cdt):
     """128 hypotheses at a 16x16 latent: the 4x4 and 2x2 levels run their 3x3 convs in position-major row order
-    (padding taps skipped); 64 hypotheses at a time do not.  Skipped K steps only ever added exact zeros, so the two
-    schedules must agree bit for bit; a slice is also checked against the oracle."""
+    (padding taps skipped); 64 hypotheses at a time do not (those launches have so few tiles that they split K instead,
+    i.e. a different f32 summation order): the two schedules agree to rounding, and a slice matches the oracle.  (The
+    bit-for-bit identity of position-major and standard order is checked at operator level on the interpreter and GPU,
+    test_conv_position_major.)"""
     from nope_amd.u_net import UNet
     from nope_amd.weights import synth_init_
     from tests.util import StubEncoder
@@ -52,15 +54,15 @@ def test_position_major_convs_inside_unet(gpu, cdt):
     m = m.cuda()
     full = m.forward_hypotheses(x.cuda(), poses.cuda())
     halves = torch.cat([m.forward_hypotheses(x.cuda(), poses[:, i:i + 64].cuda()) for i in (0, 64)], 1)
-    assert torch.equal(full, halves)
+    assert rel(full, halves) < (2e-5 if cdt == "f32" else 3e-2)
     want = R.generate_templates(sd, x, poses[:, 60:66])
     assert rel(full[:, 60:66].cpu(), want) < (1e-4 if cdt == "f32" else 6e-2)
 
 
 def test_persistent_convs_inside_unet(gpu):
     """256 hypotheses at a 32x32 latent in bf16: the level-0 convs (2048 tiles) run as persistent workgroups walking
-    4 tiles each, with fused GroupNorm statistics; 64 hypotheses at a time (512 tiles) do not.  Same arithmetic in the
-    same order -> bit-identical banks; a slice is checked against the oracle."""
+    4 tiles each, with fused GroupNorm statistics; 64 hypotheses at a time (512 tiles) do not (and their deep levels
+    split K).  The schedules agree to bf16 rounding; a slice is checked against the oracle."""
     from nope_amd.u_net import UNet
     from nope_amd.weights import synth_init_
     from tests.util import StubEncoder
@@ -72,7 +74,7 @@ def test_persistent_convs_inside_unet(gpu):
     m = m.cuda()
     full = m.forward_hypotheses(x.cuda(), poses.cuda())
     parts = torch.cat([m.forward_hypotheses(x.cuda(), poses[:, i:i + 64].cuda()) for i in range(0, 256, 64)], 1)
-    assert torch.equal(full, parts)
+    assert rel(full, parts) < 3e-2
     want = R.generate_templates(sd, x, poses[:, 250:253])
     assert rel(full[:, 250:253].cpu(), want) < 6e-2
 

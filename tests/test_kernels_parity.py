@@ -355,6 +355,11 @@ def test_conv_position_major(be, dt):
         rs = rn(128, 24, h, w)
         y = hip.op_conv(dt, hip.to_nhwc(d(x), dt), d(wt), d(b), resid=hip.to_nhwc(d(rs), dt))
         assert rel(hip.to_nchw(y, dt).cpu(), F.conv2d(q(x), q(wt), b, padding=1) + q(rs)) < tol
+        # 64 samples at a time take the standard (sample, pixel) order: the skipped K steps only ever added exact
+        # zeros, so the two orders agree bit for bit
+        xs, rss = hip.to_nhwc(d(x), dt), hip.to_nhwc(d(rs), dt)
+        y2 = torch.cat([hip.op_conv(dt, xs[i:i + 64].contiguous(), d(wt), d(b), resid=rss[i:i + 64].contiguous()) for i in (0, 64)])
+        assert torch.equal(y, y2)
     x1, x2, wt = rn(2, cin, 4, 4), rn(128, cin, 4, 4), rn(40, 2 * cin, 3, 3) / (3 * (2 * cin) ** 0.5)
     y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(wt), None, src2=hip.to_nhwc(d(x2), dt), rep1=64, rep2=1, n_hyp=128)
     ref = F.conv2d(torch.cat((q(x1).repeat_interleave(64, 0), q(x2)), 1), q(wt), padding=1)
