@@ -7,15 +7,18 @@
 One "step" = one pass of the hot path over one batch, inputs resident in HBM:
     generate_templates(reference, all_relativeR)   encoder(reference) once + U-Net for every pose hypothesis
     retrieval(query, bank)                         encoder(query) + scoring + top-5
+issued as ONE call, PoseConditional.generate_and_retrieve (same values; the query's encoder pass runs on a second HIP
+stream underneath the reference encoder and the first U-Net kernels); --two-calls times the literal two-call sequence.
 Workload at N=1: BASELINE.json configs[1] -- one 256x256 query against 512 viewpoint templates,
 bf16 (bf16 U-Net compute with f32 accumulation/statistics, bf16 bank).  For N>1 the template
 axis is sharded (weak scaling: 512 templates per GPU, N_total = 512*N) and the per-rank scores
 are all-gathered over RCCL before the top-5, as BASELINE configs[3]/[4] describe.
 
 Extra legs on rank 0 at N=1 (outside the timed region):
-  roofline      the dominant kernel of the step, conv_gemm_kernel<bf16> (94 % of the flops):
-                algorithmic flops of all its launches / their summed duration, measured with HIP
-                events around every launch on the launch stream, vs the 2.5 PFLOP/s dense bf16 peak;
+  roofline      the dominant kernel of the step, conv_gemm_dma_kernel<bf16> (the U-Net's 83 implicit-GEMM launches):
+                multiply-adds x2 those launches EXECUTE (phase convs 4/9 of the nearest-x2 MACs, padding taps of the
+                4x4 level skipped) / their summed duration, measured with HIP events around every launch on the launch
+                stream, vs the 2.5 PFLOP/s dense bf16 peak;
   scoring       the similarity kernel on a 1.07 GB resident bank, vs 8 TB/s HBM;
   cpu_baseline  the oracle (CPU restatement, kind "port") on the host cores, bounded sample.
 """
@@ -235,7 +238,8 @@ def main():
                            "algorithmic_bytes_per_launch": abytes / max(n_launch, 1), "launches_per_step": n_launch,
                            "avg_launch_ms": ms / max(n_launch, 1), "kernel_ms_per_step": ms, "flops_per_step": flops,
                            "note": "flops = executed MACs x2 of all implicit-GEMM launches of one step (the nearest-x2 convs run "
-                                   "as four 2x2 phase convs = 4/9 of the reference MACs); time = HIP events around each launch"}
+                                   "as four 2x2 phase convs = 4/9 of the reference MACs; 3x3 convs on the 4x4 level skip the taps lying in the zero "
+                                   "padding = 69 % of theirs); time = HIP events around each launch"}
         res["scoring_roofline"] = [scoring_roofline(torch.bfloat16), scoring_roofline(torch.float32)]
         res["cpu_baseline"] = cpu_baseline(model, a.size, a.templates)
         res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
