@@ -1,0 +1,84 @@
+"""GPU-only randomized sweep of the implicit-GEMM conv through the C ABI against torch's own convolution (float64) on the
+same (dtype-rounded) operands: 120 seeded draws over tap geometry, channel counts on and off the LDS-DMA path, virtual
+concat with broadcast sources, bias / residual / ReLU / NCHW epilogues and the launch regimes that switch code paths
+(position-major rows on small maps with a multiple of 128 samples, persistent tile walk above 512 tiles)."""
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(mode, hip, x, w, b):
+    if mode == hip.CONV_PLAIN:
+        return F.conv2d(x, w, b, padding=w.shape[-1] // 2)
+    if mode == hip.CONV_STRIDE2:
+        return F.conv2d(x, w, b, stride=2, padding=w.shape[-1] // 2)
+    if mode in (hip.CONV_UP2, hip.CONV_UP2P):
+        return F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+    # DOWN2: einops "b c (h p1) (w p2) -> b (c p1 p2) h w" + 1x1 (model_utils.py:168-172)
+    B, C, H, W = x.shape
+    u = x.view(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(B, C * 4, H // 2, W // 2)
+    return F.conv2d(u, w, b)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_conv_random_sweep(gpu, dt):
+    hip = gpu
+    rng = random.Random(1234 + dt)
+    g = torch.Generator(device="cuda").manual_seed(99 + dt)
+    rn = lambda *s: torch.randn(*s, generator=g, device="cuda")
+    q = lambda t: t.to(hip.torch_dtype(dt)).float()
+    tol = 1e-5 if dt == 0 else 8e-3        # f32: accumulation order only; bf16: one output rounding (2^-9) + order
+    unit = 32 if dt == 0 else 64                      # channels per 128-byte K step
+    worst = 0.0
+    for it in range(60):
+        mode = rng.choice([hip.CONV_PLAIN] * 4 + [hip.CONV_STRIDE2, hip.CONV_UP2, hip.CONV_UP2P, hip.CONV_DOWN2])
+        ks = 1 if (mode in (hip.CONV_DOWN2,) or (mode in (hip.CONV_PLAIN, hip.CONV_STRIDE2) and rng.random() < 0.35)) else 3
+        on_dma = rng.random() < 0.7
+        c1 = unit * rng.choice([1, 2, 3]) if on_dma else 8 * rng.choice([1, 3, 5])
+        c2 = 0
+        if mode == hip.CONV_PLAIN and rng.random() < 0.3:
+            c2 = unit * rng.choice([1, 2]) if on_dma else 8 * rng.choice([1, 2])
+        cout = rng.choice([8, 24, 64, 192, 200, 384])
+        regime = rng.random()
+        if mode == hip.CONV_PLAIN and ks == 3 and regime < 0.25:
+            n, h, w_ = 128 * rng.choice([1, 2]), rng.choice([2, 4]), rng.choice([2, 4])      # position-major
+        elif mode == hip.CONV_PLAIN and regime < 0.4 and cout <= 64:
+            n, h, w_ = 512, 16, 16                                                             # 1024 tiles: persistent walk
+        else:
+            n, h, w_ = rng.choice([1, 2, 3, 5]), 2 * rng.choice([1, 2, 3, 4]), 2 * rng.choice([1, 2, 3, 5])
+        rep1 = 1
+        if c2 and n % 2 == 0 and rng.random() < 0.5:
+            rep1 = 2
+        x1 = rn(n // rep1, c1, h, w_)
+        x2 = rn(n, c2, h, w_) if c2 else None
+        cin = c1 + c2
+        wshape = (cout, cin * 4, 1, 1) if mode == hip.CONV_DOWN2 else (cout, cin, ks, ks)
+        wt = rn(*wshape) / (wshape[1] * ks * ks) ** 0.5
+        b = rn(cout) if rng.random() < 0.6 else None
+        ho, wo = (2 * h, 2 * w_) if mode in (hip.CONV_UP2, hip.CONV_UP2P) else ((h // 2, w_ // 2) if mode in (hip.CONV_DOWN2, hip.CONV_STRIDE2) else (h, w_))
+        use_res = rng.random() < 0.4
+        relu = rng.random() < 0.3
+        nchw = (not use_res) and mode != hip.CONV_UP2P and rng.random() < 0.2
+        rs = rn(n, cout, ho, wo) if use_res else None
+        y = hip.op_conv(dt, hip.to_nhwc(x1, dt), wt, b, src2=None if x2 is None else hip.to_nhwc(x2, dt), mode=mode, rep1=rep1,
+                        resid=None if rs is None else hip.to_nhwc(rs, dt), n_hyp=n, out_nchw=nchw, out_dtype=hip.F32, act_relu=relu)
+        xin = q(x1).repeat_interleave(rep1, 0)
+        if x2 is not None:
+            xin = torch.cat((xin, q(x2)), 1)
+        # float64 reference (torch falls back to its direct kernel: no Winograd / FFT rounding in the comparison)
+        want = _ref(mode, hip, xin.double(), q(wt).double(), None if b is None else b.double())
+        if rs is not None:
+            want = want + q(rs).double()
+        if relu:
+            want = F.relu(want)
+        got = y if nchw else hip.to_nchw(y, dt)
+        e = rel(got.double(), want)
+        worst = max(worst, e)
+        assert e < tol, (it, mode, ks, c1, c2, cout, n, h, w_, rep1, use_res, relu, nchw, e)
+    print(f"conv sweep dtype {dt}: worst rel err {worst:.2e}")
