@@ -82,3 +82,42 @@ def test_conv_random_sweep(gpu, dt):
         worst = max(worst, e)
         assert e < tol, (it, mode, ks, c1, c2, cout, n, h, w_, rep1, use_res, relu, nchw, e)
     print(f"conv sweep dtype {dt}: worst rel err {worst:.2e}")
+
+
+def test_similarity_topk_random_sweep(gpu):
+    """40 seeded draws of the scoring + top-k entry points against the CPU restatement: batch, template count (ragged
+    against the per-workgroup split), channel count (register and LDS query paths), map size, bank dtype, k."""
+    from oracle import nope_ref as R
+    hip = gpu
+    rng = random.Random(77)
+    g = torch.Generator().manual_seed(5)
+    worst = 0.0
+    for it in range(40):
+        B = rng.choice([1, 2, 5])
+        N = rng.choice([1, 3, 17, 64, 257, 1000])
+        C = rng.choice([8, 8, 16, 4, 24])
+        h, w = rng.choice([(32, 32), (16, 16), (8, 8), (4, 8), (16, 32)])
+        bdt = rng.choice([torch.float32, torch.bfloat16])
+        q = torch.randn(B, C, h, w, generator=g)
+        bank = torch.randn(B, N, C, h, w, generator=g)
+        if N > 2:
+            bank[B - 1, N // 2] = q[B - 1].to(bdt).float() if bdt == torch.bfloat16 else q[B - 1]
+            if bdt == torch.bfloat16:
+                q[B - 1] = q[B - 1].to(bdt).float()      # planted exact match must be exact in the bank dtype too
+        bank_q = bank.to(bdt)
+        if C > 16 and C * h * w > 16384:          # documented limit of the generic path: the query tile lives in 64 KiB of LDS
+            with pytest.raises(hip.NopeError, match="unsupported"):
+                hip.similarity(q.cuda(), bank_q.cuda())
+            continue
+        s = hip.similarity(q.cuda(), bank_q.cuda())
+        want = R.similarity_scores(q, bank_q.float())
+        e = rel(s.cpu(), want)
+        worst = max(worst, e)
+        assert e < 2e-5, (it, B, N, C, h, w, bdt, e)
+        k = min(5, N)
+        vals, idx = hip.topk(s, k)
+        if N > 2:
+            assert float(s[B - 1, N // 2]) == 0.0 and int(idx[B - 1, 0]) == N // 2
+        sv, si = torch.sort(s.cpu(), dim=1, descending=True, stable=True)
+        assert torch.equal(idx.cpu(), si[:, :k]) and torch.equal(vals.cpu(), sv[:, :k])
+    print(f"similarity sweep: worst rel err {worst:.2e}")
