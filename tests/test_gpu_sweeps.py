@@ -1,4 +1,4 @@
-"""GPU-only randomized sweep of the implicit-GEMM conv through the C ABI against torch's own convolution (float64) on the
+"""GPU-only randomized sweeps of the operator entry points of the C ABI. Conv: against torch's own convolution (float64) on the
 same (dtype-rounded) operands: 120 seeded draws over tap geometry, channel counts on and off the LDS-DMA path, virtual
 concat with broadcast sources, bias / residual / ReLU / NCHW epilogues and the launch regimes that switch code paths
 (position-major rows on small maps with a multiple of 128 samples, persistent tile walk above 512 tiles)."""
@@ -121,3 +121,51 @@ def test_similarity_topk_random_sweep(gpu):
         sv, si = torch.sort(s.cpu(), dim=1, descending=True, stable=True)
         assert torch.equal(idx.cpu(), si[:, :k]) and torch.equal(vals.cpu(), sv[:, :k])
     print(f"similarity sweep: worst rel err {worst:.2e}")
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_groupnorm_attention_random_sweep(gpu, dt):
+    """Seeded draws of the fused GroupNorm(+SiLU +embedding +residual) and of the two attention cores at the shapes the
+    U-Net uses them (up to 32x32 maps, 192-1536 channels, tens of samples) against float64 torch arithmetic."""
+    hip = gpu
+    rng = random.Random(4321 + dt)
+    g = torch.Generator(device="cuda").manual_seed(17 + dt)
+    rn = lambda *s: torch.randn(*s, generator=g, device="cuda")
+    q = lambda t: t.to(hip.torch_dtype(dt)).double()
+    tol = 1e-5 if dt == 0 else 1e-2
+    for it in range(30):
+        C = rng.choice([64, 128, 192, 384, 768, 1536])
+        G = rng.choice([1, 8])
+        h, w = rng.choice([(32, 32), (16, 16), (8, 8), (4, 4), (6, 10)])
+        n = rng.choice([1, 3, 16]) if C * h * w > 200000 else rng.choice([2, 33, 64])
+        act, use_emb, use_res = rng.random() < 0.7, rng.random() < 0.5, rng.random() < 0.5
+        x = rn(n, C, h, w) * 2 + 0.3
+        ga, be = rn(C), rn(C)
+        emb = rn(n, C) if use_emb else None
+        rs = rn(n, C, h, w) if use_res else None
+        y = hip.op_group_norm(dt, hip.to_nhwc(x, dt), ga, be, G, act_silu=act, emb=emb, resid=None if rs is None else hip.to_nhwc(rs, dt))
+        ref = F.group_norm(q(x), G, ga.double(), be.double())
+        if act:
+            ref = F.silu(ref)
+        if emb is not None:
+            ref = ref + emb.double()[:, :, None, None]
+        if rs is not None:
+            ref = ref + q(rs)
+        e = rel(hip.to_nchw(y, dt).double(), ref)
+        assert e < tol, ("gn", it, C, G, h, w, n, act, use_emb, use_res, e)
+    for it in range(12):
+        h, w = rng.choice([(32, 32), (16, 16), (8, 8), (4, 4), (5, 7)])
+        n = rng.choice([1, 4, 9])
+        qkv = rn(n, 384, h, w)
+        qq, kk, vv = (t.reshape(n, 4, 32, h * w) for t in q(qkv).chunk(3, 1))
+        ctx = torch.einsum("bhdn,bhen->bhde", kk.softmax(-1), vv)
+        o = torch.einsum("bhde,bhdn->bhen", ctx, qq.softmax(-2) * 32 ** -0.5).reshape(n, 128, h, w)
+        y = hip.op_linear_attention(dt, hip.to_nhwc(qkv, dt))
+        e = rel(hip.to_nchw(y, dt).double(), o)
+        assert e < (2e-5 if dt == 0 else 2e-2), ("linattn", it, h, w, n, e)
+        if h * w <= 64:
+            sim = torch.einsum("bhdi,bhdj->bhij", qq * 32 ** -0.5, kk).softmax(-1)
+            o = torch.einsum("bhij,bhdj->bhid", sim, vv).permute(0, 1, 3, 2).reshape(n, 128, h, w)
+            y = hip.op_linear_attention(dt, hip.to_nhwc(qkv, dt), full=True)
+            e = rel(hip.to_nchw(y, dt).double(), o)
+            assert e < (2e-5 if dt == 0 else 2e-2), ("attn", it, h, w, n, e)
