@@ -70,3 +70,47 @@ def test_sharded_scoring_matches_unsharded(emu):
         assert bshape[1] == (3 if r == 0 else 2)
         assert rel(sim, sim_want) < 1e-4 and torch.equal(idx, idx_want)
     assert torch.equal(ret[0][0], ret[1][0]) and torch.equal(ret[0][2], ret[1][2])
+
+
+def _gpu_worker(rank, ws, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        from nope_amd.model import PoseConditional
+        from nope_amd.u_net import UNet
+        from nope_amd.weights import synth_init_
+        from tests.util import StubEncoder
+        torch.cuda.set_device(0)
+        g = torch.Generator().manual_seed(8)
+        feat = torch.randn(2, 8, 16, 16, generator=g).cuda()
+        qfeat = torch.randn(2, 8, 16, 16, generator=g).cuda()
+        poses = torch.randn(2, 37, 6, generator=g).cuda()          # 37 templates over 3 ranks: 13 + 12 + 12
+        outs = []
+        for tp in (False, True):
+            u = UNet(u_net_dim=64, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype="f32")
+            synth_init_(u, 2022)
+            m = PoseConditional(u, None, {"similarity_metric": "l2"}, None, bank_dtype="f32", template_parallel=tp).cuda()
+            sim, idx, bank = m.generate_and_retrieve(qfeat, feat, poses)
+            torch.cuda.synchronize()
+            outs.append((sim.cpu(), idx.cpu(), tuple(bank.shape)))
+        err = float((outs[0][0] - outs[1][0]).abs().max() / outs[0][0].abs().max())
+        ret[rank] = (err, torch.equal(outs[0][1], outs[1][1]), outs[1][2], outs[0][2])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_generate_and_retrieve_on_device(gpu):
+    """Three ranks on ONE GPU (gloo carries the score all-gather, every kernel runs on the device): the template-sharded
+    generate_and_retrieve of bench.py --gpus N returns the scores (to f32 summation order: a 12-hypothesis shard and a
+    37-hypothesis batch choose different split-K factors) and the exact top-5 indices of the unsharded call."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29600 + os.getpid() % 2000
+    mp.spawn(_gpu_worker, args=(3, port, ret), nprocs=3, join=True)
+    for r in range(3):
+        err, same_idx, shard_shape, full_shape = ret[r]
+        assert err < 1e-5 and same_idx, (r, err)
+        assert full_shape[1] == 37 and shard_shape[1] == (13 if r == 0 else 12)
