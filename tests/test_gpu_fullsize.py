@@ -148,6 +148,25 @@ def test_properties_full_size(model_f32):
     assert rel(sb, s) < 5e-3 and torch.equal(hip.topk(sb, 1)[1], hip.topk(s, 1)[1])
 
 
+@pytest.mark.parametrize("cdt,tol", [("f32", 1e-4), ("bf16", 6e-2)])
+def test_bench_batch_vs_oracle(gpu, model_f32, cdt, tol):
+    """The benchmark's own launch regime -- ONE batch of 512 pose hypotheses at a 32x32 latent through the full-size U-Net
+    (position-major 4x4 level, persistent level-0/1 launches in bf16, fused statistics) -- checked hypothesis by hypothesis
+    against the CPU restatement on a spread of 6 of the 512 (the oracle needs ~50 ms per hypothesis)."""
+    from nope_amd.harness import build_model
+    m = model_f32 if cdt == "f32" else build_model(compute_dtype="bf16", bank_dtype="f32", device="cuda")
+    g = torch.Generator().manual_seed(21)
+    feat = torch.randn(1, 8, 32, 32, generator=g)
+    poses = torch.randn(1, 512, 6, generator=g)
+    bank = m.generate_templates_from_feat(feat.cuda(), poses.cuda()).float().cpu()
+    sel = [0, 127, 128, 300, 510, 511]
+    sd = {k: v.detach().cpu() for k, v in m.u_net.own_state_dict().items()}
+    want = R.generate_templates(sd, feat, poses[:, sel])
+    e = rel(bank[:, sel], want)
+    print(f"512-hypothesis batch {cdt}: rel err {e} on hypotheses {sel}")
+    assert e < tol
+
+
 def test_generate_and_retrieve_equals_two_calls(model_f32):
     """The one-call form (query encoder on a second stream, encoder passes replayed from hipGraphs) returns the
     scores, indices and bank of generate_templates followed by retrieval bit for bit, also when called repeatedly
