@@ -167,6 +167,26 @@ def test_bench_batch_vs_oracle(gpu, model_f32, cdt, tol):
     assert e < tol
 
 
+def test_pipeline_config2_f32_vs_oracle(model_f32):
+    """BASELINE configs[1] end to end in parity mode: one 256x256 query against 512 templates -- encoder, 512-hypothesis
+    U-Net batch, scoring, top-5 -- against the CPU restatement of the same pipeline (about half a minute of host time):
+    scores within 1e-4 relative, top-5 indices bit-exact."""
+    from nope_amd.harness import synthetic_batch
+    b = synthetic_batch(1, 512, 256, seed=2022, device="cpu")
+    sim, idx, _ = model_f32.generate_and_retrieve(b["query"].cuda(), b["reference"].cuda(), b["all_relativeR"].cuda())
+    enc_sd = {k: v.detach().cpu() for k, v in model_f32.u_net.encoder.state_dict().items()}
+    sd = {k: v.detach().cpu() for k, v in model_f32.u_net.own_state_dict().items()}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref_feat = R.encode_image(enc_sd, b["reference"])
+    q_feat = R.encode_image(enc_sd, b["query"])
+    bank = torch.cat([R.generate_templates(sd, ref_feat, b["all_relativeR"][:, i:i + 16]) for i in range(0, 512, 16)], 1)
+    sim_want, idx_want = R.retrieval(q_feat, bank)
+    e = rel(sim.cpu(), sim_want)
+    print("config-2 (512 templates, 256x256) f32 similarity rel err", e, "idx", idx.tolist(), "ref", idx_want.tolist())
+    assert e < 1e-4
+    assert torch.equal(idx.cpu(), idx_want)
+
+
 def test_generate_and_retrieve_equals_two_calls(model_f32):
     """The one-call form (query encoder on a second stream, encoder passes replayed from hipGraphs) returns the
     scores, indices and bank of generate_templates followed by retrieval bit for bit, also when called repeatedly
