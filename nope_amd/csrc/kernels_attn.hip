@@ -43,7 +43,17 @@ __global__ __launch_bounds__(NT, 4) void linattn_kernel(const T* __restrict__ qk
     __shared__ __attribute__((aligned(16))) float s_ctx[D][D];
     __shared__ float s_kmax[D];
     __shared__ float s_zp[NT / 64][D];
-    const int hyp = blockIdx.x / heads, head = blockIdx.x % heads;
+    // A head's rows are 64 B (bf16): two heads share every 128-byte line of q, k and v.  Workgroup b runs on XCD b % 8, so
+    // the plain (hyp, head) = (b / heads, b % heads) order puts the two sharers on different L2s and each line is fetched
+    // from HBM twice.  With 4 heads and a grid that is a multiple of 16 the head PAIRS are dealt to the XCDs instead and
+    // the two heads of a pair take adjacent launch slots of the same XCD.
+    int hyp = blockIdx.x / heads, head = blockIdx.x % heads;
+    if (heads == 4 && (gridDim.x & 15) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int pair = (slot >> 1) * 8 + xcd;          // pair = hyp * 2 + head / 2
+        hyp = pair >> 1;
+        head = (pair & 1) * 2 + (slot & 1);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int HD = heads * D;
     const int ldq = 3 * HD;
