@@ -1,5 +1,6 @@
 /* nope_hip.h -- C ABI of libnope_hip.so: the MI355X (gfx950) implementation of the NOPE
- * inference hot path (pose-conditioned U-Net template generation + template-bank scoring).
+ * inference hot path (template encoder + pose-conditioned U-Net template generation +
+ * template-bank scoring).
  *
  * The reference (nv-nguyen/nope) is pure Python on torch ops and has no FFI of its own; the
  * drop-in boundary is its Python operator interface (src/model/model.py, u_net.py), mirrored
@@ -9,9 +10,11 @@
  *
  * Conventions
  *   - plain C types only; every pointer is a DEVICE pointer unless it says "host";
- *   - the caller owns all buffers; only nope_unet_create allocates (packed weights);
+ *   - the caller owns all buffers; only nope_unet_create / nope_encoder_create allocate device memory
+ *     (packed weights), and nope_encoder_forward keeps host-side hipGraph objects in its handle;
  *   - `stream` is a hipStream_t passed as void*; all work is asynchronous on it;
- *   - re-entrant per stream, no global state; returns 0 or a negative NOPE_ERR_* code;
+ *   - no global state; calls with different handles, or with one U-Net handle and different workspaces, may
+ *     run on different streams; returns 0 or a negative NOPE_ERR_* code;
  *   - nothing here ever falls back to the host: without a GPU the calls fail.
  */
 #ifndef NOPE_HIP_H
