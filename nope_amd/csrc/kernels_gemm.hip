@@ -287,7 +287,8 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                 for (int r = 0; r < TL::R; ++r) { const float v = acc[i][j][r] + bv; s += v; q += v * v; }
 #pragma unroll
             for (int o = TL::TM; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-            if (lane < TL::TM && n < p.Cout) {
+            // (M % 128 == 64: the second wave row of the last tile lies beyond M -- it owns no row block)
+            if (lane < TL::TM && n < p.Cout && m0 + wm * 64 < p.M) {
                 float* cs = p.colstats + ((size_t)((m0 + wm * 64) >> 6) * p.Cout + n) * 2;
                 cs[0] = s; cs[1] = q;
             }

@@ -422,3 +422,33 @@ def test_conv_persistent_walk(be):
         w3 = rn(200, 64, 3, 3) / 24
         y = hip.op_conv(dt, hip.to_nhwc(d(x), dt), d(w3), None)
         assert rel(hip.to_nchw(y, dt).cpu(), F.conv2d(q(x), q(w3), padding=1)) < BF16_TOL
+
+
+@pytest.mark.parametrize("n_hyp", [1, 3])
+def test_workspace_canary_odd_hypotheses(be, n_hyp):
+    """with M % 128 == 64 (odd hypothesis count on an 8x8 map) the fused GroupNorm-statistics epilogue of the
+    last tile's second wave row used to write one row block past the column-statistics array, i.e. past the workspace
+    `nope_unet_workspace_bytes` reports.  Run with a canary behind exactly that many bytes."""
+    hip, dev, name = be
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    if name == "emu" and n_hyp != 1:
+        pytest.skip("CPU suite: one case is enough (80 s under the interpreter)")
+    dim = 64        # (at u_net_dim 64 the column statistics are the arena's last allocation at its peak)
+    u = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer")
+    synth_init_(u, 2022)
+    sd = {k: v.clone() for k, v in u.own_state_dict().items()}
+    u = u.to(dev)
+    g = torch.Generator().manual_seed(17)
+    x, pose = torch.randn(n_hyp, 8, 8, 8, generator=g), torch.randn(n_hyp, 6, generator=g)
+    h = u._get_handle(torch.device(dev))
+    need = h.workspace_bytes(n_hyp, n_hyp, 8, 8)
+    h._ws = torch.full((need + 8192,), 0xAB, dtype=torch.uint8, device=dev)
+    out = torch.empty((n_hyp, 8, 8, 8), device=dev)
+    l = hip.lib()
+    l.check(l.dll.nope_unet_forward(h._h, x.to(dev).data_ptr(), n_hyp, 1, pose.to(dev).data_ptr(), n_hyp, 8, 8, out.data_ptr(), hip.F32,
+                                    h._ws.data_ptr(), need, None if dev == "cpu" else torch.cuda.current_stream().cuda_stream), "fwd")
+    if dev != "cpu":
+        torch.cuda.synchronize()
+    assert bool((h._ws[need:] == 0xAB).all()), "write beyond the reported workspace size"
+    assert rel(out.cpu(), R.unet_forward(sd, x, pose)) < F32_TOL
