@@ -30,20 +30,52 @@ def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+_BUFS = {}
+
+
+def gather_buffers(B: int, n_total: int, device, group=None):
+    """Cached (send (B, nmax), recv (G, B, nmax)) f32 buffers of the score all-gather, nmax = ceil(n_total / G).
+    The scoring kernel writes this rank's columns straight into `send` (nope_amd.model.retrieval_from_feat), so a
+    step allocates nothing and copies nothing on the way into the collective."""
+    _, ws = world(group)
+    nmax = (n_total + ws - 1) // ws
+    key = (B, nmax, ws, str(device))
+    b = _BUFS.get(key)
+    if b is None:
+        if len(_BUFS) > 8:
+            _BUFS.clear()
+        b = _BUFS[key] = (torch.zeros((B, nmax), dtype=torch.float32, device=device),
+                          torch.empty((ws, B, nmax), dtype=torch.float32, device=device))
+    return b
+
+
 def all_gather_scores(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
-    """local (B, n_local) f32 slice of this rank -> (B, n_total) on every rank."""
+    """local (B, n_local) f32 slice of this rank (n_local may be 0) -> (B, n_total) on every rank: ONE
+    `all_gather_into_tensor` of the padded (B, nmax) slices (RCCL on GPUs, gloo in the CPU tests) and at most two
+    strided copies to drop the padding of an uneven split."""
     rank, ws = world(group)
     if ws == 1:
         assert local.shape[1] == n_total
         return local
     B = local.shape[0]
-    nmax = (n_total + ws - 1) // ws
-    send = local.new_zeros((B, nmax))
-    send[:, : local.shape[1]] = local
-    parts = [torch.empty_like(send) for _ in range(ws)]
-    dist.all_gather(parts, send.contiguous(), group=group)
+    send, recv = gather_buffers(B, n_total, local.device, group)
+    nmax = send.shape[1]
+    if not (local.data_ptr() == send.data_ptr() and local.stride() == send.stride()) and local.shape[1] > 0:
+        send[:, : local.shape[1]].copy_(local)
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo is a host backend (the multi-rank-on-one-GPU test): stage through host memory.  Production runs use
+        # "nccl" (= RCCL), which gathers device buffers directly over xGMI.
+        h_send, h_recv = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(h_recv.view(ws * B, nmax), h_send, group=group)
+        recv.copy_(h_recv)
+    else:
+        dist.all_gather_into_tensor(recv.view(ws * B, nmax), send, group=group)
+    base, extra = divmod(n_total, ws)
+    if extra == 0:
+        return recv.permute(1, 0, 2).reshape(B, n_total)
     out = local.new_empty((B, n_total))
-    for r in range(ws):
-        lo, hi = shard_range(n_total, r, ws)
-        out[:, lo:hi] = parts[r][:, : hi - lo]
+    cut = extra * (base + 1)                       # the first `extra` ranks hold base + 1 columns each
+    out[:, :cut].view(B, extra, base + 1).copy_(recv[:extra].permute(1, 0, 2))
+    if base > 0:
+        out[:, cut:].view(B, ws - extra, base).copy_(recv[extra:, :, :base].permute(1, 0, 2))
     return out

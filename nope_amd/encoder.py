@@ -93,18 +93,21 @@ class FeatureExtractor(nn.Module):
                                        nn.Conv2d(256, descriptor_size, 1, bias=False))
         self.encoder = nn.Sequential(self.backbone, self.projector)   # aliased, as in template.py:40
         self.eval()
+        # runs for a load_state_dict on this module or on any parent (UNet, PoseConditional, a Lightning module)
+        self.register_load_state_dict_post_hook(lambda mod, _keys: mod.invalidate())
 
     def invalidate(self):
-        """Call after changing weights in place; the next device call refolds and repacks them."""
+        """Drop the folded / repacked device weights; the next device call rebuilds them."""
         self._handle = None
 
-    def load_state_dict(self, *a, **k):
-        r = super().load_state_dict(*a, **k)
-        self.invalidate()
-        return r
+    def _weights_version(self):
+        v = 0
+        for t in list(self.backbone.parameters()) + list(self.backbone.buffers()) + list(self.projector.parameters()):
+            v += t._version + (t.data_ptr() & 0xFFFFF)
+        return v
 
     def _get_handle(self, device) -> "hip.EncoderHandle":
-        key = (str(device), self.compute_dtype)
+        key = (str(device), self.compute_dtype, self._weights_version())
         if self._handle is None or self._handle_key != key:
             sd = {k: v.to(device) for k, v in self.state_dict().items() if k.startswith(("backbone.", "projector."))}
             self._handle = hip.EncoderHandle(self.latent_dim, sd, hip.dtype_code(self.compute_dtype),

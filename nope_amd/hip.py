@@ -148,6 +148,8 @@ def similarity(q: torch.Tensor, bank: torch.Tensor, out: Optional[torch.Tensor] 
         bank = bank.float()
     bank = bank.contiguous()
     N = bank.shape[1]
+    if N == 0:
+        return torch.empty((B, 0), dtype=torch.float32, device=q.device) if out is None else out
     stride_b = 0 if (bank.shape[0] == 1 and B > 1) else N * Cc * H * W
     if out is None:
         out = torch.empty((B, N), dtype=torch.float32, device=q.device)
@@ -275,7 +277,7 @@ class UNetHandle:
         stream = torch.cuda.current_stream(dev).cuda_stream if dev is not None and dev.type == "cuda" else 0
         l.check(l.dll.nope_unet_create(C.byref(c), descs, len(state_dict), stream, C.byref(h)), "nope_unet_create")
         self._h = h
-        self._ws: Optional[torch.Tensor] = None
+        self._ws: Dict[tuple, torch.Tensor] = {}     # one arena per (device, stream): forwards on different streams never share one
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -311,11 +313,14 @@ class UNetHandle:
         need = self.workspace_bytes(n_hyp, n_src, H, W)
         if need == 0:
             raise NopeError(f"unsupported U-Net problem size n_hyp={n_hyp} H={H} W={W}")
-        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        key = (str(x.device), _stream(x))
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            self._ws.pop(key, None)          # release the smaller arena before taking a bigger one
+            ws = None
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
         self._l.check(self._l.dll.nope_unet_forward(self._h, _ptr(x), n_src, x_rep, _ptr(pose), n_hyp, H, W, _ptr(out), odt,
-                                                    _ptr(self._ws), self._ws.numel(), _stream(x)), "nope_unet_forward")
+                                                    _ptr(ws), ws.numel(), _stream(x)), "nope_unet_forward")
         return out
 
 

@@ -50,7 +50,6 @@ class PoseConditional(nn.Module):
         self.bank_dtype = bank_dtype
         self.max_hyp = int(max_hypotheses_per_launch)
         self.template_parallel = bool(template_parallel)
-        self._slice = None          # (lo, hi, N) of the last sharded generate_templates
         self._side_stream = None    # second HIP stream of generate_and_retrieve
         self.global_step = 0
         self.global_rank = ndist.world()[0]
@@ -90,17 +89,19 @@ class PoseConditional(nn.Module):
     @torch.no_grad()
     def generate_templates_from_feat(self, reference_feat, all_relativeR):
         B, N = all_relativeR.shape[:2]
-        lo, hi = 0, N
+        lo, hi, ws = 0, N, 1
         if self.template_parallel:
             rank, ws = ndist.world()
             lo, hi = ndist.shard_range(N, rank, ws)
-        self._slice = (lo, hi, N)
         poses = all_relativeR[:, lo:hi].contiguous().float()
         n = hi - lo
-        C, h, w = self.u_net.out_dim, reference_feat.shape[2], reference_feat.shape[3]
+        C, h, w = self.u_net.channels, reference_feat.shape[2], reference_feat.shape[3]   # latent_dim, model.py:207-210
         bank = torch.empty((B, n, C, h, w), dtype=hip.torch_dtype(hip.dtype_code(self.bank_dtype)),
                            device=reference_feat.device)
-        if n == 0:
+        # a sharded bank carries its own placement (lo, hi, N): retrieval gathers exactly the banks made here,
+        # never a caller-supplied tensor that merely has the same local size
+        bank._nope_shard = (lo, hi, N) if ws > 1 else None
+        if n == 0:                  # more ranks than templates: this rank still takes part in the all-gather
             return bank
         if n <= self.max_hyp:
             bs = max(1, self.max_hyp // n)
@@ -152,11 +153,14 @@ class PoseConditional(nn.Module):
 
     @torch.no_grad()
     def retrieval_from_feat(self, query_feat, template_feat, k=5):
-        local = hip.similarity(query_feat, template_feat)
-        sl = self._slice
-        if self.template_parallel and sl is not None and (sl[1] - sl[0]) == template_feat.shape[1] and sl[2] != template_feat.shape[1]:
-            similarity = ndist.all_gather_scores(local, sl[2])
+        sl = getattr(template_feat, "_nope_shard", None)
+        if self.template_parallel and sl is not None:
+            B, n_local = query_feat.shape[0], template_feat.shape[1]
+            send, _ = ndist.gather_buffers(B, sl[2], query_feat.device)
+            if n_local > 0:          # this rank's columns go straight into the collective's send buffer
+                hip.similarity(query_feat, template_feat, out=send, col_offset=0)
+            similarity = ndist.all_gather_scores(send[:, :n_local], sl[2])
         else:
-            similarity = local
+            similarity = hip.similarity(query_feat, template_feat)
         _, nearest_idx = hip.topk(similarity, k)
         return similarity, nearest_idx

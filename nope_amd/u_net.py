@@ -123,6 +123,9 @@ class UNet(nn.Module):
         self.final_conv = _slot(_resnet_params(u_net_dim, u_net_dim, emb, g), _conv(u_net_dim, self.channels, 1))
         self._handle: Optional[hip.UNetHandle] = None
         self._handle_key = None
+        # nn.Module.load_state_dict on a PARENT never calls a child's load_state_dict (it recurses through
+        # _load_from_state_dict), but it does run every sub-module's post hooks: drop the repacked device copy there.
+        self.register_load_state_dict_post_hook(lambda mod, _keys: mod.invalidate())
 
     # -- device handle ------------------------------------------------------------------
     def own_state_dict(self):
@@ -130,24 +133,32 @@ class UNet(nn.Module):
         return {k: v for k, v in self.state_dict().items() if not k.startswith("encoder.")}
 
     def invalidate(self):
-        """Call after changing weights in place; the next forward repacks them."""
+        """Drop the repacked device weights (also the encoder's); the next forward repacks them.  Called
+        automatically after any load_state_dict that reaches this module and when a parameter was modified in place."""
         self._handle = None
+        inv = getattr(self.encoder, "invalidate", None)
+        if callable(inv):
+            inv()
+
+    def _weights_version(self):
+        # in-place writes (optimizer steps, p.copy_, p.data.copy_) bump a tensor's _version; re-assigned storage moves data_ptr
+        v = 0
+        for n, p in self.named_parameters(recurse=True):
+            if not n.startswith("encoder."):
+                v += p._version + (p.data_ptr() & 0xFFFFF)
+        return v
 
     def _get_handle(self, device) -> hip.UNetHandle:
-        key = (str(device), self.compute_dtype)
+        key = (str(device), self.compute_dtype, self._weights_version())
         if self._handle is None or self._handle_key != key:
             sd = {k: v.to(device) for k, v in self.own_state_dict().items()}
-            cfg = dict(u_net_dim=self.u_net_dim, channels=self.channels, out_dim=self.out_dim,
+            # (the reference stores `out_dim` but builds final_conv.1 with `channels` outputs, u_net.py:154-157)
+            cfg = dict(u_net_dim=self.u_net_dim, channels=self.channels, out_dim=self.channels,
                        pose_dim=self.rot_representation_dim, dim_mults=self.dim_mults, groups=self.groups,
                        pose_mlp_layers=self._pose_layers)
             self._handle = hip.UNetHandle(cfg, sd, hip.dtype_code(self.compute_dtype))
             self._handle_key = key
         return self._handle
-
-    def load_state_dict(self, *a, **k):
-        r = super().load_state_dict(*a, **k)
-        self.invalidate()
-        return r
 
     # -- reference call surface ---------------------------------------------------------
     @torch.no_grad()

@@ -39,6 +39,15 @@ def _worker(rank, ws, port, emu_path, q, bank, poses, ret):
         sim, idx = m.retrieval(ref_feat * 0.5, b_local)
         sim2, idx2, _ = m.generate_and_retrieve(ref_feat * 0.5, ref_feat, poses)     # what bench.py --gpus N calls per step
         assert torch.equal(sim2, sim) and torch.equal(idx2, idx)
+        # a caller-supplied bank that happens to have this rank's local size is scored as is, not gathered
+        mine = b_local.clone()
+        s_own, _ = m.retrieval_from_feat(ref_feat * 0.5, torch.cat([mine, mine, mine], 1)[:, :5].contiguous())
+        assert s_own.shape == (1, 5)
+        # fewer templates than ranks: rank 1 holds an empty shard and still takes part in the gather
+        b1, _, _ = m.generate_templates(ref_feat, poses[:, :1])
+        assert b1.shape[1] == (1 if rank == 0 else 0)
+        s1, i1 = m.retrieval_from_feat(ref_feat * 0.5, b1, k=1)
+        assert s1.shape == (1, 1) and abs(float(s1) - float(sim[0, 0])) < 1e-4 * abs(float(sim[0, 0])) and int(i1) == 0
         ret[rank] = (full, tuple(b_local.shape), sim, idx)
     finally:
         dist.destroy_process_group()
@@ -114,3 +123,57 @@ def test_sharded_generate_and_retrieve_on_device(gpu):
         err, same_idx, shard_shape, full_shape = ret[r]
         assert err < 1e-5 and same_idx, (r, err)
         assert full_shape[1] == 37 and shard_shape[1] == (13 if r == 0 else 12)
+
+
+def _nccl_worker(rank, ws, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=dev)
+    try:
+        from nope_amd import dist as nd
+        from nope_amd.model import PoseConditional
+        from nope_amd.u_net import UNet
+        from nope_amd.weights import synth_init_
+        from tests.util import StubEncoder
+        g = torch.Generator().manual_seed(8)
+        feat = torch.randn(2, 8, 16, 16, generator=g).to(dev)
+        qfeat = torch.randn(2, 8, 16, 16, generator=g).to(dev)
+        poses = torch.randn(2, 9, 6, generator=g).to(dev)            # 9 templates: 5 + 4 over two ranks
+        outs = []
+        for tp in (False, True):
+            u = UNet(u_net_dim=32, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer")
+            synth_init_(u, 2022)
+            m = PoseConditional(u, None, {"similarity_metric": "l2"}, None, template_parallel=tp).to(dev)
+            sim, idx, bank = m.generate_and_retrieve(qfeat, feat, poses)
+            torch.cuda.synchronize()
+            outs.append((sim.cpu(), idx.cpu(), tuple(bank.shape)))
+        # the collective itself on RCCL, also at world size 1 (where the sharded path short-circuits)
+        send, recv = nd.gather_buffers(2, 9, dev)
+        send.fill_(float(rank + 1))
+        dist.all_gather_into_tensor(recv.view(ws * 2, send.shape[1]), send)
+        torch.cuda.synchronize()
+        ok_coll = all(bool((recv[r] == float(r + 1)).all()) for r in range(ws))
+        err = float((outs[0][0] - outs[1][0]).abs().max() / outs[0][0].abs().max())
+        ret[rank] = (err, torch.equal(outs[0][1], outs[1][1]), outs[1][2], ok_coll)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_sharded_path(gpu):
+    """The production backend: "nccl" (= RCCL), one rank per GPU, min(device_count, 2) ranks.  On a 1-GPU box this is a
+    world-size-1 RCCL group (communicator init + one all_gather_into_tensor on device buffers); with two GPUs the
+    sharded generate_and_retrieve must match the unsharded one."""
+    ws = min(torch.cuda.device_count(), 2)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29700 + os.getpid() % 2000
+    mp.spawn(_nccl_worker, args=(ws, port, ret), nprocs=ws, join=True)
+    for r in range(ws):
+        err, same_idx, shard_shape, ok_coll = ret[r]
+        assert ok_coll and err < 1e-5 and same_idx, (r, err)
+        assert shard_shape[1] == (9 if ws == 1 else (5 if r == 0 else 4))

@@ -211,3 +211,41 @@ def test_pose_grids_and_relative_poses(tmp_path):
     allr = P.all_relative_poses(objs, objs[3])
     assert allr.shape == (42, 6) and torch.allclose(allr[7], rel, atol=1e-6)
     assert torch.allclose(allr[3], torch.tensor([1.0, 0, 0, 0, 1, 0]), atol=1e-6)
+
+
+def test_handles_are_dropped_by_parent_load_state_dict(monkeypatch):
+    """`PoseConditional.load_state_dict` (or any parent's) never calls a child's `load_state_dict`, so the
+    cached device handles of the U-Net and the encoder must be invalidated from post hooks; in-place parameter
+    writes are caught through the tensors' version counters."""
+    from nope_amd import hip
+    from nope_amd.encoder import FeatureExtractor
+    from nope_amd.model import PoseConditional
+    from nope_amd.u_net import UNet
+    made = {"unet": 0, "enc": 0}
+
+    class FakeU:
+        def __init__(self, cfg, sd, dt): made["unet"] += 1
+    class FakeE:
+        def __init__(self, d, sd, dt, bn_eps=1e-5): made["enc"] += 1
+    monkeypatch.setattr(hip, "UNetHandle", FakeU)
+    monkeypatch.setattr(hip, "EncoderHandle", FakeE)
+    enc = FeatureExtractor(8)
+    u = UNet(u_net_dim=8, rot_representation_dim=6, encoder=enc, pose_mlp_name="single_layer")
+    m = PoseConditional(u, None, {"similarity_metric": "l2"}, None)
+    dev = torch.device("cpu")
+    h1, e1 = u._get_handle(dev), enc._get_handle(dev)
+    assert u._get_handle(dev) is h1 and enc._get_handle(dev) is e1 and made == {"unet": 1, "enc": 1}
+    m.load_state_dict(m.state_dict())                       # parent load: both handles must go
+    assert u._get_handle(dev) is not h1 and enc._get_handle(dev) is not e1 and made == {"unet": 2, "enc": 2}
+    h2, e2 = u._get_handle(dev), enc._get_handle(dev)
+    u.load_state_dict(u.state_dict())                       # has encoder.* keys: the encoder handle goes too
+    assert u._get_handle(dev) is not h2 and enc._get_handle(dev) is not e2
+    h3, e3 = u._get_handle(dev), enc._get_handle(dev)
+    with torch.no_grad():
+        u.init_conv.weight.mul_(2.0)                        # in-place write without any load
+        enc.backbone.bn1.running_mean.add_(1.0)
+    assert u._get_handle(dev) is not h3 and enc._get_handle(dev) is not e3
+    h4 = u._get_handle(dev)
+    enc._get_handle(dev)
+    u.invalidate()                                          # cascades to the encoder
+    assert enc._handle is None and u._get_handle(dev) is not h4

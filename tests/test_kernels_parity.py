@@ -443,12 +443,12 @@ def test_workspace_canary_odd_hypotheses(be, n_hyp):
     x, pose = torch.randn(n_hyp, 8, 8, 8, generator=g), torch.randn(n_hyp, 6, generator=g)
     h = u._get_handle(torch.device(dev))
     need = h.workspace_bytes(n_hyp, n_hyp, 8, 8)
-    h._ws = torch.full((need + 8192,), 0xAB, dtype=torch.uint8, device=dev)
+    ws = torch.full((need + 8192,), 0xAB, dtype=torch.uint8, device=dev)
     out = torch.empty((n_hyp, 8, 8, 8), device=dev)
     l = hip.lib()
     l.check(l.dll.nope_unet_forward(h._h, x.to(dev).data_ptr(), n_hyp, 1, pose.to(dev).data_ptr(), n_hyp, 8, 8, out.data_ptr(), hip.F32,
-                                    h._ws.data_ptr(), need, None if dev == "cpu" else torch.cuda.current_stream().cuda_stream), "fwd")
+                                    ws.data_ptr(), need, None if dev == "cpu" else torch.cuda.current_stream().cuda_stream), "fwd")
     if dev != "cpu":
         torch.cuda.synchronize()
-    assert bool((h._ws[need:] == 0xAB).all()), "write beyond the reported workspace size"
+    assert bool((ws[need:] == 0xAB).all()), "write beyond the reported workspace size"
     assert rel(out.cpu(), R.unet_forward(sd, x, pose)) < F32_TOL
