@@ -11,8 +11,8 @@ Execution: device tensors go through the C ABI (`nope_en
 csrc/encoder_runtime.hip): eval-mode BatchNorm folded into the conv weights at handle creation, every
 1x1 / 3x3 / stride-2 conv on the implicit-GEMM MFMA kernel with bias + residual + ReLU in its epilogue,
 conv1 as a small direct kernel -- no PyTorch/MIOpen arithmetic, and no fallback when the library is
-missing.  The `nn.Module` tree below holds the parameters under the reference's keys; its torch
-`forward` is the host-side mirror used for CPU tensors only (CPU checks against the golden fixtures).
+missing.  The `nn.Module` tree below only holds the parameters under the reference's keys (there is no torch
+forward in it; the CPU restatement used by the tests lives in oracle/nope_ref.py).
 It runs once per query and once per reference image (the reference re-runs it N times, model.py:115).
 """
 from __future__ import annotations
@@ -20,7 +20,6 @@ from __future__ import annotations
 import math
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import hip
@@ -29,7 +28,14 @@ _LAYERS = (3, 4, 6, 3)
 _STRIDES = (1, 2, 2, 1)      # resnet.py:102-105
 
 
-class _Bottleneck(nn.Module):
+class _Holder(nn.Module):
+    """Parameter container: never called."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder; the encoder runs in libnope_hip.so (FeatureExtractor.encode_image)")
+
+
+class _Bottleneck(_Holder):
     def __init__(self, cin, planes, stride, project):
         super().__init__()
         self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
@@ -43,16 +49,8 @@ class _Bottleneck(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, planes * 4, 1, stride=stride, bias=False),
                                             nn.BatchNorm2d(planes * 4))
 
-    def forward(self, x):
-        y = F.relu(self.bn1(self.conv1(x)))
-        y = F.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        if self.downsample is not None:
-            x = self.downsample(x)
-        return F.relu(y + x)
 
-
-class _Trunk(nn.Module):
+class _Trunk(_Holder):
     def __init__(self, features=64):
         super().__init__()
         self.conv1 = nn.Conv2d(3, features, 7, stride=2, padding=3, bias=False)
@@ -70,12 +68,6 @@ class _Trunk(nn.Module):
             if isinstance(m, nn.Conv2d):
                 n_ = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
                 m.weight.data.normal_(0, math.sqrt(2.0 / n_))
-
-    def forward(self, x):
-        x = F.relu(self.bn1(self.conv1(x)))
-        for i in range(1, 5):
-            x = getattr(self, f"layer{i}")(x)
-        return x
 
 
 class FeatureExtractor(nn.Module):
@@ -116,18 +108,12 @@ class FeatureExtractor(nn.Module):
         return self._handle
 
     @torch.no_grad()
-    def encode_image_hip(self, image):
-        """template.py:47-53 through the C ABI (device tensors; CPU tensors only under tests/hipemu)."""
+    def encode_image(self, image, mode=None):
+        """template.py:47-53 through the C ABI.  `mode` is accepted and ignored, as in the reference."""
+        hip.require_device(image)
         feat = self._get_handle(image.device).forward(image)
-        if self.normalize:
-            feat = F.normalize(feat, dim=1)
+        if self.normalize:                                   # F.normalize(dim=1), eps 1e-12 (template.py:51-52)
+            feat = feat / feat.norm(dim=1, keepdim=True).clamp_min(1e-12)
         return feat
 
-    @torch.no_grad()
-    def encode_image(self, image, mode=None):
-        if image.is_cuda:
-            return self.encode_image_hip(image)
-        feat = self.projector(self.backbone(image))     # host-side mirror, CPU tensors only
-        if self.normalize:
-            feat = F.normalize(feat, dim=1)
-        return feat
+    encode_image_hip = encode_image

@@ -100,9 +100,52 @@ def lib() -> NopeLib:
 
 
 def _set_library_for_testing(l: Optional[NopeLib]):
-    """tests/ only: lets the CPU test-suite run the same host code over tests/hipemu."""
+    """tests/ only: lets the CPU test-suite run the same host code over tests/hipemu (a build of the same C ABI
+    that takes host pointers)."""
     global _lib
+    if l is not None:
+        l.host_pointers = True
     _lib = l
+
+
+def require_device(t: torch.Tensor):
+    """The product library takes device pointers only: a host tensor is an error, never a detour through torch CPU ops."""
+    if not t.is_cuda and not getattr(lib(), "host_pointers", False):
+        raise NopeError("nope_amd computes on the GPU only: pass CUDA (ROCm) tensors; there is no CPU path")
+
+
+class overlap_stream:
+    """`with overlap_stream(t) as ov: y = f(t)` issues f on a second HIP stream ordered after the current one;
+    `ov.join(y)` makes the current stream wait for it.  (Host tensors -- the interpreter build of the tests -- have no
+    streams: the body simply runs in place.)"""
+    _streams: Dict[str, "torch.cuda.Stream"] = {}
+
+    def __init__(self, t: torch.Tensor):
+        self.dev = t.device if t.is_cuda else None
+
+    def __enter__(self):
+        if self.dev is None:
+            return self
+        self.cur = torch.cuda.current_stream(self.dev)
+        side = self._streams.get(str(self.dev))
+        if side is None:
+            side = self._streams[str(self.dev)] = torch.cuda.Stream(device=self.dev)
+        self.side = side
+        side.wait_stream(self.cur)                  # whatever produced the inputs is ordered before the side work
+        self._ctx = torch.cuda.stream(side)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.dev is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self.dev is not None:
+            self.cur.wait_stream(self.side)
+            for t in tensors:
+                t.record_stream(self.cur)
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -140,6 +183,7 @@ def similarity(q: torch.Tensor, bank: torch.Tensor, out: Optional[torch.Tensor] 
                col_offset: int = 0) -> torch.Tensor:
     """score[b,n] of model.py:257-262.  q (B,C,H,W) f32; bank (B|1,N,C,H,W) f32|bf16.
     With `out` (B, Ntotal) given, writes columns [col_offset, col_offset+N)."""
+    require_device(q)
     q = _f32c(q)
     B, Cc, H, W = q.shape
     if bank.dim() != 5 or tuple(bank.shape[2:]) != (Cc, H, W) or bank.shape[0] not in (1, B):
@@ -164,6 +208,7 @@ def similarity(q: torch.Tensor, bank: torch.Tensor, out: Optional[torch.Tensor] 
 
 
 def topk(scores: torch.Tensor, k: int = 5) -> Tuple[torch.Tensor, torch.Tensor]:
+    require_device(scores)
     scores = _f32c(scores)
     B, N = scores.shape
     idx = torch.empty((B, k), dtype=torch.int64, device=scores.device)
@@ -300,6 +345,7 @@ class UNetHandle:
     def forward(self, x: torch.Tensor, pose: torch.Tensor, x_rep: int = 1, out: Optional[torch.Tensor] = None,
                 out_dtype=F32) -> torch.Tensor:
         """out[j] = UNet(x[j // x_rep], pose[j]); x (n_src,C,H,W) f32, pose (n_src*x_rep, pose_dim)."""
+        require_device(x)
         x = _f32c(x)
         pose = _f32c(pose)
         n_src, Cc, H, W = x.shape

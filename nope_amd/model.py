@@ -50,7 +50,6 @@ class PoseConditional(nn.Module):
         self.bank_dtype = bank_dtype
         self.max_hyp = int(max_hypotheses_per_launch)
         self.template_parallel = bool(template_parallel)
-        self._side_stream = None    # second HIP stream of generate_and_retrieve
         self.global_step = 0
         self.global_rank = ndist.world()[0]
         if save_dir is not None:    # model.py:63-66
@@ -133,21 +132,10 @@ class PoseConditional(nn.Module):
         stream and runs underneath the reference encoder and the first U-Net kernels."""
         if self.similarity_metric != "l2":
             return None
-        enc = self.u_net.encoder
-        if not query.is_cuda:          # host tensors exist only under tests/hipemu: same calls, one after the other
-            bank, _, _ = self.generate_templates(reference, all_relativeR, None)
-            similarity, nearest_idx = self.retrieval(query, bank)
-            return similarity, nearest_idx, bank
-        cur = torch.cuda.current_stream(query.device)
-        if self._side_stream is None or self._side_stream.device != query.device:
-            self._side_stream = torch.cuda.Stream(device=query.device)
-        side = self._side_stream
-        side.wait_stream(cur)                       # whatever produced `query` is ordered before the side work
-        with torch.cuda.stream(side):
-            query_feat = enc.encode_image(query, mode="mode")
+        with hip.overlap_stream(query) as side:
+            query_feat = self.u_net.encoder.encode_image(query, mode="mode")
         bank, _, _ = self.generate_templates(reference, all_relativeR, None)
-        cur.wait_stream(side)
-        query_feat.record_stream(cur)
+        side.join(query_feat)
         similarity, nearest_idx = self.retrieval_from_feat(query_feat, bank)
         return similarity, nearest_idx, bank
 

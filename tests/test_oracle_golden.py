@@ -53,7 +53,8 @@ def test_retrieval(golden):
         assert sim[B - 1, N // 2] == 0 and idx[B - 1, 0] == N // 2   # planted exact match (KAT)
 
 
-def test_encoder(golden):
+def test_encoder(golden, monkeypatch):
+    from nope_amd import hip
     from nope_amd.encoder import FeatureExtractor
     from nope_amd.weights import sha256_of, synth_init_
     g = golden("encoder.npz")
@@ -62,7 +63,9 @@ def test_encoder(golden):
     sd = enc.state_dict()
     assert sha256_of(sd["backbone.conv1.weight"]) == str(g["sha_conv1"])
     assert rel(R.encode_image(sd, g["img"]), g["feat"]) < TOL
-    assert rel(enc.encode_image(g["img"]), g["feat"]) < TOL       # host-side module, same arithmetic
+    monkeypatch.setattr(hip, "_lib", object())                     # "a loaded product library" (no interpreter injected)
+    with pytest.raises(hip.NopeError, match="no CPU path"):        # the product module never computes on host tensors
+        enc.encode_image(g["img"])
 
 
 def test_pipeline_config1(golden):
