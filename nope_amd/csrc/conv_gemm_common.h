@@ -1,0 +1,350 @@
+// Shared internals of the implicit-GEMM conv kernels (kernels_gemm.hip: the 128 x 192 kernels and the launcher;
+// kernels_gemm_pp.hip: the 256 x 192 eight-wave ping-pong kernel): launch parameters, the MFMA tile traits, the LDS
+// swizzle, the fragment stage and the epilogues.  Included inside each translation unit (internal linkage).
+#pragma once
+#include "nope_common.h"
+
+namespace nope {
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BN = 192;
+constexpr int NT = 256;
+constexpr int ROWB = 128;  // bytes per LDS row
+constexpr int A_ITERS = BM / 32;
+constexpr int B_ITERS = BN / 32;
+
+// Unsigned division by a launch-time constant, exact for n < 2^31: q = mulhi(n, M) >> sh with
+// M = floor(2^(32+sh) / d) + 1, sh = ceil(log2 d) - 1 (d >= 2); M == 0 encodes d == 1.  Replaces the ~35-instruction
+// integer-division sequences of the per-row index arithmetic in the conv prologue.
+struct FastDiv {
+    unsigned M, sh;
+    __device__ __forceinline__ unsigned div(unsigned n) const {
+        return M ? (unsigned)(((unsigned long long)n * M) >> 32) >> sh : n;
+    }
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f{0u, 0u};
+    if (d <= 1) return f;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;                       // s = ceil(log2 d) >= 1
+    f.sh = s - 1;
+    f.M = (unsigned)(((1ull << (31 + s)) / d) + 1);    // < 2^32 because d > 2^(s-1)
+    return f;
+}
+
+struct ConvParams {
+    const unsigned char* src1; const unsigned char* src2;
+    int C1, C2, rep1, rep2;
+    int Hs, Ws, Ho, Wo;
+    int mode, ntaps;
+    const unsigned char* w;
+    const float* bias;
+    const unsigned char* resid;
+    unsigned char* out;
+    int Cout, M;
+    int out_nchw, out_dt;
+    int act;                           // 0 none, 1 ReLU (after bias and residual)
+    int tiles_m, tiles_n, xcd_map, wide_out;
+    int variant;                       // tuning switches (NOPE_CONV_VARIANT), 0 in production
+    FastDiv d_hw, d_w, d_rep1, d_rep2; // / (Hm*Wm), / Wm, / rep1, / rep2
+    unsigned char pos_order[64];       // posmajor: pixel positions by descending number of valid taps
+    int persist_iters;                 // > 1: a workgroup walks this many tiles (tile_m advances by 64 each time)
+    unsigned persist_d1, persist_d2;   // byte advance of the A offsets per walked tile (src1 / src2)
+    int posmajor;                      // 1: GEMM rows ordered (pixel position, sample) instead of (sample, pixel) -- see launch_conv
+    FastDiv d_n;                       // / nhyp (posmajor)
+    int nhyp;
+    int splits;                        // > 1: blockIdx.z owns a K range and writes raw f32 partial sums
+    float* split_out;                  // [splits][M][Cout]
+    int Hm, Wm;                        // grid the GEMM rows enumerate: output grid, or the SOURCE grid for UP2P
+    unsigned w_phase_bytes;            // UP2P: byte stride between the 4 phase weight sets
+    float* colstats;                   // optional [M/64][Cout][2]: per 64-row block column sum / sum of squares
+    const float* pn_ms; const float* pn_c0; const float* pn_c1;   // optional fused PreNorm (see ConvArgs)
+    unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
+};
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// MFMA tile of a wave's 64 x 96 output block, per element type.
+//   f32 : v_mfma_f32_16x16x4_f32  -- 4 x 6 tiles, a lane's 16-byte fragment = 4 channels = 4 chained steps
+//   bf16: v_mfma_f32_32x32x16_bf16 -- 2 x 3 tiles (the 32x32 form sustains ~15 % more than 16x16x32 on gfx950:
+//         2382 vs 2075 TFLOP/s, cdna_hip_programming.md section 3), a lane's fragment = 8 channels = 1 step
+// frag_row / frag_slot: which tile row and 16-byte K slot a lane feeds; out_row / out_col: the C/D map.
+template <class T> struct Tile;
+template <> struct Tile<float> {
+    static constexpr int TM = 16, MT = 4, NTL = 6, R = 4, KSLOTS = 4;
+    typedef f32x4 acc_t;
+    static __device__ __forceinline__ int frag_row(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int frag_slot(int lane) { return lane >> 4; }
+    static __device__ __forceinline__ int out_row(int lane, int r) { return (lane >> 4) * 4 + r; }
+    static __device__ __forceinline__ int out_col(int lane) { return lane & 15; }
+    static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, acc_t& c) {
+        const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], c, 0, 0, 0);
+    }
+};
+template <> struct Tile<bf16_t> {
+    static constexpr int TM = 32, MT = 2, NTL = 3, R = 16, KSLOTS = 2;
+    typedef f32x16 acc_t;
+    static __device__ __forceinline__ int frag_row(int lane) { return lane & 31; }
+    static __device__ __forceinline__ int frag_slot(int lane) { return lane >> 5; }
+    static __device__ __forceinline__ int out_row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+    static __device__ __forceinline__ int out_col(int lane) { return lane & 31; }
+    static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, acc_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ void tile_coords(const ConvParams& p, int& tile_m, int& tile_n) {
+    const int g = blockIdx.x;
+    if (p.xcd_map) {   // tiles_n in {1,2,4,8}, tiles_m % (8 / tiles_n) == 0
+        // XCD x = g & 7 keeps one weight panel (tile_n) and a CONTIGUOUS run of M tiles, so the
+        // 3x3 halo rows shared by neighbouring tiles hit the same XCD's L2.
+        const int x = g & 7, j = g >> 3;
+        const int per = 8 / p.tiles_n;
+        tile_n = x % p.tiles_n;
+        tile_m = (x / p.tiles_n) * (p.tiles_m / per) + j;
+    } else {
+        tile_n = g % p.tiles_n;
+        tile_m = g / p.tiles_n;
+    }
+}
+
+// Row geometry of a staged tile: RB bytes of K per row, 16-byte slots XOR-swizzled so that the rows x one slot
+// of a ds_read_b128 lane group hit different bank positions (for both the 16- and the 32-row fragment shapes).
+template <int RB> __device__ __forceinline__ int swz_of(int row) { return RB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+template <int RB> __device__ __forceinline__ int lds_off_rb(int row, int slot) { return row * RB + ((slot ^ swz_of<RB>(row)) << 4); }
+
+// One K stage (RB bytes of K per row) of the 64 x 96 wave tile from the swizzled LDS tiles.  The fragments of
+// K sub-step kk+1 are read while the MFMAs of sub-step kk execute (two statically named register sets).
+template <class T, int RB>
+__device__ __forceinline__ void mma_stage(const unsigned char* ldsA, const unsigned char* ldsB, int wm, int wn, int lane,
+                                          typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL]) {
+    typedef Tile<T> TL;
+    constexpr int KK = RB / 16 / TL::KSLOTS;
+    u32x4 af[2][TL::MT], bfr[2][TL::NTL];
+    auto load = [&](int set, int kk) {
+        const int s = kk * TL::KSLOTS + TL::frag_slot(lane);
+#pragma unroll
+        for (int i = 0; i < TL::MT; ++i) af[set][i] = ld16(ldsA + lds_off_rb<RB>(wm * 64 + i * TL::TM + TL::frag_row(lane), s));
+#pragma unroll
+        for (int j = 0; j < TL::NTL; ++j) bfr[set][j] = ld16(ldsB + lds_off_rb<RB>(wn * 96 + j * TL::TM + TL::frag_row(lane), s));
+    };
+    load(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        if (kk + 1 < KK) load((kk + 1) & 1, kk + 1);
+#pragma unroll
+        for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+            for (int j = 0; j < TL::NTL; ++j) TL::mma(af[kk & 1][i], bfr[kk & 1][j], acc[i][j]);
+    }
+}
+
+// Output pixel row of GEMM row m.  Identity except for UP2P, whose rows walk the source grid and land on
+// output pixel (2y + py, 2x + px) of phase blockIdx.y.
+__device__ __forceinline__ size_t out_row(const ConvParams& p, int m) {
+    if (p.posmajor) {                  // row m = (position, sample) -> NHWC row (sample, position)
+        const unsigned pos = p.d_n.div((unsigned)m);
+        const unsigned b = (unsigned)m - pos * (unsigned)p.nhyp;
+        return (size_t)b * (size_t)(p.Hm * p.Wm) + pos;
+    }
+    if (p.mode != NOPE_CONV_UP2P) return (size_t)m;
+    const int hw = p.Hm * p.Wm;
+    const int b = m / hw;
+    const int r = m - b * hw;
+    const int y = r / p.Wm, x = r - y * p.Wm;
+    const int py = (int)blockIdx.y >> 1, px = (int)blockIdx.y & 1;
+    return ((size_t)b * p.Ho + 2 * y + py) * p.Wo + 2 * x + px;
+}
+
+// C/D map of the 16x16 MFMA tiles: col = lane & 15, row = (lane >> 4) * 4 + r
+template <class T, bool PN>
+__device__ __forceinline__ void epilogue(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL], int m0,
+                                         int n0, int wm, int wn, int lane) {
+    // Every index into acc must stay a compile-time constant (full unroll): a runtime index would move the
+    // accumulators to scratch for the WHOLE kernel.  Row bookkeeping (incl. the divisions) is hoisted to
+    // once per (i, r).
+    typedef Tile<T> TL;
+    const int HWo = p.Ho * p.Wo;
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* resid = reinterpret_cast<const T*>(p.resid);
+    float bv[TL::NTL];
+    int ncol[TL::NTL];
+#pragma unroll
+    for (int j = 0; j < TL::NTL; ++j) {
+        ncol[j] = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
+        bv[j] = (p.bias && ncol[j] < p.Cout) ? p.bias[ncol[j]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TL::MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < TL::R; ++r) {
+            const int m = m0 + wm * 64 + i * TL::TM + TL::out_row(lane, r);
+            const bool row_ok = m < p.M;
+            const size_t mo = out_row(p, row_ok ? m : 0);
+            float pn_mean = 0.f, pn_rstd = 1.f;
+            if (PN) { const int b = (row_ok ? m : 0) / (p.Hm * p.Wm); pn_mean = p.pn_ms[2 * b]; pn_rstd = p.pn_ms[2 * b + 1]; }
+            size_t nchw_base = 0;
+            if (p.out_nchw) {
+                const int mm = row_ok ? m : 0;
+                const int b = mm / HWo;
+                nchw_base = (size_t)b * p.Cout * HWo + (mm - b * HWo);
+            }
+#pragma unroll
+            for (int j = 0; j < TL::NTL; ++j) {
+                const int n = ncol[j];
+                if (!row_ok || n >= p.Cout) continue;
+                float v = acc[i][j][r] + bv[j];
+                if (PN) v = pn_rstd * (acc[i][j][r] - pn_mean * p.pn_c1[n]) + p.pn_c0[n] + bv[j];
+                if (resid) v += Elt<T>::ld(resid + mo * p.Cout + n);
+                if (p.act) v = v > 0.f ? v : 0.f;
+                if (p.out_nchw) {
+                    const size_t o = nchw_base + (size_t)n * HWo;
+                    if (p.out_dt == NOPE_F32) reinterpret_cast<float*>(p.out)[o] = v;
+                    else reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(v);
+                } else {
+                    Elt<T>::st(out + mo * p.Cout + n, v);
+                }
+            }
+        }
+    }
+}
+
+// Wide-store epilogue (NHWC output, Cout % VEC == 0).  The MFMA C/D layout gives a lane one column x a few
+// rows per tile, i.e. 2-byte scattered stores; instead each wave stages its 64 x 96 f32 accumulators (+bias)
+// through its private 64 x 52-word LDS panel, PANW columns at a time (48 = three 16-wide tiles for f32, 32 =
+// one 32-wide tile for bf16), and writes rows back as 16-byte vectors (residual added in f32 before the
+// single rounding to T).  On the way it emits the per-column sums the following GroupNorm needs.
+// (panel row stride: 32 + 4 words for the bf16 tiles -- four 9 KiB panels then fit into ONE 40 KiB DMA stage, which
+// lets a persistent workgroup prefetch its next tile into the other stage during the epilogue -- 48 + 4 for f32)
+template <class T> struct Ep {
+    static constexpr int LD = Tile<T>::TM == 32 ? 36 : 52;
+    static constexpr int WAVE_BYTES = 64 * LD * 4;
+};
+
+template <class T, bool PN>
+__device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL],
+                                              int m0, int n0, int wm, int wn, int lane, unsigned char* lds_wave) {
+    typedef Tile<T> TL;
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr int PANW = TL::TM == 32 ? 32 : 48;   // panel width in columns
+    constexpr int TPP = PANW / TL::TM;             // MFMA tiles per panel pass
+    constexpr int CH = PANW / VEC;                 // 16-byte output chunks per panel row
+    float* pan = reinterpret_cast<float*>(lds_wave);
+    T* out = reinterpret_cast<T*>(p.out);
+    const T* resid = reinterpret_cast<const T*>(p.resid);
+    if (p.colstats) {
+        // GroupNorm statistics of the conv output, fused: per column (sum, sum of squares) over this wave's 64
+        // rows, straight from the accumulators (f32, before the rounding to T): a lane adds up the rows it
+        // holds, the 64/TM lanes sharing a column are folded with cross-lane adds.  Fixed order and exactly one
+        // writer per [row block][column] entry -> the later fold is deterministic.  Requires M % 64 == 0
+        // (checked by the launcher).
+#pragma unroll
+        for (int j = 0; j < TL::NTL; ++j) {
+            const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
+            const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                for (int r = 0; r < TL::R; ++r) { const float v = acc[i][j][r] + bv; s += v; q += v * v; }
+#pragma unroll
+            for (int o = TL::TM; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+            // (M % 128 == 64: the second wave row of the last tile lies beyond M -- it owns no row block)
+            if (lane < TL::TM && n < p.Cout && m0 + wm * 64 < p.M) {
+                float* cs = p.colstats + ((size_t)((m0 + wm * 64) >> 6) * p.Cout + n) * 2;
+                cs[0] = s; cs[1] = q;
+            }
+        }
+    }
+#pragma unroll
+    for (int pass = 0; pass < 96 / PANW; ++pass) {
+#pragma unroll
+        for (int jj = 0; jj < TPP; ++jj) {
+            const int j = pass * TPP + jj;
+            const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
+            const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                for (int r = 0; r < TL::R; ++r)
+                    pan[(i * TL::TM + TL::out_row(lane, r)) * Ep<T>::LD + jj * TL::TM + TL::out_col(lane)] = acc[i][j][r] + bv;
+        }
+        // same-wave LDS write -> read: the LDS queue of a wave is in order, so no s_barrier; the wave
+        // barrier only pins the compiler's ordering (and is the rendezvous point of tests/hipemu)
+        __builtin_amdgcn_wave_barrier();
+        // Fused PreNorm operands, hoisted out of the chunk loop where they are loop-invariant: with 64 % CH == 0
+        // a lane keeps the same column chunk for the whole pass, and with HW % 64 == 0 the wave's 64 rows are
+        // one sample (one mean / rstd).
+        constexpr bool PN_COLS_FIXED = PN && (64 % CH == 0);
+        float pc0[VEC], pc1[VEC];
+        float pmean = 0.f, prstd = 1.f;
+        const bool pn_row_uniform = PN && ((p.Hm * p.Wm) % 64 == 0);
+        if (PN) {
+            if (PN_COLS_FIXED) {
+                const int nn = n0 + wn * 96 + pass * PANW + (lane % CH) * VEC;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const bool okc = nn + e < p.Cout;
+                    const float bias_e = (p.bias && okc) ? p.bias[nn + e] : 0.f;
+                    pc1[e] = okc ? p.pn_c1[nn + e] : 0.f;
+                    pc0[e] = (okc ? p.pn_c0[nn + e] : 0.f) + bias_e;     // v = rstd*(pan - bias - mean*c1) + c0 + bias
+                }
+            }
+            if (pn_row_uniform) {
+                const int b = (m0 + wm * 64 < p.M ? m0 + wm * 64 : 0) / (p.Hm * p.Wm);
+                pmean = p.pn_ms[2 * b]; prstd = p.pn_ms[2 * b + 1];
+            }
+        }
+        for (int idx = lane; idx < 64 * CH; idx += 64) {
+            const int row = idx / CH, ch = idx - row * CH;
+            const int m = m0 + wm * 64 + row;
+            const int n = n0 + wn * 96 + pass * PANW + ch * VEC;
+            if (m >= p.M || n >= p.Cout) continue;
+            float v[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&pan[row * Ep<T>::LD + ch * VEC + q * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[q * 4 + e] = t[e];
+            }
+            if (PN) {   // fused PreNorm: v = rstd_b * (acc - mean_b * c1[n]) + c0[n] (+ bias; the panel holds acc + bias)
+                float mean = pmean, rstd = prstd;
+                if (!pn_row_uniform) { const int b = m / (p.Hm * p.Wm); mean = p.pn_ms[2 * b]; rstd = p.pn_ms[2 * b + 1]; }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    if (PN_COLS_FIXED) {
+                        const float bias_e = p.bias ? p.bias[n + e] : 0.f;   // (qkv has no bias: folds away)
+                        v[e] = rstd * (v[e] - bias_e - mean * pc1[e]) + pc0[e];
+                    } else {
+                        const float bias_e = p.bias ? p.bias[n + e] : 0.f;
+                        v[e] = rstd * (v[e] - bias_e - mean * p.pn_c1[n + e]) + p.pn_c0[n + e] + bias_e;
+                    }
+                }
+            }
+            const size_t o = out_row(p, m) * p.Cout + n;
+            if (resid) {
+                float rv[VEC];
+                Elt<T>::unpack(ld16(resid + o), rv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] += rv[e];
+            }
+            if (p.act) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            st16(out + o, Elt<T>::pack(v));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+constexpr unsigned OOB = 0x80000000u;   // >= any num_records (tensors < 2 GiB); stays out of range after adding a K offset
+
+}  // namespace
+
+}  // namespace nope

@@ -61,12 +61,18 @@ struct WaveSync {
     alignas(16) unsigned char slot[2][kWave][64];
 };
 
+// An LDS-DMA transfer issued but not yet landed (HIPEMU_DMA=late: it lands at the issuing lane's next vmcnt wait that
+// retires it -- the LATEST moment the hardware allows, so a ds_read placed before the covering wait sees stale LDS).
+struct PendingDma { unsigned char* dst; const unsigned char* src; unsigned size; };
+
 struct Fiber {
     ucontext_t ctx;
     char* stack = nullptr;
     bool done = false;
     hipemu_uint3 tid;
     int flat = 0;
+    bool at_barrier = false;      // parked in a workgroup barrier
+    std::vector<PendingDma> dma;
 };
 
 struct BlockCtx {
@@ -101,6 +107,22 @@ inline void fiber_entry() {
     swapcontext(&b->fibers[me].ctx, &b->sched);
 }
 
+inline bool dma_late() { static const bool v = getenv("HIPEMU_DMA") && !strcmp(getenv("HIPEMU_DMA"), "late"); return v; }
+inline unsigned shuffle_seed() { static const unsigned v = getenv("HIPEMU_SHUFFLE") ? (unsigned)atoi(getenv("HIPEMU_SHUFFLE")) : 0u; return v; }
+
+// retire this lane's outstanding LDS-DMA transfers, oldest first, until at most `keep` remain (s_waitcnt vmcnt(keep))
+inline void dma_wait(size_t keep) {
+    BlockCtx* b = g_blk;
+    auto& q = b->fibers[b->cur].dma;
+    if (q.size() <= keep) return;
+    const size_t n = q.size() - keep;
+    for (size_t i = 0; i < n; ++i) {
+        if (q[i].src) memcpy(q[i].dst, q[i].src, q[i].size);
+        else memset(q[i].dst, 0, q[i].size);
+    }
+    q.erase(q.begin(), q.begin() + n);
+}
+
 inline void run_block(BlockCtx& b) {
     g_blk = &b;
     g_bid = b.bid; g_bdim = b.bdim; g_gdim = b.gdim;
@@ -108,6 +130,8 @@ inline void run_block(BlockCtx& b) {
     for (int i = 0; i < n; ++i) {
         Fiber& f = b.fibers[i];
         f.done = false;
+        f.at_barrier = false;
+        f.dma.clear();
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack;
         f.ctx.uc_stack.ss_size = kStack;
@@ -120,6 +144,33 @@ inline void run_block(BlockCtx& b) {
     b.barrier_arrived = 0; b.barrier_gen = 0;
     int remaining = n;
     long spins = 0;
+    unsigned rng = shuffle_seed() * 2654435761u + b.bid.x * 40503u + 12345u;
+    while (remaining > 0 && shuffle_seed()) {
+        // HIPEMU_SHUFFLE=seed -- adversarial wave scheduling: waves are taken in a pseudo-random order and each one runs
+        // on its own, through all its wave-level rendezvous points, until every lane of it is parked in a WORKGROUP
+        // barrier (or has finished).  A wave therefore gets as far ahead of the others as the barriers allow: an LDS
+        // hand-off that relies on waves happening to move in step (a missing barrier, a ring one stage too short)
+        // gives wrong results under some order.
+        rng = rng * 1664525u + 1013904223u;
+        const int start = (int)((rng >> 8) % (unsigned)nw), dir = (rng >> 20) & 1 ? 1 : -1;
+        for (int wi = 0; wi < nw; ++wi) {
+            const int w = ((start + dir * wi) % nw + nw) % nw;
+            const int lo = w * kWave, hi = std::min(n, lo + kWave);
+            for (;;) {
+                const unsigned gen0 = b.barrier_gen;
+                bool parked = true;
+                for (int i = lo; i < hi; ++i) {
+                    if (b.fibers[i].done) continue;
+                    b.cur = i;
+                    swapcontext(&b.sched, &b.fibers[i].ctx);
+                    if (b.fibers[i].done) { --remaining; continue; }
+                    if (!b.fibers[i].at_barrier) parked = false;
+                }
+                if (parked && b.barrier_gen == gen0) break;
+                if (++spins > 100000000L) { fprintf(stderr, "hipemu: deadlock?\n"); abort(); }
+            }
+        }
+    }
     while (remaining > 0) {
         int progressed = 0;
         for (int i = 0; i < n; ++i) {
@@ -135,11 +186,21 @@ inline void run_block(BlockCtx& b) {
     g_blk = nullptr;
 }
 
-inline void syncthreads() {
+// s_barrier alone: a rendezvous, nothing is waited for
+inline void raw_barrier() {
     BlockCtx* b = g_blk;
     unsigned gen = b->barrier_gen;
     if (++b->barrier_arrived == b->nthreads) { b->barrier_arrived = 0; ++b->barrier_gen; return; }
+    Fiber& me = b->fibers[b->cur];
+    me.at_barrier = true;
     while (b->barrier_gen == gen) yield_to_sched();
+    me.at_barrier = false;
+}
+
+// __syncthreads(): hipcc puts s_waitcnt vmcnt(0) in front of the s_barrier while an LDS-DMA is outstanding
+inline void syncthreads() {
+    dma_wait(0);
+    raw_barrier();
 }
 
 // wave rendezvous: publish `bytes` of payload, wait for the whole wave, return slot table
@@ -312,17 +373,21 @@ inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
-#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+// s_waitcnt simm16 (gfx9 encoding): vmcnt = bits [3:0] | [15:14] << 4; only the vmcnt field matters to the interpreter
+inline void hipemu_s_waitcnt(unsigned imm) { hipemu::dma_wait((imm & 0xF) | (((imm >> 14) & 3) << 4)); }
+#define __builtin_amdgcn_s_waitcnt(x) hipemu_s_waitcnt(x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
-#define __builtin_amdgcn_s_barrier() __syncthreads()
+#define __builtin_amdgcn_s_barrier() hipemu::raw_barrier()
 inline void hipemu_wave_barrier() { int z = 0; hipemu::wave_exchange(&z, sizeof(z)); }
 #define __builtin_amdgcn_wave_barrier() hipemu_wave_barrier()
 inline int hipemu_readfirstlane(int v) { return __shfl(v, 0); }
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
 
 // ---- buffer resources + LDS-DMA (buffer_load ... lds): destination = wave-uniform base + lane*size,
-// out-of-range lanes write zeros (the raw-buffer range check).  The hardware lands the data
-// asynchronously; the interpreter copies immediately, so it checks addressing, not wait placement.
+// out-of-range lanes write zeros (the raw-buffer range check).  The hardware lands the data asynchronously, any time
+// between the issue and the vmcnt wait that retires it.  The interpreter offers the two extremes: the default copies
+// immediately (EARLIEST landing: catches a DMA that overwrites LDS another wave is still reading), HIPEMU_DMA=late
+// copies at the covering wait (LATEST landing: catches a ds_read placed before that wait + barrier).
 struct hipemu_rsrc { const unsigned char* base; unsigned num; };
 inline hipemu_rsrc hipemu_make_rsrc(void* p, short, int num, int) { return hipemu_rsrc{(const unsigned char*)p, (unsigned)num}; }
 template <class P>
@@ -333,8 +398,14 @@ inline void hipemu_buffer_load_lds(hipemu_rsrc r, P ldsptr, unsigned size, unsig
     if (b0 != base) { fprintf(stderr, "hipemu: LDS-DMA base is not wave-uniform\n"); abort(); }
     unsigned char* dst = (unsigned char*)base + imm + (size_t)hipemu::lane_id() * size;
     unsigned long long off = (unsigned long long)voffset + soffset + imm;
-    if (off + size > r.num) memset(dst, 0, size);
-    else memcpy(dst, r.base + off, size);
+    const unsigned char* src = off + size > r.num ? nullptr : r.base + off;
+    if (hipemu::dma_late()) {
+        hipemu::BlockCtx* b = hipemu::g_blk;
+        b->fibers[b->cur].dma.push_back(hipemu::PendingDma{dst, src, size});
+        return;
+    }
+    if (!src) memset(dst, 0, size);
+    else memcpy(dst, src, size);
 }
 #define __builtin_amdgcn_make_buffer_rsrc hipemu_make_rsrc
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds hipemu_buffer_load_lds

@@ -1,0 +1,97 @@
+"""Runs the 256 x 192 ping-pong conv kernel (kernels_gemm_pp.hip) on small shapes under tests/hipemu and checks it
+against torch convolutions.  Executed as a subprocess by tests/test_conv_pingpong.py with different interpreter
+settings (HIPEMU_DMA=late: LDS-DMA lands at the covering wait; HIPEMU_SHUFFLE: wave scheduling order)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+import torch
+import torch.nn.functional as F
+
+import build_emu
+from nope_amd import hip
+from oracle import nope_ref as R
+from tests.util import rel
+
+
+def run(hip, dev, dts=(1, 0), light=False):
+    os.environ["NOPE_CONV_PP"] = "13"          # ping-pong kernel wherever it applies, position-major on it too
+    g = torch.Generator().manual_seed(77)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    d = lambda x: x.to(dev)
+    worst = 0.0
+    for dt in dts:
+        q = lambda x: x.to(hip.torch_dtype(dt)).float()
+        tol = 2e-5 if dt == 0 else 4e-2
+        C = 32 if dt == 0 else 64                # one 128-byte K step per tap and source
+
+        def chk(y, ref, what, t=tol):
+            nonlocal worst
+            e = rel(hip.to_nchw(y, dt).cpu(), ref)
+            worst = max(worst, e / t)
+            assert e < t, (what, dt, e)
+        # 3x3 over a virtual concat (broadcast first source), ragged M (270 rows = 2 tiles), two N tiles, bias: 18 K steps
+        x1, x2 = rn(1, C, 10, 9), rn(3, C, 10, 9)
+        w, b = rn(200, 2 * C, 3, 3) / 30, rn(200)
+        y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(w), d(b), src2=hip.to_nhwc(d(x2), dt), rep1=3, rep2=1, n_hyp=3)
+        chk(y, F.conv2d(torch.cat((q(x1).expand(3, -1, -1, -1), q(x2)), 1), q(w), b, padding=1), "3x3 concat")
+        # 1x1, one K step (nk = 1) and two (nk = 2), residual
+        w1, rs = rn(24, C, 1, 1) / 8, rn(3, 24, 10, 9)
+        y = hip.op_conv(dt, hip.to_nhwc(d(x2), dt), d(w1), None, resid=hip.to_nhwc(d(rs), dt))
+        chk(y, F.conv2d(q(x2), q(w1)) + q(rs), "1x1 nk=1")
+        x3, w2 = rn(2, 2 * C, 12, 11), rn(40, 2 * C, 1, 1) / 10
+        y = hip.op_conv(dt, hip.to_nhwc(d(x3), dt), d(w2), d(rn(40)) * 0)
+        chk(y, F.conv2d(q(x3), q(w2)), "1x1 nk=2")
+        if light:
+            continue
+        # three K steps (nk = 3: the B ring wraps once)
+        x5, w5 = rn(2, 3 * C, 12, 11), rn(16, 3 * C, 1, 1) / 12
+        y = hip.op_conv(dt, hip.to_nhwc(d(x5), dt), d(w5), None)
+        chk(y, F.conv2d(q(x5), q(w5)), "1x1 nk=3")
+        # nearest-x2 + 3x3 as four 2x2 phase convs; space-to-depth + 1x1
+        wu, bu = rn(40, C, 3, 3) / 24, rn(40)
+        y = hip.op_conv(dt, hip.to_nhwc(d(x2), dt), d(wu), d(bu), mode=hip.CONV_UP2P)
+        chk(y, R.hard_upsample(q(x2), {"1.weight": wu, "1.bias": bu}, ""), "up2p", tol if dt == 0 else 6e-2)
+        x4 = rn(5, C, 12, 10)
+        wd, bd = rn(72, 4 * C, 1, 1) / 16, rn(72)
+        y = hip.op_conv(dt, hip.to_nhwc(d(x4), dt), d(wd), d(bd), mode=hip.CONV_DOWN2)
+        chk(y, R.hard_downsample(q(x4), {"1.weight": q(wd), "1.bias": bd}, ""), "down2")
+        # position-major rows on the ping-pong kernel: 256 samples of a 2x2 map, residual
+        xp, wp, bp, rp = rn(256, C, 2, 2), rn(24, C, 3, 3) / (3 * C ** 0.5), rn(24), rn(256, 24, 2, 2)
+        y = hip.op_conv(dt, hip.to_nhwc(d(xp), dt), d(wp), d(bp), resid=hip.to_nhwc(d(rp), dt))
+        chk(y, F.conv2d(q(xp), q(wp), bp, padding=1) + q(rp), "posmajor")
+    os.environ.pop("NOPE_CONV_PP")
+    return worst
+
+
+def run_unet(hip, dev, dim, cdt, n_hyp=2, hw=8):
+    """Whole U-Net schedule with every eligible conv on the ping-pong kernel (fused GroupNorm statistics, fused PreNorm,
+    concat sources, phase convs, space-to-depth) against the oracle."""
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    from tests.util import StubEncoder
+    os.environ["NOPE_CONV_PP"] = "9"
+    try:
+        u = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype=cdt)
+        synth_init_(u, 2022)
+        sd = {k: v.clone() for k, v in u.own_state_dict().items()}
+        u = u.to(dev)
+        g = torch.Generator().manual_seed(23)
+        x, pose = torch.randn(1, 8, hw, hw, generator=g), torch.randn(1, n_hyp, 6, generator=g)
+        y = u.forward_hypotheses(x.to(dev), pose.to(dev)).cpu()[0]
+        want = R.unet_forward(sd, x.expand(n_hyp, -1, -1, -1), pose[0])
+        return rel(y, want)
+    finally:
+        os.environ.pop("NOPE_CONV_PP")
+
+
+if __name__ == "__main__":
+    hip._set_library_for_testing(hip.NopeLib(build_emu.build()))
+    w = run(hip, "cpu", light="--light" in sys.argv)
+    if "--unet" in sys.argv:
+        e = run_unet(hip, "cpu", 32, "f32")
+        assert e < 1e-4, e
+        print(f"unet f32 on the ping-pong kernel: rel err {e:.2e}")
+    print(f"pp_emu_case OK worst/tol {w:.3f}")

@@ -1,0 +1,70 @@
+"""The 256 x 192 eight-wave ping-pong conv kernel (nope_amd/csrc/kernels_gemm_pp.hip).
+
+CPU: the kernel source runs under tests/hipemu in its two adversarial settings -- LDS-DMA landing as LATE as the
+hardware allows (at the covering vmcnt wait) and as EARLY (at issue), waves scheduled one at a time as far ahead of
+each other as the workgroup barriers permit -- so a misplaced wait, a missing barrier or a ring that is one stage
+too short gives wrong numbers here, before a GPU-minute is spent (the mutations are described in DESIGN.md).
+GPU: same small shapes, then the U-Net's real launch shapes, where the kernel must agree BIT FOR BIT with the
+128 x 192 kernel (same K order, same MFMA shape, same accumulation chain) on every one of several repetitions."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pingpong_kernel_under_adversarial_interpreter(emu):
+    envs = [{"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, {"HIPEMU_SHUFFLE": "2"}]
+    procs = []
+    for e in envs:
+        env = dict(os.environ, HIPEMU_THREADS="4", **e)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pp_emu_case.py"), "--light"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for e, pr in zip(envs, procs):
+        out, _ = pr.communicate(timeout=1500)
+        assert pr.returncode == 0 and "pp_emu_case OK" in out, (e, out[-2000:])
+
+
+@pytest.mark.gpu
+def test_pingpong_small_shapes_gpu(gpu):
+    from tests import pp_emu_case
+    assert pp_emu_case.run(gpu, "cuda") < 1.0
+    e32, e16 = pp_emu_case.run_unet(gpu, "cuda", 64, "f32", n_hyp=5, hw=16), pp_emu_case.run_unet(gpu, "cuda", 64, "bf16", n_hyp=5, hw=16)
+    print(f"U-Net (u_net_dim 64) with every eligible conv on the ping-pong kernel: f32 {e32:.2e}, bf16 {e16:.2e}")
+    assert e32 < 1e-4 and e16 < 6e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [1, 0])
+def test_pingpong_bit_identical_to_128_tile_kernel(gpu, dt):
+    hip = gpu
+    g = torch.Generator(device="cuda").manual_seed(5)
+    tdt = hip.torch_dtype(dt)
+    n = 512 if dt == 1 else 128          # f32: 16x fewer MFMA flops per second -- keep the test short
+    shapes = [  # C1, C2, Cout, H, mode, ksize
+        (192, 0, 192, 32, hip.CONV_PLAIN, 3), (192, 192, 192, 32, hip.CONV_PLAIN, 3), (384, 192, 384, 16, hip.CONV_PLAIN, 3),
+        (768, 0, 768, 8, hip.CONV_PLAIN, 3), (192, 0, 384, 32, hip.CONV_PLAIN, 1), (128, 0, 192, 32, hip.CONV_PLAIN, 1),
+        (384, 0, 192, 16, hip.CONV_UP2P, 3), (192, 0, 384, 32, hip.CONV_DOWN2, 1), (1536, 0, 1536, 4, hip.CONV_PLAIN, 3),
+    ]
+    if dt == 0:
+        shapes = shapes[:1] + shapes[3:4] + shapes[6:8]
+    for c1, c2, cout, h, mode, ks in shapes:
+        cin = c1 + c2
+        w = torch.randn((cout, cin * 4, 1, 1) if mode == hip.CONV_DOWN2 else (cout, cin, ks, ks), device="cuda", generator=g) / (cin * ks * ks) ** 0.5
+        s1 = torch.randn(n, h, h, c1, device="cuda", generator=g).to(tdt)
+        s2 = torch.randn(n, h, h, c2, device="cuda", generator=g).to(tdt) if c2 else None
+        b = torch.randn(cout, device="cuda", generator=g)
+        outs = {}
+        for pp in ("0", "3"):                    # 3: the ping-pong kernel also for the 4x4 level (standard row order)
+            os.environ["NOPE_CONV_PP"] = pp
+            ys = [hip.op_conv(dt, s1, w, b, src2=s2, mode=mode) for _ in range(3)]
+            torch.cuda.synchronize()
+            assert all(torch.equal(ys[0], y) for y in ys[1:]), ("not reproducible", pp, c1, c2, cout, h, mode)
+            outs[pp] = ys[0]
+        os.environ.pop("NOPE_CONV_PP")
+        # (the 128-tile kernel runs the 4x4 shape position-major: the padding taps it skips only ever add exact zeros)
+        assert torch.equal(outs["0"], outs["3"]), ("ping-pong != 128-tile kernel", c1, c2, cout, h, mode, ks)
+        assert bool(torch.isfinite(outs["3"].float()).all()) and float(outs["3"].float().abs().max()) > 0.1

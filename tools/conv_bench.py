@@ -1,6 +1,8 @@
 """GPU micro-benchmark of the implicit-GEMM conv on the U-Net's dominant shapes (bf16 or f32).
-    python tools/conv_bench.py [--dtype bf16] [--nhyp 512]
-Prints per-shape time and TFLOP/s (algorithmic flops 2*M*Cout*taps*Cin)."""
+    python tools/conv_bench.py [--dtype bf16] [--nhyp 512] [--pp 0,1,3,5]
+Prints per-shape time and TFLOP/s (algorithmic flops 2*M*Cout*taps*Cin) for each kernel policy in --pp
+(NOPE_CONV_PP: 0 = 128 x 192 kernel everywhere, 1 = default, 3 / 5 = the 4x4 level on the ping-pong kernel in standard /
+position-major row order), interleaved in ONE process over several rounds (median)."""
 import argparse
 import ctypes as C
 import sys, os
@@ -32,11 +34,15 @@ def main():
     ap.add_argument("--nhyp", type=int, default=512)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="", help="comma-separated shape indices")
+    ap.add_argument("--pp", default="0,1", help="comma-separated NOPE_CONV_PP settings to compare")
+    ap.add_argument("--rounds", type=int, default=3)
     a = ap.parse_args()
+    pps = a.pp.split(",")
     dt = hip.dtype_code(a.dtype)
     tdt = hip.torch_dtype(dt)
     l = hip.lib()
-    tot_ms = tot_fl = 0.0
+    tot_ms = {pp: 0.0 for pp in pps}
+    tot_fl = 0.0
     for name, c1, c2, cout, hs, mode, ks, calls in SHAPES:
         if a.only and str(SHAPES.index((name, c1, c2, cout, hs, mode, ks, calls))) not in a.only.split(','):
             continue
@@ -56,20 +62,29 @@ def main():
             rc = l.dll.nope_op_conv(dt, s1.data_ptr(), c1, 1, None if s2 is None else s2.data_ptr(), c2, 1, hs, hs, mode, ntaps,
                                     pw.data_ptr(), bias.data_ptr(), None, out.data_ptr(), cout, a.nhyp, 0, 0, 0, st)
             assert rc == 0, rc
-        for _ in range(2):
-            run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.reps):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / a.reps
         fl = 2.0 * a.nhyp * ho * ho * cout * ntaps * cin
-        tot_ms += ms * calls
+        times = {pp: [] for pp in pps}
+        for rnd in range(a.rounds):
+            for pp in pps:
+                os.environ["NOPE_CONV_PP"] = pp
+                for _ in range(2):
+                    run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.reps):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                times[pp].append(e0.elapsed_time(e1) / a.reps)
         tot_fl += fl * calls
-        print(f"{name:45s} {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TF   x{calls}")
-    print(f"weighted: {tot_ms:.2f} ms per forward-equivalent, {tot_fl/tot_ms/1e9:.1f} TF")
+        line = f"{name:45s} x{calls:2d}"
+        for pp in pps:
+            ms = sorted(times[pp])[len(times[pp]) // 2]
+            tot_ms[pp] += ms * calls
+            line += f" | pp={pp}: {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF"
+        print(line, flush=True)
+    for pp in pps:
+        print(f"weighted pp={pp}: {tot_ms[pp]:.2f} ms per forward-equivalent, {tot_fl/tot_ms[pp]/1e9:.1f} TF (algorithmic flops)")
 
 
 if __name__ == "__main__":
