@@ -489,16 +489,19 @@ void launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
 constexpr int POSMAJOR_MAX_HW = 64;
 
 void launch_conv_pp(int dt, const void* params, dim3 grid, hipStream_t s);   // kernels_gemm_pp.hip
+void launch_conv_halo(int dt, const void* params, dim3 grid, hipStream_t s);
+int conv_halo_max_width();
 
 // Which kernel a conv takes.  NOPE_CONV_PP (tuning; default 1): bit 0 = the 256 x 192 ping-pong kernel for launches with
 // at least one 256-row tile per CU, bit 1 = also for the small-map 3x3 convs that would otherwise run position-major on
 // the 128 x 192 kernel (they then run in standard row order: all 9 taps), bit 2 = those run position-major on the
-// ping-pong kernel (needs nhyp % 256 == 0), bit 3 = no minimum tile count (tests: small shapes on the ping-pong kernel).
-struct ConvPlan { bool dma, pp, posmajor; };
+// ping-pong kernel (needs nhyp % 256 == 0), bit 3 = no minimum tile count (tests: small shapes on the ping-pong kernel),
+// bit 4 = 3x3 convs per tap on the ping-pong kernel instead of the tap-resident (halo) kernel.
+struct ConvPlan { bool dma, pp, posmajor, halo; };
 static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : 1;   // (read per launch: the tests toggle it)
     static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
-    ConvPlan pl{false, false, false};
+    ConvPlan pl{false, false, false, false};
     const int vec = dt == NOPE_F32 ? 4 : 8, es = dt == NOPE_F32 ? 4 : 2, bk = 8 * vec;
     const int Cin = a.C1 + a.C2;
     const unsigned long long lim = 0x7fffffffULL;
@@ -513,7 +516,10 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
                           a.Hs * a.Ws <= POSMAJOR_MAX_HW;
     const bool posmajor128 = small3x3 && a.nhyp % BM == 0 && !(variant & 8) && variant != 4;
     const long long M = (long long)a.nhyp * (phased ? a.Hs * a.Ws : a.Ho * a.Wo);
+    // (short K loops -- the 1x1 convs around the attention blocks, 2-3 K steps per tile -- stay on the 128 x 192 kernel, whose two
+    //  workgroups per CU cover each other's prologue and epilogue: measured 193 vs 234 us for 192 -> 384 at 32 x 32)
     const bool pp_shape = (a.mode == NOPE_CONV_PLAIN || a.mode == NOPE_CONV_DOWN2 || phased) && !a.out_nchw && a.Cout % vec == 0 &&
+                          ((pp_mode & 8) || a.ntaps * (Cin / bk) >= 12) &&
                           ((pp_mode & 8) || (long long)cdiv((int)M, 256) * cdiv(a.Cout, BN) * (phased ? 4 : 1) >= 256) && variant == 0;
     if (pp_shape && (pp_mode & 1)) {
         if (!posmajor128) pl.pp = true;
@@ -521,6 +527,8 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
         else if (pp_mode & 2) pl.pp = true;
     }
     if (!pl.pp) pl.posmajor = posmajor128;
+    // 3x3 convs in standard row order on the ping-pong schedule keep their A operand in LDS across the 9 taps (bit 4 = off)
+    pl.halo = pl.pp && !pl.posmajor && a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.Ws <= conv_halo_max_width() && !(pp_mode & 16);
     return pl;
 }
 
@@ -648,10 +656,12 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     const dim3 grid(gx, phased ? 4u : 1u, (unsigned)p.splits), block(NT);
     static const bool trace = getenv("NOPE_CONV_TRACE") != nullptr;     // tuning aid: one line per launch
     if (trace) fprintf(stderr, "conv %s mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u posmajor %d persist %d\n",
-                       plan.pp ? "pp256" : dma ? "dma128" : "generic", a.mode, a.ntaps, Cin, a.Cout, M, p.tiles_m, p.tiles_n, grid.x, grid.y, grid.z,
+                       plan.halo ? "halo256" : plan.pp ? "pp256" : dma ? "dma128" : "generic", a.mode, a.ntaps, Cin, a.Cout, M, p.tiles_m, p.tiles_n, grid.x, grid.y, grid.z,
                        p.posmajor, p.persist_iters);
     if (plan.pp) {
-        launch_conv_pp(dt, &p, grid, s);
+        if (const char* v = getenv("NOPE_PP_VARIANT")) p.variant = atoi(v);      // tuning ablations of the ping-pong kernel
+        if (plan.halo) launch_conv_halo(dt, &p, grid, s);
+        else launch_conv_pp(dt, &p, grid, s);
     } else if (dt == NOPE_F32) {
         if (dma && bm == 256) launch_dma<float, 128, 2, 256>(p, grid, s);
         else if (dma) launch_dma<float, 128, 2, 128>(p, grid, s);

@@ -103,6 +103,12 @@ template <bool FAST> __device__ __forceinline__ float silu_f(float x) {
     return x / (1.0f + expf(-x));
 }
 
+// Keeps a value (and the loads that produced it) alive in a tuning build that skips its consumer -- without this the
+// compiler deletes the loads too and the ablation measures less than it claims (cdna_hip_programming.md rule 17).
+#ifndef NOPE_KEEP_VGPR
+#define NOPE_KEEP_VGPR(x) asm volatile("" ::"v"(x))
+#endif
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

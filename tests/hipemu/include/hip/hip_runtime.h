@@ -37,6 +37,7 @@
 #define __shared__ static thread_local
 #define __launch_bounds__(...)
 #define HIPEMU 1
+#define NOPE_KEEP_VGPR(x) ((void)(x))   // (register-liveness pin of the tuning builds: nothing to pin on the host)
 
 struct dim3 {
     unsigned x, y, z;

@@ -37,6 +37,19 @@ def run(hip, dev, dts=(1, 0), light=False):
         w, b = rn(200, 2 * C, 3, 3) / 30, rn(200)
         y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(w), d(b), src2=hip.to_nhwc(d(x2), dt), rep1=3, rep2=1, n_hyp=3)
         chk(y, F.conv2d(torch.cat((q(x1).expand(3, -1, -1, -1), q(x2)), 1), q(w), b, padding=1), "3x3 concat")
+        # tap-resident 3x3 kernel (A stage = tile pixels + halo, loaded once per channel chunk): maps of 4x4 pixels with many
+        # samples per tile (halo rows belong to neighbouring samples), widest supported map (W = 32), a single channel chunk
+        xs, ws_, bs = rn(40, C, 4, 4), rn(24, C, 3, 3) / (3 * C ** 0.5), rn(24)
+        y = hip.op_conv(dt, hip.to_nhwc(d(xs), dt), d(ws_), d(bs))
+        chk(y, F.conv2d(q(xs), q(ws_), bs, padding=1), "halo 4x4 x 40 samples")
+        xw = rn(1, 2 * C, 9, 32)
+        ww = rn(16, 2 * C, 3, 3) / (3 * (2 * C) ** 0.5)
+        y = hip.op_conv(dt, hip.to_nhwc(d(xw), dt), d(ww), None)
+        chk(y, F.conv2d(q(xw), q(ww), padding=1), "halo W=32")
+        os.environ["NOPE_CONV_PP"] = "29"      # same shapes per tap on the ping-pong kernel: identical bits
+        y2 = hip.op_conv(dt, hip.to_nhwc(d(xw), dt), d(ww), None)
+        os.environ["NOPE_CONV_PP"] = "13"
+        assert torch.equal(y, y2), "tap-resident kernel differs from the per-tap kernel"
         # 1x1, one K step (nk = 1) and two (nk = 2), residual
         w1, rs = rn(24, C, 1, 1) / 8, rn(3, 24, 10, 9)
         y = hip.op_conv(dt, hip.to_nhwc(d(x2), dt), d(w1), None, resid=hip.to_nhwc(d(rs), dt))

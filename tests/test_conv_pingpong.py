@@ -58,7 +58,8 @@ def test_pingpong_bit_identical_to_128_tile_kernel(gpu, dt):
         s2 = torch.randn(n, h, h, c2, device="cuda", generator=g).to(tdt) if c2 else None
         b = torch.randn(cout, device="cuda", generator=g)
         outs = {}
-        for pp in ("0", "3"):                    # 3: the ping-pong kernel also for the 4x4 level (standard row order)
+        # 0: 128 x 192 kernel; 3: ping-pong schedule everywhere (3x3 convs on the tap-resident kernel); 19: 3x3 convs per tap
+        for pp in ("0", "3", "19"):
             os.environ["NOPE_CONV_PP"] = pp
             ys = [hip.op_conv(dt, s1, w, b, src2=s2, mode=mode) for _ in range(3)]
             torch.cuda.synchronize()
@@ -66,5 +67,6 @@ def test_pingpong_bit_identical_to_128_tile_kernel(gpu, dt):
             outs[pp] = ys[0]
         os.environ.pop("NOPE_CONV_PP")
         # (the 128-tile kernel runs the 4x4 shape position-major: the padding taps it skips only ever add exact zeros)
-        assert torch.equal(outs["0"], outs["3"]), ("ping-pong != 128-tile kernel", c1, c2, cout, h, mode, ks)
+        assert torch.equal(outs["0"], outs["3"]), ("ping-pong / tap-resident != 128-tile kernel", c1, c2, cout, h, mode, ks)
+        assert torch.equal(outs["0"], outs["19"]), ("per-tap ping-pong != 128-tile kernel", c1, c2, cout, h, mode, ks)
         assert bool(torch.isfinite(outs["3"].float()).all()) and float(outs["3"].float().abs().max()) > 0.1
