@@ -52,7 +52,7 @@ def _record_usage(src: str, remarks: str, objdir: str) -> None:
     with open(os.path.join(objdir, src + ".usage.txt"), "w") as f:
         for r in rows:
             f.write(" ".join(f"{k}={v}" for k, v in r.items()) + "\n")
-    bad = [r["kernel"] for r in rows if r.get("ScratchSize", 0) > 0 and any(t in r["kernel"] for t in ("conv_gemm", "sim_reg", "gn_", "linattn"))]
+    bad = [r["kernel"] for r in rows if r.get("ScratchSize", 0) > 0 and any(t in r["kernel"] for t in ("conv_gemm", "conv3x3", "sim_reg", "gn_", "linattn"))]
     if bad:
         raise RuntimeError(f"{src}: kernels use scratch memory (register spill / runtime-indexed array): {bad}")
 

@@ -492,14 +492,15 @@ void launch_conv_pp(int dt, const void* params, dim3 grid, hipStream_t s);   // 
 void launch_conv_halo(int dt, const void* params, dim3 grid, hipStream_t s);
 int conv_halo_max_width();
 
-// Which kernel a conv takes.  NOPE_CONV_PP (tuning; default 1): bit 0 = the 256 x 192 ping-pong kernel for launches with
+// Which kernel a conv takes.  NOPE_CONV_PP (tuning; default 3): bit 0 = the 256 x 192 ping-pong kernels for launches with
 // at least one 256-row tile per CU, bit 1 = also for the small-map 3x3 convs that would otherwise run position-major on
-// the 128 x 192 kernel (they then run in standard row order: all 9 taps), bit 2 = those run position-major on the
+// the 128 x 192 kernel (they then run in standard row order, all 9 taps, on the tap-resident kernel: 239 vs 257 us for
+// 1536 -> 1536 at 4 x 4 x 512 although it executes the 31 % of MACs the position-major order skips), bit 2 = those run position-major on the
 // ping-pong kernel (needs nhyp % 256 == 0), bit 3 = no minimum tile count (tests: small shapes on the ping-pong kernel),
 // bit 4 = 3x3 convs per tap on the ping-pong kernel instead of the tap-resident (halo) kernel.
 struct ConvPlan { bool dma, pp, posmajor, halo; };
 static ConvPlan plan_conv(int dt, const ConvArgs& a) {
-    const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : 1;   // (read per launch: the tests toggle it)
+    const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : 3;   // (read per launch: the tests toggle it)
     static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
     ConvPlan pl{false, false, false, false};
     const int vec = dt == NOPE_F32 ? 4 : 8, es = dt == NOPE_F32 ? 4 : 2, bk = 8 * vec;
@@ -528,7 +529,9 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     }
     if (!pl.pp) pl.posmajor = posmajor128;
     // 3x3 convs in standard row order on the ping-pong schedule keep their A operand in LDS across the 9 taps (bit 4 = off)
-    pl.halo = pl.pp && !pl.posmajor && a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.Ws <= conv_halo_max_width() && !(pp_mode & 16);
+    // (sources must not be broadcast: the kernel's A offsets are linear in the flat pixel index)
+    pl.halo = pl.pp && !pl.posmajor && a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.Ws <= conv_halo_max_width() && a.rep1 == 1 &&
+              (a.C2 == 0 || a.rep2 == 1) && !(pp_mode & 16);
     return pl;
 }
 

@@ -319,15 +319,25 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
 // same flat pixel axis.  So instead of staging 256 rows per tap (9 x 32 KiB per channel chunk), a stage holds the tile's
 // pixel range extended by W + 1 rows on either side (<= 328 rows, 41 KiB, loaded ONCE per channel chunk) and every tap
 // reads its fragments at a row offset.  A tap that leaves the image (zero padding) or wraps into a neighbouring image
-// row / sample is redirected, per lane, to a 128-byte row of zeros -- one v_cndmask on the address, none on the data.
+// row / sample is redirected, per lane, to a 128-byte row of zeros kept behind each stage -- decided once, when the
+// per-tap fragment addresses are precomputed; nothing touches the data.
 // Per channel chunk the L2 -> LDS stream is 41 KiB of A + 9 x 24 KiB of B instead of 9 x 56 KiB: half the bytes, and
-// 4 instead of 7 DMA pieces per wave per K step (the vector-memory path of a CU, ~40 B/clk, was the longest pole of the
-// LOAD phase: profiles/r02_pp_ablation.txt).  Same K order (channel chunk outer, tap inner, padding taps add exact
+// 4 instead of 7 DMA pieces per wave per K step.  Same K order (channel chunk outer, tap inner, padding taps add exact
 // zeros) and the same accumulation chain as the other conv kernels: results are bit-identical to theirs.
+//
 // Schedule, B ring, barriers and waits are those of conv_gemm_pp_kernel above; the A ring has two stages of whole
 // chunks: the (<= 6) pieces a wave owns of chunk c+1 are issued one per K step during taps 0..5 of chunk c, into the
 // stage chunk c-1 was read from (last read: K step 9c-1, one barrier-separated slot before the first such issue), and
 // have landed -- issuer's vmcnt(0) + barrier -- at least three K steps before chunk c+1 begins.
+//
+// The LOAD phase is kept SHORT IN INSTRUCTIONS.  Cycle counters on the first version of this kernel (profiles/
+// r02b_pmc_halo_L3.txt) showed the LDS ~30 % busy and the MFMA pipe 61 % busy: a LOAD phase of ~180 instructions
+// (per-step tap arithmetic, swizzle and mask VALU, scalar bookkeeping) simply takes longer to ISSUE (~5 cycles each)
+// than the 768 cycles the other group's 24 MFMAs cover.  So the nine taps are unrolled (two chunks = 18 steps of
+// straight-line code, the stage parities become immediates), the 9 x MT fragment addresses live in registers, B
+// fragment addresses are one register per K sub-step plus instruction immediates (the B ring sits at LDS offset 0 so
+// they fit 16 bits), and the K offsets of the DMA pieces travel in the scalar offset operand: ~20 ds_read + 4 DMA +
+// a few dozen scalar/vector instructions per step.
 constexpr int HALO_ROWS = 328;       // 256 + 2 * (32 + 1), rounded up to whole 8-row pieces: maps up to 32 pixels wide
 constexpr int HALO_MAX_W = 32;
 
@@ -338,17 +348,19 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     constexpr unsigned ES = (unsigned)sizeof(T);
     constexpr int RB = 128;
     constexpr int BK = RB / (int)ES;
-    constexpr int A_STAGE = HALO_ROWS * RB, B_STAGE = BN * RB;
-    constexpr int B_BASE = 2 * A_STAGE;
-    constexpr int ZERO_OFF = B_BASE + 3 * B_STAGE;                 // 128 bytes of zeros (a multiple of 128: the kk slot flips stay inside)
-    constexpr int RING = ZERO_OFF + RB;
+    constexpr int B_STAGE = BN * RB;
+    constexpr int A_BASE = 3 * B_STAGE;                            // B ring first: its addresses fit instruction immediates
+    constexpr int ZROW = HALO_ROWS * RB;                           // 128 bytes of zeros behind the rows of a stage
+    constexpr int A_STAGE = ZROW + RB;
+    constexpr int RING = A_BASE + 2 * A_STAGE;
     constexpr int PANELS = PP_WAVES * Ep<T>::WAVE_BYTES;
     constexpr int LDS_BYTES = RING > PANELS ? RING : PANELS;
     constexpr int KK = RB / 16 / TL::KSLOTS;
-    static_assert(PANELS <= ZERO_OFF, "epilogue panels must not need more than the ring");
+    static_assert(RING <= 160 * 1024 && A_STAGE < 65536 && 2 * B_STAGE + BN * RB < 65536 + B_STAGE && 2 * B_STAGE + 2 * Tile<T>::TM * RB < 65536, "LDS budget / ds_read immediates (16 bits)");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int tid = threadIdx.x;
+    if (p.variant & 128) { if (tid == 9999) lds[0] = 1; return; }   // tuning only (NOPE_PP_VARIANT): launch cost of the grid
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -359,37 +371,38 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     const int W = p.Ws, HW = p.Hs * p.Ws;
     const int halo = W + 1;
     const int Cin = p.C1 + p.C2;
-    const int npieces = (PP_BM + 2 * halo + 7) >> 3;               // 8-row pieces of a stage (<= 41)
+    const int npieces = (PP_BM + 2 * halo + 7) >> 3;               // 8-row pieces of a stage (33 .. 41)
 
     const auto r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src1, (short)0, (int)p.bytes1, 0x00020000);
     const auto r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src2 ? p.src2 : p.src1), (short)0, (int)(p.src2 ? p.bytes2 : p.bytes1), 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)p.bytesw, 0x00020000);
 
-    if (p.variant & 128) { if (tid == 9999) lds[0] = 1; return; }   // tuning only (NOPE_PP_VARIANT): launch cost of the grid
-    if (tid < 8) st16(lds + ZERO_OFF + tid * 16, u32x4{0u, 0u, 0u, 0u});
+    if (tid < 16) st16(lds + A_BASE + (tid >> 3) * A_STAGE + ZROW + (tid & 7) * 16, u32x4{0u, 0u, 0u, 0u});
 
-    // ---- A pieces of this wave: stage rows 8 q .. 8 q + 7 for q = wave, wave + 8, ... ; stage row r holds flat pixel
-    // m0 - halo + r of the (hypothesis, y, x) axis (zeros outside the tensor: out-of-range buffer offset)
+    // ---- A pieces of this wave: stage rows 8 q .. 8 q + 7 for q = wave, wave + 8, ... (<= 6 of them); stage row r holds
+    // flat pixel m0 - halo + r of the (hypothesis, y, x) axis.  Sources are not broadcast here (rep == 1, checked by the
+    // launcher), so the byte offset is LINEAR in the pixel index: piece i is piece 0 plus i * 64 pixels (a scalar), the
+    // swizzled channel chunk is the same for all of a lane's pieces (rows 64 apart), and pixels before / behind the tensor
+    // (first and last tile) give offsets that wrap above / run past num_records: the buffer range check returns zeros.
     const int rsub = lane >> 3, lslot = lane & 7;
-    unsigned a_o1[6], a_o2[6];
-    const long long m_total = (long long)p.nhyp * HW;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int q = wave + 8 * i;
-        const int r = 8 * q + rsub;
-        const long long gm = (long long)m0 - halo + r;
-        const bool ok = q < npieces && gm >= 0 && gm < m_total;
-        const unsigned g = ok ? (unsigned)gm : 0u;
-        const unsigned b = p.d_hw.div(g), pix = g - b * (unsigned)HW;
-        const unsigned cs = (unsigned)((lslot ^ swz_of<RB>(r)) * VEC);
-        a_o1[i] = ok ? ((p.d_rep1.div(b) * (unsigned)HW + pix) * p.C1 + cs) * ES : OOB;
-        a_o2[i] = ok ? ((p.d_rep2.div(b) * (unsigned)HW + pix) * p.C2 + cs) * ES : OOB;
-    }
-    auto piece_a = [&](int i, int chunk, int stage) {              // piece i of this wave, channel chunk `chunk`
+    const int r0 = 8 * wave + rsub;
+    const unsigned a_cs = (unsigned)((lslot ^ swz_of<RB>(r0)) * VEC);
+    const unsigned a_base1 = (unsigned)((m0 - halo + r0) * p.C1 + (int)a_cs) * ES;
+    const unsigned a_base2 = (unsigned)((m0 - halo + r0) * p.C2 + (int)a_cs) * ES;
+    const unsigned a_step1 = 64u * (unsigned)p.C1 * ES, a_step2 = 64u * (unsigned)p.C2 * ES;
+    const bool a_has4 = wave + 32 < npieces, a_has5 = wave + 40 < npieces;      // (pieces 0..3 of a wave always exist)
+    unsigned char* const a_dst = lds + A_BASE + wave * 1024;                    // + stage * A_STAGE + i * 8192
+    // piece i of this wave for the chunk described by (first, a_soff).  The channel offset rides in the scalar operand (it stays
+    // inside the pixel); the piece stride must be part of the VECTOR offset -- the hardware range check covers only that.
+    bool a_first = true; unsigned a_soff = 0;
+    auto piece_a = [&](int i, int stage) {
+        if (a_first) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_void_t*)(a_dst + stage * A_STAGE + i * 8192), 16, a_base1 + i * a_step1, a_soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_void_t*)(a_dst + stage * A_STAGE + i * 8192), 16, a_base2 + i * a_step2, a_soff, 0, 0);
+    };
+    auto set_chunk = [&](int chunk) {
         const int c0 = chunk * BK;
-        const bool first = c0 < p.C1;                              // wave-uniform: a chunk lies inside one source
-        const unsigned off = (first ? a_o1[i] : a_o2[i]) + (unsigned)(first ? c0 : c0 - p.C1) * ES;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? r1 : r2, (lds_void_t*)(lds + stage * A_STAGE + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
+        a_first = c0 < p.C1;                                       // wave-uniform: a chunk lies inside one source
+        a_soff = (unsigned)(a_first ? c0 : c0 - p.C1) * ES;
     };
     // ---- B pieces: 24 rows per wave (group 1: panel rows 0..95, group 0: rows 96..191), as in conv_gemm_pp_kernel
     const int brow0 = 96 * (1 - grp) + 24 * wl;
@@ -401,17 +414,21 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         const unsigned cs = (unsigned)((lslot ^ swz_of<RB>(row)) * VEC);
         b_off[j] = n < p.Cout ? ((unsigned)n * 9u * Cin + cs) * ES : OOB;
     }
-    unsigned char* const b_dst = lds + B_BASE + (brow0 >> 3) * 1024;
-    auto issue_b = [&](int tap, int chunk, int stage) {
-        const unsigned kofs = (unsigned)(tap * Cin + chunk * BK) * ES;
+    unsigned char* const b_dst = lds + (brow0 >> 3) * 1024;                     // + stage * B_STAGE + j * 1024
+    const unsigned cin_es = (unsigned)Cin * ES;
+    unsigned bkofs = 0;                                            // K offset (tap * Cin + chunk * BK) * ES of the next B step this wave issues
+    auto issue_b = [&](int stage) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(b_dst + stage * B_STAGE + j * 1024), 16, b_off[j] + kofs, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(b_dst + stage * B_STAGE + j * 1024), 16, b_off[j], bkofs, 0, 0);
     };
 
-    // ---- fragment rows of this lane: tile row, and which of the 9 taps stay inside its image
-    int f_row[TL::MT];
+    // ---- fragment rows of this lane: stage row of the centre tap, and which of the 9 taps stay inside its image.  The
+    // per-tap addresses are formed in the loop (row + scalar tap offset, swizzle, zero-row redirect: ~10 VALU per
+    // fragment row and step) -- a table of all 9 x MT of them does not fit the register file next to 96 accumulators and
+    // 80 fragment registers, and a spilled table is reloaded through vmcnt, which would drain the DMA queue.
     unsigned f_mask[TL::MT];
+    const int fslot = TL::frag_slot(lane);
 #pragma unroll
     for (int i = 0; i < TL::MT; ++i) {
         const int il = wm * 64 + i * TL::TM + TL::frag_row(lane);
@@ -420,12 +437,13 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         const int oy = (int)p.d_w.div(r), ox = (int)r - oy * W;
         const unsigned vx = (ox > 0 ? 1u : 0u) | 2u | (ox + 1 < W ? 4u : 0u);
         f_mask[i] = (oy > 0 ? vx : 0u) | (vx << 3) | (oy + 1 < p.Hs ? vx << 6 : 0u);
-        f_row[i] = il + halo;
     }
-    const int fslot = TL::frag_slot(lane);
-    int fb[TL::NTL];
+    const int f_row0 = wm * 64 + TL::frag_row(lane) + halo;       // fragment row i sits i * TM stage rows further
+    // B: the swizzle of rows wn*96 + j*TM + l does not depend on j (48 wn and j TM / 2 are multiples of 8): one address per
+    // K sub-step, tile j and ring stage are immediates
+    int fbk[KK];
 #pragma unroll
-    for (int j = 0; j < TL::NTL; ++j) fb[j] = lds_off_rb<RB>(wn * 96 + j * TL::TM + TL::frag_row(lane), fslot);
+    for (int kk = 0; kk < KK; ++kk) fbk[kk] = lds_off_rb<RB>(wn * 96 + TL::frag_row(lane), fslot) ^ ((kk * TL::KSLOTS) << 4);
 
     typename TL::acc_t acc[TL::MT][TL::NTL];
 #pragma unroll
@@ -436,86 +454,93 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             for (int r = 0; r < TL::R; ++r) acc[i][j][r] = 0.f;
 
     const int nchunks = Cin / BK;
-    const int nk = 9 * nchunks;
+    const unsigned wrap_inc = (unsigned)BK * ES - 8u * cin_es;     // K offset step from tap 8 of a chunk to tap 0 of the next
 
     // ---- prologue: the whole A stage of chunk 0, this group's half of B(0), and (group 1) its half of B(1)
+    set_chunk(0);
 #pragma unroll
     for (int i = 0; i < 6; ++i)
-        if (wave + 8 * i < npieces) piece_a(i, 0, 0);
-    int btap = 0, bchunk = 0;                          // next K step whose B pieces this wave issues
-    auto b_advance = [&]() { if (++btap == 9) { btap = 0; ++bchunk; } };
-    issue_b(btap, bchunk, 0); b_advance();
-    if (grp == 1 && nk > 1) { issue_b(btap, bchunk, 1); b_advance(); }
-    __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0 & WAIT_LGKMCNT0);       // DMA landed, zero row written
+        if (i < 4 || (i == 4 ? a_has4 : a_has5)) piece_a(i, 0);
+    issue_b(0); bkofs += cin_es;
+    if (grp == 1) { issue_b(1); bkofs += cin_es; }                 // (nk >= 9 > 2)
+    __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0 & WAIT_LGKMCNT0);       // DMA landed, zero rows written
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (grp == 1) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
+    const bool dma_on = !(p.variant & 16);                         // (tuning: 16 = no DMA stream)
 
-    int sb = 0, tap = 0, chunk = 0;
-    for (int k = 0; k < nk; ++k) {
-        // ---- LOAD k
-        const unsigned char* la = lds + (chunk & 1) * A_STAGE;
-        const unsigned char* lb = lds + B_BASE + sb * B_STAGE;
-        const int dy = tap / 3, dx = tap - dy * 3;
-        const int toff = (p.variant & 4) ? 0 : (dy - 1) * W + (dx - 1);          // (tuning: 4 = every tap reads the centre rows)
-        int fa[TL::MT];
+    // The nine K steps of channel chunk `chunk`, whose A stage is `par` (a literal at both call sites: after inlining and
+    // unrolling every tap, stage and ring index below is an immediate).
+    auto chunk_steps = [&](const int chunk, const int par) __attribute__((always_inline)) {
+        const bool last = chunk + 1 == nchunks;
+        if (!last) set_chunk(chunk + 1);
+        // The per-tap fragment addresses below are loop invariants: hoisted out of the chunk loop they would need 9 x MT
+        // registers the kernel does not have (and a spilled table is reloaded through vmcnt, draining the DMA queue).
+        int frow = f_row0;
+        NOPE_OPAQUE_VGPR(frow);
 #pragma unroll
-        for (int i = 0; i < TL::MT; ++i) {
-            const int r = f_row[i] + toff;
-            const int off = (r << 7) + (((fslot ^ (r >> 1)) & 7) << 4);
-            fa[i] = (((f_mask[i] >> tap) & 1u) || (p.variant & 2)) ? off : (ZERO_OFF - (chunk & 1) * A_STAGE);     // (relative to `la`; tuning: 2 = no padding redirect)
-        }
-        u32x4 af[KK][TL::MT], bfr[KK][TL::NTL];
+        for (int tap = 0; tap < 9; ++tap) {
+            // ---- LOAD: DMA pieces first (they fly for the rest of this phase and the whole next one), then the fragments
+            if (dma_on) {
+                if (tap < 6 && !last && (tap < 4 || (tap == 4 ? a_has4 : a_has5))) piece_a(tap, par ^ 1);
+                // group 0 issues the B half of step k+1 into ring stage (tap+1)%3, group 1 of step k+2 into (tap+2)%3
+                const bool b_more = !last || (grp == 0 ? tap < 8 : tap < 7);
+                if (b_more) {
+                    if (grp == 0) issue_b((tap + 1) % 3); else issue_b((tap + 2) % 3);
+                    bkofs += ((grp == 0 ? tap + 1 : tap + 2) % 9 == 8) ? wrap_inc : cin_es;
+                }
+            }
+            u32x4 af[KK][TL::MT], bfr[KK][TL::NTL];
+            int fa[TL::MT];
+            const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);            // scalar: the tap's row offset along the flat pixel axis
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-#pragma unroll
-            for (int i = 0; i < TL::MT; ++i) af[kk][i] = ld16(la + (fa[i] ^ ((kk * TL::KSLOTS) << 4)));
-#pragma unroll
-            for (int j = 0; j < TL::NTL; ++j) bfr[kk][j] = ld16(lb + (fb[j] ^ ((kk * TL::KSLOTS) << 4)));
-        }
-        const int sb1 = sb == 2 ? 0 : sb + 1;
-        const int sb2 = sb1 == 2 ? 0 : sb1 + 1;
-        const bool dma_on = !(p.variant & 16);                                  // (tuning: 16 = no DMA stream)
-        if (dma_on && tap < 6 && chunk + 1 < nchunks && wave + 8 * tap < npieces) {      // one piece of the NEXT chunk's A stage
-            // (static piece index for the register arrays: the switch unrolls)
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                if (i == tap) piece_a(i, chunk + 1, (chunk + 1) & 1);
-        }
-        if (grp == 0) { if (k + 1 < nk) { if (dma_on) issue_b(btap, bchunk, sb1); b_advance(); } }
-        else          { if (k + 2 < nk) { if (dma_on) issue_b(btap, bchunk, sb2); b_advance(); } }
-        __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- COMPUTE k
-        __builtin_amdgcn_s_setprio(1);
-        if (!(p.variant & 32)) {                       // (tuning: 32 = no MFMA)
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-                for (int i = 0; i < TL::MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < TL::NTL; ++j) TL::mma(af[kk][i], bfr[kk][j], acc[i][j]);
-        } else {
+            for (int i = 0; i < TL::MT; ++i) {
+                const int rr = frow + i * TL::TM + toff;
+                const int off = A_BASE + (rr << 7) + (((fslot ^ (rr >> 1)) & 7) << 4);
+                fa[i] = ((f_mask[i] >> tap) & 1u) ? off : A_BASE + ZROW;   // (absolute, stage 0)
+            }
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-                for (int i = 0; i < TL::MT; ++i) NOPE_KEEP_VGPR(af[kk][i]);
+                for (int i = 0; i < TL::MT; ++i) af[kk][i] = ld16(lds + (fa[i] ^ ((kk * TL::KSLOTS) << 4)) + par * A_STAGE);
 #pragma unroll
-                for (int j = 0; j < TL::NTL; ++j) NOPE_KEEP_VGPR(bfr[kk][j]);
+                for (int j = 0; j < TL::NTL; ++j) bfr[kk][j] = ld16(lds + fbk[kk] + ((tap % 3) * B_STAGE + j * TL::TM * RB));
             }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
-        if (!(grp == 1 && k == nk - 1)) {
+            __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);     // my reads of this step are done: after the barrier the other group may overwrite them
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            // ---- COMPUTE: registers only
+            __builtin_amdgcn_s_setprio(1);
+            if (!(p.variant & 32)) {                       // (tuning: 32 = no MFMA)
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < TL::NTL; ++j) TL::mma(af[kk][i], bfr[kk][j], acc[i][j]);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < TL::MT; ++i) NOPE_KEEP_VGPR(af[kk][i]);
+#pragma unroll
+                    for (int j = 0; j < TL::NTL; ++j) NOPE_KEEP_VGPR(bfr[kk][j]);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);       // the pieces issued in this step's LOAD have landed (they had this whole phase)
+            if (!(grp == 1 && last && tap == 8)) {         // (group 1 started one barrier late: it skips the last one)
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        sb = sb1;
-        if (++tap == 9) { tap = 0; ++chunk; }
+    };
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+        chunk_steps(chunk, 0);
+        if (chunk + 1 < nchunks) chunk_steps(chunk + 1, 1);
     }
     if (p.variant & 64) {                              // tuning only: no epilogue (keeps the accumulators live)
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;

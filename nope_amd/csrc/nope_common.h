@@ -108,6 +108,11 @@ template <bool FAST> __device__ __forceinline__ float silu_f(float x) {
 #ifndef NOPE_KEEP_VGPR
 #define NOPE_KEEP_VGPR(x) asm volatile("" ::"v"(x))
 #endif
+// Makes a per-lane value opaque at this point: nothing computed from it can be hoisted above (out of a loop) -- the handle on
+// loop-invariant code motion when the hoisted values would not fit the register file (cdna_hip_programming.md section 5.7, item 3).
+#ifndef NOPE_OPAQUE_VGPR
+#define NOPE_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
+#endif
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -38,6 +38,7 @@
 #define __launch_bounds__(...)
 #define HIPEMU 1
 #define NOPE_KEEP_VGPR(x) ((void)(x))   // (register-liveness pin of the tuning builds: nothing to pin on the host)
+#define NOPE_OPAQUE_VGPR(x) ((void)(x)) // (code-motion fence of the device compiler)
 
 struct dim3 {
     unsigned x, y, z;
@@ -398,8 +399,11 @@ inline void hipemu_buffer_load_lds(hipemu_rsrc r, P ldsptr, unsigned size, unsig
     uintptr_t b0; memcpy(&b0, s[0], sizeof(b0));
     if (b0 != base) { fprintf(stderr, "hipemu: LDS-DMA base is not wave-uniform\n"); abort(); }
     unsigned char* dst = (unsigned char*)base + imm + (size_t)hipemu::lane_id() * size;
-    unsigned long long off = (unsigned long long)voffset + soffset + imm;
-    const unsigned char* src = off + size > r.num ? nullptr : r.base + off;
+    // the raw-buffer range check covers the vector offset + instruction offset only; the scalar offset is added afterwards
+    const unsigned long long chk = (unsigned long long)voffset + imm;
+    const unsigned long long off = chk + soffset;
+    const unsigned char* src = chk + size > r.num ? nullptr : r.base + off;
+    if (src && off + size > r.num) { fprintf(stderr, "hipemu: buffer load passes the range check but reads beyond the buffer (scalar offset)\n"); abort(); }
     if (hipemu::dma_late()) {
         hipemu::BlockCtx* b = hipemu::g_blk;
         b->fibers[b->cur].dma.push_back(hipemu::PendingDma{dst, src, size});

@@ -37,6 +37,10 @@ def run(hip, dev, dts=(1, 0), light=False):
         w, b = rn(200, 2 * C, 3, 3) / 30, rn(200)
         y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(w), d(b), src2=hip.to_nhwc(d(x2), dt), rep1=3, rep2=1, n_hyp=3)
         chk(y, F.conv2d(torch.cat((q(x1).expand(3, -1, -1, -1), q(x2)), 1), q(w), b, padding=1), "3x3 concat")
+        # the same concat without a broadcast source: tap-resident 3x3 kernel, chunks from two sources, ragged M, 2 N tiles
+        x1f = rn(3, C, 10, 9)
+        y = hip.op_conv(dt, hip.to_nhwc(d(x1f), dt), d(w), d(b), src2=hip.to_nhwc(d(x2), dt))
+        chk(y, F.conv2d(torch.cat((q(x1f), q(x2)), 1), q(w), b, padding=1), "halo 3x3 concat")
         # tap-resident 3x3 kernel (A stage = tile pixels + halo, loaded once per channel chunk): maps of 4x4 pixels with many
         # samples per tile (halo rows belong to neighbouring samples), widest supported map (W = 32), a single channel chunk
         xs, ws_, bs = rn(40, C, 4, 4), rn(24, C, 3, 3) / (3 * C ** 0.5), rn(24)
