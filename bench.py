@@ -14,6 +14,10 @@ bf16 (bf16 U-Net compute with f32 accumulation/statistics, bf16 bank).  For N>1 
 axis is sharded (weak scaling: 512 templates per GPU, N_total = 512*N) and the per-rank scores
 are all-gathered over RCCL before the top-5, as BASELINE configs[3]/[4] describe.
 
+`--scoring-only` times SURVEY.md section 8(d) metric (i) instead: scoring + top-5 of `--batch` queries against a RESIDENT bank
+of `--templates` templates per GPU in `--bank-dtype` (default: BASELINE configs[4]'s per-GPU slice, 32 queries x 1024 fp16
+templates); for N>1 every rank scores its slice, the (B, N/G) scores are all-gathered over RCCL and ranked.
+
 Extra legs on rank 0 at N=1 (outside the timed region):
   roofline      the dominant kernel of the step, conv_gemm_dma_kernel<bf16> (the U-Net's 83 implicit-GEMM launches):
                 multiply-adds x2 those launches EXECUTE (phase convs 4/9 of the nearest-x2 MACs, padding taps of the
@@ -119,10 +123,21 @@ def cpu_baseline(model, size: int, n_templates: int, hyp_sample: int = 16, chunk
                       f"encoder {t_enc * 1e3:.0f} ms/image; extrapolated linearly to {n_templates} templates + 2 encoder passes"}
 
 
-def scoring_roofline(dtype: torch.dtype):
+def _csrc_sha() -> str:
+    """Hash of the kernel sources: a PMC traffic figure is only reported next to the tree it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "nope_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "nope_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def scoring_roofline(dtype: torch.dtype, N: int = 0):
     from nope_amd import hip
     B, C, h = 32, 8, 32
-    N = 512 if dtype == torch.float32 else 2048                 # 1.07 GB either way (> 256 MB Infinity Cache)
+    N = N or (512 if dtype == torch.float32 else 2048)          # 1.07 GB either way (> 256 MB Infinity Cache)
     bank = torch.randn(B, N, C, h, h, device="cuda", dtype=torch.float16).to(dtype)
     q = torch.randn(B, C, h, h, device="cuda")
     out = torch.empty(B, N, device="cuda")
@@ -153,6 +168,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--bank-dtype", default=None, choices=["bf16", "f32", "f16"], help="template-bank storage (default: --dtype; f16 for --scoring-only)")
+    ap.add_argument("--scoring-only", action="store_true", help="time scoring + top-5 on a resident bank (SURVEY 8(d) metric (i))")
     ap.add_argument("--skip-extras", action="store_true", help="skip roofline / cpu_baseline legs")
     ap.add_argument("--two-calls", action="store_true", help="generate_templates then retrieval as two calls (no stream overlap)")
     a = ap.parse_args()
@@ -170,7 +187,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from nope_amd.harness import build_model, synthetic_batch
-    model = build_model(seed=2022, compute_dtype=a.dtype, bank_dtype=a.dtype, device=dev, template_parallel=world > 1)
+    if a.scoring_only:
+        return scoring_only(a, dev, rank, world)
+    bank_dtype = a.bank_dtype or a.dtype
+    model = build_model(seed=2022, compute_dtype=a.dtype, bank_dtype=bank_dtype, device=dev, template_parallel=world > 1)
     n_total = a.templates * world
     batch = synthetic_batch(a.batch, n_total, a.size, seed=2022, device=dev)
     query, reference, poses = batch["query"], batch["reference"], batch["all_relativeR"]
@@ -211,7 +231,7 @@ def main():
                                f"{a.size // 8}x{a.size // 8} latent + ResNet-50 template encoder + l2 scoring + top-5",
                    "batch": a.batch, "templates_total": n_total, "templates_per_gpu": a.templates, "image": a.size,
                    "parallelism": f"template-shard x{world} + score all-gather" if world > 1 else "single GPU",
-                   "bank_dtype": a.dtype, "top5": idx[0].tolist()},
+                   "bank_dtype": bank_dtype, "top5": idx[0].tolist()},
     }
     if rank == 0 and world == 1 and not a.skip_extras:
         h = model.u_net._get_handle(dev)
@@ -229,20 +249,85 @@ def main():
         traffic = None
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if rec.get("dtype") == a.dtype and rec.get("templates") == a.templates and rec.get("size") == a.size:
+            # only next to the kernel sources it was measured on: a stale figure must not ride along after a kernel changes
+            if (rec.get("dtype") == a.dtype and rec.get("templates") == a.templates and rec.get("size") == a.size
+                    and rec.get("csrc_sha") == _csrc_sha()):
                 traffic = rec["bytes_per_launch"]
         except Exception:
             rec = None
-        res["roofline"] = {"bound": "mfma", "kernel": f"conv_gemm_dma_kernel<{a.dtype}>", "achieved": tf, "peak": peak,
+        res["roofline"] = {"bound": "mfma", "kernel": f"implicit-GEMM conv kernels <{a.dtype}>: conv3x3_halo_kernel (tap-resident 3x3, "
+                                                       f"256x192 ping-pong), conv_gemm_pp_kernel, conv_gemm_dma_kernel", "achieved": tf, "peak": peak,
                            "unit": "TFLOP/s", "frac": tf / peak, "traffic": traffic,
                            "algorithmic_bytes_per_launch": abytes / max(n_launch, 1), "launches_per_step": n_launch,
                            "avg_launch_ms": ms / max(n_launch, 1), "kernel_ms_per_step": ms, "flops_per_step": flops,
                            "note": "flops = executed MACs x2 of all implicit-GEMM launches of one step (the nearest-x2 convs run "
                                    "as four 2x2 phase convs = 4/9 of the reference MACs; 3x3 convs on the 4x4 level skip the taps lying in the zero "
                                    "padding = 69 % of theirs); time = HIP events around each launch"}
-        res["scoring_roofline"] = [scoring_roofline(torch.bfloat16), scoring_roofline(torch.float32)]
+        res["scoring_roofline"] = [scoring_roofline(torch.bfloat16), scoring_roofline(torch.float32),
+                                   scoring_roofline(torch.float16, N=1024)]      # BASELINE configs[4]: fp16 bank, 8192 / 8 templates per GPU
         res["cpu_baseline"] = cpu_baseline(model, a.size, a.templates)
         res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def scoring_only(a, dev, rank, world):
+    """SURVEY.md section 8(d) metric (i): K11 + K12 on a resident bank, template axis sharded over the ranks."""
+    import torch.distributed as dist
+    from nope_amd import dist as ndist
+    from nope_amd import hip
+    from nope_amd.model import PoseConditional
+    from nope_amd.u_net import UNet
+    from tests.util import StubEncoder
+    bank_dtype = a.bank_dtype or "f16"
+    B = a.batch if a.batch > 1 else 32
+    n_local = a.templates if a.templates != 512 else 1024
+    n_total = n_local * world
+    h = a.size // 8
+    g = torch.Generator(device=dev).manual_seed(2022 + rank)
+    bank = torch.randn(B, n_local, 8, h, h, device=dev, generator=g).to(hip.torch_dtype(hip.dtype_code(bank_dtype)))
+    gq = torch.Generator(device=dev).manual_seed(7)
+    qfeat = torch.randn(B, 8, h, h, device=dev, generator=gq)
+    if rank == 0:
+        bank[:, 3] = qfeat.to(bank.dtype)                       # planted exact matches (known answer: template 3 wins everywhere)
+    model = PoseConditional(UNet(u_net_dim=8, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer"),
+                            None, {"similarity_metric": "l2"}, None, bank_dtype=bank_dtype, template_parallel=world > 1)
+    lo, hi = ndist.shard_range(n_total, rank, world)
+    bank._nope_shard = (lo, hi, n_total) if world > 1 else None
+
+    def step():
+        return model.retrieval_from_feat(qfeat, bank)
+
+    for _ in range(a.warmup):
+        sim, idx = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sim, idx = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ok = bool((idx[:, 0] == 3).all()) and sim.shape == (B, n_total)
+    byts = B * n_local * (8 * h * h * bank.element_size() + 4)
+    res = {"metric": "pose-hypotheses/sec (queries x templates), scoring + top-5 on a resident bank", "value": B * n_total * a.steps / dt,
+           "unit": "pose-hypotheses/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": bank_dtype, "data": "synthetic",
+           "config": {"workload": f"{B} query embeddings x {n_local} templates per GPU ({bank_dtype} bank, 8 x {h} x {h}), BASELINE configs[4] slice; "
+                                  f"template-shard x{world} + score all-gather" if world > 1 else
+                                  f"{B} query embeddings x {n_local} templates ({bank_dtype} bank, 8 x {h} x {h}), BASELINE configs[4] per-GPU slice",
+                      "batch": B, "templates_total": n_total, "templates_per_gpu": n_local, "bank_dtype": bank_dtype, "planted_match_wins": ok},
+           "roofline": {"bound": "hbm", "kernel": "sim_reg_kernel (+ topk_kernel, all-gather)", "achieved": byts * a.steps / dt / 1e9 * 1.0,
+                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": byts * a.steps / dt / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                        "note": "per-GPU algorithmic bytes (bank slice + scores) / whole step time incl. top-k and collective"}}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-enum { NOPE_F32 = 0, NOPE_BF16 = 1 };
+enum { NOPE_F32 = 0, NOPE_BF16 = 1,
+       NOPE_F16 = 2 /* IEEE half: a STORAGE type of the template bank only (nope_similarity's bank_dtype, nope_unet_forward's
+                       out_dtype); the networks compute in NOPE_F32 or NOPE_BF16 */ };
 /* Tap geometries of nope_op_conv.  UP2P is UP2 (nearest-x2 upsample + 3x3, pad 1) rewritten as four
  * 2x2 convolutions over the un-upsampled input, one per output-pixel parity, with the 3x3 weights that
  * fall on the same source pixel pre-summed at pack time: same function, 4/9 of the multiply-adds. */
@@ -53,7 +55,7 @@ int nope_abi_version(void);
  *     score[b,n] = - sum_{h,w} sqrt( sum_c (q[b,c,h,w] - t[b,n,c,h,w])^4 )
  * without materialising the repeated query (model.py:258).
  *   q       (B,C,H,W) f32, contiguous
- *   bank    (B,N,C,H,W) of `bank_dtype` (NOPE_F32 | NOPE_BF16); sample stride `bank_stride_b`
+ *   bank    (B,N,C,H,W) of `bank_dtype` (NOPE_F32 | NOPE_BF16 | NOPE_F16); sample stride `bank_stride_b`
  *           ELEMENTS (0 = one bank shared by every query)
  *   scores  f32, row b at scores + b*score_ld  (score_ld >= N; lets a rank write its
  *           N/G slice of a gathered (B,N) matrix in place)

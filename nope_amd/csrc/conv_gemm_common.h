@@ -204,6 +204,7 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const typename Til
                 if (p.out_nchw) {
                     const size_t o = nchw_base + (size_t)n * HWo;
                     if (p.out_dt == NOPE_F32) reinterpret_cast<float*>(p.out)[o] = v;
+                    else if (p.out_dt == NOPE_F16) reinterpret_cast<f16_t*>(p.out)[o] = (f16_t)v;
                     else reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(v);
                 } else {
                     Elt<T>::st(out + mo * p.Cout + n, v);

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NT) void topk_kernel(const float* __restrict__ scor
 int launch_similarity(const float* q, const void* bank, int bank_dt, float* scores, int B, int N, int C, int HW,
                       long long bank_stride_b, int score_ld, hipStream_t s) {
     if (!q || !bank || !scores || B <= 0 || N <= 0 || C <= 0 || HW <= 0 || score_ld < N || bank_stride_b < 0) return NOPE_ERR_ARG;
-    if (bank_dt != NOPE_F32 && bank_dt != NOPE_BF16) return NOPE_ERR_UNSUPPORTED;
+    if (bank_dt != NOPE_F32 && bank_dt != NOPE_BF16 && bank_dt != NOPE_F16) return NOPE_ERR_UNSUPPORTED;
     const int vec = bank_dt == NOPE_F32 ? 4 : 8;
     if (HW % vec) return NOPE_ERR_UNSUPPORTED;
     const int P = HW / vec;
@@ -223,9 +223,12 @@ int launch_similarity(const float* q, const void* bank, int bank_dt, float* scor
         if (bank_dt == NOPE_F32) {
             if (C <= 8) hipLaunchKernelGGL((sim_reg_kernel<float, 8>), grid, block, 0, s, q, (const float*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
             else hipLaunchKernelGGL((sim_reg_kernel<float, 16>), grid, block, 0, s, q, (const float*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
-        } else {
+        } else if (bank_dt == NOPE_BF16) {
             if (C <= 8) hipLaunchKernelGGL((sim_reg_kernel<bf16_t, 8>), grid, block, 0, s, q, (const bf16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
             else hipLaunchKernelGGL((sim_reg_kernel<bf16_t, 16>), grid, block, 0, s, q, (const bf16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
+        } else {
+            if (C <= 8) hipLaunchKernelGGL((sim_reg_kernel<f16_t, 8>), grid, block, 0, s, q, (const f16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
+            else hipLaunchKernelGGL((sim_reg_kernel<f16_t, 16>), grid, block, 0, s, q, (const f16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
         }
     } else {
         if ((size_t)C * HW > 16384) return NOPE_ERR_UNSUPPORTED;
@@ -233,7 +236,8 @@ int launch_similarity(const float* q, const void* bank, int bank_dt, float* scor
         if (nsplit > N) nsplit = N;
         dim3 grid((unsigned)((long long)B * nsplit)), block(NT);
         if (bank_dt == NOPE_F32) hipLaunchKernelGGL((sim_lds_kernel<float>), grid, block, 0, s, q, (const float*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
-        else hipLaunchKernelGGL((sim_lds_kernel<bf16_t>), grid, block, 0, s, q, (const bf16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
+        else if (bank_dt == NOPE_BF16) hipLaunchKernelGGL((sim_lds_kernel<bf16_t>), grid, block, 0, s, q, (const bf16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
+        else hipLaunchKernelGGL((sim_lds_kernel<f16_t>), grid, block, 0, s, q, (const f16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
     }
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;

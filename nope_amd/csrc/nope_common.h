@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef unsigned short bf16_t;   // raw bfloat16 bits
+typedef _Float16 f16_t;          // IEEE half (bank storage only): hardware v_cvt_f16_f32 / v_cvt_f32_f16, round-to-nearest-even
 
 constexpr int kWave = 64;
 
@@ -81,6 +82,24 @@ template <> struct Elt<bf16_t> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = cvt_pk_bf16(o[2 * i], o[2 * i + 1]);
         return v;
+    }
+};
+
+template <> struct Elt<f16_t> {
+    static constexpr int VEC = 8;
+    static constexpr int DT = NOPE_F16;
+    static __device__ __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+    static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
+    static __device__ __forceinline__ void unpack(const u32x4& v, float* o) {
+        union { u32x4 u; f16_t h[8]; } x; x.u = v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (float)x.h[i];
+    }
+    static __device__ __forceinline__ u32x4 pack(const float* o) {
+        union { u32x4 u; f16_t h[8]; } x;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x.h[i] = (f16_t)o[i];
+        return x.u;
     }
 };
 

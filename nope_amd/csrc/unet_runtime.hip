@@ -603,7 +603,7 @@ int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep
     int e = check_shape(net, n_hyp, n_src, x_rep, H, W);
     if (e) return e;
     if (!x || !pose || !out || !workspace) return NOPE_ERR_ARG;
-    if (out_dtype != NOPE_F32 && out_dtype != NOPE_BF16) return NOPE_ERR_UNSUPPORTED;
+    if (out_dtype != NOPE_F32 && out_dtype != NOPE_BF16 && out_dtype != NOPE_F16) return NOPE_ERR_UNSUPPORTED;
     unsigned char* base = (unsigned char*)(((uintptr_t)workspace + 255) / 256 * 256);
     const size_t lost = (size_t)(base - (unsigned char*)workspace);
     if (workspace_bytes < lost) return NOPE_ERR_WORKSPACE;

@@ -12,7 +12,7 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2      # F16: a bank / output storage type only
 CONV_PLAIN, CONV_UP2, CONV_DOWN2, CONV_UP2P, CONV_STRIDE2 = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -159,7 +159,7 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def torch_dtype(dt: int) -> torch.dtype:
-    return torch.float32 if dt == F32 else torch.bfloat16
+    return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[dt]
 
 
 def dtype_code(dt) -> int:
@@ -167,6 +167,8 @@ def dtype_code(dt) -> int:
         return F32
     if dt in (BF16, "bf16", "bfloat16", torch.bfloat16):
         return BF16
+    if dt in (F16, "f16", "fp16", "float16", "half", torch.float16):
+        return F16
     raise NopeError(f"unsupported dtype {dt!r}")
 
 
@@ -188,7 +190,7 @@ def similarity(q: torch.Tensor, bank: torch.Tensor, out: Optional[torch.Tensor] 
     B, Cc, H, W = q.shape
     if bank.dim() != 5 or tuple(bank.shape[2:]) != (Cc, H, W) or bank.shape[0] not in (1, B):
         raise NopeError(f"bank shape {tuple(bank.shape)} does not match query {tuple(q.shape)}")
-    if bank.dtype not in (torch.float32, torch.bfloat16):
+    if bank.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         bank = bank.float()
     bank = bank.contiguous()
     N = bank.shape[1]

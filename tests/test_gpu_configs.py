@@ -1,0 +1,176 @@
+"""GPU: the BASELINE.json configurations that round 1 left without a test (configs[2], [3], [4]), `PoseConditional.sample`
+and the evaluation harness end to end.
+
+  configs[2]  batch = 32 queries x 512 templates, bf16, one GPU                 test_config2_batch32_x_512_bf16
+  configs[3]  batch = 32 x 4096 templates sharded 8-way -> 512 per rank          test_per_rank_shapes_of_configs_3_and_4[512-bf16]
+  configs[4]  fp16 bank, 8192 templates on 8 GPUs -> 1024 per rank              test_per_rank_shapes_of_configs_3_and_4[1024-f16]
+The sharded configurations run their PER-RANK shape with several ranks sharing the one GPU of the test box (gloo carries
+the score all-gather; 8-GPU RCCL runs are the driver's), and are compared with the unsharded call: same launches, same
+bits."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import nope_ref as R
+from tests.util import rel
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def model_f32(gpu):
+    from nope_amd.harness import build_model
+    return build_model(compute_dtype="f32", bank_dtype="f32", device="cuda")
+
+
+@pytest.fixture(scope="module")
+def model_bf16(gpu):
+    from nope_amd.harness import build_model
+    return build_model(compute_dtype="bf16", bank_dtype="bf16", device="cuda")
+
+
+def test_config2_batch32_x_512_bf16(model_bf16, model_f32):
+    """BASELINE configs[2] end to end: 32 queries x 512 templates (16384 pose hypotheses) through encoder, U-Net, scoring
+    and top-5 in the benchmark's bf16 mode.  (i) a spread of (b, n) hypotheses against the CPU restatement, embedding map
+    and score; (ii) per query, the best template of the bf16 run equals the best template of the f32 parity mode wherever
+    the f32 top-1 gap exceeds twice the largest bf16 score deviation (everywhere else both candidates are reported)."""
+    from nope_amd.harness import synthetic_batch
+    b = synthetic_batch(32, 512, 256, seed=77, device="cuda")
+    sim, idx, bank = model_bf16.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
+    torch.cuda.synchronize()
+    assert sim.shape == (32, 512) and idx.shape == (32, 5) and bank.shape == (32, 512, 8, 32, 32) and bool(torch.isfinite(sim).all())
+    # (i) oracle spot check
+    enc_sd = {k: v.detach().cpu() for k, v in model_bf16.u_net.encoder.state_dict().items()}
+    sd = {k: v.detach().cpu() for k, v in model_bf16.u_net.own_state_dict().items()}
+    pairs = [(0, 0), (0, 511), (7, 130), (16, 255), (31, 1), (31, 511)]
+    worst_map = worst_score = 0.0
+    for bb in sorted({p[0] for p in pairs}):
+        ref_feat = R.encode_image(enc_sd, b["reference"][bb:bb + 1].cpu())
+        q_feat = R.encode_image(enc_sd, b["query"][bb:bb + 1].cpu())
+        ns = [n for (x, n) in pairs if x == bb]
+        want = R.generate_templates(sd, ref_feat, b["all_relativeR"][bb:bb + 1, ns].cpu())
+        got = bank[bb:bb + 1, ns].float().cpu()
+        worst_map = max(worst_map, rel(got, want))
+        s_want = R.similarity_scores(q_feat, want)
+        worst_score = max(worst_score, float(((sim[bb, ns].cpu() - s_want[0]).abs() / s_want[0].abs()).max()))
+    print(f"configs[2] bf16: embedding maps rel err {worst_map:.3e}, scores rel err {worst_score:.3e} on {pairs}")
+    assert worst_map < 6e-2 and worst_score < 5e-2
+    # (ii) arg-top against the f32 parity mode (itself pinned to the reference at configs[0] / configs[1])
+    sim32, idx32, _ = model_f32.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
+    dev = float((sim - sim32).abs().max())
+    top2 = sim32.topk(2, dim=1).values
+    gap = (top2[:, 0] - top2[:, 1])
+    decided = gap > 2 * dev
+    same = idx[:, 0] == idx32[:, 0]
+    print(f"configs[2]: max |bf16 - f32| score {dev:.3f} (rel {dev / float(sim32.abs().max()):.2e}); top-1 equal for {int(same.sum())}/32 "
+          f"queries, {int(decided.sum())} of them decided by more than 2x that deviation")
+    assert bool(same[decided].all()) and int(decided.sum()) >= 8
+    # wherever they differ, the bf16 winner is among the f32 top-5
+    for q in range(32):
+        assert int(idx[q, 0]) in idx32[q].tolist()
+
+
+def test_sample_vs_oracle(model_f32):
+    """PoseConditional.sample (model.py:113-124): u_net(encode_image(reference), relativeR), no decoder for the template encoder."""
+    g = torch.Generator().manual_seed(31)
+    ref = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    pose = torch.randn(2, 6, generator=g)
+    pred, rgb = model_f32.sample(ref.cuda(), pose.cuda())
+    assert rgb is None and pred.shape == (2, 8, 8, 8)
+    enc_sd = {k: v.detach().cpu() for k, v in model_f32.u_net.encoder.state_dict().items()}
+    sd = {k: v.detach().cpu() for k, v in model_f32.u_net.own_state_dict().items()}
+    want = R.unet_forward(sd, R.encode_image(enc_sd, ref), pose)
+    e = rel(pred.cpu(), want)
+    print("sample() f32 rel err", e)
+    assert e < 1e-4
+
+
+def test_harness_eval_geodesic_config1(model_f32, golden, tmp_path):
+    """The harness body (counterpart of the missing test_shapeNet.py -> PoseConditional.eval_geodesic, model.py:268-376) on
+    BASELINE configs[0]'s batch: top-5 indices and loss equal the values recorded from the reference; the accuracy
+    dictionary is what the retrieved template poses imply; the saved prediction file holds query_pose + similarity."""
+    import numpy as np
+    from nope_amd.harness import eval_geodesic, geodesic_deg, main, synthetic_batch
+    g = golden("pipeline_cfg1.npz")
+    batch = synthetic_batch(1, 64, 128, seed=2022, device="cuda")
+    assert torch.equal(batch["query"].cpu(), g["query"]) and torch.equal(batch["all_relativeR"].cpu(), g["all_relativeR"])
+    save = str(tmp_path / "pred_step0_rank0")
+    sim, idx, res = eval_geodesic(model_f32, batch, save_path=save)
+    assert torch.equal(idx.cpu(), g["idx"]) and rel(sim.cpu(), g["sim"]) < 1e-4
+    assert abs(res["loss"] - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert set(res) == {"loss"} | {f"top{k}, {m}" for k in (1, 3, 5) for m in ("accuracy_15", "accuracy_30", "median")}
+    err = geodesic_deg(batch["template_poses"][0][idx[0]].cpu(), batch["query_pose"].cpu().expand(5, -1, -1))   # (5,) degrees
+    for k in (1, 3, 5):
+        best = float(err[:k].min())
+        assert res[f"top{k}, accuracy_15"] == (100.0 if best <= 15 else 0.0) and res[f"top{k}, accuracy_30"] == (100.0 if best <= 30 else 0.0)
+        assert abs(res[f"top{k}, median"] - best) < 2e-2
+    z = np.load(save + ".npz")
+    assert z["similarity"].shape == (1, 64) and z["query_pose"].shape == (1, 3, 3)
+    # the command-line entry point (python -m nope_amd.harness), small shape
+    main(["--batch", "2", "--templates", "6", "--size", "64", "--save-dir", str(tmp_path / "run")])
+    assert os.path.isdir(tmp_path / "run" / "predictions")
+
+
+def _shard_worker(rank, ws, port, n_per_rank, bank_dtype, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        from nope_amd.harness import build_model, synthetic_batch
+        torch.cuda.set_device(0)
+        B, N = 32, n_per_rank * ws
+        b = synthetic_batch(B, N, 256, seed=91, device="cuda")
+        m = build_model(compute_dtype="bf16", bank_dtype=bank_dtype, device="cuda", template_parallel=True)
+        sim, idx, bank = m.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
+        torch.cuda.synchronize()
+        out = {"shape": tuple(bank.shape), "dtype": str(bank.dtype), "sim": sim.cpu(), "idx": idx.cpu()}
+        if rank == 0:          # the unsharded call: same per-launch hypothesis batches (one reference image x 512 poses), so the same bits
+            m.template_parallel = False
+            sim1, idx1, _ = m.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
+            torch.cuda.synchronize()
+            out["sim1"], out["idx1"] = sim1.cpu(), idx1.cpu()
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_per_rank,ws,bank_dtype", [(512, 3, "bf16"), (1024, 2, "f16")])
+def test_per_rank_shapes_of_configs_3_and_4(gpu, n_per_rank, ws, bank_dtype):
+    """BASELINE configs[3] (32 x 4096 templates, 8-way) and configs[4] (fp16 bank, 8192 templates on 8 GPUs) at their per-rank
+    shapes -- 32 queries x 512 / 1024 templates per rank -- through the template-parallel path, several ranks on this GPU."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29800 + os.getpid() % 1500
+    mp.spawn(_shard_worker, args=(ws, port, n_per_rank, bank_dtype, ret), nprocs=ws, join=True)
+    N = n_per_rank * ws
+    for r in range(ws):
+        o = ret[r]
+        assert o["shape"] == (32, n_per_rank, 8, 32, 32) and o["dtype"] == {"bf16": "torch.bfloat16", "f16": "torch.float16"}[bank_dtype]
+        assert o["sim"].shape == (32, N) and torch.equal(o["sim"], ret[0]["sim"]) and torch.equal(o["idx"], ret[0]["idx"])
+    assert torch.equal(ret[0]["sim"], ret[0]["sim1"]) and torch.equal(ret[0]["idx"], ret[0]["idx1"])
+    assert bool(torch.isfinite(ret[0]["sim"]).all()) and len(set(ret[0]["idx"][:, 0].tolist())) > 1
+
+
+def test_geodesic_metric_on_device(gpu):
+    """GeodesicError with all three symmetry branches (loss.py:14-115) evaluated on CUDA tensors -- the
+    step right behind the hot path, on the poses' device -- equals the host evaluation (float64 branch arithmetic)."""
+    from nope_amd.harness import random_rotations
+    from nope_amd.metrics import GeodesicError
+    g = torch.Generator().manual_seed(5)
+    B = 48
+    pred = random_rotations(B * 5, g).view(B, 5, 3, 3)
+    gt = random_rotations(B, g)
+    sym = torch.arange(B).view(B, 1) % 3                       # 0: none, 1: 180 degrees about Y, 2: circular
+    for p in (pred, pred[:, 0]):
+        e_cpu, r_cpu = GeodesicError([15, 30])(p, gt, sym)
+        e_gpu, r_gpu = GeodesicError([15, 30])(p.cuda(), gt.cuda(), sym.cuda())
+        assert e_gpu.is_cuda and torch.allclose(e_gpu.cpu().double(), e_cpu.double(), atol=1e-4, equal_nan=True)
+        assert set(r_cpu) == set(r_gpu)
+        for k in r_cpu:
+            assert abs(float(r_cpu[k]) - float(r_gpu[k])) < 1e-3, k

@@ -16,7 +16,7 @@ def main(path, out, dtype="bf16", templates=512, size=256):
         if not line.startswith(" "):
             name = line.strip()
             continue
-        if name and "conv_gemm_dma_kernel<" + tag in name:
+        if name and any(k + "<" + tag in name for k in ("conv_gemm_dma_kernel", "conv_gemm_pp_kernel", "conv3x3_halo_kernel")):
             m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*(\d+)\s+mean/dispatch=\S+\s+total=(\S+)", line)
             if m:
                 if m.group(1) == "FETCH_SIZE":
@@ -24,7 +24,11 @@ def main(path, out, dtype="bf16", templates=512, size=256):
                 else:
                     write += float(m.group(3)); nw += int(m.group(2))
     assert nf and nf == nw, (nf, nw)
-    rec = {"dtype": dtype, "templates": templates, "size": size, "kernel": "conv_gemm_dma_kernel (all tap modes)",
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import _csrc_sha
+    rec = {"dtype": dtype, "templates": templates, "size": size, "csrc_sha": _csrc_sha(),
+           "kernel": "implicit-GEMM conv kernels of the U-Net (conv3x3_halo_kernel, conv_gemm_pp_kernel, conv_gemm_dma_kernel)",
            "launches": nf, "fetch_kib_per_launch_raw": fetch / nf, "write_kib_per_launch_raw": write / nw,
            "bytes_per_launch": (2.0 * fetch / nf + write / nw) * 1024.0,
            "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as reported; separate --pmc passes; "
