@@ -38,7 +38,8 @@ def test_config2_batch32_x_512_bf16(model_bf16, model_f32):
     """BASELINE configs[2] end to end: 32 queries x 512 templates (16384 pose hypotheses) through encoder, U-Net, scoring
     and top-5 in the benchmark's bf16 mode.  (i) a spread of (b, n) hypotheses against the CPU restatement, embedding map
     and score; (ii) per query, the best template of the bf16 run equals the best template of the f32 parity mode wherever
-    the f32 top-1 gap exceeds twice the largest bf16 score deviation (everywhere else both candidates are reported)."""
+    the f32 top-1 gap exceeds twice that query's largest bf16 score deviation, for at least 28 of the 32 queries overall,
+    and is always among the f32 top-5."""
     from nope_amd.harness import synthetic_batch
     b = synthetic_batch(32, 512, 256, seed=77, device="cuda")
     sim, idx, bank = model_bf16.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
@@ -62,14 +63,16 @@ def test_config2_batch32_x_512_bf16(model_bf16, model_f32):
     assert worst_map < 6e-2 and worst_score < 5e-2
     # (ii) arg-top against the f32 parity mode (itself pinned to the reference at configs[0] / configs[1])
     sim32, idx32, _ = model_f32.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
-    dev = float((sim - sim32).abs().max())
+    dev_q = (sim - sim32).abs().max(dim=1).values                # largest bf16 deviation per query
     top2 = sim32.topk(2, dim=1).values
     gap = (top2[:, 0] - top2[:, 1])
-    decided = gap > 2 * dev
+    decided = gap > 2 * dev_q
     same = idx[:, 0] == idx32[:, 0]
-    print(f"configs[2]: max |bf16 - f32| score {dev:.3f} (rel {dev / float(sim32.abs().max()):.2e}); top-1 equal for {int(same.sum())}/32 "
-          f"queries, {int(decided.sum())} of them decided by more than 2x that deviation")
-    assert bool(same[decided].all()) and int(decided.sum()) >= 8
+    print(f"configs[2]: max |bf16 - f32| score {float(dev_q.max()):.3f} (rel {float(dev_q.max()) / float(sim32.abs().max()):.2e}); top-1 equal for "
+          f"{int(same.sum())}/32 queries; {int(decided.sum())} queries have an f32 top-1 gap above twice their bf16 deviation")
+    # the bf16 error is mostly a common shift of a query's scores, so the ranking survives far more often than the worst-case
+    # bound promises: demand the bound where it applies and a large majority overall
+    assert bool(same[decided].all()) and int(same.sum()) >= 28
     # wherever they differ, the bf16 winner is among the f32 top-5
     for q in range(32):
         assert int(idx[q, 0]) in idx32[q].tolist()
