@@ -191,6 +191,29 @@ int launch_cast(int dt, const float* in, void* out, size_t n, hipStream_t s) {
     return NOPE_OK;
 }
 
+// "posEncoding" pose embedding, src/model/utils.py:36-51 with dim = classes / pose_dim: out[b, i*half + j] = sin(pose[b,i] * f_j),
+// out[b, classes/2 + i*half + j] = cos(pose[b,i] * f_j), f_j = exp(-j * ln(1e4) / (half - 1)) evaluated in f32 as torch does.
+__global__ __launch_bounds__(NT) void pos_emb_kernel(const float* __restrict__ pose, float* __restrict__ out, int n, int pose_dim, int half) {
+    const int per = pose_dim * half;
+    const size_t total = (size_t)n * per;
+    const float step = logf(10000.0f) / (float)(half - 1);
+    for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
+        const int b = (int)(idx / per), r = (int)(idx - (size_t)b * per);
+        const int i = r / half, j = r - i * half;
+        const float a = pose[(size_t)b * pose_dim + i] * expf((float)j * -step);
+        out[(size_t)b * 2 * per + r] = sinf(a);
+        out[(size_t)b * 2 * per + per + r] = cosf(a);
+    }
+}
+
+int launch_pos_emb(const float* pose, float* out, int n, int pose_dim, int classes, hipStream_t s) {
+    if (!pose || !out || n <= 0 || pose_dim <= 0 || classes % (2 * pose_dim) || classes / (2 * pose_dim) < 2) return NOPE_ERR_ARG;
+    const int half = classes / (2 * pose_dim);
+    hipLaunchKernelGGL(pos_emb_kernel, dim3(grid_for((size_t)n * pose_dim * half)), dim3(NT), 0, s, pose, out, n, pose_dim, half);
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
 int launch_silu_f32(const float* in, float* out, size_t n, hipStream_t s) {
     if (!in || !out) return NOPE_ERR_ARG;
     if (n == 0) return NOPE_OK;

@@ -369,7 +369,8 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
     // ---- input + pose embedding ----------------------------------------------------------------
     if (f.live()) {
         f.chk(launch_nchw_to_nhwc(net->dt, x, x_in, n_src, cfg.channels, HW, s));
-        f.chk(launch_linear_naive(pose, net->pose_w0, net->pose_b0, c0, n_hyp, net->classes, cfg.pose_dim, 0, net->classes, s));
+        if (cfg.pose_mlp_layers == 0) f.chk(launch_pos_emb(pose, c0, n_hyp, cfg.pose_dim, net->classes, s));   // u_net.py:73-76
+        else f.chk(launch_linear_naive(pose, net->pose_w0, net->pose_b0, c0, n_hyp, net->classes, cfg.pose_dim, 0, net->classes, s));
         const float* c = c0;
         if (cfg.pose_mlp_layers == 2) {
             f.chk(launch_linear_naive(c0, net->pose_w2, net->pose_b2, c1, n_hyp, net->classes, net->classes, 2, net->classes, s));
@@ -470,7 +471,8 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
     if (!cfg || !tensors || !out || n_tensors <= 0) return NOPE_ERR_ARG;
     if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->groups < 1 || cfg->heads < 1 || cfg->dim_head != 32) return NOPE_ERR_UNSUPPORTED;
     if (cfg->compute_dtype != NOPE_F32 && cfg->compute_dtype != NOPE_BF16) return NOPE_ERR_UNSUPPORTED;
-    if (cfg->pose_mlp_layers != 1 && cfg->pose_mlp_layers != 2) return NOPE_ERR_UNSUPPORTED;
+    if (cfg->pose_mlp_layers < 0 || cfg->pose_mlp_layers > 2) return NOPE_ERR_UNSUPPORTED;   // 0 = "posEncoding" (no parameters)
+    if (cfg->pose_mlp_layers == 0 && (cfg->pose_dim < 1 || (cfg->u_net_dim * 4) % (2 * cfg->pose_dim) || cfg->u_net_dim * 4 / cfg->pose_dim < 4)) return NOPE_ERR_UNSUPPORTED;
     if (cfg->u_net_dim % 8 || cfg->channels % 8 || cfg->u_net_dim % cfg->groups) return NOPE_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     nope_unet* net = new nope_unet();
@@ -489,8 +491,10 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
         if (tensors[i].name) ld.tab[tensors[i].name] = &tensors[i];
     std::vector<std::pair<std::string, int>> embs;
 
-    net->pose_w0 = ld.copy_f32("pose_mlp.0.weight", {net->classes, cfg->pose_dim});
-    net->pose_b0 = ld.copy_f32("pose_mlp.0.bias", {net->classes});
+    if (cfg->pose_mlp_layers >= 1) {
+        net->pose_w0 = ld.copy_f32("pose_mlp.0.weight", {net->classes, cfg->pose_dim});
+        net->pose_b0 = ld.copy_f32("pose_mlp.0.bias", {net->classes});
+    }
     if (cfg->pose_mlp_layers == 2) {
         net->pose_w2 = ld.copy_f32("pose_mlp.2.weight", {net->classes, net->classes});
         net->pose_b2 = ld.copy_f32("pose_mlp.2.bias", {net->classes});

@@ -93,6 +93,10 @@ class UNet(nn.Module):
         elif pose_mlp_name == "two_layers":
             self.pose_mlp = _slot(nn.Linear(rot_representation_dim, emb), None, nn.Linear(emb, emb))
             self._pose_layers = 2
+        elif pose_mlp_name == "posEncoding":          # u_net.py:73-76: parameter-free SinusoidalPosEmb(dim = emb / 6)
+            assert emb % (2 * rot_representation_dim) == 0, "classes_dim must be divisible by 2 * rot_representation_dim"
+            self.pose_mlp = _Params()
+            self._pose_layers = 0
         else:
             raise NotImplementedError(f"pose_mlp_name={pose_mlp_name!r} (reference default is 'single_layer')")
         dims = [u_net_dim] + [u_net_dim * m for m in dim_mults]

@@ -118,7 +118,15 @@ def hard_upsample(x: Tensor, sd: SD, p: str) -> Tensor:
 # --------------------------------------------------------------------------------------
 def pose_mlp(pose: Tensor, sd: SD) -> Tensor:
     """`pose_mlp`, u_net.py:61-76: "single_layer" = Linear(6, 4*dim); "two_layers" adds
-    GELU + Linear.  The variant is inferred from the keys present."""
+    GELU + Linear; "posEncoding" = the parameter-free SinusoidalPosEmb(dim = 4*u_net_dim / 6) of src/model/utils.py:36-51
+    (per pose component: frequencies exp(-j * ln(1e4) / (half - 1)), all sines then all cosines).  The variant is
+    inferred from the keys present."""
+    if "pose_mlp.0.weight" not in sd:
+        classes = sd["downs.0.0.mlp.1.weight"].shape[1]
+        half = classes // pose.shape[1] // 2
+        freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+        emb = (pose[:, :, None] * freq[None, None, :]).reshape(pose.shape[0], -1)
+        return torch.cat((emb.sin(), emb.cos()), dim=-1)
     c = F.linear(pose, sd["pose_mlp.0.weight"], sd["pose_mlp.0.bias"])
     if "pose_mlp.2.weight" in sd:
         c = F.linear(F.gelu(c), sd["pose_mlp.2.weight"], sd["pose_mlp.2.bias"])

@@ -85,7 +85,8 @@ def unets():
     U = RI.ref_unet_cls()
     out = {}
     g = torch.Generator().manual_seed(SEED + 1)
-    for tag, dim, hw, mlp in (("d8", 8, 8, "single_layer"), ("d16", 16, 16, "single_layer"), ("d16two", 16, 8, "two_layers")):
+    for tag, dim, hw, mlp in (("d8", 8, 8, "single_layer"), ("d16", 16, 16, "single_layer"), ("d16two", 16, 8, "two_layers"),
+                              ("d24pos", 24, 8, "posEncoding")):
         mine = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=RI.StubEncoder(8), pose_mlp_name=mlp)
         synth_init_(mine, SEED)
         ref = U(u_net_dim=dim, rot_representation_dim=6, encoder=RI.StubEncoder(8), pose_mlp_name=mlp)

@@ -30,7 +30,8 @@ def test_blocks(golden):
     assert rel(R.hard_upsample(g["up/in0"], sub(g, "up"), ""), g["up/out"]) < TOL
 
 
-@pytest.mark.parametrize("tag,dim,mlp", [("d8", 8, "single_layer"), ("d16", 16, "single_layer"), ("d16two", 16, "two_layers")])
+@pytest.mark.parametrize("tag,dim,mlp", [("d8", 8, "single_layer"), ("d16", 16, "single_layer"), ("d16two", 16, "two_layers"),
+                                         ("d24pos", 24, "posEncoding")])
 def test_tiny_unets(golden, tag, dim, mlp):
     from nope_amd.u_net import UNet
     from nope_amd.weights import sha256_of, synth_init_
