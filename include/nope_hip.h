@@ -126,6 +126,39 @@ int nope_unet_profile(nope_unet* net, int enable);
 int nope_unet_profile_read(nope_unet* net, int* n_launches, double* total_ms, double* total_flops, double* total_bytes);
 
 /* ------------------------------------------------------------------------------------------
+ * LDM cross-attention U-Net variant.  Replaces UNetModelPose.__init__/forward,
+ * src/model/u_net/ldm/adapt_openaimodel.py:14-158 (over UNetModel, ldm/openaimodel.py:428-760; ResBlock :177-288, Downsample /
+ * Upsample :93-174; SpatialTransformer / BasicTransformerBlock / CrossAttention / GEGLU, ldm/attention.py:37-277): the variant
+ * whose pose conditioning is cross-attention against context = pose_mlp(pose).  Tensor names are UNetModelPose's own
+ * state-dict keys ("input_blocks.1.1.transformer_blocks.0.attn2.to_v.weight", "middle_block.0.in_layers.2.weight", ...).
+ * Supported: use_spatial_transformer = true with transformer_depth = 1 and num_head_channels = 32 (the shipped
+ * configs/model/vae_cin_ldm.yaml), conv_resample, no scale-shift norm, no resblock_updown; pose_mlp "single_layer" /
+ * "two_layers"; injecting_condition_twice on or off. */
+typedef struct nope_ldm nope_ldm;
+typedef struct {
+    int in_channels;        /* 4 in vae_cin_ldm.yaml (bf16 compute needs a multiple of 8) */
+    int model_channels;     /* 256 */
+    int out_channels;       /* 4 */
+    int num_res_blocks;     /* 2 */
+    int n_levels;           /* len(channel_mult) = 3 */
+    int channel_mult[8];    /* (1,2,4) */
+    int attn_levels[8];     /* 1 where the level's downsampling factor is in attention_resolutions: (1,1,1) */
+    int num_head_channels;  /* 32 */
+    int context_dim;        /* 512 */
+    int pose_dim;           /* rot_representation_dim, 6 */
+    int pose_mlp_layers;    /* 1 = "single_layer", 2 = "two_layers" */
+    int injecting_condition_twice;   /* 0: timestep embedding is zeros; 1: emb = pose_mlp_timesteps(pose) */
+    int compute_dtype;      /* NOPE_F32 | NOPE_BF16, as nope_unet_config */
+} nope_ldm_config;
+
+int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors, int n_tensors, nope_stream_t stream, nope_ldm** out);
+void nope_ldm_destroy(nope_ldm* net);
+size_t nope_ldm_workspace_bytes(const nope_ldm* net, int n_hyp, int n_src, int H, int W);
+/* out[j] = UNetModelPose(x[j / x_rep], pose[j]); arguments as nope_unet_forward. */
+int nope_ldm_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, const float* pose, int n_hyp, int H, int W,
+                     void* out, int out_dtype, void* workspace, size_t workspace_bytes, nope_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Template encoder.  Replaces FeatureExtractor.encode_image, src/model/encoder/template.py:47-53
  * (ResNet-50 trunk src/model/encoder/resnet.py:92-152 with eval-mode BatchNorm, then the
  * ReLU/1x1/ReLU/1x1 projector template.py:33-38).  Tensor names are the FeatureExtractor's own
@@ -187,6 +220,13 @@ int nope_op_attention(int dtype, const void* qkv, void* out, int n_hyp, int HW, 
  * pose_mlp (u_net.py:63-72) and ResnetBlock.mlp (model_utils.py:261-265). */
 int nope_op_linear(const float* in, const float* w, const float* bias, float* out, int M, int N, int K, int act_in,
                    nope_stream_t s);
+
+/* Token-space operators of the LDM variant (ldm/attention.py), tokens = NHWC pixels [M][C]:
+ * LayerNorm over C (:210-212); GEGLU in [M][2D] -> out [M][D] (:37-44); softmax self-attention over the N tokens of each
+ * sample on a fused [n][N][3C] q|k|v tensor, heads of 32 channels (:168-189). */
+int nope_op_layer_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, int64_t M, int C, float eps, nope_stream_t s);
+int nope_op_geglu(int dtype, const void* in, void* out, int64_t M, int D, nope_stream_t s);
+int nope_op_token_attention(int dtype, const void* qkv, void* out, int n, int N, int C, int dim_head, nope_stream_t s);
 
 #ifdef __cplusplus
 }

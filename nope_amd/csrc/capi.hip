@@ -84,6 +84,15 @@ int nope_op_linear_attention(int dtype, const void* qkv, void* out, int n_hyp, i
 int nope_op_attention(int dtype, const void* qkv, void* out, int n_hyp, int HW, int heads, int dim_head, nope_stream_t s) {
     return launch_attn(dtype, qkv, out, n_hyp, HW, heads, dim_head, (hipStream_t)s);
 }
+int nope_op_layer_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, int64_t M, int C, float eps, nope_stream_t s) {
+    return launch_layernorm(dtype, x, y, gamma, beta, (long long)M, C, eps, (hipStream_t)s);
+}
+int nope_op_geglu(int dtype, const void* in, void* out, int64_t M, int D, nope_stream_t s) {
+    return launch_geglu(dtype, in, out, (long long)M, D, (hipStream_t)s);
+}
+int nope_op_token_attention(int dtype, const void* qkv, void* out, int n, int N, int C, int dim_head, nope_stream_t s) {
+    return launch_token_attention(dtype, qkv, out, n, N, C, dim_head, (hipStream_t)s);
+}
 int nope_op_linear(const float* in, const float* w, const float* bias, float* out, int M, int N, int K, int act_in, nope_stream_t s) {
     return launch_linear_naive(in, w, bias, out, M, N, K, act_in, N, (hipStream_t)s);
 }

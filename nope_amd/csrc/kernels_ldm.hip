@@ -1,0 +1,235 @@
+// Token-space kernels of the LDM cross-attention U-Net variant (src/model/u_net/ldm/attention.py:149-277): LayerNorm over the
+// channels of a token, GEGLU, softmax self-attention over the h*w tokens of a sample, and the per-sample broadcast add
+// that the single-token cross-attention collapses to.  Activations are NHWC, i.e. already (sample, token, channel).
+#include "nope_common.h"
+
+namespace nope {
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---- LayerNorm(C) per token (attention.py:210-212, eps 1e-5): one wave per token, 16-byte vectors -----------------------
+template <class T>
+__global__ __launch_bounds__(NT) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, long long M, int C, float eps) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const long long tok = (long long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (tok >= M) return;
+    const T* xr = x + tok * C;
+    T* yr = y + tok * C;
+    const int nv = C / VEC;
+    float s = 0.f, q = 0.f;
+    for (int v = lane; v < nv; v += 64) {
+        float t[VEC];
+        Elt<T>::unpack(ld16(xr + v * VEC), t);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s += t[e]; q += t[e] * t[e]; }
+    }
+    s = wave_sum(s); q = wave_sum(q);
+    const float mean = s / (float)C;
+    float var = q / (float)C - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    for (int v = lane; v < nv; v += 64) {
+        float t[VEC];
+        Elt<T>::unpack(ld16(xr + v * VEC), t);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) t[e] = (t[e] - mean) * rstd * gamma[v * VEC + e] + beta[v * VEC + e];
+        st16(yr + v * VEC, Elt<T>::pack(t));
+    }
+}
+
+// ---- GEGLU (attention.py:37-44): in (M, 2*D) = [x | gate] -> out (M, D) = x * gelu(gate), exact (erf) GELU ---------------
+template <class T>
+__global__ __launch_bounds__(NT) void geglu_kernel(const T* __restrict__ in, T* __restrict__ out, long long M, int D) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int nv = D / VEC;
+    const long long total = M * nv;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const long long m = i / nv;
+        const int v = (int)(i - m * nv);
+        float a[VEC], g[VEC];
+        Elt<T>::unpack(ld16(in + m * 2 * D + v * VEC), a);
+        Elt<T>::unpack(ld16(in + m * 2 * D + D + v * VEC), g);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = a[e] * (0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752f)));
+        st16(out + m * D + v * VEC, Elt<T>::pack(a));
+    }
+}
+
+// ---- y[s, t, :] = x[s, t, :] + u[s, :]: what cross-attention against ONE context token is (softmax over a single key == 1,
+// so attn2(x, context) = to_out(to_v(context)) for every query token, attention.py:168-189 with j = 1) ------------------------
+template <class T>
+__global__ __launch_bounds__(NT) void add_rowvec_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ u,
+                                                        long long M, int tokens, int C) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int nv = C / VEC;
+    const long long total = M * nv;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const long long m = i / nv;
+        const int v = (int)(i - m * nv);
+        const float* ur = u + (m / tokens) * C + v * VEC;
+        float t[VEC];
+        Elt<T>::unpack(ld16(x + m * C + v * VEC), t);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) t[e] += ur[e];
+        st16(y + m * C + v * VEC, Elt<T>::pack(t));
+    }
+}
+
+// ---- softmax self-attention over the tokens of a sample (CrossAttention with context = x, attention.py:168-189) ------------
+// qkv (S, N, 3*C): [q | k | v], head h = channels h*D .. h*D+D-1 (rearrange "b n (h d)"), D = 32.  One thread owns one query
+// (q and the output accumulator in registers); keys / values of the (sample, head) stream through LDS in f32 chunks that all
+// threads read at the same address (broadcast), with an online softmax.  f32 arithmetic throughout.
+// (A VALU kernel: at D = 32 this op is ~5 % of the variant's FLOPs; the convolutions and linears run on the MFMA kernels.)
+constexpr int AD = 32;
+constexpr int KCH = 128;
+template <class T>
+__global__ __launch_bounds__(NT) void token_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int C, float scale) {
+    __shared__ __attribute__((aligned(16))) float s_k[KCH][AD];
+    __shared__ __attribute__((aligned(16))) float s_v[KCH][AD];
+    const int tid = threadIdx.x;
+    const int head = blockIdx.y, smp = blockIdx.z;
+    const int qi = blockIdx.x * NT + tid;
+    const T* base = qkv + (size_t)smp * N * 3 * C;
+    float q[AD], o[AD];
+    const bool qok = qi < N;
+    {
+        const T* qp = base + (size_t)(qok ? qi : 0) * 3 * C + head * AD;
+        constexpr int VEC = Elt<T>::VEC;
+#pragma unroll
+        for (int v = 0; v < AD / VEC; ++v) {
+            float t[VEC];
+            Elt<T>::unpack(ld16(qp + v * VEC), t);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) q[v * VEC + e] = t[e] * scale;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < AD; ++d) o[d] = 0.f;
+    float mx = -3.0e38f, den = 0.f;
+    for (int k0 = 0; k0 < N; k0 += KCH) {
+        __syncthreads();
+        // stage KCH keys and values of this head as f32: thread -> (key, 16-byte vector)
+        constexpr int VEC = Elt<T>::VEC;
+        constexpr int VPK = AD / VEC;
+        for (int i = tid; i < KCH * VPK * 2; i += NT) {
+            const int which = i / (KCH * VPK), r = i - which * (KCH * VPK);
+            const int key = r / VPK, v = r - key * VPK;
+            float t[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) t[e] = 0.f;
+            if (k0 + key < N) Elt<T>::unpack(ld16(base + (size_t)(k0 + key) * 3 * C + (1 + which) * C + head * AD + v * VEC), t);
+            float* dst = which ? &s_v[key][v * VEC] : &s_k[key][v * VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dst[e] = t[e];
+        }
+        __syncthreads();
+        const int kn = N - k0 < KCH ? N - k0 : KCH;
+        for (int j = 0; j < kn; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < AD; ++d) s += q[d] * s_k[j][d];
+            const float nm = s > mx ? s : mx;
+            const float corr = __expf(mx - nm), p = __expf(s - nm);
+            den = den * corr + p;
+#pragma unroll
+            for (int d = 0; d < AD; ++d) o[d] = o[d] * corr + p * s_v[j][d];
+            mx = nm;
+        }
+    }
+    if (qok) {
+        const float inv = 1.0f / den;
+        T* op = out + ((size_t)smp * N + qi) * C + head * AD;
+        constexpr int VEC = Elt<T>::VEC;
+#pragma unroll
+        for (int v = 0; v < AD / VEC; ++v) {
+            float t[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) t[e] = o[v * VEC + e] * inv;
+            st16(op + v * VEC, Elt<T>::pack(t));
+        }
+    }
+}
+
+// x (M, C) -> y (M, C2) [:, off .. off + C): concatenation of token tensors along the channel axis (th.cat of the skip,
+// adapt_openaimodel.py:152: GroupNorm(32) groups of the ResBlock that follows may straddle the two sources)
+template <class T>
+__global__ __launch_bounds__(NT) void copy_cols_kernel(const T* __restrict__ x, T* __restrict__ y, long long M, int C, int C2, int off) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int nv = C / VEC;
+    const long long total = M * nv;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+        const long long m = i / nv;
+        const int v = (int)(i - m * nv);
+        st16(y + m * C2 + off + v * VEC, ld16(x + m * C + v * VEC));
+    }
+}
+
+unsigned grid_for_ll(long long n) {
+    long long b = (n + NT - 1) / NT;
+    if (b > 65535 * 8) b = 65535 * 8;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+int launch_layernorm(int dt, const void* x, void* y, const float* gamma, const float* beta, long long M, int C, float eps, hipStream_t s) {
+    const int vec = dt == NOPE_F32 ? 4 : 8;
+    if (!x || !y || !gamma || !beta || M <= 0 || C <= 0 || C % vec) return NOPE_ERR_ARG;
+    const dim3 grid((unsigned)((M + NT / 64 - 1) / (NT / 64)));
+    if (dt == NOPE_F32) hipLaunchKernelGGL((layernorm_kernel<float>), grid, dim3(NT), 0, s, (const float*)x, (float*)y, gamma, beta, M, C, eps);
+    else if (dt == NOPE_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t>), grid, dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)y, gamma, beta, M, C, eps);
+    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_geglu(int dt, const void* in, void* out, long long M, int D, hipStream_t s) {
+    const int vec = dt == NOPE_F32 ? 4 : 8;
+    if (!in || !out || M <= 0 || D <= 0 || D % vec) return NOPE_ERR_ARG;
+    const dim3 grid(grid_for_ll(M * (D / vec)));
+    if (dt == NOPE_F32) hipLaunchKernelGGL((geglu_kernel<float>), grid, dim3(NT), 0, s, (const float*)in, (float*)out, M, D);
+    else if (dt == NOPE_BF16) hipLaunchKernelGGL((geglu_kernel<bf16_t>), grid, dim3(NT), 0, s, (const bf16_t*)in, (bf16_t*)out, M, D);
+    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_add_rowvec(int dt, const void* x, void* y, const float* u, long long M, int tokens, int C, hipStream_t s) {
+    const int vec = dt == NOPE_F32 ? 4 : 8;
+    if (!x || !y || !u || M <= 0 || tokens <= 0 || C % vec) return NOPE_ERR_ARG;
+    const dim3 grid(grid_for_ll(M * (C / vec)));
+    if (dt == NOPE_F32) hipLaunchKernelGGL((add_rowvec_kernel<float>), grid, dim3(NT), 0, s, (const float*)x, (float*)y, u, M, tokens, C);
+    else if (dt == NOPE_BF16) hipLaunchKernelGGL((add_rowvec_kernel<bf16_t>), grid, dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)y, u, M, tokens, C);
+    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_token_attention(int dt, const void* qkv, void* out, int nsmp, int N, int C, int dim_head, hipStream_t s) {
+    if (!qkv || !out || nsmp <= 0 || N <= 0 || C <= 0 || dim_head != AD || C % AD) return NOPE_ERR_ARG;
+    const dim3 grid((unsigned)cdiv(N, NT), (unsigned)(C / AD), (unsigned)nsmp);
+    const float scale = 1.0f / sqrtf((float)dim_head);
+    if (dt == NOPE_F32) hipLaunchKernelGGL((token_attn_kernel<float>), grid, dim3(NT), 0, s, (const float*)qkv, (float*)out, N, C, scale);
+    else if (dt == NOPE_BF16) hipLaunchKernelGGL((token_attn_kernel<bf16_t>), grid, dim3(NT), 0, s, (const bf16_t*)qkv, (bf16_t*)out, N, C, scale);
+    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_copy_cols(int dt, const void* x, void* y, long long M, int C, int C2, int off, hipStream_t s) {
+    const int vec = dt == NOPE_F32 ? 4 : 8;
+    if (!x || !y || M <= 0 || C % vec || C2 % vec || off % vec || off + C > C2) return NOPE_ERR_ARG;
+    const dim3 grid(grid_for_ll(M * (C / vec)));
+    if (dt == NOPE_F32) hipLaunchKernelGGL((copy_cols_kernel<float>), grid, dim3(NT), 0, s, (const float*)x, (float*)y, M, C, C2, off);
+    else if (dt == NOPE_BF16) hipLaunchKernelGGL((copy_cols_kernel<bf16_t>), grid, dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)y, M, C, C2, off);
+    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+}  // namespace nope

@@ -1,0 +1,509 @@
+// Host-side runtime of the LDM cross-attention U-Net variant: `UNetModelPose`
+// (src/model/u_net/ldm/adapt_openaimodel.py:14-158 over openaimodel.py:428-760 and attention.py:149-277) -- the variant whose
+// pose conditioning is the cross-attention `context = pose_mlp(pose).unsqueeze(1)` north_star names.
+//
+// Op order follows UNetModelPose.forward exactly; the execution model is the one of unet_runtime.hip (NHWC activations = token
+// major, every conv / linear on the implicit-GEMM MFMA kernels, all pose hypotheses of a reference latent as one batch, bump
+// arena over caller-provided workspace).  What the MI355X schedule does differently from the module tree, same arithmetic:
+//   * SpatialTransformer tokens are the NHWC activations themselves: the two `rearrange`s are no-ops;
+//   * attn1's to_q / to_k / to_v are one GEMM against the row-concatenated weights;
+//   * attn2 is cross-attention against ONE context token: softmax over a single key is exactly 1, so its output is
+//     to_out(to_v(context)) for every query -- two tiny per-sample linears and a broadcast add; to_q, to_k and norm2 never
+//     influence the result and are not evaluated (their weights are still validated at create time);
+//   * with injecting_condition_twice = false the timestep embedding is zeros, so emb_layers(emb) is its bias: folded into the
+//     bias of in_layers' conv at create time;
+//   * th.cat((h, skip)) is materialised (GroupNorm(32) groups of the following ResBlock can straddle the two halves).
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "nope_common.h"
+
+using namespace nope;
+
+namespace {
+
+struct LConv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; };
+struct LNorm { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
+struct LRes { LNorm n1, n2; LConv c1, c2, skip; bool has_skip = false; float *emb_w = nullptr, *emb_b = nullptr; int Cin = 0, Cout = 0; };
+struct LST { LNorm norm, ln1, ln3; LConv proj_in, qkv, out1, ff1, ff2, proj_out; float *v2_w = nullptr, *o2_w = nullptr, *o2_b = nullptr; int C = 0; };
+struct LBlock { bool has_res = false, has_st = false, has_resample = false; LRes res; LST st; LConv resample; };
+
+}  // namespace
+
+struct nope_ldm {
+    nope_ldm_config cfg;
+    int dt = NOPE_F32;
+    std::vector<void*> allocs;
+    LConv conv_in, conv_out;
+    LNorm norm_out;
+    std::vector<LBlock> input_blocks, output_blocks;     // input_blocks[0] is conv_in
+    LRes mid1, mid2;
+    LST mid_st;
+    std::vector<int> skip_ch;                            // channels pushed by each input block
+    float *pose_w0 = nullptr, *pose_b0 = nullptr, *pose_w2 = nullptr, *pose_b2 = nullptr;
+    float *tw = nullptr, *tb = nullptr;                  // pose_mlp_timesteps (injecting_condition_twice)
+    int emb_dim = 0;
+};
+
+namespace {
+
+struct Loader {
+    nope_ldm* net;
+    hipStream_t s;
+    std::map<std::string, const nope_tensor_desc*> tab;
+    int err = NOPE_OK;
+    std::string missing;
+    void fail(const std::string& n) { if (err == NOPE_OK) { err = NOPE_ERR_WEIGHT; missing = n; } }
+    void chk(int e) { if (e && err == NOPE_OK) err = e; }
+    const nope_tensor_desc* get(const std::string& name, std::initializer_list<int64_t> shape) {
+        auto it = tab.find(name);
+        if (it == tab.end() || !it->second->data || it->second->ndim != (int)shape.size()) { fail(name); return nullptr; }
+        int i = 0;
+        for (int64_t v : shape) if (it->second->shape[i++] != v) { fail(name); return nullptr; }
+        return it->second;
+    }
+    void* dmalloc(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { if (err == NOPE_OK) err = NOPE_ERR_ALLOC; return nullptr; }
+        net->allocs.push_back(p);
+        return p;
+    }
+    float* copy_f32(const std::string& name, std::initializer_list<int64_t> shape) {
+        const nope_tensor_desc* d = get(name, shape);
+        if (!d) return nullptr;
+        size_t n = 1;
+        for (int64_t v : shape) n *= (size_t)v;
+        float* p = (float*)dmalloc(n * 4);
+        if (p) hipMemcpyAsync(p, d->data, n * 4, hipMemcpyDeviceToDevice, s);
+        return p;
+    }
+    // conv (4-d weight) or linear (2-d weight) packed for the implicit-GEMM kernel
+    LConv conv(const std::string& pfx, int Cin, int Cout, int ksz, int mode, bool has_bias, bool linear = false) {
+        LConv c;
+        c.Cin = Cin; c.Cout = Cout; c.mode = mode;
+        c.ntaps = mode == NOPE_CONV_UP2P ? 4 : ksz * ksz;
+        const nope_tensor_desc* d = linear ? get(pfx + "weight", {Cout, Cin}) : get(pfx + "weight", {Cout, Cin, ksz, ksz});
+        if (d) {
+            const size_t es = net->dt == NOPE_F32 ? 4 : 2;
+            c.w = dmalloc((size_t)Cout * c.ntaps * Cin * es * (mode == NOPE_CONV_UP2P ? 4 : 1));
+            if (c.w) chk(launch_pack_conv_w(net->dt, d->data, c.w, Cout, Cin, c.ntaps, mode, s));
+        }
+        if (has_bias) c.bias = copy_f32(pfx + "bias", {Cout});
+        return c;
+    }
+    LNorm norm(const std::string& pfx, int C) {
+        LNorm n;
+        n.C = C;
+        n.gamma = copy_f32(pfx + "weight", {C});
+        n.beta = copy_f32(pfx + "bias", {C});
+        return n;
+    }
+    LRes res(const std::string& p, int Cin, int Cout) {
+        LRes r;
+        r.Cin = Cin; r.Cout = Cout;
+        r.n1 = norm(p + "in_layers.0.", Cin);
+        r.c1 = conv(p + "in_layers.2.", Cin, Cout, 3, NOPE_CONV_PLAIN, true);
+        r.emb_w = copy_f32(p + "emb_layers.1.weight", {Cout, net->emb_dim});
+        r.emb_b = copy_f32(p + "emb_layers.1.bias", {Cout});
+        r.n2 = norm(p + "out_layers.0.", Cout);
+        r.c2 = conv(p + "out_layers.3.", Cout, Cout, 3, NOPE_CONV_PLAIN, true);
+        r.has_skip = Cin != Cout;
+        if (r.has_skip) r.skip = conv(p + "skip_connection.", Cin, Cout, 1, NOPE_CONV_PLAIN, true);
+        if (!net->cfg.injecting_condition_twice && r.c1.bias && r.emb_b)     // emb == 0: emb_layers(emb) = its bias, folded into conv1's
+            chk(launch_add_rowvec(NOPE_F32, r.c1.bias, r.c1.bias, r.emb_b, 1, 1, Cout, s));
+        return r;
+    }
+    LST st(const std::string& p, int C) {
+        LST t;
+        t.C = C;
+        const int ctx = net->cfg.context_dim;
+        t.norm = norm(p + "norm.", C);
+        t.proj_in = conv(p + "proj_in.", C, C, 1, NOPE_CONV_PLAIN, true);
+        const std::string b = p + "transformer_blocks.0.";
+        t.ln1 = norm(b + "norm1.", C);
+        t.ln3 = norm(b + "norm3.", C);
+        get(b + "norm2.weight", {C}); get(b + "norm2.bias", {C});                     // validated, provably without effect (see header)
+        get(b + "attn2.to_q.weight", {C, C}); get(b + "attn2.to_k.weight", {C, ctx});
+        // attn1: q, k, v as one [3C][C] weight
+        const nope_tensor_desc* wq = get(b + "attn1.to_q.weight", {C, C});
+        const nope_tensor_desc* wk = get(b + "attn1.to_k.weight", {C, C});
+        const nope_tensor_desc* wv = get(b + "attn1.to_v.weight", {C, C});
+        t.qkv.Cin = C; t.qkv.Cout = 3 * C; t.qkv.ntaps = 1;
+        if (wq && wk && wv) {
+            float* cat = (float*)dmalloc((size_t)3 * C * C * 4);
+            const size_t es = net->dt == NOPE_F32 ? 4 : 2;
+            t.qkv.w = dmalloc((size_t)3 * C * C * es);
+            if (cat && t.qkv.w) {
+                hipMemcpyAsync(cat, wq->data, (size_t)C * C * 4, hipMemcpyDeviceToDevice, s);
+                hipMemcpyAsync(cat + (size_t)C * C, wk->data, (size_t)C * C * 4, hipMemcpyDeviceToDevice, s);
+                hipMemcpyAsync(cat + (size_t)2 * C * C, wv->data, (size_t)C * C * 4, hipMemcpyDeviceToDevice, s);
+                chk(launch_pack_conv_w(net->dt, cat, t.qkv.w, 3 * C, C, 1, NOPE_CONV_PLAIN, s));
+            }
+        }
+        t.out1 = conv(b + "attn1.to_out.0.", C, C, 1, NOPE_CONV_PLAIN, true, true);
+        t.v2_w = copy_f32(b + "attn2.to_v.weight", {C, ctx});
+        t.o2_w = copy_f32(b + "attn2.to_out.0.weight", {C, C});
+        t.o2_b = copy_f32(b + "attn2.to_out.0.bias", {C});
+        t.ff1 = conv(b + "ff.net.0.proj.", C, 8 * C, 1, NOPE_CONV_PLAIN, true, true);
+        t.ff2 = conv(b + "ff.net.2.", 4 * C, C, 1, NOPE_CONV_PLAIN, true, true);
+        t.proj_out = conv(p + "proj_out.", C, C, 1, NOPE_CONV_PLAIN, true);
+        return t;
+    }
+};
+
+struct Arena {
+    unsigned char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    bool dry = false;
+    void* alloc(size_t bytes) {
+        const size_t o = align_up(off, 256);
+        off = o + bytes;
+        if (off > peak) peak = off;
+        if (dry) return (void*)(uintptr_t)(0x1000 + o);
+        if (off > cap) return nullptr;
+        return base + o;
+    }
+};
+
+struct Act { void* p = nullptr; int C = 0, H = 0, W = 0; };
+
+struct Fwd {
+    const nope_ldm* net;
+    hipStream_t s;
+    Arena ar;
+    int nhyp = 0, err = NOPE_OK;
+    size_t es = 4;
+    float* gn_partial = nullptr;
+    const float* ctx = nullptr;       // (nhyp, context_dim)
+    const float* emb = nullptr;       // (nhyp, emb_dim) or null (zeros)
+
+    void chk(int e) { if (e != NOPE_OK && err == NOPE_OK) err = e; }
+    bool live() const { return !ar.dry && err == NOPE_OK; }
+    void* alloc_act(size_t elems) {
+        void* p = ar.alloc(elems * es);
+        if (!p && err == NOPE_OK) err = NOPE_ERR_WORKSPACE;
+        return p;
+    }
+    float* alloc_f32(size_t n) {
+        float* p = (float*)ar.alloc(n * 4);
+        if (!p && err == NOPE_OK) err = NOPE_ERR_WORKSPACE;
+        return p;
+    }
+    void conv(const LConv& c, const Act& a, void* out, int Ho, int Wo, const void* resid = nullptr, int out_nchw = 0, int out_dt = NOPE_F32,
+              int rep = 1, int n = -1) {
+        if (!live()) return;
+        ConvArgs ca;
+        ca.src1 = a.p; ca.C1 = a.C; ca.rep1 = rep; ca.Hs = a.H; ca.Ws = a.W; ca.Ho = Ho; ca.Wo = Wo;
+        ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.bias = c.bias; ca.resid = resid; ca.out = out; ca.Cout = c.Cout;
+        ca.nhyp = n < 0 ? nhyp : n; ca.out_nchw = out_nchw; ca.out_dt = out_dt;
+        if (a.C != c.Cin) { chk(NOPE_ERR_ARG); return; }
+        chk(launch_conv(net->dt, ca, s));
+    }
+    // y = [silu](GroupNorm(32, eps)(x))
+    void gn(const LNorm& nm, const void* x, void* y, int HW, int act, float eps) {
+        if (!live()) return;
+        const int nch = gn_stats_chunks(HW, nm.C, net->dt);
+        chk(launch_gn_stats(net->dt, x, gn_partial, nhyp, HW, nm.C, 32, nch, s));
+        GnApplyArgs ga;
+        ga.x = x; ga.y = y; ga.partial = gn_partial; ga.nchunk = nch; ga.gamma = nm.gamma; ga.beta = nm.beta;
+        ga.nhyp = nhyp; ga.HW = HW; ga.C = nm.C; ga.G = 32; ga.act = act; ga.eps = eps;
+        chk(launch_gn_apply(net->dt, ga, s));
+    }
+    // ResBlock._forward, openaimodel.py:262-288 (no up/down, no scale-shift norm)
+    void res(const LRes& R, const Act& x, void* out) {
+        const int HW = x.H * x.W;
+        const size_t M = (size_t)nhyp * HW;
+        const size_t mark = ar.off;
+        void* t = alloc_act(M * R.Cin);
+        void* h = alloc_act(M * R.Cout);
+        gn(R.n1, x.p, t, HW, 1, 1e-5f);
+        conv(R.c1, Act{t, R.Cin, x.H, x.W}, h, x.H, x.W);
+        if (emb) {                                  // h + emb_layers(emb)[..., None, None]
+            float* e = alloc_f32((size_t)nhyp * R.Cout);
+            if (live()) {
+                chk(launch_linear_naive(emb, R.emb_w, R.emb_b, e, nhyp, R.Cout, net->emb_dim, 1, R.Cout, s));
+                chk(launch_add_rowvec(net->dt, h, h, e, (long long)M, HW, R.Cout, s));
+            }
+        }
+        void* t2 = alloc_act(M * R.Cout);
+        gn(R.n2, h, t2, HW, 1, 1e-5f);
+        const void* resid = x.p;
+        if (R.has_skip) {
+            void* sk = alloc_act(M * R.Cout);
+            conv(R.skip, x, sk, x.H, x.W);
+            resid = sk;
+        }
+        conv(R.c2, Act{t2, R.Cout, x.H, x.W}, out, x.H, x.W, resid);
+        ar.off = mark;
+    }
+    // SpatialTransformer.forward with one BasicTransformerBlock, attention.py:214-277
+    void st(const LST& T, const Act& x, void* out) {
+        const int HW = x.H * x.W, C = T.C;
+        const long long M = (long long)nhyp * HW;
+        const size_t mark = ar.off;
+        void* xn = alloc_act((size_t)M * C);
+        void* tok = alloc_act((size_t)M * C);
+        gn(T.norm, x.p, xn, HW, 0, 1e-6f);
+        conv(T.proj_in, Act{xn, C, x.H, x.W}, tok, x.H, x.W);
+        // attn1 (self-attention) + residual
+        void* a = xn;                                    // reuse: LN1(tok)
+        void* qkv = alloc_act((size_t)M * 3 * C);
+        void* o = alloc_act((size_t)M * C);
+        void* tok1 = alloc_act((size_t)M * C);
+        if (live()) chk(launch_layernorm(net->dt, tok, a, T.ln1.gamma, T.ln1.beta, M, C, 1e-5f, s));
+        conv(T.qkv, Act{a, C, x.H, x.W}, qkv, x.H, x.W);
+        if (live()) chk(launch_token_attention(net->dt, qkv, o, nhyp, HW, C, 32, s));
+        conv(T.out1, Act{o, C, x.H, x.W}, tok1, x.H, x.W, tok);
+        // attn2 against the single pose token: + to_out(to_v(context)) for every token
+        float* v = alloc_f32((size_t)nhyp * C);
+        float* u = alloc_f32((size_t)nhyp * C);
+        if (live()) {
+            chk(launch_linear_naive(ctx, T.v2_w, nullptr, v, nhyp, C, net->cfg.context_dim, 0, C, s));
+            chk(launch_linear_naive(v, T.o2_w, T.o2_b, u, nhyp, C, C, 0, C, s));
+            chk(launch_add_rowvec(net->dt, tok1, tok1, u, M, HW, C, s));
+        }
+        // feed-forward (GEGLU) + residual
+        void* f = o;                                     // reuse: LN3(tok1)
+        if (live()) chk(launch_layernorm(net->dt, tok1, f, T.ln3.gamma, T.ln3.beta, M, C, 1e-5f, s));
+        void* g = alloc_act((size_t)M * 8 * C);
+        void* gg = alloc_act((size_t)M * 4 * C);
+        conv(T.ff1, Act{f, C, x.H, x.W}, g, x.H, x.W);
+        if (live()) chk(launch_geglu(net->dt, g, gg, M, 4 * C, s));
+        void* tok3 = tok;                                // tok is dead after the attn1 residual
+        conv(T.ff2, Act{gg, 4 * C, x.H, x.W}, tok3, x.H, x.W, tok1);
+        conv(T.proj_out, Act{tok3, C, x.H, x.W}, out, x.H, x.W, x.p);
+        ar.off = mark;
+    }
+};
+
+int run_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, const float* pose, int n_hyp, int H, int W, void* out,
+                int out_dtype, void* ws, size_t ws_bytes, hipStream_t s, bool dry, size_t* peak) {
+    const nope_ldm_config& cfg = net->cfg;
+    Fwd f;
+    f.net = net; f.s = s; f.nhyp = n_hyp; f.es = net->dt == NOPE_F32 ? 4 : 2;
+    f.ar.base = (unsigned char*)ws; f.ar.cap = ws_bytes; f.ar.dry = dry;
+    const int HW = H * W;
+    void* x_in = f.alloc_act((size_t)n_src * HW * cfg.in_channels);
+    float* ctx = f.alloc_f32((size_t)n_hyp * cfg.context_dim);
+    float* ctx2 = f.alloc_f32((size_t)n_hyp * cfg.context_dim);
+    float* emb = cfg.injecting_condition_twice ? f.alloc_f32((size_t)n_hyp * net->emb_dim) : nullptr;
+    f.gn_partial = f.alloc_f32((size_t)n_hyp * 16 * 32 * 2);
+    if (f.err) return f.err;
+    if (f.live()) {
+        f.chk(launch_nchw_to_nhwc(net->dt, x, x_in, n_src, cfg.in_channels, HW, s));
+        // context = pose_mlp(pose), adapt_openaimodel.py:105-116,145
+        f.chk(launch_linear_naive(pose, net->pose_w0, net->pose_b0, ctx, n_hyp, cfg.context_dim, cfg.pose_dim, 0, cfg.context_dim, s));
+        if (cfg.pose_mlp_layers == 2) {
+            f.chk(launch_linear_naive(ctx, net->pose_w2, net->pose_b2, ctx2, n_hyp, cfg.context_dim, cfg.context_dim, 2, cfg.context_dim, s));
+            f.ctx = ctx2;
+        } else f.ctx = ctx;
+        if (emb) {     // emb = pose_mlp_timesteps(pose), :119-123,141-142
+            f.chk(launch_linear_naive(pose, net->tw, net->tb, emb, n_hyp, net->emb_dim, cfg.pose_dim, 0, net->emb_dim, s));
+            f.emb = emb;
+        }
+    } else if (emb) f.emb = emb;
+
+    // persistent skip stack
+    std::vector<Act> hs;
+    int curH = H, curW = W;
+    // input_blocks[0]: the input conv, evaluated once per hypothesis from the shared latent (source broadcast)
+    Act h{f.alloc_act((size_t)n_hyp * HW * net->conv_in.Cout), net->conv_in.Cout, H, W};
+    f.conv(net->conv_in, Act{x_in, cfg.in_channels, H, W}, h.p, H, W, nullptr, 0, NOPE_F32, x_rep);
+    hs.push_back(h);
+    for (size_t b = 1; b < net->input_blocks.size(); ++b) {
+        const LBlock& B = net->input_blocks[b];
+        Act nxt;
+        if (B.has_resample) {            // Downsample: conv 3x3, stride 2, pad 1 (openaimodel.py:143-174)
+            nxt = Act{f.alloc_act((size_t)n_hyp * (curH / 2) * (curW / 2) * B.resample.Cout), B.resample.Cout, curH / 2, curW / 2};
+            f.conv(B.resample, h, nxt.p, curH / 2, curW / 2);
+            curH /= 2; curW /= 2;
+        } else {
+            nxt = Act{f.alloc_act((size_t)n_hyp * curH * curW * B.res.Cout), B.res.Cout, curH, curW};
+            if (B.has_st) {
+                const size_t mark = f.ar.off;
+                void* t = f.alloc_act((size_t)n_hyp * curH * curW * B.res.Cout);
+                f.res(B.res, h, t);
+                f.st(B.st, Act{t, B.res.Cout, curH, curW}, nxt.p);
+                f.ar.off = mark;
+            } else f.res(B.res, h, nxt.p);
+        }
+        h = nxt;
+        hs.push_back(h);
+    }
+    // middle block
+    {
+        const size_t e = (size_t)n_hyp * curH * curW * h.C;
+        Act a{f.alloc_act(e), h.C, curH, curW}, b{f.alloc_act(e), h.C, curH, curW}, c{f.alloc_act(e), h.C, curH, curW};
+        f.res(net->mid1, h, a.p);
+        f.st(net->mid_st, a, b.p);
+        f.res(net->mid2, b, c.p);
+        h = c;
+    }
+    // output blocks
+    for (size_t b = 0; b < net->output_blocks.size(); ++b) {
+        const LBlock& B = net->output_blocks[b];
+        const Act sk = hs.back();
+        hs.pop_back();
+        const long long M = (long long)n_hyp * curH * curW;
+        Act cat{f.alloc_act((size_t)M * (h.C + sk.C)), h.C + sk.C, curH, curW};
+        if (f.live()) {
+            f.chk(launch_copy_cols(net->dt, h.p, cat.p, M, h.C, cat.C, 0, s));
+            f.chk(launch_copy_cols(net->dt, sk.p, cat.p, M, sk.C, cat.C, h.C, s));
+        }
+        Act r{f.alloc_act((size_t)M * B.res.Cout), B.res.Cout, curH, curW};
+        f.res(B.res, cat, r.p);
+        if (B.has_st) {
+            Act t{f.alloc_act((size_t)M * B.res.Cout), B.res.Cout, curH, curW};
+            f.st(B.st, r, t.p);
+            r = t;
+        }
+        if (B.has_resample) {            // Upsample: nearest x2 + conv 3x3 (openaimodel.py:93-124) as four 2x2 phase convs
+            Act u{f.alloc_act((size_t)M * 4 * B.resample.Cout), B.resample.Cout, curH * 2, curW * 2};
+            f.conv(B.resample, r, u.p, curH * 2, curW * 2);
+            curH *= 2; curW *= 2;
+            r = u;
+        }
+        h = r;
+    }
+    // out: GroupNorm32 + SiLU + conv 3x3 (openaimodel.py:733-737) straight into the NCHW output
+    {
+        void* t = f.alloc_act((size_t)n_hyp * HW * h.C);
+        f.gn(net->norm_out, h.p, t, HW, 1, 1e-5f);
+        f.conv(net->conv_out, Act{t, h.C, H, W}, out, H, W, nullptr, 1, out_dtype);
+    }
+    if (peak) *peak = f.ar.peak;
+    return f.err;
+}
+
+int check_shape(const nope_ldm* net, int n_hyp, int n_src, int x_rep, int H, int W) {
+    if (!net || n_hyp <= 0 || n_src <= 0 || x_rep <= 0 || (long long)n_src * x_rep != n_hyp || H <= 0 || W <= 0) return NOPE_ERR_ARG;
+    const int f = 1 << (net->cfg.n_levels - 1);
+    if (H % f || W % f) return NOPE_ERR_UNSUPPORTED;
+    return NOPE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors, int n_tensors, nope_stream_t stream, nope_ldm** out) {
+    if (!cfg || !tensors || !out || n_tensors <= 0) return NOPE_ERR_ARG;
+    if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->num_res_blocks < 1 || cfg->num_head_channels != 32) return NOPE_ERR_UNSUPPORTED;
+    if (cfg->compute_dtype != NOPE_F32 && cfg->compute_dtype != NOPE_BF16) return NOPE_ERR_UNSUPPORTED;
+    if (cfg->pose_mlp_layers != 1 && cfg->pose_mlp_layers != 2) return NOPE_ERR_UNSUPPORTED;
+    if (cfg->model_channels % 32 || cfg->in_channels % 4 || cfg->context_dim <= 0) return NOPE_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    nope_ldm* net = new nope_ldm();
+    net->cfg = *cfg;
+    net->dt = cfg->compute_dtype;
+    net->emb_dim = cfg->model_channels * 4;
+    const int mc = cfg->model_channels;
+    Loader ld;
+    ld.net = net; ld.s = s;
+    for (int i = 0; i < n_tensors; ++i)
+        if (tensors[i].name) ld.tab[tensors[i].name] = &tensors[i];
+
+    net->pose_w0 = ld.copy_f32("pose_mlp.0.weight", {cfg->context_dim, cfg->pose_dim});
+    net->pose_b0 = ld.copy_f32("pose_mlp.0.bias", {cfg->context_dim});
+    if (cfg->pose_mlp_layers == 2) {
+        net->pose_w2 = ld.copy_f32("pose_mlp.2.weight", {cfg->context_dim, cfg->context_dim});
+        net->pose_b2 = ld.copy_f32("pose_mlp.2.bias", {cfg->context_dim});
+    }
+    if (cfg->injecting_condition_twice) {
+        net->tw = ld.copy_f32("pose_mlp_timesteps.0.weight", {net->emb_dim, cfg->pose_dim});
+        net->tb = ld.copy_f32("pose_mlp_timesteps.0.bias", {net->emb_dim});
+    }
+    // openaimodel.py:511-612 -- input blocks
+    net->conv_in = ld.conv("input_blocks.0.0.", cfg->in_channels, mc, 3, NOPE_CONV_PLAIN, true);
+    net->input_blocks.emplace_back();
+    std::vector<int> chans{mc};
+    int ch = mc, idx = 1;
+    for (int level = 0; level < cfg->n_levels; ++level) {
+        for (int r = 0; r < cfg->num_res_blocks; ++r) {
+            LBlock B;
+            const std::string p = "input_blocks." + std::to_string(idx) + ".";
+            B.has_res = true;
+            B.res = ld.res(p + "0.", ch, cfg->channel_mult[level] * mc);
+            ch = cfg->channel_mult[level] * mc;
+            if (cfg->attn_levels[level]) { B.has_st = true; B.st = ld.st(p + "1.", ch); }
+            net->input_blocks.push_back(B);
+            chans.push_back(ch);
+            ++idx;
+        }
+        if (level != cfg->n_levels - 1) {
+            LBlock B;
+            B.has_resample = true;
+            B.resample = ld.conv("input_blocks." + std::to_string(idx) + ".0.op.", ch, ch, 3, NOPE_CONV_STRIDE2, true);
+            net->input_blocks.push_back(B);
+            chans.push_back(ch);
+            ++idx;
+        }
+    }
+    // :618-648 -- middle block
+    net->mid1 = ld.res("middle_block.0.", ch, ch);
+    net->mid_st = ld.st("middle_block.1.", ch);
+    net->mid2 = ld.res("middle_block.2.", ch, ch);
+    // :651-731 -- output blocks
+    idx = 0;
+    for (int level = cfg->n_levels - 1; level >= 0; --level) {
+        for (int i = 0; i <= cfg->num_res_blocks; ++i) {
+            const int ich = chans.back();
+            chans.pop_back();
+            LBlock B;
+            const std::string p = "output_blocks." + std::to_string(idx) + ".";
+            B.has_res = true;
+            B.res = ld.res(p + "0.", ch + ich, mc * cfg->channel_mult[level]);
+            ch = mc * cfg->channel_mult[level];
+            int sub = 1;
+            if (cfg->attn_levels[level]) { B.has_st = true; B.st = ld.st(p + std::to_string(sub++) + ".", ch); }
+            if (level && i == cfg->num_res_blocks) {
+                B.has_resample = true;
+                B.resample = ld.conv(p + std::to_string(sub) + ".conv.", ch, ch, 3, NOPE_CONV_UP2P, true);
+            }
+            net->output_blocks.push_back(B);
+            ++idx;
+        }
+    }
+    net->norm_out = ld.norm("out.0.", ch);
+    net->conv_out = ld.conv("out.2.", mc, cfg->out_channels, 3, NOPE_CONV_PLAIN, true);
+    if (ch != mc) ld.fail("out.2.weight");
+
+    if (ld.err == NOPE_OK && hipStreamSynchronize(s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
+    if (ld.err != NOPE_OK) {
+        if (!ld.missing.empty()) fprintf(stderr, "nope_ldm_create: missing or mis-shaped tensor '%s'\n", ld.missing.c_str());
+        nope_ldm_destroy(net);
+        return ld.err;
+    }
+    *out = net;
+    return NOPE_OK;
+}
+
+void nope_ldm_destroy(nope_ldm* net) {
+    if (!net) return;
+    for (void* p : net->allocs) hipFree(p);
+    delete net;
+}
+
+size_t nope_ldm_workspace_bytes(const nope_ldm* net, int n_hyp, int n_src, int H, int W) {
+    if (!net || n_src <= 0 || n_hyp % n_src) return 0;
+    if (check_shape(net, n_hyp, n_src, n_hyp / n_src, H, W) != NOPE_OK) return 0;
+    size_t peak = 0;
+    run_forward(net, nullptr, n_src, n_hyp / n_src, nullptr, n_hyp, H, W, nullptr, NOPE_F32, nullptr, 0, nullptr, true, &peak);
+    return align_up(peak, 256) + 256;
+}
+
+int nope_ldm_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, const float* pose, int n_hyp, int H, int W, void* out,
+                     int out_dtype, void* workspace, size_t workspace_bytes, nope_stream_t stream) {
+    int e = check_shape(net, n_hyp, n_src, x_rep, H, W);
+    if (e) return e;
+    if (!x || !pose || !out || !workspace) return NOPE_ERR_ARG;
+    if (out_dtype != NOPE_F32 && out_dtype != NOPE_BF16 && out_dtype != NOPE_F16) return NOPE_ERR_UNSUPPORTED;
+    unsigned char* base = (unsigned char*)(((uintptr_t)workspace + 255) / 256 * 256);
+    const size_t lost = (size_t)(base - (unsigned char*)workspace);
+    if (workspace_bytes < lost) return NOPE_ERR_WORKSPACE;
+    return run_forward(net, x, n_src, x_rep, pose, n_hyp, H, W, out, out_dtype, base, workspace_bytes - lost, (hipStream_t)stream, false, nullptr);
+}
+
+}  // extern "C"

@@ -32,6 +32,12 @@ class UNetConfig(C.Structure):
                 ("compute_dtype", _i)]
 
 
+class LdmConfig(C.Structure):
+    _fields_ = [("in_channels", _i), ("model_channels", _i), ("out_channels", _i), ("num_res_blocks", _i), ("n_levels", _i),
+                ("channel_mult", _i * 8), ("attn_levels", _i * 8), ("num_head_channels", _i), ("context_dim", _i), ("pose_dim", _i),
+                ("pose_mlp_layers", _i), ("injecting_condition_twice", _i), ("compute_dtype", _i)]
+
+
 class EncoderConfig(C.Structure):
     _fields_ = [("descriptor_size", _i), ("compute_dtype", _i), ("bn_eps", C.c_float)]
 
@@ -61,6 +67,13 @@ _PROTOS = {
     "nope_op_linear_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "nope_op_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "nope_op_linear": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "nope_ldm_create": (_i, [C.POINTER(LdmConfig), C.POINTER(TensorDesc), _i, _vp, C.POINTER(_vp)]),
+    "nope_ldm_destroy": (None, [_vp]),
+    "nope_ldm_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "nope_ldm_forward": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "nope_op_layer_norm": (_i, [_i, _vp, _vp, _vp, _vp, _i64, _i, C.c_float, _vp]),
+    "nope_op_geglu": (_i, [_i, _vp, _vp, _i64, _i, _vp]),
+    "nope_op_token_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
@@ -370,6 +383,92 @@ class UNetHandle:
         self._l.check(self._l.dll.nope_unet_forward(self._h, _ptr(x), n_src, x_rep, _ptr(pose), n_hyp, H, W, _ptr(out), odt,
                                                     _ptr(ws), ws.numel(), _stream(x)), "nope_unet_forward")
         return out
+
+
+# --------------------------------------------------------------------------------------------
+# LDM cross-attention U-Net handle
+# --------------------------------------------------------------------------------------------
+class LdmHandle:
+    """Owns a `nope_ldm*` built from a UNetModelPose state dict (reference keys)."""
+
+    def __init__(self, cfg: dict, state_dict: Dict[str, torch.Tensor], compute_dtype=F32):
+        l = lib()
+        self._l = l
+        c = LdmConfig()
+        for k in ("in_channels", "model_channels", "out_channels", "num_res_blocks", "num_head_channels", "context_dim", "pose_dim",
+                  "pose_mlp_layers", "injecting_condition_twice"):
+            setattr(c, k, int(cfg[k]))
+        mult = tuple(cfg["channel_mult"])
+        c.n_levels = len(mult)
+        for i, m in enumerate(mult):
+            c.channel_mult[i] = m
+            c.attn_levels[i] = int(cfg["attn_levels"][i])
+        c.compute_dtype = dtype_code(compute_dtype)
+        self.in_channels, self.out_channels, self.pose_dim = c.in_channels, c.out_channels, c.pose_dim
+        descs, keep, dev = _tensor_descs(state_dict)
+        self.device = dev
+        h = _vp()
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev is not None and dev.type == "cuda" else 0
+        l.check(l.dll.nope_ldm_create(C.byref(c), descs, len(state_dict), stream, C.byref(h)), "nope_ldm_create")
+        self._h = h
+        self._ws: Dict[tuple, torch.Tensor] = {}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._l.dll.nope_ldm_destroy(h)
+            self._h = None
+
+    def forward(self, x: torch.Tensor, pose: torch.Tensor, x_rep: int = 1, out: Optional[torch.Tensor] = None, out_dtype=F32) -> torch.Tensor:
+        require_device(x)
+        x, pose = _f32c(x), _f32c(pose)
+        n_src, Cc, H, W = x.shape
+        n_hyp = pose.shape[0]
+        if Cc != self.in_channels or pose.shape[1] != self.pose_dim or n_src * x_rep != n_hyp:
+            raise NopeError(f"shape mismatch: x {tuple(x.shape)}, pose {tuple(pose.shape)}, x_rep {x_rep}")
+        odt = dtype_code(out_dtype)
+        if out is None:
+            out = torch.empty((n_hyp, self.out_channels, H, W), dtype=torch_dtype(odt), device=x.device)
+        assert out.is_contiguous() and out.numel() == n_hyp * self.out_channels * H * W and out.dtype == torch_dtype(odt)
+        need = int(self._l.dll.nope_ldm_workspace_bytes(self._h, n_hyp, n_src, H, W))
+        if need == 0:
+            raise NopeError(f"unsupported LDM U-Net problem size n_hyp={n_hyp} H={H} W={W}")
+        key = (str(x.device), _stream(x))
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            self._ws.pop(key, None)
+            ws = None
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+        self._l.check(self._l.dll.nope_ldm_forward(self._h, _ptr(x), n_src, x_rep, _ptr(pose), n_hyp, H, W, _ptr(out), odt,
+                                                   _ptr(ws), ws.numel(), _stream(x)), "nope_ldm_forward")
+        return out
+
+
+def op_layer_norm(dt: int, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """x (..., C) of dtype dt: LayerNorm over the last axis."""
+    y = torch.empty_like(x)
+    l = lib()
+    l.check(l.dll.nope_op_layer_norm(dt, _ptr(x), _ptr(y), _ptr(_f32c(gamma)), _ptr(_f32c(beta)), x.numel() // x.shape[-1], x.shape[-1], eps,
+                                     _stream(x)), "nope_op_layer_norm")
+    return y
+
+
+def op_geglu(dt: int, x: torch.Tensor) -> torch.Tensor:
+    """x (..., 2D) = [a | gate] -> a * gelu(gate), (..., D)."""
+    D = x.shape[-1] // 2
+    y = torch.empty((*x.shape[:-1], D), dtype=x.dtype, device=x.device)
+    l = lib()
+    l.check(l.dll.nope_op_geglu(dt, _ptr(x), _ptr(y), x.numel() // x.shape[-1], D, _stream(x)), "nope_op_geglu")
+    return y
+
+
+def op_token_attention(dt: int, qkv: torch.Tensor, dim_head: int = 32) -> torch.Tensor:
+    """qkv (n, N, 3C) -> softmax(q k^T / sqrt(d)) v per head of `dim_head` channels, (n, N, C)."""
+    n, N, c3 = qkv.shape
+    out = torch.empty((n, N, c3 // 3), dtype=qkv.dtype, device=qkv.device)
+    l = lib()
+    l.check(l.dll.nope_op_token_attention(dt, _ptr(qkv), _ptr(out), n, N, c3 // 3, dim_head, _stream(qkv)), "nope_op_token_attention")
+    return out
 
 
 # --------------------------------------------------------------------------------------------

@@ -277,3 +277,90 @@ def geodesic_deg(predR: Tensor, gtR: Tensor) -> Tensor:
     rel = predR.to(torch.float64) @ gtR.to(torch.float64).transpose(-1, -2)
     cos = ((rel.diagonal(dim1=-2, dim2=-1).sum(-1)) - 1.0) / 2.0
     return torch.rad2deg(torch.acos(cos.clamp(-1.0, 1.0)))
+
+
+# --------------------------------------------------------------------------------------
+# LDM cross-attention variant  (src/model/u_net/ldm/adapt_openaimodel.py:130-158)
+# --------------------------------------------------------------------------------------
+def _ldm_res(x: Tensor, emb: Tensor, sd: SD, p: str) -> Tensor:
+    """ResBlock._forward, ldm/openaimodel.py:262-288 (no up/down, use_scale_shift_norm = False)."""
+    h = F.conv2d(F.silu(F.group_norm(x, 32, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"], 1e-5)),
+                 sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=1)
+    e = F.linear(F.silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"])
+    h = h + e[:, :, None, None]
+    h = F.conv2d(F.silu(F.group_norm(h, 32, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"], 1e-5)),
+                 sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
+    if p + "skip_connection.weight" in sd:
+        x = F.conv2d(x, sd[p + "skip_connection.weight"], sd[p + "skip_connection.bias"])
+    return x + h
+
+
+def _ldm_cross_attention(x: Tensor, ctx: Tensor, sd: SD, p: str, d_head: int = 32) -> Tensor:
+    """CrossAttention.forward, ldm/attention.py:168-189.  x (B,N,C); ctx (B,J,Cc)."""
+    B, N, C = x.shape
+    h = C // d_head
+    q, k, v = F.linear(x, sd[p + "to_q.weight"]), F.linear(ctx, sd[p + "to_k.weight"]), F.linear(ctx, sd[p + "to_v.weight"])
+    split = lambda t: t.reshape(B, t.shape[1], h, d_head).permute(0, 2, 1, 3).reshape(B * h, t.shape[1], d_head)
+    q, k, v = split(q), split(k), split(v)
+    attn = (torch.einsum("bid,bjd->bij", q, k) * d_head ** -0.5).softmax(dim=-1)
+    out = torch.einsum("bij,bjd->bid", attn, v).reshape(B, h, N, d_head).permute(0, 2, 1, 3).reshape(B, N, C)
+    return F.linear(out, sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
+
+
+def _ldm_transformer(x: Tensor, ctx: Tensor, sd: SD, p: str) -> Tensor:
+    """SpatialTransformer.forward with one BasicTransformerBlock, ldm/attention.py:214-277."""
+    B, C, H, W = x.shape
+    t = F.conv2d(F.group_norm(x, 32, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6), sd[p + "proj_in.weight"], sd[p + "proj_in.bias"])
+    t = t.reshape(B, C, H * W).permute(0, 2, 1)
+    b = p + "transformer_blocks.0."
+    ln = lambda y, n: F.layer_norm(y, (C,), sd[b + n + ".weight"], sd[b + n + ".bias"], 1e-5)
+    y = ln(t, "norm1")
+    t = _ldm_cross_attention(y, y, sd, b + "attn1.") + t
+    t = _ldm_cross_attention(ln(t, "norm2"), ctx, sd, b + "attn2.") + t
+    a, gate = F.linear(ln(t, "norm3"), sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"]).chunk(2, dim=-1)
+    t = F.linear(a * F.gelu(gate), sd[b + "ff.net.2.weight"], sd[b + "ff.net.2.bias"]) + t
+    t = t.permute(0, 2, 1).reshape(B, C, H, W)
+    return F.conv2d(t, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"]) + x
+
+
+def _ldm_block(h: Tensor, emb: Tensor, ctx: Tensor, sd: SD, p: str) -> Tensor:
+    """TimestepEmbedSequential.forward, ldm/openaimodel.py:83-92: children by index; the kind is read off the keys."""
+    i = 0
+    while True:
+        q = f"{p}{i}."
+        if q + "in_layers.0.weight" in sd:
+            h = _ldm_res(h, emb, sd, q)
+        elif q + "proj_in.weight" in sd:
+            h = _ldm_transformer(h, ctx, sd, q)
+        elif q + "op.weight" in sd:                                   # Downsample, :143-174
+            h = F.conv2d(h, sd[q + "op.weight"], sd[q + "op.bias"], stride=2, padding=1)
+        elif q + "conv.weight" in sd:                                 # Upsample, :93-124
+            h = F.conv2d(F.interpolate(h, scale_factor=2, mode="nearest"), sd[q + "conv.weight"], sd[q + "conv.bias"], padding=1)
+        elif q + "weight" in sd:                                      # the input conv
+            h = F.conv2d(h, sd[q + "weight"], sd[q + "bias"], padding=1)
+        else:
+            return h
+        i += 1
+
+
+def ldm_forward(sd: SD, x: Tensor, pose: Tensor) -> Tensor:
+    """`UNetModelPose.forward(x, pose)`, ldm/adapt_openaimodel.py:130-158: context = pose_mlp(pose)[:, None]; the timestep
+    embedding is zeros unless `pose_mlp_timesteps.*` is present (injecting_condition_twice)."""
+    emb_dim = sd["input_blocks.1.0.emb_layers.1.weight"].shape[1]
+    if "pose_mlp_timesteps.0.weight" in sd:
+        emb = F.linear(pose, sd["pose_mlp_timesteps.0.weight"], sd["pose_mlp_timesteps.0.bias"])
+    else:
+        emb = torch.zeros(x.shape[0], emb_dim)
+    ctx = pose_mlp(pose, sd).unsqueeze(1)
+    hs = []
+    h = x
+    n_in = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("input_blocks."))
+    for i in range(n_in):
+        h = _ldm_block(h, emb, ctx, sd, f"input_blocks.{i}.")
+        hs.append(h)
+    h = _ldm_block(h, emb, ctx, sd, "middle_block.")
+    n_out = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("output_blocks."))
+    for i in range(n_out):
+        h = torch.cat([h, hs.pop()], dim=1)
+        h = _ldm_block(h, emb, ctx, sd, f"output_blocks.{i}.")
+    return F.conv2d(F.silu(F.group_norm(h, 32, sd["out.0.weight"], sd["out.0.bias"], 1e-5)), sd["out.2.weight"], sd["out.2.bias"], padding=1)

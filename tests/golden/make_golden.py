@@ -168,6 +168,35 @@ def encoder_and_pipeline():
     save("unet_full_32.npz", x=x, pose=pose, out=y)
 
 
+@torch.no_grad()
+def ldm():
+    """The LDM cross-attention variant (UNetModelPose): tiny configurations with synthesised weights -- every zero_module
+    conv is overwritten, so the outputs are not identically zero as they are at the reference's own initialisation."""
+    RI.install()
+    from src.model.u_net.ldm.adapt_openaimodel import UNetModelPose as RefLdm
+    from nope_amd.ldm import UNetModelPose
+    out = {}
+    g = torch.Generator().manual_seed(SEED + 7)
+    for tag, kw, hw in (("m32", dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[1, 2], context_dim=24,
+                                     pose_mlp_name="single_layer", injecting_condition_twice=False), 8),
+                        ("m64two", dict(model_channels=64, channel_mult=(1, 2, 2), num_res_blocks=2, attention_resolutions=[2, 4], context_dim=40,
+                                        pose_mlp_name="two_layers", injecting_condition_twice=True), 8)):
+        common = dict(rot_representation_dim=6, image_size=hw, in_channels=8, out_channels=8, num_head_channels=32,
+                      use_spatial_transformer=True, transformer_depth=1, **kw)
+        mine = UNetModelPose(encoder=RI.StubEncoder(8), **common)
+        synth_init_(mine, SEED)
+        ref = RefLdm(encoder=RI.StubEncoder(8), **common)
+        ref.load_state_dict(mine.state_dict(), strict=True)       # proves key / shape parity
+        ref.eval()
+        x = torch.randn(3, 8, hw, hw, generator=g)
+        pose = torch.randn(3, 6, generator=g)
+        y = ref(x, pose)
+        assert float(y.abs().max()) > 1e-3
+        out[f"{tag}/x"], out[f"{tag}/pose"], out[f"{tag}/out"] = x, pose, y
+        out[f"{tag}/sha_in"] = np.array(sha256_of(mine.state_dict()["input_blocks.0.0.weight"]))
+    save("ldm_tiny.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(SEED)
     which = sys.argv[1:] or ["blocks", "unets", "retrieval", "pipeline"]
@@ -179,3 +208,5 @@ if __name__ == "__main__":
         retrieval()
     if "pipeline" in which:
         encoder_and_pipeline()
+    if "ldm" in which:
+        ldm()

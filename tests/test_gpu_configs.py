@@ -177,3 +177,40 @@ def test_geodesic_metric_on_device(gpu):
         assert set(r_cpu) == set(r_gpu)
         for k in r_cpu:
             assert abs(float(r_cpu[k]) - float(r_gpu[k])) < 1e-3, k
+
+
+def test_ldm_variant_full_size(gpu):
+    """The LDM cross-attention variant at the size configs/model/vae_cin_ldm.yaml ships (model_channels 256, channel_mult
+    (1,2,4), two ResBlocks per level, SpatialTransformers at all three resolutions, context_dim 512; latent channels 8 instead of
+    4 so the bf16 mode applies) at a 32x32 latent: f32 mode against the CPU restatement on 2 pose hypotheses, bf16 mode on a
+    batch of 32 against the f32 mode."""
+    import time
+    from nope_amd.ldm import UNetModelPose
+    from nope_amd.weights import synth_init_
+    from tests.util import StubEncoder
+    kw = dict(injecting_condition_twice=False, pose_mlp_name="single_layer", rot_representation_dim=6, image_size=32, in_channels=8,
+              model_channels=256, out_channels=8, num_res_blocks=2, attention_resolutions=[4, 2, 1], channel_mult=(1, 2, 4),
+              num_head_channels=32, use_spatial_transformer=True, transformer_depth=1, context_dim=512)
+    m = UNetModelPose(encoder=StubEncoder(8), compute_dtype="f32", **kw)
+    synth_init_(m, 2022)
+    nparam = sum(v.numel() for k, v in m.own_state_dict().items())
+    sd = {k: v.clone() for k, v in m.own_state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    x, poses = torch.randn(1, 8, 32, 32, generator=g), torch.randn(1, 32, 6, generator=g)
+    m = m.cuda()
+    y32 = m.forward_hypotheses(x.cuda(), poses.cuda())
+    torch.cuda.synchronize()
+    want = R.ldm_forward(sd, x.expand(2, -1, -1, -1), poses[0, :2])
+    e = rel(y32[0, :2].cpu(), want)
+    mb = UNetModelPose(encoder=StubEncoder(8), compute_dtype="bf16", **kw)
+    mb.load_state_dict(m.state_dict())
+    mb = mb.cuda()
+    yb = mb.forward_hypotheses(x.cuda(), poses.cuda())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    yb = mb.forward_hypotheses(x.cuda(), poses.cuda())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eb = rel(yb.float(), y32)
+    print(f"LDM variant, {nparam / 1e6:.1f} M parameters, 32x32 latent: f32 vs oracle {e:.2e}; bf16 vs f32 {eb:.2e}; bf16 {32 / dt:.0f} hypotheses/s (batch of 32)")
+    assert e < 1e-4 and eb < 8e-2

@@ -88,3 +88,31 @@ def test_pipeline_config1(golden):
     s = R.similarity_scores(qf, bank)
     assert rel(s, g["sim"][:, :4]) < 1e-5
     assert torch.equal(R.topk_desc_lowest_index(g["sim"], 5), g["idx"])
+
+
+LDM_CASES = {"m32": dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[1, 2], context_dim=24,
+                         pose_mlp_name="single_layer", injecting_condition_twice=False),
+             "m64two": dict(model_channels=64, channel_mult=(1, 2, 2), num_res_blocks=2, attention_resolutions=[2, 4], context_dim=40,
+                            pose_mlp_name="two_layers", injecting_condition_twice=True)}
+
+
+def build_ldm(tag, compute_dtype="f32"):
+    from nope_amd.ldm import UNetModelPose
+    from nope_amd.weights import synth_init_
+    from tests.util import StubEncoder
+    m = UNetModelPose(encoder=StubEncoder(8), rot_representation_dim=6, image_size=8, in_channels=8, out_channels=8, num_head_channels=32,
+                      use_spatial_transformer=True, transformer_depth=1, compute_dtype=compute_dtype, **LDM_CASES[tag])
+    synth_init_(m, 2022)
+    return m
+
+
+@pytest.mark.parametrize("tag", ["m32", "m64two"])
+def test_ldm_variant(golden, tag):
+    """The LDM cross-attention variant (UNetModelPose, adapt_openaimodel.py:130-158): the oracle's restatement against outputs
+    recorded from the reference class (tests/golden/make_golden.py ldm), same synthesised weights."""
+    from nope_amd.weights import sha256_of
+    g = golden("ldm_tiny.npz")
+    m = build_ldm(tag)
+    sd = m.own_state_dict()
+    assert sha256_of(sd["input_blocks.0.0.weight"]) == str(g[f"{tag}/sha_in"])
+    assert rel(R.ldm_forward(sd, g[f"{tag}/x"], g[f"{tag}/pose"]), g[f"{tag}/out"]) < TOL
