@@ -221,6 +221,12 @@ int nope_op_attention(int dtype, const void* qkv, void* out, int n_hyp, int HW, 
 int nope_op_linear(const float* in, const float* w, const float* bias, float* out, int M, int N, int K, int act_in,
                    nope_stream_t s);
 
+/* Dataset-side crop (caller of the hot path): cv2.warpPerspective(img, M, (Wd, Hd)) of crop_frame, src/poses/utils.py:262-270
+ * (bilinear, zero border), fused with the loader's image transform (dataloader/shapeNet.py:64-69):
+ *   dst[c,y,x] = scale * bilinear(src, Minv (x,y,1)) + shift.   src (Hs,Ws,C) uint8 (src_is_u8) or f32, HWC;
+ *   minv9_host: HOST pointer to the 3x3 inverse map, row-major; dst (C,Hd,Wd) f32. */
+int nope_op_warp_perspective(const void* src, int src_is_u8, int Hs, int Ws, int C, const float* minv9_host, float* dst_chw, int Hd, int Wd,
+                             float scale, float shift, nope_stream_t s);
 /* Token-space operators of the LDM variant (ldm/attention.py), tokens = NHWC pixels [M][C]:
  * LayerNorm over C (:210-212); GEGLU in [M][2D] -> out [M][D] (:37-44); softmax self-attention over the N tokens of each
  * sample on a fused [n][N][3C] q|k|v tensor, heads of 32 channels (:168-189). */

@@ -93,6 +93,10 @@ int nope_op_geglu(int dtype, const void* in, void* out, int64_t M, int D, nope_s
 int nope_op_token_attention(int dtype, const void* qkv, void* out, int n, int N, int C, int dim_head, nope_stream_t s) {
     return launch_token_attention(dtype, qkv, out, n, N, C, dim_head, (hipStream_t)s);
 }
+int nope_op_warp_perspective(const void* src, int src_is_u8, int Hs, int Ws, int C, const float* minv9_host, float* dst_chw, int Hd, int Wd,
+                             float scale, float shift, nope_stream_t s) {
+    return launch_warp_perspective(src, src_is_u8, Hs, Ws, C, minv9_host, dst_chw, Hd, Wd, scale, shift, (hipStream_t)s);
+}
 int nope_op_linear(const float* in, const float* w, const float* bias, float* out, int M, int N, int K, int act_in, nope_stream_t s) {
     return launch_linear_naive(in, w, bias, out, M, N, K, act_in, N, (hipStream_t)s);
 }

@@ -214,6 +214,48 @@ int launch_pos_emb(const float* pose, float* out, int n, int pose_dim, int class
     return NOPE_OK;
 }
 
+// Perspective warp of the dataset-side crop (src/poses/utils.py:204-272: cv2.warpPerspective(img, M, (S, S)), bilinear, constant
+// zero border) fused with the image transform of the loader (dataloader/shapeNet.py:64-69: /255, *2-1, HWC -> CHW):
+//   dst[c, y, x] = scale * bilinear(src, Minv * (x, y, 1)) + shift,   src (Hs, Ws, C) uint8 or f32, dst (C, Hd, Wd) f32.
+// Pixel centres sit on integer coordinates, as in OpenCV; samples outside the source contribute zeros tap by tap.
+struct Mat3 { float m[9]; };
+template <class TIN>
+__global__ __launch_bounds__(NT) void warp_perspective_kernel(const TIN* __restrict__ src, int Hs, int Ws, int C, Mat3 inv, float* __restrict__ dst,
+                                                              int Hd, int Wd, float scale, float shift) {
+    const int total = Hd * Wd;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < total; i += gridDim.x * NT) {
+        const int y = i / Wd, x = i - y * Wd;
+        const float w = inv.m[6] * x + inv.m[7] * y + inv.m[8];
+        const float sx = (inv.m[0] * x + inv.m[1] * y + inv.m[2]) / w;
+        const float sy = (inv.m[3] * x + inv.m[4] * y + inv.m[5]) / w;
+        const float fx = floorf(sx), fy = floorf(sy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float ax = sx - fx, ay = sy - fy;
+        for (int c = 0; c < C; ++c) {
+            float v = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+                const float wt = ((t & 1) ? ax : 1.f - ax) * ((t >> 1) ? ay : 1.f - ay);
+                if (xx >= 0 && xx < Ws && yy >= 0 && yy < Hs && w != 0.f) v += wt * (float)src[((size_t)yy * Ws + xx) * C + c];
+            }
+            dst[(size_t)c * total + i] = scale * v + shift;
+        }
+    }
+}
+
+int launch_warp_perspective(const void* src, int src_u8, int Hs, int Ws, int C, const float* minv9, float* dst, int Hd, int Wd, float scale,
+                            float shift, hipStream_t s) {
+    if (!src || !minv9 || !dst || Hs <= 0 || Ws <= 0 || C <= 0 || Hd <= 0 || Wd <= 0) return NOPE_ERR_ARG;
+    Mat3 m;
+    for (int i = 0; i < 9; ++i) m.m[i] = minv9[i];
+    const dim3 grid(grid_for((size_t)Hd * Wd));
+    if (src_u8) hipLaunchKernelGGL((warp_perspective_kernel<unsigned char>), grid, dim3(NT), 0, s, (const unsigned char*)src, Hs, Ws, C, m, dst, Hd, Wd, scale, shift);
+    else hipLaunchKernelGGL((warp_perspective_kernel<float>), grid, dim3(NT), 0, s, (const float*)src, Hs, Ws, C, m, dst, Hd, Wd, scale, shift);
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
 int launch_silu_f32(const float* in, float* out, size_t n, hipStream_t s) {
     if (!in || !out) return NOPE_ERR_ARG;
     if (n == 0) return NOPE_OK;

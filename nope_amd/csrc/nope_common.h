@@ -213,6 +213,8 @@ int launch_rowsum(int dt, const void* packed, float* out, int rows, int K, hipSt
 int launch_linear_naive(const float* in, const float* w, const float* bias, float* out, int M, int N, int K, int act_in,
                         int ldo, hipStream_t s);
 int launch_silu_f32(const float* in, float* out, size_t n, hipStream_t s);
+int launch_warp_perspective(const void* src, int src_u8, int Hs, int Ws, int C, const float* minv9, float* dst, int Hd, int Wd, float scale,
+                            float shift, hipStream_t s);
 int launch_pos_emb(const float* pose, float* out, int n, int pose_dim, int classes, hipStream_t s);
 int launch_cast(int dt, const float* in, void* out, size_t n, hipStream_t s);
 

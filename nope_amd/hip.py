@@ -71,6 +71,7 @@ _PROTOS = {
     "nope_ldm_destroy": (None, [_vp]),
     "nope_ldm_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "nope_ldm_forward": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "nope_op_warp_perspective": (_i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_float), _vp, _i, _i, C.c_float, C.c_float, _vp]),
     "nope_op_layer_norm": (_i, [_i, _vp, _vp, _vp, _vp, _i64, _i, C.c_float, _vp]),
     "nope_op_geglu": (_i, [_i, _vp, _vp, _i64, _i, _vp]),
     "nope_op_token_attention": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -442,6 +443,21 @@ class LdmHandle:
         self._l.check(self._l.dll.nope_ldm_forward(self._h, _ptr(x), n_src, x_rep, _ptr(pose), n_hyp, H, W, _ptr(out), odt,
                                                    _ptr(ws), ws.numel(), _stream(x)), "nope_ldm_forward")
         return out
+
+
+def op_warp_perspective(img: torch.Tensor, minv, size: int, scale: float = 1.0, shift: float = 0.0) -> torch.Tensor:
+    """img (H,W,C) uint8 or f32 on the device, minv 3x3 (host) mapping output pixels to source pixels -> (C,size,size) f32."""
+    require_device(img)
+    img = img.contiguous()
+    if img.dtype not in (torch.uint8, torch.float32):
+        img = img.float()
+    H, W, Cc = img.shape
+    out = torch.empty((Cc, size, size), dtype=torch.float32, device=img.device)
+    m = (C.c_float * 9)(*[float(v) for v in list(minv.reshape(-1))])
+    l = lib()
+    l.check(l.dll.nope_op_warp_perspective(_ptr(img), int(img.dtype == torch.uint8), H, W, Cc, m, _ptr(out), size, size, scale, shift,
+                                           _stream(img)), "nope_op_warp_perspective")
+    return out
 
 
 def op_layer_norm(dt: int, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:

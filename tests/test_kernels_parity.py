@@ -509,3 +509,57 @@ def test_ldm_unet_vs_reference_golden(be, golden, tag):
             yh = m.forward_hypotheses(x[:1].to(dev), pose[None].to(dev)).cpu()[0]
             want = R.ldm_forward(m.cpu().own_state_dict(), x[:1].expand(3, -1, -1, -1), pose)
             assert rel(yh, want) < tol
+
+
+def test_dataset_crop_and_sample_assembly(be):
+    """SURVEY section 8 row f3, image side: the four-point perspective solve, the device warp (bilinear, zero border, fused
+    /255*2-1 + HWC->CHW) against torch.grid_sample, crop_frame's geometry, and the test-split sample dict of
+    ShapeNet.process / __getitem__ (shapeNet.py:265-357).  OpenCV itself is not installed: parity-unpinned (see nope_amd/dataset.py)."""
+    import numpy as np
+    hip, dev, _ = be
+    from nope_amd import dataset as D
+    from nope_amd.poses import synthesize_grid
+    rng = np.random.default_rng(0)
+    src = np.array([[10, 20], [15, 200], [180, 30], [210, 190]], np.float32)
+    dst = np.array([[0, 0], [0, 64], [64, 0], [64, 64]], np.float32)
+    M = D.get_perspective_transform(src, dst)
+    p = (M @ np.c_[src, np.ones(4)].T).T
+    assert np.allclose(p[:, :2] / p[:, 2:], dst, atol=1e-9)
+    # warp vs grid_sample (align_corners=True == pixel centres on integers), f32 and uint8 sources, samples beyond the border
+    g = torch.Generator().manual_seed(4)
+    img = torch.rand(40, 52, 3, generator=g)
+    Minv = np.linalg.inv(M * 1.0)
+    Minv = np.array([[0.55, 0.06, -3.0], [-0.04, 0.47, 2.5], [1e-4, -2e-4, 1.0]])
+    out = hip.op_warp_perspective(img.to(dev), Minv, 64).cpu()
+    ys, xs = torch.meshgrid(torch.arange(64.0), torch.arange(64.0), indexing="ij")
+    w = Minv[2, 0] * xs + Minv[2, 1] * ys + Minv[2, 2]
+    sx = (Minv[0, 0] * xs + Minv[0, 1] * ys + Minv[0, 2]) / w
+    sy = (Minv[1, 0] * xs + Minv[1, 1] * ys + Minv[1, 2]) / w
+    grid = torch.stack([2 * sx / (52 - 1) - 1, 2 * sy / (40 - 1) - 1], -1)[None].float()
+    want = F.grid_sample(img.permute(2, 0, 1)[None], grid, mode="bilinear", padding_mode="zeros", align_corners=True)[0]
+    assert float((out - want).abs().max()) < 2e-5 and float(out[:, 0, 0].abs().max()) == 0.0     # (0,0) maps outside: zero border
+    u8 = (img * 255).to(torch.uint8)
+    out8 = hip.op_warp_perspective(u8.to(dev), Minv, 64, 2.0 / 255.0, -1.0).cpu()
+    want8 = F.grid_sample(u8.float().permute(2, 0, 1)[None], grid, mode="bilinear", padding_mode="zeros", align_corners=True)[0] * (2 / 255.0) - 1
+    assert float((out8 - want8).abs().max()) < 2e-5
+    # crop_frame geometry: the projected virtual bounding box lands on the output corners
+    cams, objs = synthesize_grid(0)
+    pose = np.linalg.inv(objs[5]) if False else objs[5].copy()
+    pose[:3, 3] = [0.02, -0.03, 1.1]
+    Mc = D.crop_transform(D.SHAPENET_INTRINSIC, pose, 128, virtual_bbox_size=1)
+    origin = pose[:3, 3]
+    centre = D.SHAPENET_INTRINSIC @ origin
+    c2 = Mc @ np.array([centre[0] / centre[2], centre[1] / centre[2], 1.0])
+    assert np.allclose(c2[:2] / c2[2], [64, 64], atol=1.5)          # object centre -> crop centre (int truncation of the corners: ~1 px)
+    frame = torch.zeros(512, 512, 3, dtype=torch.uint8)
+    frame[200:312, 200:312] = 255
+    crop = D.crop_frame(frame.to(dev), None, D.SHAPENET_INTRINSIC, pose, 128, virtual_bbox_size=1, normalize=True)
+    assert crop.shape == (3, 128, 128) and float(crop.min()) >= -1 - 1e-6 and float(crop.max()) <= 1 + 1e-6 and float(crop.mean()) > -1
+    # sample assembly
+    tpl_poses = objs[:4].copy()
+    for t in tpl_poses:
+        t[:3, 3] = [0, 0, 1.0]
+    sample = D.process_test_sample(frame.to(dev), frame.to(dev), [frame.to(dev)] * 4, pose, tpl_poses[0], list(tpl_poses), objs[:4], img_size=64)
+    assert sample["query"].shape == (3, 64, 64) and sample["gt_templates"].shape == (4, 3, 64, 64)
+    assert sample["all_relativeR"].shape == (4, 6) and sample["gt_relativeR"].shape == (6,) and sample["template_poses"].shape == (4, 3, 3)
+    assert sample["query_pose"].shape == (3, 3) and sample["symmetry"].shape == (1,)
