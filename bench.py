@@ -141,7 +141,7 @@ def scoring_roofline(dtype: torch.dtype, N: int = 0):
     bank = torch.randn(B, N, C, h, h, device="cuda", dtype=torch.float16).to(dtype)
     q = torch.randn(B, C, h, h, device="cuda")
     out = torch.empty(B, N, device="cuda")
-    for _ in range(3):
+    for _ in range(25):                       # (clock / page warm-up: the first ~10 launches of a process run 10-20 % slower)
         hip.similarity(q, bank, out=out)
     reps = 20
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]   # kernels run on torch's current stream

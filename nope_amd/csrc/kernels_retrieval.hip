@@ -11,6 +11,8 @@
 // Arithmetic is ~1.2 flop/byte: far below the VALU ridge, purely HBM-bound.
 // Accumulation is f32; reductions are fixed-shape (wave xor-tree + ordered LDS fold), so
 // scores are run-to-run deterministic.
+#include <cstdlib>
+
 #include "nope_common.h"
 
 namespace nope {
@@ -34,7 +36,14 @@ __device__ __forceinline__ void accum_quartic(const u32x4& raw, const float* q, 
 
 // P = HW / VEC pixel-vectors per plane; requires P <= 256 and 256 % P == 0.
 // hpi = 256 / P hypotheses are scored per iteration (thread -> (sub-hypothesis, pixel-vector)).
-template <class T, int CMAX>
+// 16-byte streaming load of bank data: each byte is read exactly once per launch, so it is marked non-temporal (no point in
+// keeping it in L2 / Infinity Cache ahead of the query tiles and the next kernel's operands).
+template <bool NTL> __device__ __forceinline__ u32x4 ld16_stream(const void* p) {
+    if (NTL) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return *reinterpret_cast<const u32x4*>(p);
+}
+
+template <class T, int CMAX, bool NTL>
 __global__ __launch_bounds__(NT) void sim_reg_kernel(const float* __restrict__ q, const T* __restrict__ bank, float* __restrict__ scores,
                                                      int N, int C, int HW, long long bank_stride_b, int score_ld, int nsplit) {
     constexpr int VEC = Elt<T>::VEC;
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(NT) void sim_reg_kernel(const float* __restrict__ q
         const T* tp = bb + (size_t)(n < N ? n : 0) * hyp_elems + (size_t)pv * VEC;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
-            if (c < C) raw[c] = ld16(tp + (size_t)c * HW);
+            if (c < C) raw[c] = ld16_stream<NTL>(tp + (size_t)c * HW);
     };
     auto reduce = [&](const u32x4 (&raw)[CMAX], int g) {
         const int n = g * hpi + sub;
@@ -212,24 +221,27 @@ int launch_similarity(const float* q, const void* bank, int bank_dt, float* scor
     if (HW % vec) return NOPE_ERR_UNSUPPORTED;
     const int P = HW / vec;
     const bool reg_ok = (P <= NT) && (NT % P == 0) && (C <= 16);
+    static const int variant = getenv("NOPE_SIM_VARIANT") ? atoi(getenv("NOPE_SIM_VARIANT")) : 1;    // tuning: 1 = non-temporal bank loads (0.69 -> 0.75-0.82 of HBM peak), 2 = ~1024 long workgroups (0.9x)
     int nsplit;
     if (reg_ok) {
         const int hpi = NT / P;
         const int groups = cdiv(N, hpi);
-        nsplit = cdiv(4096, B);
+        // ~4096 workgroups of ~16 hypotheses each (fewer, longer ones measured 10 % slower: profiles/r02e_sim_bench.txt)
+        nsplit = cdiv((variant & 2) ? 1024 : 4096, B);
         if (nsplit > groups) nsplit = groups;
         if (nsplit < 1) nsplit = 1;
         dim3 grid((unsigned)((long long)B * nsplit)), block(NT);
-        if (bank_dt == NOPE_F32) {
-            if (C <= 8) hipLaunchKernelGGL((sim_reg_kernel<float, 8>), grid, block, 0, s, q, (const float*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
-            else hipLaunchKernelGGL((sim_reg_kernel<float, 16>), grid, block, 0, s, q, (const float*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
-        } else if (bank_dt == NOPE_BF16) {
-            if (C <= 8) hipLaunchKernelGGL((sim_reg_kernel<bf16_t, 8>), grid, block, 0, s, q, (const bf16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
-            else hipLaunchKernelGGL((sim_reg_kernel<bf16_t, 16>), grid, block, 0, s, q, (const bf16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
-        } else {
-            if (C <= 8) hipLaunchKernelGGL((sim_reg_kernel<f16_t, 8>), grid, block, 0, s, q, (const f16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
-            else hipLaunchKernelGGL((sim_reg_kernel<f16_t, 16>), grid, block, 0, s, q, (const f16_t*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit);
-        }
+#define NOPE_SIM_LAUNCH(T, CM, NTLOAD) hipLaunchKernelGGL((sim_reg_kernel<T, CM, NTLOAD>), grid, block, 0, s, q, (const T*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit)
+#define NOPE_SIM_T(T)                                                                                         \
+        do {                                                                                                  \
+            if (variant & 1) { if (C <= 8) NOPE_SIM_LAUNCH(T, 8, true); else NOPE_SIM_LAUNCH(T, 16, true); }   \
+            else { if (C <= 8) NOPE_SIM_LAUNCH(T, 8, false); else NOPE_SIM_LAUNCH(T, 16, false); }            \
+        } while (0)
+        if (bank_dt == NOPE_F32) NOPE_SIM_T(float);
+        else if (bank_dt == NOPE_BF16) NOPE_SIM_T(bf16_t);
+        else NOPE_SIM_T(f16_t);
+#undef NOPE_SIM_T
+#undef NOPE_SIM_LAUNCH
     } else {
         if ((size_t)C * HW > 16384) return NOPE_ERR_UNSUPPORTED;
         nsplit = cdiv(4096, B);
