@@ -19,9 +19,9 @@ of `--templates` templates per GPU in `--bank-dtype` (default: BASELINE configs[
 templates); for N>1 every rank scores its slice, the (B, N/G) scores are all-gathered over RCCL and ranked.
 
 Extra legs on rank 0 at N=1 (outside the timed region):
-  roofline      the dominant kernel of the step, conv_gemm_dma_kernel<bf16> (the U-Net's 83 implicit-GEMM launches):
-                multiply-adds x2 those launches EXECUTE (phase convs 4/9 of the nearest-x2 MACs, padding taps of the
-                4x4 level skipped) / their summed duration, measured with HIP events around every launch on the launch
+  roofline      the dominant kernels of the step, the implicit-GEMM convs (conv3x3_halo_kernel, conv_gemm_pp_kernel,
+                conv_gemm_dma_kernel: the U-Net's 83 launches): multiply-adds x2 those launches EXECUTE (phase convs 4/9 of
+                the nearest-x2 MACs) / their summed duration, measured with HIP events around every launch on the launch
                 stream, vs the 2.5 PFLOP/s dense bf16 peak;
   scoring       the similarity kernel on a 1.07 GB resident bank, vs 8 TB/s HBM;
   cpu_baseline  the oracle (CPU restatement, kind "port") on the host cores, bounded sample.
@@ -261,8 +261,9 @@ def main():
                            "algorithmic_bytes_per_launch": abytes / max(n_launch, 1), "launches_per_step": n_launch,
                            "avg_launch_ms": ms / max(n_launch, 1), "kernel_ms_per_step": ms, "flops_per_step": flops,
                            "note": "flops = executed MACs x2 of all implicit-GEMM launches of one step (the nearest-x2 convs run "
-                                   "as four 2x2 phase convs = 4/9 of the reference MACs; 3x3 convs on the 4x4 level skip the taps lying in the zero "
-                                   "padding = 69 % of theirs); time = HIP events around each launch"}
+                                   "as four 2x2 phase convs = 4/9 of the reference MACs; the few 4x4-level launches that stay on the 128x192 kernel in "
+                                   "position-major order skip the taps lying in the zero padding, everything else executes every tap); time = HIP "
+                                   "events around each launch"}
         res["scoring_roofline"] = [scoring_roofline(torch.bfloat16), scoring_roofline(torch.float32),
                                    scoring_roofline(torch.float16, N=1024)]      # BASELINE configs[4]: fp16 bank, 8192 / 8 templates per GPU
         res["cpu_baseline"] = cpu_baseline(model, a.size, a.templates)
