@@ -52,6 +52,7 @@ struct ConvParams {
     unsigned char pos_order[64];       // posmajor: pixel positions by descending number of valid taps
     int persist_iters;                 // > 1: a workgroup walks this many tiles (tile_m advances by 64 each time)
     unsigned persist_d1, persist_d2;   // byte advance of the A offsets per walked tile (src1 / src2)
+    unsigned* timeline;                // tuning only (NOPE_PP_VARIANT & 256): cycle stamps of workgroup 0, see conv3x3_halo_kernel
     int posmajor;                      // 1: GEMM rows ordered (pixel position, sample) instead of (sample, pixel) -- see launch_conv
     FastDiv d_n;                       // / nhyp (posmajor)
     int nhyp;
@@ -226,9 +227,12 @@ template <class T> struct Ep {
     static constexpr int WAVE_BYTES = 64 * LD * 4;
 };
 
-template <class T, bool PN>
+// DRAIN: wait for the vector-memory queue (a prefetch issued before the call) after the first panel is filled, before the
+// first store.
+struct NoStamp { __device__ __forceinline__ void operator()() const {} };
+template <class T, bool PN, bool DRAIN = false, class Stamp = NoStamp>
 __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL],
-                                              int m0, int n0, int wm, int wn, int lane, unsigned char* lds_wave) {
+                                              int m0, int n0, int wm, int wn, int lane, unsigned char* lds_wave, Stamp stamp = Stamp()) {
     typedef Tile<T> TL;
     constexpr int VEC = Elt<T>::VEC;
     constexpr int PANW = TL::TM == 32 ? 32 : 48;   // panel width in columns
@@ -237,6 +241,13 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
     float* pan = reinterpret_cast<float*>(lds_wave);
     T* out = reinterpret_cast<T*>(p.out);
     const T* resid = reinterpret_cast<const T*>(p.resid);
+    // the bias of this lane's NTL columns: all loads in flight at once, ahead of everything that waits for them
+    float bvj[TL::NTL];
+#pragma unroll
+    for (int j = 0; j < TL::NTL; ++j) {
+        const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
+        bvj[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+    }
     if (p.colstats) {
         // GroupNorm statistics of the conv output, fused: per column (sum, sum of squares) over this wave's 64
         // rows, straight from the accumulators (f32, before the rounding to T): a lane adds up the rows it
@@ -246,7 +257,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
 #pragma unroll
         for (int j = 0; j < TL::NTL; ++j) {
             const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
-            const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+            const float bv = bvj[j];
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int i = 0; i < TL::MT; ++i)
@@ -261,13 +272,65 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
             }
         }
     }
+    if constexpr (sizeof(T) == 2 && TL::TM == 32 && !PN) {
+        if (!resid) {
+            // bf16 without a residual: the values are final before they leave the registers, so the panel holds them ROUNDED,
+            // two rows per dword (a lane's accumulator registers r, r + 1 are rows 2q, 2q + 1 of one column): half the LDS
+            // stores of the f32 panel -- the LDS store path (64 B/clk) is what bounds the fill -- and half the reads; the
+            // store side splits 8 dwords (8 columns x 2 rows) into the two rows' 16-byte chunks.
+            constexpr int PLD = 36;                                   // dwords per row pair (32 columns + pad)
+            unsigned* pk = reinterpret_cast<unsigned*>(lds_wave);
+#pragma unroll
+            for (int pass = 0; pass < TL::NTL; ++pass) {
+                const float bv = bvj[pass];
+#pragma unroll
+                for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < TL::R; r += 2) {
+                        float v0 = acc[i][pass][r] + bv, v1 = acc[i][pass][r + 1] + bv;
+                        if (p.act) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+                        pk[((i * TL::TM + TL::out_row(lane, r)) >> 1) * PLD + TL::out_col(lane)] = cvt_pk_bf16(v0, v1);
+                    }
+                __builtin_amdgcn_wave_barrier();                      // (same-wave LDS write -> read, see below)
+                stamp();
+                if (DRAIN && pass == 0) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+                stamp();
+                const int ch = lane & 3;
+                const int n = n0 + wn * 96 + pass * TL::TM + ch * 8;
+                u32x4 d[2][2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int rp = (lane >> 2) + 16 * t;
+                    d[t][0] = ld16(&pk[rp * PLD + ch * 8]);
+                    d[t][1] = ld16(&pk[rp * PLD + ch * 8 + 4]);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int m = m0 + wm * 64 + 2 * ((lane >> 2) + 16 * t);
+                    u32x4 lo, hi;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned e = d[t][k >> 1][(2 * k) & 3], o = d[t][k >> 1][(2 * k + 1) & 3];
+                        lo[k] = (e & 0xffffu) | (o << 16);
+                        hi[k] = (e >> 16) | (o & 0xffff0000u);
+                    }
+                    if (n < p.Cout) {
+                        if (m < p.M) st16(out + out_row(p, m) * p.Cout + n, lo);
+                        if (m + 1 < p.M) st16(out + out_row(p, m + 1) * p.Cout + n, hi);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                stamp();
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int pass = 0; pass < 96 / PANW; ++pass) {
 #pragma unroll
         for (int jj = 0; jj < TPP; ++jj) {
             const int j = pass * TPP + jj;
-            const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
-            const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+            const float bv = bvj[j];
 #pragma unroll
             for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
@@ -277,6 +340,9 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
         // same-wave LDS write -> read: the LDS queue of a wave is in order, so no s_barrier; the wave
         // barrier only pins the compiler's ordering (and is the rendezvous point of tests/hipemu)
         __builtin_amdgcn_wave_barrier();
+        stamp();
+        if (DRAIN && pass == 0) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+        stamp();
         // Fused PreNorm operands, hoisted out of the chunk loop where they are loop-invariant: with 64 % CH == 0
         // a lane keeps the same column chunk for the whole pass, and with HW % 64 == 0 the wave's 64 rows are
         // one sample (one mean / rstd).
@@ -340,6 +406,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
             st16(out + o, Elt<T>::pack(v));
         }
         __builtin_amdgcn_wave_barrier();
+        stamp();
     }
 }
 

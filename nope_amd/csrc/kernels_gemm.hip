@@ -642,7 +642,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         if (p.splits > 1) p.split_out = (float*)a.splitk_ws;
     }
     // Persistent walk: 512 workgroups (2 per CU), each `iters` tiles 64 tile_m apart (same XCD under xcd_map).
-    p.persist_iters = 1; p.persist_d1 = p.persist_d2 = 0;
+    p.persist_iters = 1; p.persist_d1 = p.persist_d2 = 0; p.timeline = nullptr;
     unsigned gx = (unsigned)nblocks;
     {
         const long long hw = (long long)a.Hs * a.Ws;
@@ -654,6 +654,17 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
             p.persist_d1 = (unsigned)(64ll * BM * a.C1 * es);
             p.persist_d2 = (unsigned)(64ll * BM * a.C2 * es);
             gx = 512;
+        }
+    }
+    // The tap-resident kernel walks tiles too (bf16): one workgroup per CU, tiles gx / 8 apart inside the XCD's run of M tiles,
+    // the next tile's prologue in flight under the epilogue.  NOPE_HALO_PERSIST = workgroups (default 256, 0 = one tile per
+    // workgroup; read per launch: the tests use small grids).
+    if (plan.halo && dt == NOPE_BF16 && p.xcd_map) {
+        const int want = getenv("NOPE_HALO_PERSIST") ? atoi(getenv("NOPE_HALO_PERSIST")) : 256;
+        const long long hw = (long long)a.Hs * a.Ws;
+        if (want >= 8 && want % 8 == 0 && nblocks > want && nblocks % want == 0 && ((long long)(want / 8) * 256) % hw == 0) {
+            gx = (unsigned)want;
+            p.persist_iters = (int)(nblocks / want);
         }
     }
     const dim3 grid(gx, phased ? 4u : 1u, (unsigned)p.splits), block(NT);

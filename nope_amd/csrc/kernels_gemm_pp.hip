@@ -34,6 +34,8 @@
 // out-of-range offsets for padding, position-major rows with skipped padding taps, wide-store epilogue with fused
 // GroupNorm statistics / PreNorm -- is shared with the 128 x 192 kernel (conv_gemm_common.h).
 #include "conv_gemm_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace nope {
 
@@ -341,7 +343,9 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
 constexpr int HALO_ROWS = 328;       // 256 + 2 * (32 + 1), rounded up to whole 8-row pieces: maps up to 32 pixels wide
 constexpr int HALO_MAX_W = 32;
 
-template <class T>
+constexpr int TIMELINE_STAMPS = 720;  // per group; 5 per K step (tuning instantiation only)
+
+template <class T, bool TIMELINE = false>
 __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvParams p) {
     typedef Tile<T> TL;
     constexpr int VEC = Elt<T>::VEC;
@@ -354,9 +358,10 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     constexpr int A_STAGE = ZROW + RB;
     constexpr int RING = A_BASE + 2 * A_STAGE;
     constexpr int PANELS = PP_WAVES * Ep<T>::WAVE_BYTES;
-    constexpr int LDS_BYTES = RING > PANELS ? RING : PANELS;
+    constexpr int LDS_USED = RING > PANELS ? RING : PANELS;
+    constexpr int LDS_BYTES = LDS_USED + (TIMELINE ? 2 * TIMELINE_STAMPS * 4 : 0);
     constexpr int KK = RB / 16 / TL::KSLOTS;
-    static_assert(RING <= 160 * 1024 && A_STAGE < 65536 && 2 * B_STAGE + BN * RB < 65536 + B_STAGE && 2 * B_STAGE + 2 * Tile<T>::TM * RB < 65536, "LDS budget / ds_read immediates (16 bits)");
+    static_assert(LDS_BYTES <= 160 * 1024 && A_STAGE < 65536 && 2 * B_STAGE + BN * RB < 65536 + B_STAGE && 2 * B_STAGE + 2 * Tile<T>::TM * RB < 65536, "LDS budget / ds_read immediates (16 bits)");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int tid = threadIdx.x;
@@ -365,9 +370,35 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int grp = wave >> 2, wl = wave & 3;
+    // (tuning instantiation: the first wave of each group of workgroup 0 stamps the shader clock at five points of every K
+    //  step -- LOAD reads done / barrier passed / MFMAs issued / DMA landed / barrier passed -- into the LDS tail)
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if constexpr (TIMELINE) {
+            if (blockIdx.x == 0 && wl == 0 && n_stamp < TIMELINE_STAMPS - 4) {
+                const unsigned t = (unsigned)__builtin_readcyclecounter();
+                if (lane == 0) reinterpret_cast<unsigned*>(lds + LDS_USED)[grp * TIMELINE_STAMPS + n_stamp] = t;
+                ++n_stamp;
+            }
+        }
+    };
+    // (... and the shader clock next to the constant 100 MHz clock at both ends of the kernel: the actual clock rate)
+    auto stamp_clocks = [&](int slot) {
+        if constexpr (TIMELINE) {
+            if (blockIdx.x == 0 && wave == 0) {
+                const unsigned t = (unsigned)__builtin_readcyclecounter(), rt = (unsigned)__builtin_amdgcn_s_memrealtime();
+                if (lane == 0) {
+                    reinterpret_cast<unsigned*>(lds + LDS_USED)[TIMELINE_STAMPS - 4 + 2 * slot] = t;
+                    reinterpret_cast<unsigned*>(lds + LDS_USED)[TIMELINE_STAMPS - 3 + 2 * slot] = rt;
+                }
+            }
+        }
+    };
+    stamp_clocks(0);
     int tile_m, tile_n;
     tile_coords(p, tile_m, tile_n);
-    const int m0 = tile_m * PP_BM, n0 = tile_n * BN;
+    int m0 = tile_m * PP_BM;                                       // (advances when the workgroup walks several tiles, see below)
+    const int n0 = tile_n * BN;
     const int W = p.Ws, HW = p.Hs * p.Ws;
     const int halo = W + 1;
     const int Cin = p.C1 + p.C2;
@@ -387,8 +418,8 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     const int rsub = lane >> 3, lslot = lane & 7;
     const int r0 = 8 * wave + rsub;
     const unsigned a_cs = (unsigned)((lslot ^ swz_of<RB>(r0)) * VEC);
-    const unsigned a_base1 = (unsigned)((m0 - halo + r0) * p.C1 + (int)a_cs) * ES;
-    const unsigned a_base2 = (unsigned)((m0 - halo + r0) * p.C2 + (int)a_cs) * ES;
+    unsigned a_base1 = (unsigned)((m0 - halo + r0) * p.C1 + (int)a_cs) * ES;
+    unsigned a_base2 = (unsigned)((m0 - halo + r0) * p.C2 + (int)a_cs) * ES;
     const unsigned a_step1 = 64u * (unsigned)p.C1 * ES, a_step2 = 64u * (unsigned)p.C2 * ES;
     const bool a_has4 = wave + 32 < npieces, a_has5 = wave + 40 < npieces;      // (pieces 0..3 of a wave always exist)
     unsigned char* const a_dst = lds + A_BASE + wave * 1024;                    // + stage * A_STAGE + i * 8192
@@ -456,20 +487,30 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     const int nchunks = Cin / BK;
     const unsigned wrap_inc = (unsigned)BK * ES - 8u * cin_es;     // K offset step from tap 8 of a chunk to tap 0 of the next
 
-    // ---- prologue: the whole A stage of chunk 0, this group's half of B(0), and (group 1) its half of B(1)
-    set_chunk(0);
+    // ---- prologue of a tile: the whole A stage of chunk 0, this group's half of B(0), and (group 1) its half of B(1)
+    auto tile_prologue = [&]() {
+        set_chunk(0);
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-        if (i < 4 || (i == 4 ? a_has4 : a_has5)) piece_a(i, 0);
-    issue_b(0); bkofs += cin_es;
-    if (grp == 1) { issue_b(1); bkofs += cin_es; }                 // (nk >= 9 > 2)
-    __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0 & WAIT_LGKMCNT0);       // DMA landed, zero rows written
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (grp == 1) {
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 6; ++i)
+            if (i < 4 || (i == 4 ? a_has4 : a_has5)) piece_a(i, 0);
+        bkofs = 0;
+        issue_b(0); bkofs += cin_es;
+        if (grp == 1) { issue_b(1); bkofs += cin_es; }             // (nk >= 9 > 2)
+    };
+    // ---- the epilogue panels of a wave.  bf16: outside everything the NEXT tile's prologue writes (A stage 0, B stage 0
+    // and the first half of B stage 1), so a workgroup that walks several tiles can have that prologue in flight while it
+    // stores this tile: group 0 in the second half of B stage 1 + B stage 2, group 1 in A stage 1 (below its zero row).
+    unsigned char* lds_panel = lds + wave * Ep<T>::WAVE_BYTES;
+    if constexpr (sizeof(T) == 2) {
+        static_assert(sizeof(T) != 2 || (4 * Ep<T>::WAVE_BYTES <= B_STAGE + B_STAGE / 2 && 4 * Ep<T>::WAVE_BYTES <= ZROW), "panel placement");
+        lds_panel = lds + (grp == 0 ? B_STAGE + B_STAGE / 2 : A_BASE + A_STAGE) + wl * Ep<T>::WAVE_BYTES;
     }
+    // A workgroup walks `iters` tiles of the same weight panel, gridDim.x / 8 M tiles apart (a multiple of the image size:
+    // checked by the launcher, so the padding masks above hold for every tile of the walk).
+    const int iters = sizeof(T) == 2 && p.persist_iters > 1 ? p.persist_iters : 1;
+    const int walk_rows = (int)(gridDim.x >> 3) * PP_BM;
+    tile_prologue();
+    __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                       // DMA landed
     const bool dma_on = !(p.variant & 16);                         // (tuning: 16 = no DMA stream)
 
     // The nine K steps of channel chunk `chunk`, whose A stage is `par` (a literal at both call sites: after inlining and
@@ -510,8 +551,10 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                 for (int j = 0; j < TL::NTL; ++j) bfr[kk][j] = ld16(lds + fbk[kk] + ((tap % 3) * B_STAGE + j * TL::TM * RB));
             }
             __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);     // my reads of this step are done: after the barrier the other group may overwrite them
+            stamp();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            stamp();
             // ---- COMPUTE: registers only
             __builtin_amdgcn_s_setprio(1);
             if (!(p.variant & 32)) {                       // (tuning: 32 = no MFMA)
@@ -531,22 +574,63 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                 }
             }
             __builtin_amdgcn_s_setprio(0);
+            stamp();
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);       // the pieces issued in this step's LOAD have landed (they had this whole phase)
+            stamp();
             if (!(grp == 1 && last && tap == 8)) {         // (group 1 started one barrier late: it skips the last one)
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
+            stamp();
         }
     };
-    for (int chunk = 0; chunk < nchunks; chunk += 2) {
-        chunk_steps(chunk, 0);
-        if (chunk + 1 < nchunks) chunk_steps(chunk + 1, 1);
+    for (int it = 0; it < iters; ++it) {
+        __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);                 // zero rows written / my panel reads of the previous tile done
+        __builtin_amdgcn_s_barrier();                              // every wave's prologue pieces have landed (waited by their issuers)
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1) {                                            // group 1 runs one slot behind
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp();
+        for (int chunk = 0; chunk < nchunks; chunk += 2) {
+            chunk_steps(chunk, 0);
+            if (chunk + 1 < nchunks) chunk_steps(chunk + 1, 1);
+        }
+        if (p.variant & 64) {                          // tuning only: no epilogue (keeps the accumulators live)
+            if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;
+            return;
+        }
+        // All fragment reads of this tile are behind a barrier every wave has passed (group 0: the one after its last
+        // COMPUTE, which group 1 reached after its last LOAD), nothing is in flight: the ring is free.  Start the next tile's
+        // prologue now -- it lands while the panels are filled -- and wait for it before the first store of the epilogue
+        // (so the K loop's vmcnt never has to wait for a prologue behind a queue of stores).
+        const int m_this = m0;
+        const bool more = it + 1 < iters;
+        if (more) {
+            m0 += walk_rows;
+            a_base1 += (unsigned)walk_rows * (unsigned)p.C1 * ES;
+            a_base2 += (unsigned)walk_rows * (unsigned)p.C2 * ES;
+            if (dma_on) tile_prologue();
+        }
+        if constexpr (TIMELINE) epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel, stamp);
+        else epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel);
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                for (int j = 0; j < TL::NTL; ++j)
+#pragma unroll
+                    for (int r = 0; r < TL::R; ++r) acc[i][j][r] = 0.f;
+        }
+        stamp();
     }
-    if (p.variant & 64) {                              // tuning only: no epilogue (keeps the accumulators live)
-        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;
-        return;
+    stamp_clocks(1);
+    if constexpr (TIMELINE) {
+        __syncthreads();
+        if (blockIdx.x == 0 && p.timeline)
+            for (int i = tid; i < 2 * TIMELINE_STAMPS; i += PP_WAVES * 64) p.timeline[i] = reinterpret_cast<unsigned*>(lds + LDS_USED)[i];
     }
-    epilogue_wide<T, false>(p, acc, m0, n0, wm, wn, lane, lds + wave * Ep<T>::WAVE_BYTES);
 }
 
 template <class T>
@@ -573,6 +657,25 @@ int conv_halo_max_width() { return HALO_MAX_W; }
 void launch_conv_halo(int dt, const void* params, dim3 grid, hipStream_t s) {
     const ConvParams& p = *static_cast<const ConvParams*>(params);
     const dim3 block(PP_WAVES * 64);
+    if (dt == NOPE_BF16 && (p.variant & 256)) {        // tuning only: cycle stamps of workgroup 0 appended to $NOPE_PP_TIMELINE
+        static unsigned* dev = nullptr;
+        if (!dev && hipMalloc((void**)&dev, 2 * TIMELINE_STAMPS * 4) != hipSuccess) return;
+        (void)hipMemsetAsync(dev, 0, 2 * TIMELINE_STAMPS * 4, s);
+        ConvParams q = p;
+        q.timeline = dev;
+        hipLaunchKernelGGL((conv3x3_halo_kernel<bf16_t, true>), grid, block, 0, s, q);
+        unsigned host[2 * TIMELINE_STAMPS];
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(host, dev, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE* f = fopen(getenv("NOPE_PP_TIMELINE") ? getenv("NOPE_PP_TIMELINE") : "/tmp/nope_pp_timeline.txt", "a")) {
+                fprintf(f, "halo Cin %d Cout %d M %d W %d iters %d\n", p.C1 + p.C2, p.Cout, p.M, p.Ws, p.persist_iters);
+                for (int g = 0; g < 2; ++g) {
+                    for (int i = 0; i < TIMELINE_STAMPS; ++i) fprintf(f, "%u ", host[g * TIMELINE_STAMPS + i]);
+                    fprintf(f, "\n");
+                }
+                fclose(f);
+            }
+        return;
+    }
     if (dt == NOPE_F32) hipLaunchKernelGGL((conv3x3_halo_kernel<float>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((conv3x3_halo_kernel<bf16_t>), grid, block, 0, s, p);
 }

@@ -46,6 +46,9 @@ def run(hip, dev, dts=(1, 0), light=False):
         xs, ws_, bs = rn(40, C, 4, 4), rn(24, C, 3, 3) / (3 * C ** 0.5), rn(24)
         y = hip.op_conv(dt, hip.to_nhwc(d(xs), dt), d(ws_), d(bs))
         chk(y, F.conv2d(q(xs), q(ws_), bs, padding=1), "halo 4x4 x 40 samples")
+        # (bf16 without a residual leaves through the packed two-rows-per-dword panel, with one through the f32 panel: same bits)
+        y0 = hip.op_conv(dt, hip.to_nhwc(d(xs), dt), d(ws_), d(bs), resid=torch.zeros_like(y))
+        assert torch.equal(y, y0), "packed epilogue panel differs from the f32 panel"
         xw = rn(1, 2 * C, 9, 32)
         ww = rn(16, 2 * C, 3, 3) / (3 * (2 * C) ** 0.5)
         y = hip.op_conv(dt, hip.to_nhwc(d(xw), dt), d(ww), None)
@@ -54,6 +57,21 @@ def run(hip, dev, dts=(1, 0), light=False):
         y2 = hip.op_conv(dt, hip.to_nhwc(d(xw), dt), d(ww), None)
         os.environ["NOPE_CONV_PP"] = "13"
         assert torch.equal(y, y2), "tap-resident kernel differs from the per-tap kernel"
+        if dt == 1:
+            # a workgroup walking several tiles (next tile's prologue in flight under the epilogue): 8 workgroups, 3 tiles each
+            # with one channel chunk, then 2 tiles each with two chunks (the walk ends on the other A stage); same bits as
+            # one tile per workgroup
+            for (ns, cc) in ((384, C), (256, 2 * C)):
+                xq, wq, bq = rn(ns, cc, 4, 4), rn(24, cc, 3, 3) / (3 * cc ** 0.5), rn(24)
+                os.environ["NOPE_CONV_PP"] = "11"      # (4x4 maps in (sample, pixel) row order too)
+                os.environ["NOPE_HALO_PERSIST"] = "8"
+                y = hip.op_conv(dt, hip.to_nhwc(d(xq), dt), d(wq), d(bq))
+                os.environ["NOPE_HALO_PERSIST"] = "0"
+                y2 = hip.op_conv(dt, hip.to_nhwc(d(xq), dt), d(wq), d(bq))
+                os.environ.pop("NOPE_HALO_PERSIST")
+                os.environ["NOPE_CONV_PP"] = "13"
+                chk(y, F.conv2d(q(xq), q(wq), bq, padding=1), f"halo walk {ns}x{cc}")
+                assert torch.equal(y, y2), "walking workgroups differ from one tile per workgroup"
         # 1x1, one K step (nk = 1) and two (nk = 2), residual
         w1, rs = rn(24, C, 1, 1) / 8, rn(3, 24, 10, 9)
         y = hip.op_conv(dt, hip.to_nhwc(d(x2), dt), d(w1), None, resid=hip.to_nhwc(d(rs), dt))

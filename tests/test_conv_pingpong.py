@@ -70,3 +70,12 @@ def test_pingpong_bit_identical_to_128_tile_kernel(gpu, dt):
         assert torch.equal(outs["0"], outs["3"]), ("ping-pong / tap-resident != 128-tile kernel", c1, c2, cout, h, mode, ks)
         assert torch.equal(outs["0"], outs["19"]), ("per-tap ping-pong != 128-tile kernel", c1, c2, cout, h, mode, ks)
         assert bool(torch.isfinite(outs["3"].float()).all()) and float(outs["3"].float().abs().max()) > 0.1
+        if mode == hip.CONV_PLAIN:
+            # the epilogue without a residual (bf16: packed two-rows-per-dword panel) against the one with (f32 panel), and
+            # workgroups walking several tiles against one tile per workgroup
+            y0 = hip.op_conv(dt, s1, w, b, src2=s2, mode=mode, resid=torch.zeros_like(outs["3"]))
+            os.environ["NOPE_HALO_PERSIST"] = "0"
+            y1 = hip.op_conv(dt, s1, w, b, src2=s2, mode=mode)
+            os.environ.pop("NOPE_HALO_PERSIST")
+            assert torch.equal(outs["3"], y0), ("epilogue panels differ", c1, c2, cout, h, ks)
+            assert torch.equal(outs["3"], y1), ("tile walk differs", c1, c2, cout, h, ks)
