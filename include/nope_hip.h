@@ -132,8 +132,8 @@ int nope_unet_profile_read(nope_unet* net, int* n_launches, double* total_ms, do
  * whose pose conditioning is cross-attention against context = pose_mlp(pose).  Tensor names are UNetModelPose's own
  * state-dict keys ("input_blocks.1.1.transformer_blocks.0.attn2.to_v.weight", "middle_block.0.in_layers.2.weight", ...).
  * Supported: use_spatial_transformer = true with transformer_depth = 1 and num_head_channels = 32 (the shipped
- * configs/model/vae_cin_ldm.yaml), conv_resample, no scale-shift norm, no resblock_updown; pose_mlp "single_layer" /
- * "two_layers"; injecting_condition_twice on or off. */
+ * configs/model/vae_cin_ldm.yaml), conv_resample, ResBlocks with or without use_scale_shift_norm (FiLM, openaimodel.py:277-281),
+ * no resblock_updown; pose_mlp "single_layer" / "two_layers"; injecting_condition_twice on or off. */
 typedef struct nope_ldm nope_ldm;
 typedef struct {
     int in_channels;        /* 4 in vae_cin_ldm.yaml (bf16 compute needs a multiple of 8) */
@@ -149,6 +149,7 @@ typedef struct {
     int pose_mlp_layers;    /* 1 = "single_layer", 2 = "two_layers" */
     int injecting_condition_twice;   /* 0: timestep embedding is zeros; 1: emb = pose_mlp_timesteps(pose) */
     int compute_dtype;      /* NOPE_F32 | NOPE_BF16, as nope_unet_config */
+    int use_scale_shift_norm;        /* 1: ResBlocks apply out_norm(h) * (1 + scale) + shift with (scale, shift) = emb_layers(emb) */
 } nope_ldm_config;
 
 int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors, int n_tensors, nope_stream_t stream, nope_ldm** out);

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
                                                       int nchunk, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       int HW, int C, int G, int act, const float* __restrict__ emb, int emb_stride,
                                                       const T* __restrict__ resid, float eps, int blocks_per_hyp, int x_rep, int resid_rep,
-                                                      float* __restrict__ out_stats) {
+                                                      float* __restrict__ out_stats, const float* __restrict__ film, int film_stride) {
     constexpr int VEC = Elt<T>::VEC;
     __shared__ float s_mean[64];
     __shared__ float s_rstd[64];
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
     T* yb = y + (size_t)hyp * HW * C;
     const T* rb = resid ? resid + (size_t)(hyp / resid_rep) * HW * C : nullptr;
     const float* eb = emb ? emb + (size_t)hyp * emb_stride : nullptr;
+    const float* fb = film ? film + (size_t)hyp * film_stride : nullptr;      // FiLM: [scale (C) | shift (C)] of this hypothesis
     const int cvecs = C / VEC;
     const int tpr = cvecs < NT ? cvecs : NT;
     const int rows = NT / tpr;
@@ -176,6 +177,11 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
             const float a = s_rstd[g] * gamma[c];
             sc[e] = a;
             sh[e] = beta[c] - s_mean[g] * a;
+            if (fb) {                                  // norm(x) * (1 + scale) + shift: still one fma per element
+                const float f = 1.0f + fb[c];
+                sc[e] = a * f;
+                sh[e] = sh[e] * f + fb[C + c];
+            }
             ev[e] = eb ? eb[c] : 0.f;
         }
         const size_t coff = (size_t)cv * VEC;
@@ -314,7 +320,7 @@ int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
 #define NOPE_GN_APPLY(T, FAST, OS)                                                                                              \
     hipLaunchKernelGGL((gn_apply_kernel<T, FAST, OS>), grid, block, 0, s, (const T*)a.x, (T*)a.y, a.partial, a.nchunk, a.gamma,  \
                        a.beta, a.HW, a.C, a.G, a.act, a.emb, a.emb_stride, (const T*)a.resid, a.eps, bph, a.x_rep, a.resid_rep,   \
-                       a.out_stats)
+                       a.out_stats, a.film, a.film_stride)
     if (dt == NOPE_F32) {
         if (a.out_stats) NOPE_GN_APPLY(float, false, true); else NOPE_GN_APPLY(float, false, false);
     } else if (dt == NOPE_BF16) {

@@ -11,7 +11,9 @@
 //     to_out(to_v(context)) for every query -- two tiny per-sample linears and a broadcast add; to_q, to_k and norm2 never
 //     influence the result and are not evaluated (their weights are still validated at create time);
 //   * with injecting_condition_twice = false the timestep embedding is zeros, so emb_layers(emb) is its bias: folded into the
-//     bias of in_layers' conv at create time;
+//     bias of in_layers' conv at create time (use_scale_shift_norm: that bias row is the FiLM (scale | shift) of every sample);
+//   * FiLM (use_scale_shift_norm) costs no pass: out_norm(h) * (1 + scale) + shift is folded into the per-channel affine the
+//     GroupNorm-apply kernel evaluates anyway (kernels_norm.hip);
 //   * th.cat((h, skip)) is materialised (GroupNorm(32) groups of the following ResBlock can straddle the two halves).
 #include <cstdio>
 #include <map>
@@ -105,13 +107,14 @@ struct Loader {
         r.Cin = Cin; r.Cout = Cout;
         r.n1 = norm(p + "in_layers.0.", Cin);
         r.c1 = conv(p + "in_layers.2.", Cin, Cout, 3, NOPE_CONV_PLAIN, true);
-        r.emb_w = copy_f32(p + "emb_layers.1.weight", {Cout, net->emb_dim});
-        r.emb_b = copy_f32(p + "emb_layers.1.bias", {Cout});
+        const int film = net->cfg.use_scale_shift_norm ? 2 : 1;          // emb_layers.1: Linear(emb, 2 C) for FiLM, openaimodel.py:233-239
+        r.emb_w = copy_f32(p + "emb_layers.1.weight", {film * Cout, net->emb_dim});
+        r.emb_b = copy_f32(p + "emb_layers.1.bias", {film * Cout});
         r.n2 = norm(p + "out_layers.0.", Cout);
         r.c2 = conv(p + "out_layers.3.", Cout, Cout, 3, NOPE_CONV_PLAIN, true);
         r.has_skip = Cin != Cout;
         if (r.has_skip) r.skip = conv(p + "skip_connection.", Cin, Cout, 1, NOPE_CONV_PLAIN, true);
-        if (!net->cfg.injecting_condition_twice && r.c1.bias && r.emb_b)     // emb == 0: emb_layers(emb) = its bias, folded into conv1's
+        if (!net->cfg.injecting_condition_twice && !net->cfg.use_scale_shift_norm && r.c1.bias && r.emb_b)     // emb == 0: emb_layers(emb) = its bias, folded into conv1's
             chk(launch_add_rowvec(NOPE_F32, r.c1.bias, r.c1.bias, r.emb_b, 1, 1, Cout, s));
         return r;
     }
@@ -202,33 +205,40 @@ struct Fwd {
         chk(launch_conv(net->dt, ca, s));
     }
     // y = [silu](GroupNorm(32, eps)(x))
-    void gn(const LNorm& nm, const void* x, void* y, int HW, int act, float eps) {
+    void gn(const LNorm& nm, const void* x, void* y, int HW, int act, float eps, const float* film = nullptr, int film_stride = 0) {
         if (!live()) return;
         const int nch = gn_stats_chunks(HW, nm.C, net->dt);
         chk(launch_gn_stats(net->dt, x, gn_partial, nhyp, HW, nm.C, 32, nch, s));
         GnApplyArgs ga;
         ga.x = x; ga.y = y; ga.partial = gn_partial; ga.nchunk = nch; ga.gamma = nm.gamma; ga.beta = nm.beta;
         ga.nhyp = nhyp; ga.HW = HW; ga.C = nm.C; ga.G = 32; ga.act = act; ga.eps = eps;
+        ga.film = film; ga.film_stride = film_stride;
         chk(launch_gn_apply(net->dt, ga, s));
     }
-    // ResBlock._forward, openaimodel.py:262-288 (no up/down, no scale-shift norm)
+    // ResBlock._forward, openaimodel.py:262-288 (no up/down)
     void res(const LRes& R, const Act& x, void* out) {
         const int HW = x.H * x.W;
         const size_t M = (size_t)nhyp * HW;
         const size_t mark = ar.off;
+        const bool film_on = net->cfg.use_scale_shift_norm != 0;
         void* t = alloc_act(M * R.Cin);
         void* h = alloc_act(M * R.Cout);
         gn(R.n1, x.p, t, HW, 1, 1e-5f);
         conv(R.c1, Act{t, R.Cin, x.H, x.W}, h, x.H, x.W);
-        if (emb) {                                  // h + emb_layers(emb)[..., None, None]
-            float* e = alloc_f32((size_t)nhyp * R.Cout);
+        const float* film = nullptr;                // FiLM rows [scale | shift]: emb == 0 -> the bias row, shared by every sample
+        int film_stride = 0;
+        if (film_on && !emb) film = R.emb_b;
+        if (emb) {                                  // emb_layers(emb): added to h, or (FiLM) applied by the GroupNorm below
+            const int ne = film_on ? 2 * R.Cout : R.Cout;
+            float* e = alloc_f32((size_t)nhyp * ne);
             if (live()) {
-                chk(launch_linear_naive(emb, R.emb_w, R.emb_b, e, nhyp, R.Cout, net->emb_dim, 1, R.Cout, s));
-                chk(launch_add_rowvec(net->dt, h, h, e, (long long)M, HW, R.Cout, s));
+                chk(launch_linear_naive(emb, R.emb_w, R.emb_b, e, nhyp, ne, net->emb_dim, 1, ne, s));
+                if (!film_on) chk(launch_add_rowvec(net->dt, h, h, e, (long long)M, HW, R.Cout, s));
             }
+            if (film_on) { film = e; film_stride = ne; }
         }
         void* t2 = alloc_act(M * R.Cout);
-        gn(R.n2, h, t2, HW, 1, 1e-5f);
+        gn(R.n2, h, t2, HW, 1, 1e-5f, film, film_stride);
         const void* resid = x.p;
         if (R.has_skip) {
             void* sk = alloc_act(M * R.Cout);

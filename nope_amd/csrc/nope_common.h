@@ -183,6 +183,8 @@ struct GnApplyArgs {
     int nhyp = 0, HW = 0, C = 0, G = 1;
     int act = 0;                       // 1 = SiLU
     const float* emb = nullptr; int emb_stride = 0;   // optional per-(hyp, channel) add after the activation
+    const float* film = nullptr; int film_stride = 0; // optional FiLM rows [scale (C) | shift (C)] per hypothesis (stride 0: one row for
+                                                      // all): y = act(norm(x) * (1 + scale) + shift)
     const void* resid = nullptr;       // optional NHWC tensor added last
     int x_rep = 1;                     // x (and its statistics) shared by x_rep consecutive hypotheses
     int resid_rep = 1;                 // resid shared by resid_rep consecutive hypotheses

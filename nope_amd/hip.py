@@ -35,7 +35,7 @@ class UNetConfig(C.Structure):
 class LdmConfig(C.Structure):
     _fields_ = [("in_channels", _i), ("model_channels", _i), ("out_channels", _i), ("num_res_blocks", _i), ("n_levels", _i),
                 ("channel_mult", _i * 8), ("attn_levels", _i * 8), ("num_head_channels", _i), ("context_dim", _i), ("pose_dim", _i),
-                ("pose_mlp_layers", _i), ("injecting_condition_twice", _i), ("compute_dtype", _i)]
+                ("pose_mlp_layers", _i), ("injecting_condition_twice", _i), ("compute_dtype", _i), ("use_scale_shift_norm", _i)]
 
 
 class EncoderConfig(C.Structure):
@@ -405,6 +405,7 @@ class LdmHandle:
             c.channel_mult[i] = m
             c.attn_levels[i] = int(cfg["attn_levels"][i])
         c.compute_dtype = dtype_code(compute_dtype)
+        c.use_scale_shift_norm = int(cfg.get("use_scale_shift_norm", 0))
         self.in_channels, self.out_channels, self.pose_dim = c.in_channels, c.out_channels, c.pose_dim
         descs, keep, dev = _tensor_descs(state_dict)
         self.device = dev

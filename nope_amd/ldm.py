@@ -9,8 +9,8 @@ Same constructor arguments as the reference class (the ones configs/model/vae_ci
 (`forward_hypotheses` is the batched form `generate_templates` uses).  The module tree only holds parameters.
 
 Supported configuration: `use_spatial_transformer=True`, `transformer_depth=1`, `num_head_channels=32`,
-`conv_resample=True`, no scale-shift norm, no `resblock_updown`, `pose_mlp_name` "single_layer" / "two_layers",
-`injecting_condition_twice` on or off; anything else raises NotImplementedError.
+`conv_resample=True`, `use_scale_shift_norm` (FiLM ResBlocks) on or off, no `resblock_updown`, `pose_mlp_name`
+"single_layer" / "two_layers", `injecting_condition_twice` on or off; anything else raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -23,10 +23,10 @@ from . import hip
 from .u_net import _Params, _slot
 
 
-def _res_params(cin, cout, emb_dim):
+def _res_params(cin, cout, emb_dim, film=False):
     m = _Params()
-    m.in_layers = _slot(nn.GroupNorm(32, cin), None, nn.Conv2d(cin, cout, 3, padding=1))            # openaimodel.py:224-228
-    m.emb_layers = _slot(None, nn.Linear(emb_dim, cout))                                              # :241-247
+    m.in_layers = _slot(nn.GroupNorm(32, cin), None, nn.Conv2d(cin, cout, 3, padding=1))            # openaimodel.py:214-218
+    m.emb_layers = _slot(None, nn.Linear(emb_dim, 2 * cout if film else cout))                        # :233-239 (FiLM: scale | shift)
     m.out_layers = _slot(nn.GroupNorm(32, cout), None, None, nn.Conv2d(cout, cout, 3, padding=1))     # :248-255
     if cin != cout:
         m.skip_connection = nn.Conv2d(cin, cout, 1)                                                   # :257-264
@@ -70,7 +70,7 @@ class UNetModelPose(nn.Module):
         super().__init__()
         if not use_spatial_transformer or transformer_depth != 1 or context_dim is None:
             raise NotImplementedError("only use_spatial_transformer=True with transformer_depth=1 (configs/model/vae_cin_ldm.yaml)")
-        if num_head_channels != 32 or use_scale_shift_norm or resblock_updown or not conv_resample or dims != 2 \
+        if num_head_channels != 32 or resblock_updown or not conv_resample or dims != 2 \
                 or num_classes is not None or n_embed is not None:
             raise NotImplementedError("unsupported UNetModel option (see module docstring)")
         if pose_mlp_name not in ("single_layer", "two_layers"):
@@ -83,6 +83,7 @@ class UNetModelPose(nn.Module):
         self.attention_resolutions = tuple(attention_resolutions)
         self.context_dim, self.rot_representation_dim = context_dim, rot_representation_dim
         self.injecting_condition_twice = bool(injecting_condition_twice)
+        self.use_scale_shift_norm = film = bool(use_scale_shift_norm)
         self.compute_dtype = compute_dtype
         emb = model_channels * 4
         self.time_embed_dim = emb
@@ -91,7 +92,7 @@ class UNetModelPose(nn.Module):
         chans, ch, ds = [model_channels], model_channels, 1
         for level, mult in enumerate(self.channel_mult):                                              # openaimodel.py:523-612
             for _ in range(num_res_blocks):
-                layers = [_res_params(ch, mult * model_channels, emb)]
+                layers = [_res_params(ch, mult * model_channels, emb, film)]
                 ch = mult * model_channels
                 if ds in self.attention_resolutions:
                     layers.append(_transformer_params(ch, context_dim))
@@ -103,12 +104,12 @@ class UNetModelPose(nn.Module):
                 self.input_blocks.append(_slot(down))
                 chans.append(ch)
                 ds *= 2
-        self.middle_block = _slot(_res_params(ch, ch, emb), _transformer_params(ch, context_dim), _res_params(ch, ch, emb))
+        self.middle_block = _slot(_res_params(ch, ch, emb, film), _transformer_params(ch, context_dim), _res_params(ch, ch, emb, film))
         self.output_blocks = nn.ModuleList()
         for level, mult in list(enumerate(self.channel_mult))[::-1]:                                  # :651-731
             for i in range(num_res_blocks + 1):
                 ich = chans.pop()
-                layers = [_res_params(ch + ich, model_channels * mult, emb)]
+                layers = [_res_params(ch + ich, model_channels * mult, emb, film)]
                 ch = model_channels * mult
                 if ds in self.attention_resolutions:
                     layers.append(_transformer_params(ch, context_dim))
@@ -156,7 +157,8 @@ class UNetModelPose(nn.Module):
                        num_res_blocks=self.num_res_blocks, channel_mult=self.channel_mult,
                        attn_levels=tuple(int((1 << l) in self.attention_resolutions) for l in range(levels)),
                        num_head_channels=32, context_dim=self.context_dim, pose_dim=self.rot_representation_dim,
-                       pose_mlp_layers=self._pose_layers, injecting_condition_twice=int(self.injecting_condition_twice))
+                       pose_mlp_layers=self._pose_layers, injecting_condition_twice=int(self.injecting_condition_twice),
+                       use_scale_shift_norm=int(self.use_scale_shift_norm))
             self._handle = hip.LdmHandle(cfg, sd, hip.dtype_code(self.compute_dtype))
             self._handle_key = key
         return self._handle

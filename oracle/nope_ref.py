@@ -283,13 +283,17 @@ def geodesic_deg(predR: Tensor, gtR: Tensor) -> Tensor:
 # LDM cross-attention variant  (src/model/u_net/ldm/adapt_openaimodel.py:130-158)
 # --------------------------------------------------------------------------------------
 def _ldm_res(x: Tensor, emb: Tensor, sd: SD, p: str) -> Tensor:
-    """ResBlock._forward, ldm/openaimodel.py:262-288 (no up/down, use_scale_shift_norm = False)."""
+    """ResBlock._forward, ldm/openaimodel.py:262-288 (no up/down).  `use_scale_shift_norm` (FiLM, :277-281) is read off the
+    shape of emb_layers.1: twice the block's channels -> out_norm(h) * (1 + scale) + shift instead of h + emb_out."""
     h = F.conv2d(F.silu(F.group_norm(x, 32, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"], 1e-5)),
                  sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=1)
     e = F.linear(F.silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"])
-    h = h + e[:, :, None, None]
-    h = F.conv2d(F.silu(F.group_norm(h, 32, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"], 1e-5)),
-                 sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
+    if e.shape[1] == 2 * h.shape[1]:
+        scale, shift = e[:, :, None, None].chunk(2, dim=1)
+        h = F.group_norm(h, 32, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"], 1e-5) * (1 + scale) + shift
+    else:
+        h = F.group_norm(h + e[:, :, None, None], 32, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"], 1e-5)
+    h = F.conv2d(F.silu(h), sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
     if p + "skip_connection.weight" in sd:
         x = F.conv2d(x, sd[p + "skip_connection.weight"], sd[p + "skip_connection.bias"])
     return x + h

@@ -180,7 +180,12 @@ def ldm():
     for tag, kw, hw in (("m32", dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[1, 2], context_dim=24,
                                      pose_mlp_name="single_layer", injecting_condition_twice=False), 8),
                         ("m64two", dict(model_channels=64, channel_mult=(1, 2, 2), num_res_blocks=2, attention_resolutions=[2, 4], context_dim=40,
-                                        pose_mlp_name="two_layers", injecting_condition_twice=True), 8)):
+                                        pose_mlp_name="two_layers", injecting_condition_twice=True), 8),
+                        # FiLM ResBlocks (use_scale_shift_norm, openaimodel.py:277-281): timestep embedding zeros / from the pose
+                        ("m32film", dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[1, 2], context_dim=24,
+                                         pose_mlp_name="single_layer", injecting_condition_twice=False, use_scale_shift_norm=True), 8),
+                        ("m64film", dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[2], context_dim=40,
+                                         pose_mlp_name="single_layer", injecting_condition_twice=True, use_scale_shift_norm=True), 8)):
         common = dict(rot_representation_dim=6, image_size=hw, in_channels=8, out_channels=8, num_head_channels=32,
                       use_spatial_transformer=True, transformer_depth=1, **kw)
         mine = UNetModelPose(encoder=RI.StubEncoder(8), **common)

@@ -93,7 +93,11 @@ def test_pipeline_config1(golden):
 LDM_CASES = {"m32": dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[1, 2], context_dim=24,
                          pose_mlp_name="single_layer", injecting_condition_twice=False),
              "m64two": dict(model_channels=64, channel_mult=(1, 2, 2), num_res_blocks=2, attention_resolutions=[2, 4], context_dim=40,
-                            pose_mlp_name="two_layers", injecting_condition_twice=True)}
+                            pose_mlp_name="two_layers", injecting_condition_twice=True),
+             "m32film": dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[1, 2], context_dim=24,
+                             pose_mlp_name="single_layer", injecting_condition_twice=False, use_scale_shift_norm=True),
+             "m64film": dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[2], context_dim=40,
+                             pose_mlp_name="single_layer", injecting_condition_twice=True, use_scale_shift_norm=True)}
 
 
 def build_ldm(tag, compute_dtype="f32"):
@@ -106,7 +110,7 @@ def build_ldm(tag, compute_dtype="f32"):
     return m
 
 
-@pytest.mark.parametrize("tag", ["m32", "m64two"])
+@pytest.mark.parametrize("tag", ["m32", "m64two", "m32film", "m64film"])
 def test_ldm_variant(golden, tag):
     """The LDM cross-attention variant (UNetModelPose, adapt_openaimodel.py:130-158): the oracle's restatement against outputs
     recorded from the reference class (tests/golden/make_golden.py ldm), same synthesised weights."""
