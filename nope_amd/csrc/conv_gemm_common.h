@@ -47,11 +47,13 @@ struct ConvParams {
     int out_nchw, out_dt;
     int act;                           // 0 none, 1 ReLU (after bias and residual)
     int tiles_m, tiles_n, xcd_map, wide_out;
+    int xcd_gn;                        // xcd_map == 2: XCD columns the weight panels are split over (tile_coords)
     int variant;                       // tuning switches (NOPE_CONV_VARIANT), 0 in production
     FastDiv d_hw, d_w, d_rep1, d_rep2; // / (Hm*Wm), / Wm, / rep1, / rep2
     unsigned char pos_order[64];       // posmajor: pixel positions by descending number of valid taps
-    int persist_iters;                 // > 1: a workgroup walks this many tiles (tile_m advances by 64 each time)
+    int persist_iters;                 // > 1: a workgroup walks this many tiles
     unsigned persist_d1, persist_d2;   // byte advance of the A offsets per walked tile (src1 / src2)
+    int persist_dm;                    // GEMM rows between the tiles a workgroup of the 128 x 192 kernel walks
     unsigned* timeline;                // tuning only (NOPE_PP_VARIANT & 256): cycle stamps of workgroup 0, see conv3x3_halo_kernel
     int posmajor;                      // 1: GEMM rows ordered (pixel position, sample) instead of (sample, pixel) -- see launch_conv
     FastDiv d_n;                       // / nhyp (posmajor)
@@ -100,7 +102,17 @@ template <> struct Tile<bf16_t> {
 
 __device__ __forceinline__ void tile_coords(const ConvParams& p, int& tile_m, int& tile_n) {
     const int g = blockIdx.x;
-    if (p.xcd_map) {   // tiles_n in {1,2,4,8}, tiles_m % (8 / tiles_n) == 0
+    if (p.xcd_map == 2) {   // ping-pong kernels with several weight panels
+        // The 8 XCDs form a (8 / xcd_gn) x xcd_gn grid: XCD (xm, xn) owns a contiguous run of tiles_m / (8 / xcd_gn) M tiles and
+        // tiles_n / xcd_gn weight panels, and walks the run with its panels fastest.  Every activation row then crosses the
+        // fabric xcd_gn times and every weight panel 8 / xcd_gn times (each XCD has its own L2); the launcher picks xcd_gn to
+        // minimise that (xcd_gn = tiles_n is the one-panel-per-XCD map below).
+        const int x = g & 7, j = g >> 3;
+        const int span = p.tiles_n / p.xcd_gn;              // panels per XCD
+        const int xm = x / p.xcd_gn, xn = x - xm * p.xcd_gn;
+        tile_n = xn * span + (j & (span - 1));
+        tile_m = xm * (p.tiles_m / (8 / p.xcd_gn)) + j / span;
+    } else if (p.xcd_map) {   // tiles_n in {1,2,4,8}, tiles_m % (8 / tiles_n) == 0
         // XCD x = g & 7 keeps one weight panel (tile_n) and a CONTIGUOUS run of M tiles, so the
         // 3x3 halo rows shared by neighbouring tiles hit the same XCD's L2.
         const int x = g & 7, j = g >> 3;

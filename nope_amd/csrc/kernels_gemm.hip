@@ -443,7 +443,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
                 __syncthreads();                   // every wave is done reading the last stage
                 const int m0e = m0;
                 if (it + 1 < iters) {
-                    m0 += 64 * BMT;
+                    m0 += p.persist_dm;
 #pragma unroll
                     for (int i = 0; i < AI; ++i) { a_b1[i] += p.persist_d1; a_b2[i] += p.persist_d2; }
                     ld_tap = 0; ld_kc = 0;
@@ -641,18 +641,36 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         if ((size_t)p.splits * (size_t)M * a.Cout * 4 > a.splitk_bytes) p.splits = 1;
         if (p.splits > 1) p.split_out = (float*)a.splitk_ws;
     }
-    // Persistent walk: 512 workgroups (2 per CU), each `iters` tiles 64 tile_m apart (same XCD under xcd_map).
-    p.persist_iters = 1; p.persist_d1 = p.persist_d2 = 0; p.timeline = nullptr;
+    // LDS-DMA launches with several weight panels: split the panels over gn XCD columns and the M tiles over 8 / gn XCD rows
+    // so that the bytes crossing the fabric, gn x activations + (8 / gn) x weights, are fewest (tile_coords, map 2).
+    // NOPE_XCD_MAP=1 keeps one panel per XCD (gn = tiles_n).
+    p.xcd_gn = tn;
+    if (dma && p.xcd_map && tn > 1 && !(getenv("NOPE_XCD_MAP") && atoi(getenv("NOPE_XCD_MAP")) == 1)) {
+        const double abytes = (double)b1 + (double)b2, wbytes = (double)bw * (phased ? 4 : 1);
+        double best = tn * abytes + (8 / tn) * wbytes;
+        for (int gn = 1; gn < tn; gn *= 2)
+            if (p.tiles_m % (8 / gn) == 0 && gn * abytes + (8 / gn) * wbytes < best) { best = gn * abytes + (8 / gn) * wbytes; p.xcd_gn = gn; }
+        if (const char* f = getenv("NOPE_XCD_GN")) {            // tests: force the split
+            const int gn = atoi(f);
+            if (gn >= 1 && gn <= tn && (gn & (gn - 1)) == 0 && p.tiles_m % (8 / gn) == 0) p.xcd_gn = gn;
+        }
+        if (p.xcd_gn != tn) p.xcd_map = 2;
+    }
+    // Persistent walk: 512 workgroups (2 per CU), each `iters` tiles 64 / span tile_m apart (same XCD, same weight panel; span =
+    // panels an XCD interleaves under map 2).
+    p.persist_iters = 1; p.persist_d1 = p.persist_d2 = 0; p.persist_dm = 0; p.timeline = nullptr;
     unsigned gx = (unsigned)nblocks;
     {
         const long long hw = (long long)a.Hs * a.Ws;
         static const int persist_on = getenv("NOPE_CONV_PERSIST") ? atoi(getenv("NOPE_CONV_PERSIST")) : 1;
+        const int span = p.xcd_map == 2 ? tn / p.xcd_gn : 1;
         if (persist_on && dma && bm == BM && dt == NOPE_BF16 && a.mode == NOPE_CONV_PLAIN && !p.posmajor && p.splits == 1 && p.xcd_map &&
-            p.wide_out && a.rep1 == 1 && a.rep2 == 1 && M % BM == 0 && nblocks > 512 && nblocks % 512 == 0 && (64ll * BM) % hw == 0 &&
-            !(variant & 2)) {
+            p.wide_out && a.rep1 == 1 && a.rep2 == 1 && M % BM == 0 && nblocks > 512 && nblocks % 512 == 0 && 64 % span == 0 &&
+            ((64ll / span) * BM) % hw == 0 && !(variant & 2)) {
             p.persist_iters = (int)(nblocks / 512);
-            p.persist_d1 = (unsigned)(64ll * BM * a.C1 * es);
-            p.persist_d2 = (unsigned)(64ll * BM * a.C2 * es);
+            p.persist_dm = (64 / span) * BM;
+            p.persist_d1 = (unsigned)((long long)p.persist_dm * a.C1 * es);
+            p.persist_d2 = (unsigned)((long long)p.persist_dm * a.C2 * es);
             gx = 512;
         }
     }
@@ -662,16 +680,17 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     if (plan.halo && dt == NOPE_BF16 && p.xcd_map) {
         const int want = getenv("NOPE_HALO_PERSIST") ? atoi(getenv("NOPE_HALO_PERSIST")) : 256;
         const long long hw = (long long)a.Hs * a.Ws;
-        if (want >= 8 && want % 8 == 0 && nblocks > want && nblocks % want == 0 && ((long long)(want / 8) * 256) % hw == 0) {
+        const int span = p.xcd_map == 2 ? tn / p.xcd_gn : 1;     // workgroups of one XCD that share an M tile
+        if (want >= 8 && want % (8 * span) == 0 && nblocks > want && nblocks % want == 0 && ((long long)(want / 8 / span) * 256) % hw == 0) {
             gx = (unsigned)want;
             p.persist_iters = (int)(nblocks / want);
         }
     }
     const dim3 grid(gx, phased ? 4u : 1u, (unsigned)p.splits), block(NT);
     static const bool trace = getenv("NOPE_CONV_TRACE") != nullptr;     // tuning aid: one line per launch
-    if (trace) fprintf(stderr, "conv %s mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u posmajor %d persist %d\n",
+    if (trace) fprintf(stderr, "conv %s mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u posmajor %d persist %d xcd %d/%d\n",
                        plan.halo ? "halo256" : plan.pp ? "pp256" : dma ? "dma128" : "generic", a.mode, a.ntaps, Cin, a.Cout, M, p.tiles_m, p.tiles_n, grid.x, grid.y, grid.z,
-                       p.posmajor, p.persist_iters);
+                       p.posmajor, p.persist_iters, p.xcd_map, p.xcd_gn);
     if (plan.pp) {
         if (const char* v = getenv("NOPE_PP_VARIANT")) p.variant = atoi(v);      // tuning ablations of the ping-pong kernel
         if (plan.halo) launch_conv_halo(dt, &p, grid, s);

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     // A workgroup walks `iters` tiles of the same weight panel, gridDim.x / 8 M tiles apart (a multiple of the image size:
     // checked by the launcher, so the padding masks above hold for every tile of the walk).
     const int iters = sizeof(T) == 2 && p.persist_iters > 1 ? p.persist_iters : 1;
-    const int walk_rows = (int)(gridDim.x >> 3) * PP_BM;
+    const int walk_rows = (int)(gridDim.x >> 3) / (p.xcd_map == 2 ? p.tiles_n / p.xcd_gn : 1) * PP_BM;
     tile_prologue();
     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                       // DMA landed
     const bool dma_on = !(p.variant & 16);                         // (tuning: 16 = no DMA stream)

@@ -61,14 +61,19 @@ def run(hip, dev, dts=(1, 0), light=False):
             # a workgroup walking several tiles (next tile's prologue in flight under the epilogue): 8 workgroups, 3 tiles each
             # with one channel chunk, then 2 tiles each with two chunks (the walk ends on the other A stage); same bits as
             # one tile per workgroup
-            for (ns, cc) in ((384, C), (256, 2 * C)):
-                xq, wq, bq = rn(ns, cc, 4, 4), rn(24, cc, 3, 3) / (3 * cc ** 0.5), rn(24)
+            # (third case: two weight panels -- every XCD takes both panels of its run of M tiles, 16 workgroups x 2 tiles)
+            # (and four panels over a 4 x 2 XCD grid: each XCD two panels of its run, 16 workgroups x 4 tiles)
+            for (ns, cc, side, co, wgs, gn) in ((384, C, 4, 24, "8", "1"), (256, 2 * C, 4, 24, "8", "1"), (64, C, 8, 200, "16", "1"), (64, C, 8, 600, "16", "2")):
+                xq, wq, bq = rn(ns, cc, side, side), rn(co, cc, 3, 3) / (3 * cc ** 0.5), rn(co)
                 os.environ["NOPE_CONV_PP"] = "11"      # (4x4 maps in (sample, pixel) row order too)
-                os.environ["NOPE_HALO_PERSIST"] = "8"
+                os.environ["NOPE_HALO_PERSIST"] = wgs
+                os.environ["NOPE_XCD_GN"] = gn
                 y = hip.op_conv(dt, hip.to_nhwc(d(xq), dt), d(wq), d(bq))
                 os.environ["NOPE_HALO_PERSIST"] = "0"
+                os.environ["NOPE_XCD_MAP"] = "1"
                 y2 = hip.op_conv(dt, hip.to_nhwc(d(xq), dt), d(wq), d(bq))
-                os.environ.pop("NOPE_HALO_PERSIST")
+                for k in ("NOPE_HALO_PERSIST", "NOPE_XCD_MAP", "NOPE_XCD_GN"):
+                    os.environ.pop(k)
                 os.environ["NOPE_CONV_PP"] = "13"
                 chk(y, F.conv2d(q(xq), q(wq), bq, padding=1), f"halo walk {ns}x{cc}")
                 assert torch.equal(y, y2), "walking workgroups differ from one tile per workgroup"
