@@ -21,51 +21,84 @@ namespace {
 
 constexpr int NT = 256;
 
-template <class T>
-__device__ __forceinline__ void accum_quartic(const u32x4& raw, const float* q, float* acc) {
-    constexpr int VEC = Elt<T>::VEC;
-    float t[VEC];
-    Elt<T>::unpack(raw, t);
+// A lane's share of one channel plane: LV consecutive pixels = W 32-bit words (16 bytes, or 8 for the narrow 16-bit form).
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+template <int W> struct RawVec { unsigned w[W]; };
+
+// streaming load of bank data: each byte is read exactly once per launch, so it is marked non-temporal (no point in keeping
+// it in L2 / Infinity Cache ahead of the query tiles and the next kernel's operands).
+template <bool NTL, int W> __device__ __forceinline__ RawVec<W> ld_stream(const void* p) {
+    RawVec<W> r;
+    if constexpr (W == 4) {
+        const u32x4 v = NTL ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)) : *reinterpret_cast<const u32x4*>(p);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
+        for (int i = 0; i < 4; ++i) r.w[i] = v[i];
+    } else {
+        const u32x2 v = NTL ? __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p)) : *reinterpret_cast<const u32x2*>(p);
+        r.w[0] = v[0]; r.w[1] = v[1];
+    }
+    return r;
+}
+
+template <class T, int W> __device__ __forceinline__ void unpack_words(const RawVec<W>& raw, float* t) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < W; ++i) t[i] = __builtin_bit_cast(float, raw.w[i]);
+    } else if constexpr (Elt<T>::DT == NOPE_BF16) {
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            t[2 * i] = __builtin_bit_cast(float, raw.w[i] << 16);
+            t[2 * i + 1] = __builtin_bit_cast(float, raw.w[i] & 0xffff0000u);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            union { unsigned u; f16_t h[2]; } x; x.u = raw.w[i];
+            t[2 * i] = (float)x.h[0];
+            t[2 * i + 1] = (float)x.h[1];
+        }
+    }
+}
+
+template <class T, int LV, int W>
+__device__ __forceinline__ void accum_quartic(const RawVec<W>& raw, const float* q, float* acc) {
+    float t[LV];
+    unpack_words<T, W>(raw, t);
+#pragma unroll
+    for (int e = 0; e < LV; ++e) {
         const float d = q[e] - t[e];
         const float d2 = d * d;
         acc[e] += d2 * d2;
     }
 }
 
-// P = HW / VEC pixel-vectors per plane; requires P <= 256 and 256 % P == 0.
-// hpi = 256 / P hypotheses are scored per iteration (thread -> (sub-hypothesis, pixel-vector)).
-// 16-byte streaming load of bank data: each byte is read exactly once per launch, so it is marked non-temporal (no point in
-// keeping it in L2 / Infinity Cache ahead of the query tiles and the next kernel's operands).
-template <bool NTL> __device__ __forceinline__ u32x4 ld16_stream(const void* p) {
-    if (NTL) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-    return *reinterpret_cast<const u32x4*>(p);
-}
-
-template <class T, int CMAX, bool NTL>
+// A lane owns LV consecutive pixels of every channel plane; P = HW / LV lanes make a hypothesis; requires P <= 256 and
+// 256 % P == 0.  hpi = 256 / P hypotheses are scored per iteration (thread -> (sub-hypothesis, pixel-vector)).
+// LV = 16 bytes' worth.  (LV = 4 for the 16-bit banks -- 8-byte loads, half the registers, five resident workgroups per CU
+// instead of three -- is kept as tuning variant 8: measured 4-7 % slower, 8-byte loads do not reach the 16-byte rate.)
+template <class T, int CMAX, bool NTL, int LV>
 __global__ __launch_bounds__(NT) void sim_reg_kernel(const float* __restrict__ q, const T* __restrict__ bank, float* __restrict__ scores,
                                                      int N, int C, int HW, long long bank_stride_b, int score_ld, int nsplit) {
-    constexpr int VEC = Elt<T>::VEC;
+    constexpr int W = LV * (int)sizeof(T) / 4;
     __shared__ float s_part[2][NT / 64];
-    const int P = HW / VEC;
+    const int P = HW / LV;
     const int hpi = NT / P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = tid / P, pv = tid - sub * P;
+    // Workgroup (b, split) scores template groups split, split + nsplit, split + 2 nsplit, ... of sample b (a group = hpi
+    // templates): at any moment the resident workgroups of a sample read adjacent groups, i.e. the chip walks B sequential
+    // streams through the bank (contiguous per-workgroup ranges, as in round 1, made it thousands of streams).
     const int b = blockIdx.x / nsplit, split = blockIdx.x - b * nsplit;
-    // contiguous template range of this workgroup, in units of hpi
     const int groups = (N + hpi - 1) / hpi;
-    const int gper = (groups + nsplit - 1) / nsplit;
-    const int g0 = split * gper;
-    const int g1 = (g0 + gper < groups) ? g0 + gper : groups;
+    const int g0 = split, g1 = groups, gs = nsplit;
 
-    float qr[CMAX][VEC];
+    float qr[CMAX][LV];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
         if (c < C) {
-            const float* qp = q + ((size_t)b * C + c) * HW + (size_t)pv * VEC;
+            const float* qp = q + ((size_t)b * C + c) * HW + (size_t)pv * LV;
 #pragma unroll
-            for (int v4 = 0; v4 < VEC / 4; ++v4) {
+            for (int v4 = 0; v4 < LV / 4; ++v4) {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(qp + 4 * v4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) qr[c][4 * v4 + e] = x[e];
@@ -76,27 +109,27 @@ __global__ __launch_bounds__(NT) void sim_reg_kernel(const float* __restrict__ q
     const size_t hyp_elems = (size_t)C * HW;
     int buf = 0;
     // Software pipeline, depth 1: the C plane loads of group g+1 are issued before group g is
-    // reduced, so every workgroup keeps C x 16 B per lane in flight across the reduction + barrier
+    // reduced, so every workgroup keeps C loads per lane in flight across the reduction + barrier
     // (without it the memory pipe of a workgroup drains once per hypothesis).
-    u32x4 rawA[CMAX], rawB[CMAX];
-    auto fetch = [&](u32x4 (&raw)[CMAX], int g) {
+    RawVec<W> rawA[CMAX], rawB[CMAX];
+    auto fetch = [&](RawVec<W> (&raw)[CMAX], int g) {
         const int n = g * hpi + sub;
-        const T* tp = bb + (size_t)(n < N ? n : 0) * hyp_elems + (size_t)pv * VEC;
+        const T* tp = bb + (size_t)(n < N ? n : 0) * hyp_elems + (size_t)pv * LV;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
-            if (c < C) raw[c] = ld16_stream<NTL>(tp + (size_t)c * HW);
+            if (c < C) raw[c] = ld_stream<NTL, W>(tp + (size_t)c * HW);
     };
-    auto reduce = [&](const u32x4 (&raw)[CMAX], int g) {
+    auto reduce = [&](const RawVec<W> (&raw)[CMAX], int g) {
         const int n = g * hpi + sub;
-        float acc[VEC];
+        float acc[LV];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        for (int e = 0; e < LV; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
-            if (c < C) accum_quartic<T>(raw[c], qr[c], acc);
+            if (c < C) accum_quartic<T, LV, W>(raw[c], qr[c], acc);
         float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) s += sqrtf(acc[e]);
+        for (int e = 0; e < LV; ++e) s += sqrtf(acc[e]);
         // reduce over the P threads of this sub-hypothesis
         if (P >= 64) {
             s = wave_sum(s);
@@ -115,12 +148,12 @@ __global__ __launch_bounds__(NT) void sim_reg_kernel(const float* __restrict__ q
         }
     };
     if (g0 < g1) fetch(rawA, g0);
-    for (int g = g0; g < g1; g += 2) {
-        if (g + 1 < g1) fetch(rawB, g + 1);
+    for (int g = g0; g < g1; g += 2 * gs) {
+        if (g + gs < g1) fetch(rawB, g + gs);
         reduce(rawA, g);
-        if (g + 1 < g1) {
-            if (g + 2 < g1) fetch(rawA, g + 2);
-            reduce(rawB, g + 1);
+        if (g + gs < g1) {
+            if (g + 2 * gs < g1) fetch(rawA, g + 2 * gs);
+            reduce(rawB, g + gs);
         }
     }
 }
@@ -149,7 +182,7 @@ __global__ __launch_bounds__(NT) void sim_lds_kernel(const float* __restrict__ q
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
             for (int c = 0; c < C; ++c)
-                accum_quartic<T>(ld16(tp + (size_t)c * HW + (size_t)pv * VEC), &s_q[c * HW + pv * VEC], acc);
+                accum_quartic<T, VEC, 4>(ld_stream<false, 4>(tp + (size_t)c * HW + (size_t)pv * VEC), &s_q[c * HW + pv * VEC], acc);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) s += sqrtf(acc[e]);
         }
@@ -219,27 +252,38 @@ int launch_similarity(const float* q, const void* bank, int bank_dt, float* scor
     if (bank_dt != NOPE_F32 && bank_dt != NOPE_BF16 && bank_dt != NOPE_F16) return NOPE_ERR_UNSUPPORTED;
     const int vec = bank_dt == NOPE_F32 ? 4 : 8;
     if (HW % vec) return NOPE_ERR_UNSUPPORTED;
-    const int P = HW / vec;
+    static const int variant = getenv("NOPE_SIM_VARIANT") ? atoi(getenv("NOPE_SIM_VARIANT")) : 1;    // tuning: 1 = non-temporal bank loads (0.69 -> 0.75-0.82 of HBM peak), 2 = one residency round of long workgroups, 8 = 4 pixels per lane for 16-bit banks
+    const int lv = (bank_dt != NOPE_F32 && (variant & 8) && C <= 8 && HW % 4 == 0 && HW / 4 <= NT) ? 4 : vec;
+    const int P = HW / lv;
     const bool reg_ok = (P <= NT) && (NT % P == 0) && (C <= 16);
-    static const int variant = getenv("NOPE_SIM_VARIANT") ? atoi(getenv("NOPE_SIM_VARIANT")) : 1;    // tuning: 1 = non-temporal bank loads (0.69 -> 0.75-0.82 of HBM peak), 2 = ~1024 long workgroups (0.9x)
     int nsplit;
     if (reg_ok) {
         const int hpi = NT / P;
         const int groups = cdiv(N, hpi);
-        // ~4096 workgroups of ~16 hypotheses each (fewer, longer ones measured 10 % slower: profiles/r02e_sim_bench.txt)
-        nsplit = cdiv((variant & 2) ? 1024 : 4096, B);
-        if (nsplit > groups) nsplit = groups;
-        if (nsplit < 1) nsplit = 1;
-        dim3 grid((unsigned)((long long)B * nsplit)), block(NT);
-#define NOPE_SIM_LAUNCH(T, CM, NTLOAD) hipLaunchKernelGGL((sim_reg_kernel<T, CM, NTLOAD>), grid, block, 0, s, q, (const T*)bank, scores, N, C, HW, bank_stride_b, score_ld, nsplit)
-#define NOPE_SIM_T(T)                                                                                         \
-        do {                                                                                                  \
-            if (variant & 1) { if (C <= 8) NOPE_SIM_LAUNCH(T, 8, true); else NOPE_SIM_LAUNCH(T, 16, true); }   \
-            else { if (C <= 8) NOPE_SIM_LAUNCH(T, 8, false); else NOPE_SIM_LAUNCH(T, 16, false); }            \
+        // nsplit workgroups per sample, ~4096 in all (several residency rounds: the workgroups drift out of phase, which the
+        // memory system likes better than one round of long workgroups running load / reduce in lockstep -- NOPE_SIM_VARIANT & 2
+        // sizes the grid to exactly one round, CUs x resident workgroups: bf16 +3 %, f32 -9 %, fp16 -6 %, profiles/r02i_sim_bench.txt)
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+#define NOPE_SIM_LAUNCH(T, CM, NTLOAD, LV)                                                                                         \
+        do {                                                                                                                       \
+            static int occ = 0;        /* (per instantiation; a property of the kernel's register count) */                       \
+            if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sim_reg_kernel<T, CM, NTLOAD, LV>, NT, 0) != hipSuccess || occ < 1)) occ = 2; \
+            nsplit = ((variant & 2) ? cus * occ : 4096) / B;                                                                       \
+            if (nsplit > groups) nsplit = groups;                                                                                  \
+            if (nsplit < 1) nsplit = 1;                                                                                            \
+            hipLaunchKernelGGL((sim_reg_kernel<T, CM, NTLOAD, LV>), dim3((unsigned)((long long)B * nsplit)), dim3(NT), 0, s, q, (const T*)bank, scores, \
+                               N, C, HW, bank_stride_b, score_ld, nsplit);                                                         \
         } while (0)
-        if (bank_dt == NOPE_F32) NOPE_SIM_T(float);
-        else if (bank_dt == NOPE_BF16) NOPE_SIM_T(bf16_t);
-        else NOPE_SIM_T(f16_t);
+#define NOPE_SIM_T(T, LVD)                                                                                              \
+        do {                                                                                                            \
+            if (lv != LVD) { if (variant & 1) NOPE_SIM_LAUNCH(T, 8, true, 4); else NOPE_SIM_LAUNCH(T, 8, false, 4); }    \
+            else if (variant & 1) { if (C <= 8) NOPE_SIM_LAUNCH(T, 8, true, LVD); else NOPE_SIM_LAUNCH(T, 16, true, LVD); } \
+            else { if (C <= 8) NOPE_SIM_LAUNCH(T, 8, false, LVD); else NOPE_SIM_LAUNCH(T, 16, false, LVD); }             \
+        } while (0)
+        if (bank_dt == NOPE_F32) NOPE_SIM_T(float, 4);
+        else if (bank_dt == NOPE_BF16) NOPE_SIM_T(bf16_t, 8);
+        else NOPE_SIM_T(f16_t, 8);
 #undef NOPE_SIM_T
 #undef NOPE_SIM_LAUNCH
     } else {

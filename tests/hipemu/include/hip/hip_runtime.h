@@ -375,6 +375,7 @@ inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sqrtf(x) sqrtf(x)
 #define __builtin_amdgcn_s_memrealtime() 0ull   // (clock stamps of the tuning instantiations: no clock on the host)
 // s_waitcnt simm16 (gfx9 encoding): vmcnt = bits [3:0] | [15:14] << 4; only the vmcnt field matters to the interpreter
 inline void hipemu_s_waitcnt(unsigned imm) { hipemu::dma_wait((imm & 0xF) | (((imm >> 14) & 3) << 4)); }
@@ -444,6 +445,11 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+// device queries: a small pretend device (2 CUs x 2 resident workgroups), so launches sized by residency stay cheap to interpret
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16 };
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 2; return hipSuccess; }
+template <class F> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 2; return hipSuccess; }
 inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 // stream capture / graphs: not emulated -- BeginCapture fails, callers take their direct-launch path

@@ -1,11 +1,11 @@
 """Scoring-kernel micro-benchmark: GB/s of nope_similarity on a resident bank larger than the Infinity Cache.
-    NOPE_SIM_VARIANT=<bits> python tools/sim_bench.py      (1 = non-temporal bank loads, 2 = ~1024 long workgroups; default 3)"""
+    NOPE_SIM_VARIANT=<bits> python tools/sim_bench.py      (1 = non-temporal bank loads, 2 = one residency round of long workgroups, 8 = 8-byte loads for 16-bit banks; default 1)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nope_amd import hip
 
-for dtype, N in ((torch.bfloat16, 2048), (torch.float32, 512), (torch.float16, 1024), (torch.float16, 4096)):
+for dtype, N in ((torch.bfloat16, 512), (torch.bfloat16, 2048), (torch.float32, 512), (torch.float16, 1024), (torch.float16, 4096)):
     B, C, h = 32, 8, 32
     bank = torch.randn(B, N, C, h, h, device="cuda", dtype=torch.float16).to(dtype)
     q = torch.randn(B, C, h, h, device="cuda")
