@@ -33,7 +33,7 @@ enum { NOPE_F32 = 0, NOPE_BF16 = 1,
  * 2x2 convolutions over the un-upsampled input, one per output-pixel parity, with the 3x3 weights that
  * fall on the same source pixel pre-summed at pack time: same function, 4/9 of the multiply-adds. */
 enum { NOPE_CONV_PLAIN = 0, NOPE_CONV_UP2 = 1, NOPE_CONV_DOWN2 = 2, NOPE_CONV_UP2P = 3,
-       NOPE_CONV_STRIDE2 = 4 /* stride 2: 3x3 pad 1 or 1x1 pad 0 (ResNet Bottleneck, encoder/resnet.py:64-65,122-123) */ };
+       NOPE_CONV_STRIDE2 = 4 /* stride 2: 3x3 pad 1 or 1x1 pad 0 (ResNet Bottleneck, encoder/resnet.py:64-65,122-123), 4x4 pad 1 (Downsample, model_utils.py:129-136) */ };
 enum {
     NOPE_OK = 0,
     NOPE_ERR_ARG = -1,        /* bad argument (null pointer, unsupported size/dtype) */
@@ -95,6 +95,9 @@ typedef struct {
     int pose_mlp_layers;   /* 1 = "single_layer", 2 = "two_layers" (u_net.py:63-72) */
     int compute_dtype;     /* NOPE_F32: f32 storage + f32-input MFMA (bit-faithful fp32 sums);
                               NOPE_BF16: bf16 storage + bf16 MFMA, f32 accumulate / statistics */
+    int soft_up_down;      /* 0: use_hard_up_down = True, the shipped configuration (HardDownsample / HardUpsample, u_net.py:54-56);
+                              1: use_hard_up_down = False -- Downsample = Conv2d(4, stride 2, pad 1) at "downs.l.3.weight",
+                              Upsample = ConvTranspose2d(4, stride 2, pad 1) at "ups.l.3.weight" (model_utils.py:119-136) */
 } nope_unet_config;
 
 /* Validates and repacks the reference state dict for the device (the only allocating call). */

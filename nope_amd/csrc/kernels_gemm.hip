@@ -108,6 +108,7 @@ __device__ __forceinline__ void tap_delta(const ConvParams& p, int tap, int& dy,
     if (p.mode == NOPE_CONV_DOWN2) { dy = tap >> 1; dx = tap & 1; }
     else if (p.mode == NOPE_CONV_UP2P) { dy = (tap >> 1) + ((int)blockIdx.y >> 1) - 1; dx = (tap & 1) + ((int)blockIdx.y & 1) - 1; }
     else if (p.ntaps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+    else if (p.ntaps == 16) { dy = (tap >> 2) - 1; dx = (tap & 3) - 1; }      // 4x4, pad 1 (STRIDE2 only)
 }
 
 // ---- generic kernel: global -> VGPR -> LDS staging, any channel counts ----------------------------
@@ -511,7 +512,8 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     const unsigned long long b2 = a.C2 ? (unsigned long long)cdiv(a.nhyp, a.rep2) * a.Hs * a.Ws * a.C2 * es : 0;
     const unsigned long long bw = (unsigned long long)a.Cout * a.ntaps * Cin * es;
     // LDS-DMA kernels: a K step (128 B of channels) never straddles sources and 32-bit offsets suffice
-    pl.dma = !a.force_generic && Cin % bk == 0 && (a.C2 == 0 || (a.C1 % bk == 0 && a.mode == NOPE_CONV_PLAIN)) && b1 < lim && b2 < lim && bw < lim;
+    // (the 4x4 stride-2 conv of the non-default soft downsampling runs on the generic kernel: its tap geometry is not a 3x3 mask)
+    pl.dma = !a.force_generic && a.ntaps != 16 && Cin % bk == 0 && (a.C2 == 0 || (a.C1 % bk == 0 && a.mode == NOPE_CONV_PLAIN)) && b1 < lim && b2 < lim && bw < lim;
     if (!pl.dma) return pl;
     const bool small3x3 = a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && !a.colstats && !a.pn_ms && !a.out_nchw && !a.splitk_ws &&
                           a.Hs * a.Ws <= POSMAJOR_MAX_HW;
@@ -577,7 +579,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     } else if (a.mode == NOPE_CONV_UP2P) {
         if (a.ntaps != 4 || a.Ho != 2 * a.Hs || a.Wo != 2 * a.Ws || a.C2 != 0 || a.out_nchw) return NOPE_ERR_ARG;
     } else if (a.mode == NOPE_CONV_STRIDE2) {
-        if ((a.ntaps != 1 && a.ntaps != 9) || a.Hs != 2 * a.Ho || a.Ws != 2 * a.Wo || a.C2 != 0) return NOPE_ERR_ARG;
+        if ((a.ntaps != 1 && a.ntaps != 9 && a.ntaps != 16) || a.Hs != 2 * a.Ho || a.Ws != 2 * a.Wo || a.C2 != 0) return NOPE_ERR_ARG;
     } else return NOPE_ERR_ARG;
     const bool phased = a.mode == NOPE_CONV_UP2P;
     const long long M = phased ? (long long)a.nhyp * a.Hs * a.Ws : (long long)a.nhyp * a.Ho * a.Wo;

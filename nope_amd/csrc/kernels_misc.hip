@@ -87,6 +87,22 @@ __global__ __launch_bounds__(NT) void pack_up2p_w_kernel(const float* __restrict
     }
 }
 
+// Upsample = ConvTranspose2d(4, stride 2, pad 1), weight [Cin][Cout][4][4] (model_utils.py:119-126), as the same four phase
+// sets: output pixel (2y + py, 2x + px) receives source pixel (y + ty + py - 1, x + tx + px - 1) through kernel element
+// (3 - py - 2 ty, 3 - px - 2 tx) -- two source rows per output row, exactly the footprint of the nearest-x2 + 3x3 phases.
+template <class T>
+__global__ __launch_bounds__(NT) void pack_convT4_w_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % Cin);
+        size_t t = i / Cin;
+        const int tap = (int)(t % 4); t /= 4;
+        const int co = (int)(t % Cout);
+        const int ph = (int)(t / Cout);
+        const int ky = 3 - (ph >> 1) - 2 * (tap >> 1), kx = 3 - (ph & 1) - 2 * (tap & 1);
+        Elt<T>::st(out + i, w[(((size_t)c * Cout + co) * 4 + ky) * 4 + kx]);
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(NT) void cast_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) Elt<T>::st(out + i, in[i]);
@@ -154,6 +170,15 @@ int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int
                        const float* cout_scale) {
     if (!w || !out || Cout <= 0 || Cin <= 0 || ntaps <= 0) return NOPE_ERR_ARG;
     if (mode == NOPE_CONV_DOWN2 && ntaps != 4) return NOPE_ERR_ARG;
+    if (mode == NOPE_CONV_UP2P && ntaps == 16) {     // source is a ConvTranspose2d(4, 2, 1) weight
+        if (cin_scale || cout_scale) return NOPE_ERR_ARG;
+        const size_t tot = (size_t)4 * Cout * 4 * Cin;
+        if (dt == NOPE_F32) hipLaunchKernelGGL((pack_convT4_w_kernel<float>), dim3(grid_for(tot)), dim3(NT), 0, s, w, (float*)out, Cout, Cin, tot);
+        else if (dt == NOPE_BF16) hipLaunchKernelGGL((pack_convT4_w_kernel<bf16_t>), dim3(grid_for(tot)), dim3(NT), 0, s, w, (bf16_t*)out, Cout, Cin, tot);
+        else return NOPE_ERR_UNSUPPORTED;
+        NOPE_CHECK_LAUNCH();
+        return NOPE_OK;
+    }
     if (mode == NOPE_CONV_UP2P) {
         if (ntaps != 4 || cin_scale || cout_scale) return NOPE_ERR_ARG;
         const size_t tot = (size_t)4 * Cout * 4 * Cin;

@@ -95,16 +95,19 @@ struct Loader {
         if (p) hipMemcpyAsync(p, d->data, n * 4, hipMemcpyDeviceToDevice, s);
         return p;
     }
+    // (ksz 4 with UP2P: the weight is a ConvTranspose2d(4, 2, 1)'s, [Cin][Cout][4][4], repacked into the same four phase sets)
     Conv conv(const std::string& pfx, int Cin, int Cout, int ksz, int mode, bool has_bias, const float* cin_scale = nullptr) {
         Conv c;
         c.Cin = Cin; c.Cout = Cout; c.mode = mode;
         c.ntaps = (mode == NOPE_CONV_DOWN2 || mode == NOPE_CONV_UP2P) ? 4 : ksz * ksz;
+        const bool convT = mode == NOPE_CONV_UP2P && ksz == 4;
         const nope_tensor_desc* d = mode == NOPE_CONV_DOWN2 ? get(pfx + "weight", {Cout, (int64_t)Cin * 4, 1, 1})
-                                                            : get(pfx + "weight", {Cout, Cin, ksz, ksz});
+                                    : convT             ? get(pfx + "weight", {Cin, Cout, 4, 4})
+                                                        : get(pfx + "weight", {Cout, Cin, ksz, ksz});
         if (d) {
             const size_t es = net->dt == NOPE_F32 ? 4 : 2;
             c.w = dmalloc((size_t)Cout * c.ntaps * Cin * es * (mode == NOPE_CONV_UP2P ? 4 : 1));
-            if (c.w) { int e = launch_pack_conv_w(net->dt, d->data, c.w, Cout, Cin, c.ntaps, mode, s, cin_scale); if (e && err == NOPE_OK) err = e; }
+            if (c.w) { int e = launch_pack_conv_w(net->dt, d->data, c.w, Cout, Cin, convT ? 16 : c.ntaps, mode, s, cin_scale); if (e && err == NOPE_OK) err = e; }
         }
         if (has_bias) c.bias = copy_f32(pfx + "bias", {Cout});
         return c;
@@ -513,7 +516,8 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
         D.r0 = ld.res(p + "0.", dims[l], dims[l], true, embs);
         D.r1 = ld.res(p + "1.", dims[l], dims[l], true, embs);
         D.attn = linattn(p + "2.", dims[l]);
-        if (l < L - 1) D.resample = ld.conv(p + "3.1.", dims[l], dims[l + 1], 1, NOPE_CONV_DOWN2, true);
+        if (l < L - 1 && cfg->soft_up_down) D.resample = ld.conv(p + "3.", dims[l], dims[l + 1], 4, NOPE_CONV_STRIDE2, true);   // Conv2d(4, 2, 1)
+        else if (l < L - 1) D.resample = ld.conv(p + "3.1.", dims[l], dims[l + 1], 1, NOPE_CONV_DOWN2, true);
         else D.resample = ld.conv(p + "3.", dims[l], dims[l + 1], 3, NOPE_CONV_PLAIN, true);
     }
     net->mid1 = ld.res("mid_block1.", dims[L], dims[L], true, embs);
@@ -527,7 +531,8 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
         U.r0 = ld.res(p + "0.", dims[r + 1] + dims[r], dims[r + 1], true, embs);
         U.r1 = ld.res(p + "1.", dims[r + 1] + dims[r], dims[r + 1], true, embs);
         U.attn = linattn(p + "2.", dims[r + 1]);
-        if (l < L - 1) U.resample = ld.conv(p + "3.1.", dims[r + 1], dims[r], 3, NOPE_CONV_UP2P, true);   // 4 phase 2x2 convs
+        if (l < L - 1 && cfg->soft_up_down) U.resample = ld.conv(p + "3.", dims[r + 1], dims[r], 4, NOPE_CONV_UP2P, true);   // ConvTranspose2d(4, 2, 1)
+        else if (l < L - 1) U.resample = ld.conv(p + "3.1.", dims[r + 1], dims[r], 3, NOPE_CONV_UP2P, true);   // 4 phase 2x2 convs
         else U.resample = ld.conv(p + "3.", dims[r + 1], dims[r], 3, NOPE_CONV_PLAIN, true);
     }
     net->final_res = ld.res("final_res_block.", cfg->u_net_dim * 2, cfg->u_net_dim, true, embs);

@@ -29,7 +29,7 @@ class TensorDesc(C.Structure):
 class UNetConfig(C.Structure):
     _fields_ = [("u_net_dim", _i), ("channels", _i), ("out_dim", _i), ("pose_dim", _i), ("n_levels", _i),
                 ("dim_mults", _i * 8), ("groups", _i), ("heads", _i), ("dim_head", _i), ("pose_mlp_layers", _i),
-                ("compute_dtype", _i)]
+                ("compute_dtype", _i), ("soft_up_down", _i)]
 
 
 class LdmConfig(C.Structure):
@@ -329,6 +329,7 @@ class UNetHandle:
         c.groups = cfg.get("groups", 8); c.heads = 4; c.dim_head = 32
         c.pose_mlp_layers = cfg.get("pose_mlp_layers", 1)
         c.compute_dtype = dtype_code(compute_dtype)
+        c.soft_up_down = int(cfg.get("soft_up_down", 0))
         self.cfg = dict(cfg)
         self.compute_dtype = c.compute_dtype
         self.channels, self.out_dim, self.pose_dim = c.channels, c.out_dim, c.pose_dim

@@ -73,8 +73,6 @@ class UNet(nn.Module):
     def __init__(self, u_net_dim, rot_representation_dim, encoder, pose_mlp_name, init_dim=None, out_dim=None,
                  use_hard_up_down=True, dim_mults=(1, 2, 4, 8), resnet_block_groups=8, compute_dtype="f32", **kwargs):
         super().__init__()
-        if not use_hard_up_down:
-            raise NotImplementedError("only use_hard_up_down=True (the shipped configuration) is implemented")
         if init_dim not in (None, u_net_dim):
             raise NotImplementedError("init_dim != u_net_dim")
         self.encoder = encoder
@@ -83,6 +81,7 @@ class UNet(nn.Module):
         self.out_dim = out_dim if out_dim is not None else self.channels
         self.rot_representation_dim = rot_representation_dim
         self.u_net_dim = u_net_dim
+        self.use_hard_up_down = bool(use_hard_up_down)
         self.dim_mults = tuple(dim_mults)
         self.groups = resnet_block_groups
         self.compute_dtype = compute_dtype
@@ -110,7 +109,8 @@ class UNet(nn.Module):
             last = l == n - 1
             self.downs.append(nn.ModuleList([
                 _resnet_params(cin, cin, emb, g), _resnet_params(cin, cin, emb, g), _attention_params(cin, True),
-                _conv(cin, cout, 3) if last else _slot(None, _conv(4 * cin, cout, 1))]))
+                _conv(cin, cout, 3) if last else (_slot(None, _conv(4 * cin, cout, 1)) if use_hard_up_down       # u_net.py:54-59
+                                                  else nn.Conv2d(cin, cout, 4, 2, 1))]))                           # model_utils.py:129-136
         mid = dims[-1]
         self.mid_attn = _attention_params(mid, False)
         self.mid_block1 = _resnet_params(mid, mid, emb, g)
@@ -122,7 +122,8 @@ class UNet(nn.Module):
             self.ups.append(nn.ModuleList([
                 _resnet_params(cout + cin, cout, emb, g), _resnet_params(cout + cin, cout, emb, g),
                 _attention_params(cout, True),
-                _conv(cout, cin, 3) if last else _slot(None, _conv(cout, cin, 3))]))
+                _conv(cout, cin, 3) if last else (_slot(None, _conv(cout, cin, 3)) if use_hard_up_down
+                                                  else nn.ConvTranspose2d(cout, cin, 4, 2, 1))]))                   # model_utils.py:119-126
         self.final_res_block = _resnet_params(2 * u_net_dim, u_net_dim, emb, g)
         self.final_conv = _slot(_resnet_params(u_net_dim, u_net_dim, emb, g), _conv(u_net_dim, self.channels, 1))
         self._handle: Optional[hip.UNetHandle] = None
@@ -159,7 +160,7 @@ class UNet(nn.Module):
             # (the reference stores `out_dim` but builds final_conv.1 with `channels` outputs, u_net.py:154-157)
             cfg = dict(u_net_dim=self.u_net_dim, channels=self.channels, out_dim=self.channels,
                        pose_dim=self.rot_representation_dim, dim_mults=self.dim_mults, groups=self.groups,
-                       pose_mlp_layers=self._pose_layers)
+                       pose_mlp_layers=self._pose_layers, soft_up_down=int(not self.use_hard_up_down))
             self._handle = hip.UNetHandle(cfg, sd, hip.dtype_code(self.compute_dtype))
             self._handle_key = key
         return self._handle

@@ -103,12 +103,18 @@ def pixel_unshuffle_c_p1_p2(x: Tensor) -> Tensor:
 
 
 def hard_downsample(x: Tensor, sd: SD, p: str) -> Tensor:
-    """`HardDownsample`, model_utils.py:168-172: space-to-depth 2x2 then conv1x1 (key `<p>1.*`)."""
+    """`HardDownsample`, model_utils.py:168-172: space-to-depth 2x2 then conv1x1 (key `<p>1.*`).  With `use_hard_up_down=False`
+    (u_net.py:54-59) the slot holds `Downsample` = Conv2d(4, stride 2, pad 1) instead (model_utils.py:129-136, key `<p>weight`)."""
+    if p + "weight" in sd:
+        return F.conv2d(x, sd[p + "weight"], sd[p + "bias"], stride=2, padding=1)
     return F.conv2d(pixel_unshuffle_c_p1_p2(x), sd[p + "1.weight"], sd[p + "1.bias"])
 
 
 def hard_upsample(x: Tensor, sd: SD, p: str) -> Tensor:
-    """`HardUpsample`, model_utils.py:161-165: nearest x2 then conv3x3 pad 1 (key `<p>1.*`)."""
+    """`HardUpsample`, model_utils.py:161-165: nearest x2 then conv3x3 pad 1 (key `<p>1.*`).  With `use_hard_up_down=False` the
+    slot holds `Upsample` = ConvTranspose2d(4, stride 2, pad 1) instead (model_utils.py:119-126, key `<p>weight`)."""
+    if p + "weight" in sd:
+        return F.conv_transpose2d(x, sd[p + "weight"], sd[p + "bias"], stride=2, padding=1)
     x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
     return F.conv2d(x, sd[p + "1.weight"], sd[p + "1.bias"], padding=1)
 

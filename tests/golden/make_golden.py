@@ -85,11 +85,13 @@ def unets():
     U = RI.ref_unet_cls()
     out = {}
     g = torch.Generator().manual_seed(SEED + 1)
-    for tag, dim, hw, mlp in (("d8", 8, 8, "single_layer"), ("d16", 16, 16, "single_layer"), ("d16two", 16, 8, "two_layers"),
-                              ("d24pos", 24, 8, "posEncoding")):
-        mine = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=RI.StubEncoder(8), pose_mlp_name=mlp)
+    # (d16soft: use_hard_up_down=False -- Conv2d(4, 2, 1) / ConvTranspose2d(4, 2, 1) resampling, u_net.py:54-59; last, so that the
+    #  draws of the earlier cases stay what they were)
+    for tag, dim, hw, mlp, hard in (("d8", 8, 8, "single_layer", True), ("d16", 16, 16, "single_layer", True), ("d16two", 16, 8, "two_layers", True),
+                                    ("d24pos", 24, 8, "posEncoding", True), ("d16soft", 16, 16, "single_layer", False)):
+        mine = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=RI.StubEncoder(8), pose_mlp_name=mlp, use_hard_up_down=hard)
         synth_init_(mine, SEED)
-        ref = U(u_net_dim=dim, rot_representation_dim=6, encoder=RI.StubEncoder(8), pose_mlp_name=mlp)
+        ref = U(u_net_dim=dim, rot_representation_dim=6, encoder=RI.StubEncoder(8), pose_mlp_name=mlp, use_hard_up_down=hard)
         ref.load_state_dict(mine.state_dict(), strict=True)       # also proves key/shape parity
         x = torch.randn(3, 8, hw, hw, generator=g)
         pose = torch.randn(3, 6, generator=g)

@@ -190,9 +190,11 @@ def test_blocks_vs_reference_golden(be, golden):
         assert rel(hip.to_nchw(y, dt).cpu(), g[f"{tag}/out"]) < F32_TOL
 
 
-@pytest.mark.parametrize("tag,dim,mlp", [("d8", 8, "single_layer"), ("d16two", 16, "two_layers"), ("d24pos", 24, "posEncoding")])
+@pytest.mark.parametrize("tag,dim,mlp", [("d8", 8, "single_layer"), ("d16two", 16, "two_layers"), ("d24pos", 24, "posEncoding"),
+                                         ("d16soft", 16, "single_layer")])
 def test_tiny_unet_vs_reference_golden(be, golden, tag, dim, mlp):
-    """Whole U-Net schedule (C++ runtime + all kernels) vs the reference module's output."""
+    """Whole U-Net schedule (C++ runtime + all kernels) vs the reference module's output.  d16soft: use_hard_up_down=False
+    (Conv2d(4, 2, 1) on the generic kernel's 16-tap stride-2 mode, ConvTranspose2d(4, 2, 1) as four 2x2 phase convs)."""
     hip, dev, name = be
     from nope_amd.u_net import UNet
     from nope_amd.weights import synth_init_
@@ -201,12 +203,13 @@ def test_tiny_unet_vs_reference_golden(be, golden, tag, dim, mlp):
     for cdt, tol in (("f32", F32_TOL), ("bf16", 6e-2)):
         if (name == "emu" and cdt == "bf16" and tag != "d8") or (name == "emu" and tag == "d24pos" and cdt == "bf16"):
             continue      # keep the CPU suite short
-        m = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name=mlp, compute_dtype=cdt)
+        m = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name=mlp, compute_dtype=cdt,
+                 use_hard_up_down=tag != "d16soft")
         synth_init_(m, 2022)
         m = m.to(dev)
         y = m(x.to(dev), pose.to(dev)).cpu()
         assert rel(y, ref) < tol, (cdt, rel(y, ref))
-        if cdt == "f32" and not (name == "emu" and tag == "d24pos"):
+        if cdt == "f32" and not (name == "emu" and tag in ("d24pos", "d16soft")):
             # batched-hypothesis form == per-pose form (x shared by 3 poses, exercises rep / hoisting)
             yh = m.forward_hypotheses(x[:1].to(dev), pose[None].to(dev)).cpu()[0]
             want = R.unet_forward(m.cpu().own_state_dict(), x[:1].expand(3, -1, -1, -1), pose)

@@ -31,13 +31,13 @@ def test_blocks(golden):
 
 
 @pytest.mark.parametrize("tag,dim,mlp", [("d8", 8, "single_layer"), ("d16", 16, "single_layer"), ("d16two", 16, "two_layers"),
-                                         ("d24pos", 24, "posEncoding")])
+                                         ("d24pos", 24, "posEncoding"), ("d16soft", 16, "single_layer")])
 def test_tiny_unets(golden, tag, dim, mlp):
     from nope_amd.u_net import UNet
     from nope_amd.weights import sha256_of, synth_init_
     from tests.util import StubEncoder
     g = golden("unet_tiny.npz")
-    m = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name=mlp)
+    m = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name=mlp, use_hard_up_down=tag != "d16soft")
     synth_init_(m, 2022)
     sd = m.own_state_dict()
     assert sha256_of(sd["init_conv.weight"]) == str(g[f"{tag}/sha_init_conv"])      # generator drift check
