@@ -531,9 +531,9 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     }
     if (!pl.pp) pl.posmajor = posmajor128;
     // 3x3 convs in standard row order on the ping-pong schedule keep their A operand in LDS across the 9 taps (bit 4 = off)
-    // (sources must not be broadcast: the kernel's A offsets are linear in the flat pixel index)
+    // (the first source must not be broadcast: its A offsets are linear in the flat pixel index; a broadcast second source is fine)
     pl.halo = pl.pp && !pl.posmajor && a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.Ws <= conv_halo_max_width() && a.rep1 == 1 &&
-              (a.C2 == 0 || a.rep2 == 1) && !(pp_mode & 16);
+              !(pp_mode & 16);
     return pl;
 }
 

@@ -411,24 +411,42 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     if (tid < 16) st16(lds + A_BASE + (tid >> 3) * A_STAGE + ZROW + (tid & 7) * 16, u32x4{0u, 0u, 0u, 0u});
 
     // ---- A pieces of this wave: stage rows 8 q .. 8 q + 7 for q = wave, wave + 8, ... (<= 6 of them); stage row r holds
-    // flat pixel m0 - halo + r of the (hypothesis, y, x) axis.  Sources are not broadcast here (rep == 1, checked by the
-    // launcher), so the byte offset is LINEAR in the pixel index: piece i is piece 0 plus i * 64 pixels (a scalar), the
+    // flat pixel m0 - halo + r of the (hypothesis, y, x) axis.  The first source is never broadcast here (rep1 == 1, checked by
+    // the launcher), so its byte offset is LINEAR in the pixel index: piece i is piece 0 plus i * 64 pixels (a scalar), the
     // swizzled channel chunk is the same for all of a lane's pieces (rows 64 apart), and pixels before / behind the tensor
     // (first and last tile) give offsets that wrap above / run past num_records: the buffer range check returns zeros.
     const int rsub = lane >> 3, lslot = lane & 7;
     const int r0 = 8 * wave + rsub;
     const unsigned a_cs = (unsigned)((lslot ^ swz_of<RB>(r0)) * VEC);
     unsigned a_base1 = (unsigned)((m0 - halo + r0) * p.C1 + (int)a_cs) * ES;
-    unsigned a_base2 = (unsigned)((m0 - halo + r0) * p.C2 + (int)a_cs) * ES;
-    const unsigned a_step1 = 64u * (unsigned)p.C1 * ES, a_step2 = 64u * (unsigned)p.C2 * ES;
+    const unsigned a_step1 = 64u * (unsigned)p.C1 * ES;
     const bool a_has4 = wave + 32 < npieces, a_has5 = wave + 40 < npieces;      // (pieces 0..3 of a wave always exist)
     unsigned char* const a_dst = lds + A_BASE + wave * 1024;                    // + stage * A_STAGE + i * 8192
     // piece i of this wave for the chunk described by (first, a_soff).  The channel offset rides in the scalar operand (it stays
     // inside the pixel); the piece stride must be part of the VECTOR offset -- the hardware range check covers only that.
     bool a_first = true; unsigned a_soff = 0;
-    auto piece_a = [&](int i, int stage) {
+    // A broadcast second source (rep2 > 1: the U-Net's final block concatenates the per-reference skip `r` behind the
+    // per-hypothesis activations) is not linear in the pixel index: sample b reads sample b / rep2.  Its six piece offsets are
+    // kept per lane instead (rows before the tensor or behind it: out of range -> zeros); without the broadcast they are the
+    // linear offsets.
+    const bool a_rep2 = p.C2 > 0 && p.rep2 > 1;
+    unsigned a_off2[6];
+#define NOPE_HALO_SET_OFF2()                                                                                                     \
+    do {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                                           \
+            const int m = m0 - halo + r0 + 64 * i;                                                                               \
+            unsigned o = (unsigned)(m * p.C2 + (int)a_cs) * ES;                                                                  \
+            if (a_rep2) {                                                                                                        \
+                const unsigned b = p.d_hw.div((unsigned)(m < 0 ? 0 : m)), r = (unsigned)m - b * (unsigned)HW;                    \
+                o = (m >= 0 && m < p.M) ? ((p.d_rep2.div(b) * (unsigned)HW + r) * (unsigned)p.C2 + a_cs) * ES : OOB;             \
+            }                                                                                                                    \
+            a_off2[i] = o;                                                                                                       \
+        }                                                                                                                        \
+    } while (0)
+    NOPE_HALO_SET_OFF2();
+    auto piece_a = [&](int i, int stage) __attribute__((always_inline)) {
         if (a_first) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_void_t*)(a_dst + stage * A_STAGE + i * 8192), 16, a_base1 + i * a_step1, a_soff, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_void_t*)(a_dst + stage * A_STAGE + i * 8192), 16, a_base2 + i * a_step2, a_soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_void_t*)(a_dst + stage * A_STAGE + i * 8192), 16, a_off2[i], a_soff, 0, 0);
     };
     auto set_chunk = [&](int chunk) {
         const int c0 = chunk * BK;
@@ -488,7 +506,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     const unsigned wrap_inc = (unsigned)BK * ES - 8u * cin_es;     // K offset step from tap 8 of a chunk to tap 0 of the next
 
     // ---- prologue of a tile: the whole A stage of chunk 0, this group's half of B(0), and (group 1) its half of B(1)
-    auto tile_prologue = [&]() {
+    auto tile_prologue = [&]() __attribute__((always_inline)) {
         set_chunk(0);
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -610,7 +628,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         if (more) {
             m0 += walk_rows;
             a_base1 += (unsigned)walk_rows * (unsigned)p.C1 * ES;
-            a_base2 += (unsigned)walk_rows * (unsigned)p.C2 * ES;
+            NOPE_HALO_SET_OFF2();
             if (dma_on) tile_prologue();
         }
         if constexpr (TIMELINE) epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel, stamp);

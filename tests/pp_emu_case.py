@@ -41,6 +41,11 @@ def run(hip, dev, dts=(1, 0), light=False):
         x1f = rn(3, C, 10, 9)
         y = hip.op_conv(dt, hip.to_nhwc(d(x1f), dt), d(w), d(b), src2=hip.to_nhwc(d(x2), dt))
         chk(y, F.conv2d(torch.cat((q(x1f), q(x2)), 1), q(w), b, padding=1), "halo 3x3 concat")
+        # ... and with a broadcast SECOND source (the U-Net's final block: per-hypothesis activations ++ per-reference skip): still
+        # the tap-resident kernel, per-piece offsets for the broadcast source
+        w2 = torch.cat((w[:, C:], w[:, :C]), 1)
+        y = hip.op_conv(dt, hip.to_nhwc(d(x2), dt), d(w2), d(b), src2=hip.to_nhwc(d(x1), dt), rep1=1, rep2=3, n_hyp=3)
+        chk(y, F.conv2d(torch.cat((q(x2), q(x1).expand(3, -1, -1, -1)), 1), q(w2), b, padding=1), "halo 3x3 concat, broadcast second source")
         # tap-resident 3x3 kernel (A stage = tile pixels + halo, loaded once per channel chunk): maps of 4x4 pixels with many
         # samples per tile (halo rows belong to neighbouring samples), widest supported map (W = 32), a single channel chunk
         xs, ws_, bs = rn(40, C, 4, 4), rn(24, C, 3, 3) / (3 * C ** 0.5), rn(24)
