@@ -501,7 +501,9 @@ int conv_halo_max_width();
 // bit 4 = 3x3 convs per tap on the ping-pong kernel instead of the tap-resident (halo) kernel.
 struct ConvPlan { bool dma, pp, posmajor, halo; };
 static ConvPlan plan_conv(int dt, const ConvArgs& a) {
-    const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : 3;   // (read per launch: the tests toggle it)
+    // (read per launch: the tests toggle it.  f32 -- the parity mode -- stays on the 128 x 192 kernel unless asked: its MFMA phase is
+    //  16x longer per K step, loads were never its bound, and two workgroups per CU beat one: 126 vs 135 ms per 512-template step)
+    const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : (dt == NOPE_BF16 ? 3 : 0);
     static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
     ConvPlan pl{false, false, false, false};
     const int vec = dt == NOPE_F32 ? 4 : 8, es = dt == NOPE_F32 ? 4 : 2, bk = 8 * vec;
