@@ -1,6 +1,8 @@
 // Token-space kernels of the LDM cross-attention U-Net variant (src/model/u_net/ldm/attention.py:149-277): LayerNorm over the
 // channels of a token, GEGLU, softmax self-attention over the h*w tokens of a sample, and the per-sample broadcast add
 // that the single-token cross-attention collapses to.  Activations are NHWC, i.e. already (sample, token, channel).
+#include <cstdlib>
+
 #include "nope_common.h"
 
 namespace nope {
@@ -154,6 +156,124 @@ __global__ __launch_bounds__(NT) void token_attn_kernel(const T* __restrict__ qk
     }
 }
 
+// ---- the same op on the matrix cores (bf16 storage) ---------------------------------------------------------------------
+// One wave owns 32 queries of a (sample, head); a workgroup of four waves shares the key / value blocks (64 keys per
+// iteration) through LDS.  Everything is computed TRANSPOSED, so that a lane's accumulator column is one query throughout:
+//   S^T = K Q^T        (v_mfma_f32_32x32x16_bf16: A = 32 keys x 16 d from LDS, B = Q^T from registers, two per 32 keys)
+//   online softmax     per query = per lane pair (l, l ^ 32): the 16 + 16 keys of a block a pair holds; max / sum exchanged with
+//                      one cross-lane move; the running output is rescaled by one factor per lane
+//   O^T += V^T P^T     the B operand P^T is the lane's OWN 16 exponentials rounded to bf16 -- no data crosses lanes: the MFMA's
+//                      k slot (8 h + j) of step t is defined to be key 16 t + 8 (j >> 2) + 4 h + (j & 3), which is where the
+//                      accumulator layout left it, and the A operand V^T (staged transposed, [d][key]) is read in that key order
+//                      (two 8-byte LDS reads per step)
+// P is rounded to bf16 before P V (as V is stored); scores, max, sums and the output accumulate in f32.
+constexpr int MQ = 128;          // queries per workgroup
+constexpr int MK = 64;           // keys per iteration
+constexpr int K_LD = 40;         // bf16 per staged K row (32 + pad: conflict-free 16-byte fragment reads)
+constexpr int VT_LD = 68;        // bf16 per staged V^T row (64 keys + pad: conflict-free 8-byte reads)
+__global__ __launch_bounds__(NT) void token_attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int N, int C, float scale_log2e) {
+    typedef __attribute__((ext_vector_type(16))) float f32x16;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    __shared__ __attribute__((aligned(16))) bf16_t s_k[MK][K_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t s_vt[AD][VT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = blockIdx.y, smp = blockIdx.z;
+    const int h = lane >> 5, li = lane & 31;
+    const bf16_t* base = qkv + (size_t)smp * N * 3 * C + head * AD;
+    const int q = blockIdx.x * MQ + wave * 32 + li;            // this lane's query (accumulator column)
+    // Q^T fragments (B operand): column = query, k = d: 8 consecutive d at 8 h (+ 16 for the second step)
+    u32x4 qf[2];
+    {
+        const bf16_t* qp = base + (size_t)(q < N ? q : N - 1) * 3 * C + 8 * h;
+        qf[0] = ld16(qp); qf[1] = ld16(qp + 16);
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float mx = -3.0e38f, den = 0.f;                              // (in log2 units; den: this lane's half of the row sum)
+    // staging role: thread -> (key, 16-byte vector of its K row and of its V row); the next block's loads fly under the MFMAs
+    const int skey = tid >> 2, svec = tid & 3;
+    u32x4 nk, nv;
+    auto fetch = [&](int k0) {
+        const int key = k0 + skey;
+        const bf16_t* kp = base + (size_t)(key < N ? key : N - 1) * 3 * C + C + svec * 8;
+        nk = ld16(kp); nv = ld16(kp + C);
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < N; k0 += MK) {
+        __syncthreads();                                         // everyone is done reading the previous block
+        st16(&s_k[skey][svec * 8], nk);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                            // V^T: [d][key]
+            const unsigned w = nv[e >> 1];
+            s_vt[svec * 8 + e][skey] = (bf16_t)((e & 1) ? (w >> 16) : (w & 0xffffu));
+        }
+        __syncthreads();
+        if (k0 + MK < N) fetch(k0 + MK);
+        f32x16 sc[2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[sb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const u32x4 kf = ld16(&s_k[sb * 32 + li][8 * h + 16 * kk]);
+                sc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[kk]), sc[sb], 0, 0, 0);
+            }
+        }
+        // scores in log2 units; keys behind N (last block of a ragged N) drop out
+        float bm = -3.0e38f;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + sb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                const float v = key < N ? sc[sb][r] * scale_log2e : -3.0e38f;
+                sc[sb][r] = v;
+                bm = fmaxf(bm, v);
+            }
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));                  // the other half of this query's keys
+        const float nm = fmaxf(mx, bm);
+        const float corr = __builtin_amdgcn_exp2f(mx - nm);
+        mx = nm;
+        float ps = 0.f;
+        u32x4 pf[2][2];                                          // P^T fragments: [32-key block][MFMA step]
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p0 = __builtin_amdgcn_exp2f(sc[sb][8 * t + 2 * j] - nm), p1 = __builtin_amdgcn_exp2f(sc[sb][8 * t + 2 * j + 1] - nm);
+                    ps += p0 + p1;
+                    pf[sb][t][j] = cvt_pk_bf16(p0, p1);
+                }
+        den = den * corr + ps;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= corr;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kb = sb * 32 + 16 * t + 4 * h;        // keys kb .. kb + 3 and kb + 8 .. kb + 11 are this lane's 8 k slots
+                const u32x2 v0 = *reinterpret_cast<const u32x2*>(&s_vt[li][kb]);
+                const u32x2 v1 = *reinterpret_cast<const u32x2*>(&s_vt[li][kb + 8]);
+                const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[sb][t]), o, 0, 0, 0);
+            }
+    }
+    den += __shfl_xor(den, 32, 64);
+    if (q < N) {
+        const float inv = 1.0f / den;
+        bf16_t* op = out + ((size_t)smp * N + q) * C + head * AD + 4 * h;       // rows of O^T this lane holds: d = 8 g + 4 h + (r & 3)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const unsigned long long lo = cvt_pk_bf16(o[4 * g] * inv, o[4 * g + 1] * inv), hi = cvt_pk_bf16(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            *reinterpret_cast<unsigned long long*>(op + 8 * g) = lo | (hi << 32);
+        }
+    }
+}
+
 // x (M, C) -> y (M, C2) [:, off .. off + C): concatenation of token tensors along the channel axis (th.cat of the skip,
 // adapt_openaimodel.py:152: GroupNorm(32) groups of the ResBlock that follows may straddle the two sources)
 template <class T>
@@ -214,7 +334,13 @@ int launch_token_attention(int dt, const void* qkv, void* out, int nsmp, int N, 
     if (!qkv || !out || nsmp <= 0 || N <= 0 || C <= 0 || dim_head != AD || C % AD) return NOPE_ERR_ARG;
     const dim3 grid((unsigned)cdiv(N, NT), (unsigned)(C / AD), (unsigned)nsmp);
     const float scale = 1.0f / sqrtf((float)dim_head);
-    if (dt == NOPE_F32) hipLaunchKernelGGL((token_attn_kernel<float>), grid, dim3(NT), 0, s, (const float*)qkv, (float*)out, N, C, scale);
+    // bf16: the matrix-core kernel (NOPE_LDM_ATTN=0 keeps the VALU one: the tests compare the two); f32 -- the parity mode -- stays
+    // on the all-f32 VALU kernel
+    const bool mfma = dt == NOPE_BF16 && !(getenv("NOPE_LDM_ATTN") && atoi(getenv("NOPE_LDM_ATTN")) == 0);
+    if (mfma) {
+        const dim3 g2((unsigned)cdiv(N, MQ), (unsigned)(C / AD), (unsigned)nsmp);
+        hipLaunchKernelGGL(token_attn_mfma_kernel, g2, dim3(NT), 0, s, (const bf16_t*)qkv, (bf16_t*)out, N, C, scale * 1.4426950408889634f);
+    } else if (dt == NOPE_F32) hipLaunchKernelGGL((token_attn_kernel<float>), grid, dim3(NT), 0, s, (const float*)qkv, (float*)out, N, C, scale);
     else if (dt == NOPE_BF16) hipLaunchKernelGGL((token_attn_kernel<bf16_t>), grid, dim3(NT), 0, s, (const bf16_t*)qkv, (bf16_t*)out, N, C, scale);
     else return NOPE_ERR_UNSUPPORTED;
     NOPE_CHECK_LAUNCH();

@@ -376,6 +376,7 @@ inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_s_memrealtime() 0ull   // (clock stamps of the tuning instantiations: no clock on the host)
 // s_waitcnt simm16 (gfx9 encoding): vmcnt = bits [3:0] | [15:14] << 4; only the vmcnt field matters to the interpreter
 inline void hipemu_s_waitcnt(unsigned imm) { hipemu::dma_wait((imm & 0xF) | (((imm >> 14) & 3) << 4)); }
