@@ -65,14 +65,14 @@ __global__ __launch_bounds__(NT) void geglu_kernel(const T* __restrict__ in, T* 
 // so attn2(x, context) = to_out(to_v(context)) for every query token, attention.py:168-189 with j = 1) ------------------------
 template <class T>
 __global__ __launch_bounds__(NT) void add_rowvec_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ u,
-                                                        long long M, int tokens, int C) {
+                                                        long long M, int tokens, int C, int u_stride) {
     constexpr int VEC = Elt<T>::VEC;
     const int nv = C / VEC;
     const long long total = M * nv;
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
         const long long m = i / nv;
         const int v = (int)(i - m * nv);
-        const float* ur = u + (m / tokens) * C + v * VEC;
+        const float* ur = u + (m / tokens) * u_stride + v * VEC;
         float t[VEC];
         Elt<T>::unpack(ld16(x + m * C + v * VEC), t);
 #pragma unroll
@@ -319,12 +319,13 @@ int launch_geglu(int dt, const void* in, void* out, long long M, int D, hipStrea
     return NOPE_OK;
 }
 
-int launch_add_rowvec(int dt, const void* x, void* y, const float* u, long long M, int tokens, int C, hipStream_t s) {
+int launch_add_rowvec(int dt, const void* x, void* y, const float* u, long long M, int tokens, int C, hipStream_t s, int u_stride) {
+    if (u_stride <= 0) u_stride = C;
     const int vec = dt == NOPE_F32 ? 4 : 8;
     if (!x || !y || !u || M <= 0 || tokens <= 0 || C % vec) return NOPE_ERR_ARG;
     const dim3 grid(grid_for_ll(M * (C / vec)));
-    if (dt == NOPE_F32) hipLaunchKernelGGL((add_rowvec_kernel<float>), grid, dim3(NT), 0, s, (const float*)x, (float*)y, u, M, tokens, C);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((add_rowvec_kernel<bf16_t>), grid, dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)y, u, M, tokens, C);
+    if (dt == NOPE_F32) hipLaunchKernelGGL((add_rowvec_kernel<float>), grid, dim3(NT), 0, s, (const float*)x, (float*)y, u, M, tokens, C, u_stride);
+    else if (dt == NOPE_BF16) hipLaunchKernelGGL((add_rowvec_kernel<bf16_t>), grid, dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)y, u, M, tokens, C, u_stride);
     else return NOPE_ERR_UNSUPPORTED;
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;

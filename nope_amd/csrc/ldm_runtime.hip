@@ -8,8 +8,10 @@
 //   * SpatialTransformer tokens are the NHWC activations themselves: the two `rearrange`s are no-ops;
 //   * attn1's to_q / to_k / to_v are one GEMM against the row-concatenated weights;
 //   * attn2 is cross-attention against ONE context token: softmax over a single key is exactly 1, so its output is
-//     to_out(to_v(context)) for every query -- two tiny per-sample linears and a broadcast add; to_q, to_k and norm2 never
-//     influence the result and are not evaluated (their weights are still validated at create time);
+//     to_out(to_v(context)) for every query; to_q, to_k and norm2 never influence the result and are not evaluated (their
+//     weights are still validated at create time).  Two linear maps in a row are one: W_out W_v is formed at create time, the
+//     products of ALL transformer blocks are stacked, and a forward computes every block's per-sample row in ONE small
+//     linear launch (context -> sum of the blocks' channels), each block adding its slice to its tokens;
 //   * with injecting_condition_twice = false the timestep embedding is zeros, so emb_layers(emb) is its bias: folded into the
 //     bias of in_layers' conv at create time (use_scale_shift_norm: that bias row is the FiLM (scale | shift) of every sample);
 //   * FiLM (use_scale_shift_norm) costs no pass: out_norm(h) * (1 + scale) + shift is folded into the per-channel affine the
@@ -29,7 +31,7 @@ namespace {
 struct LConv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; };
 struct LNorm { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct LRes { LNorm n1, n2; LConv c1, c2, skip; bool has_skip = false; float *emb_w = nullptr, *emb_b = nullptr; int Cin = 0, Cout = 0; };
-struct LST { LNorm norm, ln1, ln3; LConv proj_in, qkv, out1, ff1, ff2, proj_out; float *v2_w = nullptr, *o2_w = nullptr, *o2_b = nullptr; int C = 0; };
+struct LST { LNorm norm, ln1, ln3; LConv proj_in, qkv, out1, ff1, ff2, proj_out; int u_off = 0; int C = 0; };   // u_off: its slice of nope_ldm::u_w
 struct LBlock { bool has_res = false, has_st = false, has_resample = false; LRes res; LST st; LConv resample; };
 
 }  // namespace
@@ -46,6 +48,8 @@ struct nope_ldm {
     std::vector<int> skip_ch;                            // channels pushed by each input block
     float *pose_w0 = nullptr, *pose_b0 = nullptr, *pose_w2 = nullptr, *pose_b2 = nullptr;
     float *tw = nullptr, *tb = nullptr;                  // pose_mlp_timesteps (injecting_condition_twice)
+    float *u_w = nullptr, *u_b = nullptr;                // stacked attn2 maps to_out.0 o to_v of every transformer block: [u_total][context_dim], [u_total]
+    int u_total = 0;
     int emb_dim = 0;
 };
 
@@ -57,6 +61,9 @@ struct Loader {
     std::map<std::string, const nope_tensor_desc*> tab;
     int err = NOPE_OK;
     std::string missing;
+    struct UPart { float* comb; float* bias; int C, off; };
+    std::vector<UPart> u_parts;
+    int u_total = 0;
     void fail(const std::string& n) { if (err == NOPE_OK) { err = NOPE_ERR_WEIGHT; missing = n; } }
     void chk(int e) { if (e && err == NOPE_OK) err = e; }
     const nope_tensor_desc* get(const std::string& name, std::initializer_list<int64_t> shape) {
@@ -146,9 +153,20 @@ struct Loader {
             }
         }
         t.out1 = conv(b + "attn1.to_out.0.", C, C, 1, NOPE_CONV_PLAIN, true, true);
-        t.v2_w = copy_f32(b + "attn2.to_v.weight", {C, ctx});
-        t.o2_w = copy_f32(b + "attn2.to_out.0.weight", {C, C});
-        t.o2_b = copy_f32(b + "attn2.to_out.0.bias", {C});
+        {   // attn2: W = to_out.0.weight x to_v.weight, [C][ctx] (see the header)
+            const nope_tensor_desc* wv2 = get(b + "attn2.to_v.weight", {C, ctx});
+            const nope_tensor_desc* wo2 = get(b + "attn2.to_out.0.weight", {C, C});
+            float* o2_b = copy_f32(b + "attn2.to_out.0.bias", {C});
+            float* vT = (float*)dmalloc((size_t)ctx * C * 4);
+            float* comb = (float*)dmalloc((size_t)C * ctx * 4);
+            if (wv2 && wo2 && vT && comb) {
+                chk(launch_nhwc_to_nchw_f32(NOPE_F32, wv2->data, vT, 1, ctx, C, s));                 // to_v.weight^T: [ctx][C]
+                chk(launch_linear_naive(wo2->data, vT, nullptr, comb, C, ctx, C, 0, ctx, s));        // comb[c][j] = sum_k Wout[c][k] Wv[k][j]
+            }
+            t.u_off = u_total;
+            u_parts.push_back(UPart{comb, o2_b, C, u_total});
+            u_total += C;
+        }
         t.ff1 = conv(b + "ff.net.0.proj.", C, 8 * C, 1, NOPE_CONV_PLAIN, true, true);
         t.ff2 = conv(b + "ff.net.2.", 4 * C, C, 1, NOPE_CONV_PLAIN, true, true);
         t.proj_out = conv(p + "proj_out.", C, C, 1, NOPE_CONV_PLAIN, true);
@@ -181,6 +199,7 @@ struct Fwd {
     float* gn_partial = nullptr;
     const float* ctx = nullptr;       // (nhyp, context_dim)
     const float* emb = nullptr;       // (nhyp, emb_dim) or null (zeros)
+    const float* u_all = nullptr;     // (nhyp, u_total): every transformer block's to_out(to_v(context)) row
 
     void chk(int e) { if (e != NOPE_OK && err == NOPE_OK) err = e; }
     bool live() const { return !ar.dry && err == NOPE_OK; }
@@ -266,14 +285,8 @@ struct Fwd {
         conv(T.qkv, Act{a, C, x.H, x.W}, qkv, x.H, x.W);
         if (live()) chk(launch_token_attention(net->dt, qkv, o, nhyp, HW, C, 32, s));
         conv(T.out1, Act{o, C, x.H, x.W}, tok1, x.H, x.W, tok);
-        // attn2 against the single pose token: + to_out(to_v(context)) for every token
-        float* v = alloc_f32((size_t)nhyp * C);
-        float* u = alloc_f32((size_t)nhyp * C);
-        if (live()) {
-            chk(launch_linear_naive(ctx, T.v2_w, nullptr, v, nhyp, C, net->cfg.context_dim, 0, C, s));
-            chk(launch_linear_naive(v, T.o2_w, T.o2_b, u, nhyp, C, C, 0, C, s));
-            chk(launch_add_rowvec(net->dt, tok1, tok1, u, M, HW, C, s));
-        }
+        // attn2 against the single pose token: + to_out(to_v(context)) for every token -- this block's slice of u_all
+        if (live()) chk(launch_add_rowvec(net->dt, tok1, tok1, u_all + T.u_off, M, HW, C, s, net->u_total));
         // feed-forward (GEGLU) + residual
         void* f = o;                                     // reuse: LN3(tok1)
         if (live()) chk(launch_layernorm(net->dt, tok1, f, T.ln3.gamma, T.ln3.beta, M, C, 1e-5f, s));
@@ -299,6 +312,8 @@ int run_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, const
     float* ctx = f.alloc_f32((size_t)n_hyp * cfg.context_dim);
     float* ctx2 = f.alloc_f32((size_t)n_hyp * cfg.context_dim);
     float* emb = cfg.injecting_condition_twice ? f.alloc_f32((size_t)n_hyp * net->emb_dim) : nullptr;
+    float* u_all = f.alloc_f32((size_t)n_hyp * (net->u_total > 0 ? net->u_total : 1));
+    f.u_all = u_all;
     f.gn_partial = f.alloc_f32((size_t)n_hyp * 16 * 32 * 2);
     if (f.err) return f.err;
     if (f.live()) {
@@ -309,6 +324,8 @@ int run_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, const
             f.chk(launch_linear_naive(ctx, net->pose_w2, net->pose_b2, ctx2, n_hyp, cfg.context_dim, cfg.context_dim, 2, cfg.context_dim, s));
             f.ctx = ctx2;
         } else f.ctx = ctx;
+        if (net->u_total > 0)     // attn2 of every transformer block at once (see the header)
+            f.chk(launch_linear_naive(f.ctx, net->u_w, net->u_b, u_all, n_hyp, net->u_total, cfg.context_dim, 0, net->u_total, s));
         if (emb) {     // emb = pose_mlp_timesteps(pose), :119-123,141-142
             f.chk(launch_linear_naive(pose, net->tw, net->tb, emb, n_hyp, net->emb_dim, cfg.pose_dim, 0, net->emb_dim, s));
             f.emb = emb;
@@ -480,6 +497,19 @@ int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors,
     net->conv_out = ld.conv("out.2.", mc, cfg->out_channels, 3, NOPE_CONV_PLAIN, true);
     if (ch != mc) ld.fail("out.2.weight");
 
+    // stack the attn2 maps of all transformer blocks (in load order: LST::u_off)
+    net->u_total = ld.u_total;
+    if (ld.err == NOPE_OK && ld.u_total > 0) {
+        const int ctx = cfg->context_dim;
+        net->u_w = (float*)ld.dmalloc((size_t)ld.u_total * ctx * 4);
+        net->u_b = (float*)ld.dmalloc((size_t)ld.u_total * 4);
+        if (net->u_w && net->u_b)
+            for (const auto& up : ld.u_parts) {
+                if (!up.comb || !up.bias) continue;
+                hipMemcpyAsync(net->u_w + (size_t)up.off * ctx, up.comb, (size_t)up.C * ctx * 4, hipMemcpyDeviceToDevice, s);
+                hipMemcpyAsync(net->u_b + up.off, up.bias, (size_t)up.C * 4, hipMemcpyDeviceToDevice, s);
+            }
+    }
     if (ld.err == NOPE_OK && hipStreamSynchronize(s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
     if (ld.err != NOPE_OK) {
         if (!ld.missing.empty()) fprintf(stderr, "nope_ldm_create: missing or mis-shaped tensor '%s'\n", ld.missing.c_str());

@@ -223,7 +223,7 @@ int launch_cast(int dt, const float* in, void* out, size_t n, hipStream_t s);
 // LDM variant (kernels_ldm.hip)
 int launch_layernorm(int dt, const void* x, void* y, const float* gamma, const float* beta, long long M, int C, float eps, hipStream_t s);
 int launch_geglu(int dt, const void* in, void* out, long long M, int D, hipStream_t s);
-int launch_add_rowvec(int dt, const void* x, void* y, const float* u, long long M, int tokens, int C, hipStream_t s);
+int launch_add_rowvec(int dt, const void* x, void* y, const float* u, long long M, int tokens, int C, hipStream_t s, int u_stride = 0);   // (u_stride 0 = C)
 int launch_token_attention(int dt, const void* qkv, void* out, int nsmp, int N, int C, int dim_head, hipStream_t s);
 int launch_copy_cols(int dt, const void* x, void* y, long long M, int C, int C2, int off, hipStream_t s);
 
