@@ -88,6 +88,28 @@ def test_state_dict_contract():
     assert m.channels == 8 and m.out_dim == 8 and m.name == "template" and m.rot_representation_dim == 6
 
 
+def test_state_dict_contract_of_the_non_default_variants():
+    """use_hard_up_down=False (u_net.py:54-59: Conv2d(4, 2, 1) / ConvTranspose2d(4, 2, 1) in slot 3 of a level) and the LDM variant
+    with FiLM ResBlocks (openaimodel.py:233-239: emb_layers.1 twice as wide): key names and shapes.  (That the reference classes
+    load these state dicts strictly is checked where the fixtures are recorded, tests/golden/make_golden.py.)"""
+    from nope_amd.ldm import UNetModelPose
+    from nope_amd.u_net import UNet
+    from tests.util import StubEncoder
+    sd = UNet(u_net_dim=16, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", use_hard_up_down=False).state_dict()
+    assert tuple(sd["downs.0.3.weight"].shape) == (16, 16, 4, 4) and tuple(sd["downs.1.3.weight"].shape) == (32, 16, 4, 4)
+    assert tuple(sd["ups.0.3.weight"].shape) == (128, 64, 4, 4)        # ConvTranspose2d: [in, out, kh, kw]
+    assert tuple(sd["downs.3.3.weight"].shape) == (128, 64, 3, 3) and "downs.0.3.1.weight" not in sd
+    kw = dict(injecting_condition_twice=True, pose_mlp_name="single_layer", rot_representation_dim=6, image_size=8, in_channels=8,
+              model_channels=32, out_channels=8, num_res_blocks=1, attention_resolutions=[1, 2], channel_mult=(1, 2),
+              num_head_channels=32, use_spatial_transformer=True, transformer_depth=1, context_dim=24)
+    plain = UNetModelPose(encoder=StubEncoder(8), **kw).state_dict()
+    film = UNetModelPose(encoder=StubEncoder(8), use_scale_shift_norm=True, **kw).state_dict()
+    assert set(plain) == set(film)
+    assert tuple(plain["input_blocks.1.0.emb_layers.1.weight"].shape) == (32, 128) and tuple(film["input_blocks.1.0.emb_layers.1.weight"].shape) == (64, 128)
+    assert tuple(film["pose_mlp_timesteps.0.weight"].shape) == (128, 6)
+    assert tuple(film["input_blocks.1.1.transformer_blocks.0.attn2.to_v.weight"].shape) == (32, 24)
+
+
 def test_shard_range_partitions():
     from nope_amd.dist import shard_range
     for n in (0, 1, 5, 64, 341, 512, 8192):
