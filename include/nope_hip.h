@@ -27,8 +27,12 @@ extern "C" {
 #endif
 
 enum { NOPE_F32 = 0, NOPE_BF16 = 1,
-       NOPE_F16 = 2 /* IEEE half: a STORAGE type of the template bank only (nope_similarity's bank_dtype, nope_unet_forward's
-                       out_dtype); the networks compute in NOPE_F32 or NOPE_BF16 */ };
+       NOPE_F16 = 2,   /* IEEE half: storage type of the template bank (nope_similarity's bank_dtype, nope_unet_forward's out_dtype,
+                          BASELINE configs[4]) and a compute mode of the networks: f16 storage + f16 MFMA, f32 accumulate / statistics
+                          -- the MFMA rate of NOPE_BF16 with 3 more mantissa bits (values beyond +-65504 overflow) */
+       NOPE_BF16X3 = 3 /* compute mode only: f32 storage, every conv / linear as three bf16 MFMA passes over (hi, lo) bf16 splits of
+                          both operands (hi*hi + hi*lo + lo*hi, f32 accumulate): ~2^-17 relative per product instead of bf16's 2^-9
+                          at 3/16 of the exact-f32 MFMA cost -- the fast mode that meets the 1e-4 score tolerance */ };
 /* Tap geometries of nope_op_conv.  UP2P is UP2 (nearest-x2 upsample + 3x3, pad 1) rewritten as four
  * 2x2 convolutions over the un-upsampled input, one per output-pixel parity, with the 3x3 weights that
  * fall on the same source pixel pre-summed at pack time: same function, 4/9 of the multiply-adds. */
@@ -46,6 +50,10 @@ enum {
 
 typedef void* nope_stream_t;
 
+/* Bumped whenever a struct of this header changes layout or an enum gains a meaning (2: nope_unet_config.soft_up_down,
+ * NOPE_F16 / NOPE_BF16X3 compute modes, 4x4 STRIDE2).  Callers compare nope_abi_version() against the header they were
+ * built with before passing any struct (nope_amd/hip.py does at load time). */
+#define NOPE_ABI_VERSION 2
 const char* nope_strerror(int code);
 int nope_abi_version(void);
 
@@ -94,7 +102,8 @@ typedef struct {
     int heads, dim_head;   /* 4, 32 (model_utils.py:368,394) */
     int pose_mlp_layers;   /* 1 = "single_layer", 2 = "two_layers" (u_net.py:63-72) */
     int compute_dtype;     /* NOPE_F32: f32 storage + f32-input MFMA (bit-faithful fp32 sums);
-                              NOPE_BF16: bf16 storage + bf16 MFMA, f32 accumulate / statistics */
+                              NOPE_BF16 / NOPE_F16: 16-bit storage + 16-bit MFMA, f32 accumulate / statistics;
+                              NOPE_BF16X3: f32 storage, split-precision bf16 MFMA (see the enum) */
     int soft_up_down;      /* 0: use_hard_up_down = True, the shipped configuration (HardDownsample / HardUpsample, u_net.py:54-56);
                               1: use_hard_up_down = False -- Downsample = Conv2d(4, stride 2, pad 1) at "downs.l.3.weight",
                               Upsample = ConvTranspose2d(4, stride 2, pad 1) at "ups.l.3.weight" (model_utils.py:119-136) */
@@ -171,7 +180,7 @@ int nope_ldm_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, 
 typedef struct nope_encoder nope_encoder;
 typedef struct {
     int descriptor_size;   /* 8 (configs/model/template_base.yaml:10) */
-    int compute_dtype;     /* NOPE_F32 | NOPE_BF16 storage of weights and activations (f32 accumulation) */
+    int compute_dtype;     /* NOPE_F32 | NOPE_BF16 | NOPE_F16 | NOPE_BF16X3, as nope_unet_config */
     float bn_eps;          /* BatchNorm2d eps; <= 0 selects the torch default 1e-5 */
 } nope_encoder_config;
 

@@ -6,7 +6,7 @@ using namespace nope;
 
 extern "C" {
 
-int nope_abi_version(void) { return 1; }
+int nope_abi_version(void) { return NOPE_ABI_VERSION; }
 
 const char* nope_strerror(int code) {
     switch (code) {

@@ -73,32 +73,90 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 //   f32 : v_mfma_f32_16x16x4_f32  -- 4 x 6 tiles, a lane's 16-byte fragment = 4 channels = 4 chained steps
 //   bf16: v_mfma_f32_32x32x16_bf16 -- 2 x 3 tiles (the 32x32 form sustains ~15 % more than 16x16x32 on gfx950:
 //         2382 vs 2075 TFLOP/s, cdna_hip_programming.md section 3), a lane's fragment = 8 channels = 1 step
-// frag_row / frag_slot: which tile row and 16-byte K slot a lane feeds; out_row / out_col: the C/D map.
+//   f16 : v_mfma_f32_32x32x16_f16, as bf16
+//   f32s (NOPE_BF16X3): f32 data, three v_mfma_f32_32x32x16_bf16 per 16 channels over (hi, lo) bf16 splits, below
+// A K STEP is what one round of MFMAs over the wave tile consumes: STEP_SLOTS 16-byte slots of a staged row, of which a lane
+// reads RAW (slot = step * STEP_SLOTS + frag_slot(lane) + r).  frag_row / frag_slot: which tile row and first slot a lane
+// feeds; out_row / out_col: the C/D map.  prep_step turns the raw A reads into MFMA operands (a no-op except for f32s).
 template <class T> struct Tile;
 template <> struct Tile<float> {
-    static constexpr int TM = 16, MT = 4, NTL = 6, R = 4, KSLOTS = 4;
+    static constexpr int TM = 16, MT = 4, NTL = 6, R = 4, STEP_SLOTS = 4, RAW = 1;
     typedef f32x4 acc_t;
     static __device__ __forceinline__ int frag_row(int lane) { return lane & 15; }
     static __device__ __forceinline__ int frag_slot(int lane) { return lane >> 4; }
     static __device__ __forceinline__ int out_row(int lane, int r) { return (lane >> 4) * 4 + r; }
     static __device__ __forceinline__ int out_col(int lane) { return lane & 15; }
-    static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, acc_t& c) {
-        const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+    static __device__ __forceinline__ void prep_step(u32x4 (&)[RAW][MT]) {}
+    static constexpr int TERMS = 1;
+    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c) {
+        const f32x4 fa = __builtin_bit_cast(f32x4, a[0][i]), fb = __builtin_bit_cast(f32x4, b[0][j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], c, 0, 0, 0);
+        for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q], fb[q], c, 0, 0, 0);
     }
 };
-template <> struct Tile<bf16_t> {
-    static constexpr int TM = 32, MT = 2, NTL = 3, R = 16, KSLOTS = 2;
+// shared geometry of the 32x32x16 tiles
+struct Tile32 {
+    static constexpr int TM = 32, MT = 2, NTL = 3, R = 16;
     typedef f32x16 acc_t;
     static __device__ __forceinline__ int frag_row(int lane) { return lane & 31; }
-    static __device__ __forceinline__ int frag_slot(int lane) { return lane >> 5; }
     static __device__ __forceinline__ int out_row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
     static __device__ __forceinline__ int out_col(int lane) { return lane & 31; }
-    static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, acc_t& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+};
+template <> struct Tile<bf16_t> : Tile32 {
+    static constexpr int STEP_SLOTS = 2, RAW = 1;
+    static __device__ __forceinline__ int frag_slot(int lane) { return lane >> 5; }
+    static __device__ __forceinline__ void prep_step(u32x4 (&)[RAW][MT]) {}
+    static constexpr int TERMS = 1;
+    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0][i]), __builtin_bit_cast(bf16x8, b[0][j]), c, 0, 0, 0);
     }
 };
+template <> struct Tile<f16_t> : Tile32 {
+    static constexpr int STEP_SLOTS = 2, RAW = 1;
+    static __device__ __forceinline__ int frag_slot(int lane) { return lane >> 5; }
+    static __device__ __forceinline__ void prep_step(u32x4 (&)[RAW][MT]) {}
+    static constexpr int TERMS = 1;
+    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0][i]), __builtin_bit_cast(f16x8, b[0][j]), c, 0, 0, 0);
+    }
+};
+// NOPE_BF16X3.  A rows are f32 in LDS (straight from the f32 activations, LDS-DMA included), weight rows were split at pack
+// time: 8 channels = 32 bytes = [hi x 8 | lo x 8] bf16 with hi = rn(w), lo = rn(w - hi) (kernels_misc.hip) -- so both operands
+// have 32 channels per 128-byte row and every loader, swizzle and DMA path is the f32 one.  A K step is 16 channels: lanes
+// 0..31 own channels 0..7 of it (slots 0, 1), lanes 32..63 channels 8..15 (slots 2, 3), two raw reads per row each; prep_step
+// splits a lane's 8 f32 A values into (hi, lo) in place (~3 VALU per element, issued in the LOAD phase of the ping-pong
+// kernels, under the other group's MFMAs) and the step issues  acc += a_lo w_hi;  acc += a_hi w_lo;  acc += a_hi w_hi  --
+// the three products whose error is O(2^-17) per operand; a_lo w_lo (2^-18 relative) is dropped.
+template <> struct Tile<f32s_t> : Tile32 {
+    static constexpr int STEP_SLOTS = 4, RAW = 2;
+    static __device__ __forceinline__ int frag_slot(int lane) { return (lane >> 5) * 2; }
+    static __device__ __forceinline__ void prep_step(u32x4 (&a)[RAW][MT]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {      // (through a scalar: __builtin_bit_cast straight from a vector-element lvalue reads element 0)
+                const unsigned u0 = a[0][i][e], u1 = a[1][i][e];
+                x[e] = __builtin_bit_cast(float, u0); x[4 + e] = __builtin_bit_cast(float, u1);
+            }
+            u32x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned h = cvt_pk_bf16(x[2 * e], x[2 * e + 1]);
+                const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xffff0000u);
+                hi[e] = h;
+                lo[e] = cvt_pk_bf16(x[2 * e] - h0, x[2 * e + 1] - h1);
+            }
+            a[0][i] = hi; a[1][i] = lo;
+        }
+    }
+    static constexpr int TERMS = 3;           // (lo, hi), (hi, lo), (hi, hi): term outer in the callers' loops, so MFMAs on one accumulator sit 6 apart
+    static __device__ __forceinline__ void mma(int t, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t == 0 ? 1 : 0][i]), __builtin_bit_cast(bf16x8, b[t == 1 ? 1 : 0][j]), c, 0, 0, 0);
+    }
+};
+// slot offset of raw read q (= step * RAW + r) of a staged row, to be XORed into a fragment address (<< 4)
+template <class T> __device__ __forceinline__ constexpr int raw_slot(int q) { return (q / Tile<T>::RAW) * Tile<T>::STEP_SLOTS + (q % Tile<T>::RAW); }
 
 __device__ __forceinline__ void tile_coords(const ConvParams& p, int& tile_m, int& tile_n) {
     const int g = blockIdx.x;
@@ -131,28 +189,34 @@ template <int RB> __device__ __forceinline__ int swz_of(int row) { return RB == 
 template <int RB> __device__ __forceinline__ int lds_off_rb(int row, int slot) { return row * RB + ((slot ^ swz_of<RB>(row)) << 4); }
 
 // One K stage (RB bytes of K per row) of the 64 x 96 wave tile from the swizzled LDS tiles.  The fragments of
-// K sub-step kk+1 are read while the MFMAs of sub-step kk execute (two statically named register sets).
+// K step ks+1 are read while the MFMAs of step ks execute (two statically named register sets).
 template <class T, int RB>
 __device__ __forceinline__ void mma_stage(const unsigned char* ldsA, const unsigned char* ldsB, int wm, int wn, int lane,
                                           typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL]) {
     typedef Tile<T> TL;
-    constexpr int KK = RB / 16 / TL::KSLOTS;
-    u32x4 af[2][TL::MT], bfr[2][TL::NTL];
-    auto load = [&](int set, int kk) {
-        const int s = kk * TL::KSLOTS + TL::frag_slot(lane);
+    constexpr int KS = RB / 16 / TL::STEP_SLOTS;
+    u32x4 af[2][TL::RAW][TL::MT], bfr[2][TL::RAW][TL::NTL];
+    auto load = [&](int set, int ks) {
 #pragma unroll
-        for (int i = 0; i < TL::MT; ++i) af[set][i] = ld16(ldsA + lds_off_rb<RB>(wm * 64 + i * TL::TM + TL::frag_row(lane), s));
+        for (int r = 0; r < TL::RAW; ++r) {
+            const int s = ks * TL::STEP_SLOTS + TL::frag_slot(lane) + r;
 #pragma unroll
-        for (int j = 0; j < TL::NTL; ++j) bfr[set][j] = ld16(ldsB + lds_off_rb<RB>(wn * 96 + j * TL::TM + TL::frag_row(lane), s));
+            for (int i = 0; i < TL::MT; ++i) af[set][r][i] = ld16(ldsA + lds_off_rb<RB>(wm * 64 + i * TL::TM + TL::frag_row(lane), s));
+#pragma unroll
+            for (int j = 0; j < TL::NTL; ++j) bfr[set][r][j] = ld16(ldsB + lds_off_rb<RB>(wn * 96 + j * TL::TM + TL::frag_row(lane), s));
+        }
+        TL::prep_step(af[set]);
     };
     load(0, 0);
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-        if (kk + 1 < KK) load((kk + 1) & 1, kk + 1);
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) load((ks + 1) & 1, ks + 1);
 #pragma unroll
-        for (int i = 0; i < TL::MT; ++i)
+        for (int t = 0; t < TL::TERMS; ++t)
 #pragma unroll
-            for (int j = 0; j < TL::NTL; ++j) TL::mma(af[kk & 1][i], bfr[kk & 1][j], acc[i][j]);
+            for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                for (int j = 0; j < TL::NTL; ++j) TL::mma(t, af[ks & 1], bfr[ks & 1], i, j, acc[i][j]);
     }
 }
 
@@ -301,7 +365,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                     for (int r = 0; r < TL::R; r += 2) {
                         float v0 = acc[i][pass][r] + bv, v1 = acc[i][pass][r + 1] + bv;
                         if (p.act) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-                        pk[((i * TL::TM + TL::out_row(lane, r)) >> 1) * PLD + TL::out_col(lane)] = cvt_pk_bf16(v0, v1);
+                        pk[((i * TL::TM + TL::out_row(lane, r)) >> 1) * PLD + TL::out_col(lane)] = Elt<T>::cvt_pk(v0, v1);
                     }
                 __builtin_amdgcn_wave_barrier();                      // (same-wave LDS write -> read, see below)
                 stamp();

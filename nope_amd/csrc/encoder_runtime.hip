@@ -95,7 +95,7 @@ struct ELoader {
         float* scale = nullptr;
         if (!bnpfx.empty()) { if (!bn(bnpfx, Cout, scale, c.bias)) return c; }
         if (d) {
-            const size_t es = enc->dt == NOPE_F32 ? 4 : 2;
+            const size_t es = (size_t)dt_es(enc->dt);
             c.w = dmalloc((size_t)Cout * c.ntaps * Cin * es);
             if (c.w) chk(launch_pack_conv_w(enc->dt, d->data, c.w, Cout, Cin, c.ntaps, NOPE_CONV_PLAIN, s, nullptr, scale));
         }
@@ -141,7 +141,7 @@ Plan plan_for(int H, int W) {
 }
 
 int run_encoder(const nope_encoder* enc, const float* image, int n_img, int H, int W, float* out, EArena& ar, hipStream_t s) {
-    const size_t es = enc->dt == NOPE_F32 ? 4 : 2;
+    const size_t es = (size_t)dt_es(enc->dt);
     const Plan pl = plan_for(H, W);
     void* X[3] = {nullptr, nullptr, nullptr};
     void *T1 = nullptr, *T2 = nullptr, *SK = nullptr;
@@ -165,7 +165,7 @@ int run_encoder(const nope_encoder* enc, const float* image, int n_img, int H, i
     };
     auto walk = [&]() -> int {
         int e = NOPE_OK;
-        if (!measure && (e = launch_stem_conv(enc->dt, image, enc->stem_w, enc->stem_shift, X[0], n_img, H, W, s))) return e;   // resnet.py:136-138
+        if (!measure && (e = launch_stem_conv(dt_storage(enc->dt), image, enc->stem_w, enc->stem_shift, X[0], n_img, H, W, s))) return e;   // resnet.py:136-138
         int cur = 0, h = H / 2, w = W / 2;
         for (size_t i = 0; i < enc->blocks.size(); ++i) {      // Bottleneck.forward, resnet.py:70-90
             const Bottleneck& b = enc->blocks[i];
@@ -207,7 +207,7 @@ extern "C" {
 int nope_encoder_create(const nope_encoder_config* cfg, const nope_tensor_desc* tensors, int n_tensors, nope_stream_t stream,
                         nope_encoder** out) {
     if (!cfg || !tensors || !out || n_tensors <= 0) return NOPE_ERR_ARG;
-    if (cfg->compute_dtype != NOPE_F32 && cfg->compute_dtype != NOPE_BF16) return NOPE_ERR_UNSUPPORTED;
+    if (!dt_is_compute(cfg->compute_dtype)) return NOPE_ERR_UNSUPPORTED;
     const int D = cfg->descriptor_size;
     if (D <= 0 || D > 2048) return NOPE_ERR_UNSUPPORTED;
     nope_encoder* enc = new nope_encoder();

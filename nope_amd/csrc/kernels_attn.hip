@@ -28,6 +28,12 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const f32x
     *reinterpret_cast<unsigned long long*>(p) = lo | (hi << 32);
 }
 
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, const f32x4& v) {
+    const unsigned long long lo = cvt_pk_f16(v[0], v[1]);
+    const unsigned long long hi = cvt_pk_f16(v[2], v[3]);
+    *reinterpret_cast<unsigned long long*>(p) = lo | (hi << 32);
+}
+
 template <bool FAST> __device__ __forceinline__ float fexp(float x) { return FAST ? __expf(x) : expf(x); }
 
 // All global traffic is 16-byte vectors: a head row is 32 channels = CG = 32/VEC vectors.
@@ -246,9 +252,7 @@ int launch_linattn(int dt, const void* qkv, void* out, int nhyp, int HW, int hea
     if (!qkv || !out || nhyp <= 0 || HW <= 0 || heads <= 0) return NOPE_ERR_ARG;
     if (dim_head != D) return NOPE_ERR_UNSUPPORTED;
     dim3 grid((unsigned)(nhyp * heads)), block(NT);
-    if (dt == NOPE_F32) hipLaunchKernelGGL((linattn_kernel<float>), grid, block, 0, s, (const float*)qkv, (float*)out, HW, heads);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((linattn_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, HW, heads);
-    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((linattn_kernel<T>), grid, block, 0, s, (const T*)qkv, (T*)out, HW, heads));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }
@@ -257,9 +261,7 @@ int launch_attn(int dt, const void* qkv, void* out, int nhyp, int HW, int heads,
     if (!qkv || !out || nhyp <= 0 || HW <= 0 || heads <= 0) return NOPE_ERR_ARG;
     if (dim_head != D || HW > AT_MAXN) return NOPE_ERR_UNSUPPORTED;
     dim3 grid((unsigned)(nhyp * heads)), block(64);
-    if (dt == NOPE_F32) hipLaunchKernelGGL((attn_kernel<float>), grid, block, 0, s, (const float*)qkv, (float*)out, HW, heads);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, HW, heads);
-    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((attn_kernel<T>), grid, block, 0, s, (const T*)qkv, (T*)out, HW, heads));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

@@ -111,9 +111,7 @@ int launch_stem_conv(int dt, const float* img, const float* w_packed, const floa
     const int Ho = H / 2, Wo = W / 2;
     if (n_img > 65535) return NOPE_ERR_UNSUPPORTED;
     dim3 grid((unsigned)cdiv(Wo, STEM_TILE), (unsigned)cdiv(Ho, STEM_TILE), (unsigned)n_img);
-    if (dt == NOPE_F32) hipLaunchKernelGGL((stem_conv_kernel<float>), grid, dim3(NT), 0, s, img, w_packed, shift, (float*)out, H, W, Ho, Wo);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((stem_conv_kernel<bf16_t>), grid, dim3(NT), 0, s, img, w_packed, shift, (bf16_t*)out, H, W, Ho, Wo);
-    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((stem_conv_kernel<T>), grid, dim3(NT), 0, s, img, w_packed, shift, (T*)out, H, W, Ho, Wo));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

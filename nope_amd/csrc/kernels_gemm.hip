@@ -503,10 +503,10 @@ struct ConvPlan { bool dma, pp, posmajor, halo; };
 static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     // (read per launch: the tests toggle it.  f32 -- the parity mode -- stays on the 128 x 192 kernel unless asked: its MFMA phase is
     //  16x longer per K step, loads were never its bound, and two workgroups per CU beat one: 126 vs 135 ms per 512-template step)
-    const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : (dt == NOPE_BF16 ? 3 : 0);
+    const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : (dt != NOPE_F32 ? 3 : 0);
     static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
     ConvPlan pl{false, false, false, false};
-    const int vec = dt == NOPE_F32 ? 4 : 8, es = dt == NOPE_F32 ? 4 : 2, bk = 8 * vec;
+    const int vec = dt_vec(dt), es = dt_es(dt), bk = 8 * vec;
     const int Cin = a.C1 + a.C2;
     const unsigned long long lim = 0x7fffffffULL;
     const bool phased = a.mode == NOPE_CONV_UP2P;
@@ -552,7 +552,7 @@ double conv_executed_flops(int dt, const ConvArgs& a) {
 
 int conv_splitk_factor(int dt, const ConvArgs& a) {
     if (a.colstats || a.pn_ms || a.mode == NOPE_CONV_UP2P || a.mode == NOPE_CONV_UP2) return 1;
-    const int vec = dt == NOPE_F32 ? 4 : 8;
+    const int vec = dt_vec(dt);
     const int Cin = a.C1 + a.C2;
     if (Cin % (8 * vec)) return 1;
     const long long M = (long long)a.nhyp * a.Ho * a.Wo;
@@ -568,9 +568,10 @@ int conv_splitk_factor(int dt, const ConvArgs& a) {
 int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     if (!a.src1 || !a.w || !a.out || a.C1 <= 0 || a.Cout <= 0 || a.nhyp <= 0) return NOPE_ERR_ARG;
     if (a.C2 > 0 && !a.src2) return NOPE_ERR_ARG;
-    const int vec = dt == NOPE_F32 ? 4 : 8;
-    if (dt != NOPE_F32 && dt != NOPE_BF16) return NOPE_ERR_UNSUPPORTED;
+    const int vec = dt_vec(dt);
+    if (!dt_is_compute(dt)) return NOPE_ERR_UNSUPPORTED;
     if (a.C1 % vec || a.C2 % vec) return NOPE_ERR_UNSUPPORTED;
+    if (dt == NOPE_BF16X3 && (a.C1 % 8 || a.C2 % 8)) return NOPE_ERR_UNSUPPORTED;     // (hi, lo) weight groups hold 8 channels
     if (a.rep1 < 1 || a.rep2 < 1) return NOPE_ERR_ARG;
     if (a.mode == NOPE_CONV_PLAIN) {
         if ((a.ntaps != 1 && a.ntaps != 9) || a.Hs != a.Ho || a.Ws != a.Wo) return NOPE_ERR_ARG;
@@ -602,7 +603,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.pn_ms = a.pn_ms; p.pn_c0 = a.pn_c0; p.pn_c1 = a.pn_c1;
     if (a.pn_ms && (!a.pn_c0 || !a.pn_c1 || a.mode != NOPE_CONV_PLAIN || a.ntaps != 1 || a.colstats)) return NOPE_ERR_ARG;
     if (a.colstats && (!p.wide_out || M % 64 != 0 || phased || a.resid)) return NOPE_ERR_ARG;
-    const int es = dt == NOPE_F32 ? 4 : 2;
+    const int es = dt_es(dt);
     const int Cin = a.C1 + a.C2;
     const unsigned long long b1 = (unsigned long long)cdiv(a.nhyp, a.rep1) * a.Hs * a.Ws * a.C1 * es;
     const unsigned long long b2 = a.C2 ? (unsigned long long)cdiv(a.nhyp, a.rep2) * a.Hs * a.Ws * a.C2 * es : 0;
@@ -617,7 +618,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.variant = variant;
     p.d_hw = make_fastdiv((unsigned)(p.Hm * p.Wm)); p.d_w = make_fastdiv((unsigned)p.Wm);
     p.d_rep1 = make_fastdiv((unsigned)p.rep1); p.d_rep2 = make_fastdiv((unsigned)p.rep2);
-    const int bm = (plan.pp || (dma && variant == 4 && M >= 256 * 256)) ? 256 : BM;
+    const int bm = (plan.pp || (dma && variant == 4 && M >= 256 * 256 && (dt == NOPE_F32 || dt == NOPE_BF16))) ? 256 : BM;
     p.tiles_m = cdiv((int)M, bm); p.tiles_n = cdiv(a.Cout, BN);
     const int tn = p.tiles_n;
     p.xcd_map = (tn == 1 || tn == 2 || tn == 4 || tn == 8) && (p.tiles_m % (8 / tn) == 0) ? 1 : 0;
@@ -668,7 +669,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         const long long hw = (long long)a.Hs * a.Ws;
         static const int persist_on = getenv("NOPE_CONV_PERSIST") ? atoi(getenv("NOPE_CONV_PERSIST")) : 1;
         const int span = p.xcd_map == 2 ? tn / p.xcd_gn : 1;
-        if (persist_on && dma && bm == BM && dt == NOPE_BF16 && a.mode == NOPE_CONV_PLAIN && !p.posmajor && p.splits == 1 && p.xcd_map &&
+        if (persist_on && dma && bm == BM && dt != NOPE_F32 && a.mode == NOPE_CONV_PLAIN && !p.posmajor && p.splits == 1 && p.xcd_map &&
             p.wide_out && a.rep1 == 1 && a.rep2 == 1 && M % BM == 0 && nblocks > 512 && nblocks % 512 == 0 && 64 % span == 0 &&
             ((64ll / span) * BM) % hw == 0 && !(variant & 2)) {
             p.persist_iters = (int)(nblocks / 512);
@@ -681,7 +682,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     // The tap-resident kernel walks tiles too (bf16): one workgroup per CU, tiles gx / 8 apart inside the XCD's run of M tiles,
     // the next tile's prologue in flight under the epilogue.  NOPE_HALO_PERSIST = workgroups (default 256, 0 = one tile per
     // workgroup; read per launch: the tests use small grids).
-    if (plan.halo && dt == NOPE_BF16 && p.xcd_map) {
+    if (plan.halo && dt != NOPE_F32 && p.xcd_map) {
         const int want = getenv("NOPE_HALO_PERSIST") ? atoi(getenv("NOPE_HALO_PERSIST")) : 256;
         const long long hw = (long long)a.Hs * a.Ws;
         const int span = p.xcd_map == 2 ? tn / p.xcd_gn : 1;     // workgroups of one XCD that share an M tile
@@ -704,6 +705,14 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         else if (dma) launch_dma<float, 128, 2, 128>(p, grid, s);
         else if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_kernel<float, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((conv_gemm_kernel<float, false>), grid, block, 0, s, p);
+    } else if (dt == NOPE_BF16X3) {
+        if (dma) launch_dma<f32s_t, 128, 2, 128>(p, grid, s);
+        else if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_kernel<f32s_t, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_gemm_kernel<f32s_t, false>), grid, block, 0, s, p);
+    } else if (dt == NOPE_F16) {
+        if (dma) launch_dma<f16_t, 128, 2, 128>(p, grid, s);
+        else if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_kernel<f16_t, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_gemm_kernel<f16_t, false>), grid, block, 0, s, p);
     } else {
         if (dma && bm == 256) launch_dma<bf16_t, 128, 2, 256>(p, grid, s);
         else if (dma && (variant & 2)) launch_dma<bf16_t, 64, 2, 128>(p, grid, s);
@@ -715,8 +724,10 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     if (p.splits > 1) {
         const size_t MN = (size_t)M * a.Cout;
         const unsigned rb = (unsigned)((MN + 255) / 256 < 4096 ? (MN + 255) / 256 : 4096);
-        if (dt == NOPE_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(rb), dim3(256), 0, s, p.split_out, p.splits, (int)M, a.Cout,
+        if (dt_es(dt) == 4) hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(rb), dim3(256), 0, s, p.split_out, p.splits, (int)M, a.Cout,
                                                a.bias, (const float*)a.resid, a.act, (float*)a.out, a.out_nchw, a.Ho * a.Wo);
+        else if (dt == NOPE_F16) hipLaunchKernelGGL((splitk_reduce_kernel<f16_t>), dim3(rb), dim3(256), 0, s, p.split_out, p.splits, (int)M, a.Cout,
+                                a.bias, (const f16_t*)a.resid, a.act, (f16_t*)a.out, a.out_nchw, a.Ho * a.Wo);
         else hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(rb), dim3(256), 0, s, p.split_out, p.splits, (int)M, a.Cout,
                                 a.bias, (const bf16_t*)a.resid, a.act, (bf16_t*)a.out, a.out_nchw, a.Ho * a.Wo);
         NOPE_CHECK_LAUNCH();

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
     constexpr int RING = 2 * A_STAGE + 3 * B_STAGE;
     constexpr int PANELS = PP_WAVES * Ep<T>::WAVE_BYTES;
     constexpr int LDS_BYTES = RING > PANELS ? RING : PANELS;
-    constexpr int KK = RB / 16 / TL::KSLOTS;
+    constexpr int KS = RB / 16 / TL::STEP_SLOTS, RAW = TL::RAW, KK = KS * RAW;     // K steps per stage, raw 16-byte reads per row and step
     static_assert(MODE == NOPE_CONV_PLAIN || MODE == NOPE_CONV_DOWN2 || MODE == NOPE_CONV_UP2P, "modes of the U-Net's large launches");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];     // the ONLY LDS object (cdna_hip_programming.md, section 5 trap (a))
 
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
 #pragma unroll
             for (int r = 0; r < TL::R; ++r) acc[i][j][r] = 0.f;
 
-    // fragment addresses of K sub-step 0 inside a stage; sub-step kk flips slot bits: off ^ (kk * KSLOTS << 4)
+    // fragment addresses of raw read 0 inside a stage; raw read q flips slot bits: off ^ (raw_slot(q) << 4)
     int fa[TL::MT], fb[TL::NTL];
 #pragma unroll
     for (int i = 0; i < TL::MT; ++i) fa[i] = lds_off_rb<RB>(wm * 64 + i * TL::TM + TL::frag_row(lane), TL::frag_slot(lane));
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
         // ---- LOAD k: fragments of step k into registers, then the DMA pieces of the steps after it
         const unsigned char* la = lds + sa * A_STAGE;
         const unsigned char* lb = lds + B_BASE + sb * B_STAGE;
-        u32x4 af[KK][TL::MT], bfr[KK][TL::NTL];
+        u32x4 af[KS][RAW][TL::MT], bfr[KS][RAW][TL::NTL];
         const int sa1 = sa ^ 1;
         const int sb1 = sb == 2 ? 0 : sb + 1;
         const int sb2 = sb1 == 2 ? 0 : sb1 + 1;
@@ -241,9 +241,9 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-                for (int i = 0; i < TL::MT; ++i) af[kk][i] = ld16(la + (fa[i] ^ ((kk * TL::KSLOTS) << 4)));
+                for (int i = 0; i < TL::MT; ++i) af[kk / RAW][kk % RAW][i] = ld16(la + (fa[i] ^ (raw_slot<T>(kk) << 4)));
 #pragma unroll
-                for (int j = 0; j < TL::NTL; ++j) bfr[kk][j] = ld16(lb + (fb[j] ^ ((kk * TL::KSLOTS) << 4)));
+                for (int j = 0; j < TL::NTL; ++j) bfr[kk / RAW][kk % RAW][j] = ld16(lb + (fb[j] ^ (raw_slot<T>(kk) << 4)));
             }
             if (do_a) {
 #pragma unroll
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
             constexpr int NFR = KK * (TL::MT + TL::NTL);
             auto frag = [&](int f) {      // f-th fragment read of the step, K sub-step major (static index after unrolling)
                 const int kk = f / (TL::MT + TL::NTL), r = f - kk * (TL::MT + TL::NTL);
-                if (r < TL::MT) af[kk][r] = ld16(la + (fa[r] ^ ((kk * TL::KSLOTS) << 4)));
-                else bfr[kk][r - TL::MT] = ld16(lb + (fb[r - TL::MT] ^ ((kk * TL::KSLOTS) << 4)));
+                if (r < TL::MT) af[kk / RAW][kk % RAW][r] = ld16(la + (fa[r] ^ (raw_slot<T>(kk) << 4)));
+                else bfr[kk / RAW][kk % RAW][r - TL::MT] = ld16(lb + (fb[r - TL::MT] ^ (raw_slot<T>(kk) << 4)));
             };
 #pragma unroll
             for (int q = 0; q < 7; ++q) {
@@ -276,6 +276,10 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
         }
         if (k + 1 < nk) advance(ka);
         if (grp == 0 ? k + 1 < nk : k + 2 < nk) advance(kb);
+        if constexpr (RAW > 1) {                       // (bf16x3: split the f32 A values into hi / lo, still in the LOAD phase)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) TL::prep_step(af[ks]);
+        }
         __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);     // my reads of stage k are done: after the barrier the other group may overwrite it
         if (p.variant & 4) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
@@ -284,18 +288,20 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
         if (!(p.variant & 2)) __builtin_amdgcn_s_setprio(1);       // (tuning: 2 = no priority for the MFMA phase)
         if (!(p.variant & 32)) {                       // (tuning: 32 = no MFMA)
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int i = 0; i < TL::MT; ++i)
+                for (int t = 0; t < TL::TERMS; ++t)
 #pragma unroll
-                    for (int j = 0; j < TL::NTL; ++j) TL::mma(af[kk][i], bfr[kk][j], acc[i][j]);
+                    for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < TL::NTL; ++j) TL::mma(t, af[ks], bfr[ks], i, j, acc[i][j]);
         } else {
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {          // keep the fragment reads alive
 #pragma unroll
-                for (int i = 0; i < TL::MT; ++i) NOPE_KEEP_VGPR(af[kk][i]);
+                for (int i = 0; i < TL::MT; ++i) NOPE_KEEP_VGPR(af[kk / RAW][kk % RAW][i]);
 #pragma unroll
-                for (int j = 0; j < TL::NTL; ++j) NOPE_KEEP_VGPR(bfr[kk][j]);
+                for (int j = 0; j < TL::NTL; ++j) NOPE_KEEP_VGPR(bfr[kk / RAW][kk % RAW][j]);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     constexpr int PANELS = PP_WAVES * Ep<T>::WAVE_BYTES;
     constexpr int LDS_USED = RING > PANELS ? RING : PANELS;
     constexpr int LDS_BYTES = LDS_USED + (TIMELINE ? 2 * TIMELINE_STAMPS * 4 : 0);
-    constexpr int KK = RB / 16 / TL::KSLOTS;
+    constexpr int KS = RB / 16 / TL::STEP_SLOTS, RAW = TL::RAW, KK = KS * RAW;
     static_assert(LDS_BYTES <= 160 * 1024 && A_STAGE < 65536 && 2 * B_STAGE + BN * RB < 65536 + B_STAGE && 2 * B_STAGE + 2 * Tile<T>::TM * RB < 65536, "LDS budget / ds_read immediates (16 bits)");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     // K sub-step, tile j and ring stage are immediates
     int fbk[KK];
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) fbk[kk] = lds_off_rb<RB>(wn * 96 + TL::frag_row(lane), fslot) ^ ((kk * TL::KSLOTS) << 4);
+    for (int kk = 0; kk < KK; ++kk) fbk[kk] = lds_off_rb<RB>(wn * 96 + TL::frag_row(lane), fslot) ^ (raw_slot<T>(kk) << 4);
 
     typename TL::acc_t acc[TL::MT][TL::NTL];
 #pragma unroll
@@ -519,13 +525,13 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     // and the first half of B stage 1), so a workgroup that walks several tiles can have that prologue in flight while it
     // stores this tile: group 0 in the second half of B stage 1 + B stage 2, group 1 in A stage 1 (below its zero row).
     unsigned char* lds_panel = lds + wave * Ep<T>::WAVE_BYTES;
-    if constexpr (sizeof(T) == 2) {
-        static_assert(sizeof(T) != 2 || (4 * Ep<T>::WAVE_BYTES <= B_STAGE + B_STAGE / 2 && 4 * Ep<T>::WAVE_BYTES <= ZROW), "panel placement");
+    if constexpr (TL::TM == 32) {
+        static_assert(TL::TM != 32 || (4 * Ep<T>::WAVE_BYTES <= B_STAGE + B_STAGE / 2 && 4 * Ep<T>::WAVE_BYTES <= ZROW), "panel placement");
         lds_panel = lds + (grp == 0 ? B_STAGE + B_STAGE / 2 : A_BASE + A_STAGE) + wl * Ep<T>::WAVE_BYTES;
     }
     // A workgroup walks `iters` tiles of the same weight panel, gridDim.x / 8 M tiles apart (a multiple of the image size:
     // checked by the launcher, so the padding masks above hold for every tile of the walk).
-    const int iters = sizeof(T) == 2 && p.persist_iters > 1 ? p.persist_iters : 1;
+    const int iters = TL::TM == 32 && p.persist_iters > 1 ? p.persist_iters : 1;
     const int walk_rows = (int)(gridDim.x >> 3) / (p.xcd_map == 2 ? p.tiles_n / p.xcd_gn : 1) * PP_BM;
     tile_prologue();
     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                       // DMA landed
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                     bkofs += ((grp == 0 ? tap + 1 : tap + 2) % 9 == 8) ? wrap_inc : cin_es;
                 }
             }
-            u32x4 af[KK][TL::MT], bfr[KK][TL::NTL];
+            u32x4 af[KS][RAW][TL::MT], bfr[KS][RAW][TL::NTL];
             int fa[TL::MT];
             const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);            // scalar: the tap's row offset along the flat pixel axis
 #pragma unroll
@@ -564,9 +570,13 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-                for (int i = 0; i < TL::MT; ++i) af[kk][i] = ld16(lds + (fa[i] ^ ((kk * TL::KSLOTS) << 4)) + par * A_STAGE);
+                for (int i = 0; i < TL::MT; ++i) af[kk / RAW][kk % RAW][i] = ld16(lds + (fa[i] ^ (raw_slot<T>(kk) << 4)) + par * A_STAGE);
 #pragma unroll
-                for (int j = 0; j < TL::NTL; ++j) bfr[kk][j] = ld16(lds + fbk[kk] + ((tap % 3) * B_STAGE + j * TL::TM * RB));
+                for (int j = 0; j < TL::NTL; ++j) bfr[kk / RAW][kk % RAW][j] = ld16(lds + fbk[kk] + ((tap % 3) * B_STAGE + j * TL::TM * RB));
+            }
+            if constexpr (RAW > 1) {                       // (bf16x3: hi / lo split of the f32 A values, in the LOAD phase)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) TL::prep_step(af[ks]);
             }
             __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);     // my reads of this step are done: after the barrier the other group may overwrite them
             stamp();
@@ -577,18 +587,20 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             __builtin_amdgcn_s_setprio(1);
             if (!(p.variant & 32)) {                       // (tuning: 32 = no MFMA)
 #pragma unroll
-                for (int kk = 0; kk < KK; ++kk)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int i = 0; i < TL::MT; ++i)
+                    for (int t = 0; t < TL::TERMS; ++t)
 #pragma unroll
-                        for (int j = 0; j < TL::NTL; ++j) TL::mma(af[kk][i], bfr[kk][j], acc[i][j]);
+                        for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                            for (int j = 0; j < TL::NTL; ++j) TL::mma(t, af[ks], bfr[ks], i, j, acc[i][j]);
             } else {
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-                    for (int i = 0; i < TL::MT; ++i) NOPE_KEEP_VGPR(af[kk][i]);
+                    for (int i = 0; i < TL::MT; ++i) NOPE_KEEP_VGPR(af[kk / RAW][kk % RAW][i]);
 #pragma unroll
-                    for (int j = 0; j < TL::NTL; ++j) NOPE_KEEP_VGPR(bfr[kk][j]);
+                    for (int j = 0; j < TL::NTL; ++j) NOPE_KEEP_VGPR(bfr[kk / RAW][kk % RAW][j]);
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -667,6 +679,8 @@ void launch_pp_t(const ConvParams& p, dim3 grid, hipStream_t s) {
 void launch_conv_pp(int dt, const void* params, dim3 grid, hipStream_t s) {
     const ConvParams& p = *static_cast<const ConvParams*>(params);
     if (dt == NOPE_F32) launch_pp_t<float>(p, grid, s);
+    else if (dt == NOPE_BF16X3) launch_pp_t<f32s_t>(p, grid, s);
+    else if (dt == NOPE_F16) launch_pp_t<f16_t>(p, grid, s);
     else launch_pp_t<bf16_t>(p, grid, s);
 }
 
@@ -695,6 +709,8 @@ void launch_conv_halo(int dt, const void* params, dim3 grid, hipStream_t s) {
         return;
     }
     if (dt == NOPE_F32) hipLaunchKernelGGL((conv3x3_halo_kernel<float>), grid, block, 0, s, p);
+    else if (dt == NOPE_BF16X3) hipLaunchKernelGGL((conv3x3_halo_kernel<f32s_t>), grid, block, 0, s, p);
+    else if (dt == NOPE_F16) hipLaunchKernelGGL((conv3x3_halo_kernel<f16_t>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((conv3x3_halo_kernel<bf16_t>), grid, block, 0, s, p);
 }
 

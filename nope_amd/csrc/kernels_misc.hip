@@ -8,6 +8,19 @@ namespace {
 
 constexpr int NT = 256;
 
+// Store element i of a packed weight tensor whose rows hold Cin values along K.  For NOPE_BF16X3 a row is 4 Cin bytes of
+// 32-byte groups [hi x 8 | lo x 8] bf16, hi = rn(v), lo = rn(v - hi): channel c of a row sits in group c / 8 (Tile<f32s_t>,
+// conv_gemm_common.h).  Cin % 8 == 0 (checked by the launcher).
+template <class T> __device__ __forceinline__ void st_w(T* out, size_t i, int Cin, float v) { (void)Cin; Elt<T>::st(out + i, v); }
+template <> __device__ __forceinline__ void st_w<f32s_t>(f32s_t* out, size_t i, int Cin, float v) {
+    const size_t row = i / (size_t)Cin;
+    const int c = (int)(i - row * (size_t)Cin);
+    bf16_t* o = reinterpret_cast<bf16_t*>(out) + row * 2 * (size_t)Cin + (size_t)(c >> 3) * 16 + (c & 7);
+    const bf16_t hi = f32_to_bf16(v);
+    o[0] = hi;
+    o[8] = f32_to_bf16(v - bf16_to_f32(hi));
+}
+
 // (n, C, HW) f32 NCHW -> [n][HW][C] T.  C is small (8 latent channels) at this boundary.
 template <class T>
 __global__ __launch_bounds__(NT) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int C, int HW, size_t total) {
@@ -50,7 +63,7 @@ __global__ __launch_bounds__(NT) void pack_conv_w_kernel(const float* __restrict
         float v = w[src];
         if (cin_scale) v *= cin_scale[c];      // per-input-channel scale (PreNorm gamma)
         if (cout_scale) v *= cout_scale[co];   // per-output-channel scale (folded eval-mode BatchNorm)
-        Elt<T>::st(out + i, v);
+        st_w<T>(out, i, Cin, v);
     }
 }
 
@@ -83,7 +96,7 @@ __global__ __launch_bounds__(NT) void pack_up2p_w_kernel(const float* __restrict
         float a = 0.f;
         for (int yy = y0; yy <= y1; ++yy)
             for (int xx = x0; xx <= x1; ++xx) a += w[(((size_t)co * Cin + c) * 3 + yy) * 3 + xx];
-        Elt<T>::st(out + i, a);
+        st_w<T>(out, i, Cin, a);
     }
 }
 
@@ -99,7 +112,7 @@ __global__ __launch_bounds__(NT) void pack_convT4_w_kernel(const float* __restri
         const int co = (int)(t % Cout);
         const int ph = (int)(t / Cout);
         const int ky = 3 - (ph >> 1) - 2 * (tap >> 1), kx = 3 - (ph & 1) - 2 * (tap & 1);
-        Elt<T>::st(out + i, w[(((size_t)c * Cout + co) * 4 + ky) * 4 + kx]);
+        st_w<T>(out, i, Cin, w[(((size_t)c * Cout + co) * 4 + ky) * 4 + kx]);
     }
 }
 
@@ -149,9 +162,7 @@ inline unsigned grid_for(size_t n) {
 int launch_nchw_to_nhwc(int dt, const float* x, void* y, int n, int C, int HW, hipStream_t s) {
     if (!x || !y || n <= 0 || C <= 0 || HW <= 0) return NOPE_ERR_ARG;
     const size_t total = (size_t)n * C * HW;
-    if (dt == NOPE_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(grid_for(total)), dim3(NT), 0, s, x, (float*)y, C, HW, total);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(grid_for(total)), dim3(NT), 0, s, x, (bf16_t*)y, C, HW, total);
-    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(total)), dim3(NT), 0, s, x, (T*)y, C, HW, total));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }
@@ -159,9 +170,7 @@ int launch_nchw_to_nhwc(int dt, const float* x, void* y, int n, int C, int HW, h
 int launch_nhwc_to_nchw_f32(int dt, const void* x, float* y, int n, int C, int HW, hipStream_t s) {
     if (!x || !y || n <= 0 || C <= 0 || HW <= 0) return NOPE_ERR_ARG;
     const size_t total = (size_t)n * C * HW;
-    if (dt == NOPE_F32) hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), dim3(grid_for(total)), dim3(NT), 0, s, (const float*)x, y, C, HW, total);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16_t>), dim3(grid_for(total)), dim3(NT), 0, s, (const bf16_t*)x, y, C, HW, total);
-    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid_for(total)), dim3(NT), 0, s, (const T*)x, y, C, HW, total));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }
@@ -170,38 +179,33 @@ int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int
                        const float* cout_scale) {
     if (!w || !out || Cout <= 0 || Cin <= 0 || ntaps <= 0) return NOPE_ERR_ARG;
     if (mode == NOPE_CONV_DOWN2 && ntaps != 4) return NOPE_ERR_ARG;
+    if (dt == NOPE_BF16X3 && Cin % 8) return NOPE_ERR_UNSUPPORTED;      // (hi, lo) groups of 8 channels
     if (mode == NOPE_CONV_UP2P && ntaps == 16) {     // source is a ConvTranspose2d(4, 2, 1) weight
         if (cin_scale || cout_scale) return NOPE_ERR_ARG;
         const size_t tot = (size_t)4 * Cout * 4 * Cin;
-        if (dt == NOPE_F32) hipLaunchKernelGGL((pack_convT4_w_kernel<float>), dim3(grid_for(tot)), dim3(NT), 0, s, w, (float*)out, Cout, Cin, tot);
-        else if (dt == NOPE_BF16) hipLaunchKernelGGL((pack_convT4_w_kernel<bf16_t>), dim3(grid_for(tot)), dim3(NT), 0, s, w, (bf16_t*)out, Cout, Cin, tot);
-        else return NOPE_ERR_UNSUPPORTED;
+        NOPE_DISPATCH_W(dt, T, hipLaunchKernelGGL((pack_convT4_w_kernel<T>), dim3(grid_for(tot)), dim3(NT), 0, s, w, (T*)out, Cout, Cin, tot));
         NOPE_CHECK_LAUNCH();
         return NOPE_OK;
     }
     if (mode == NOPE_CONV_UP2P) {
         if (ntaps != 4 || cin_scale || cout_scale) return NOPE_ERR_ARG;
         const size_t tot = (size_t)4 * Cout * 4 * Cin;
-        if (dt == NOPE_F32) hipLaunchKernelGGL((pack_up2p_w_kernel<float>), dim3(grid_for(tot)), dim3(NT), 0, s, w, (float*)out, Cout, Cin, tot);
-        else if (dt == NOPE_BF16) hipLaunchKernelGGL((pack_up2p_w_kernel<bf16_t>), dim3(grid_for(tot)), dim3(NT), 0, s, w, (bf16_t*)out, Cout, Cin, tot);
-        else return NOPE_ERR_UNSUPPORTED;
+        NOPE_DISPATCH_W(dt, T, hipLaunchKernelGGL((pack_up2p_w_kernel<T>), dim3(grid_for(tot)), dim3(NT), 0, s, w, (T*)out, Cout, Cin, tot));
         NOPE_CHECK_LAUNCH();
         return NOPE_OK;
     }
     const size_t total = (size_t)Cout * ntaps * Cin;
-    if (dt == NOPE_F32) hipLaunchKernelGGL((pack_conv_w_kernel<float>), dim3(grid_for(total)), dim3(NT), 0, s, w, (float*)out, Cin, ntaps, mode, total, cin_scale, cout_scale);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((pack_conv_w_kernel<bf16_t>), dim3(grid_for(total)), dim3(NT), 0, s, w, (bf16_t*)out, Cin, ntaps, mode, total, cin_scale, cout_scale);
-    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_DISPATCH_W(dt, T, hipLaunchKernelGGL((pack_conv_w_kernel<T>), dim3(grid_for(total)), dim3(NT), 0, s, w, (T*)out, Cin, ntaps, mode, total, cin_scale, cout_scale));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }
 
+// (NOPE_BF16X3: a packed row of K channels is 2 K bf16 values, hi and lo parts: their plain sum is the row sum the MFMAs see)
 int launch_rowsum(int dt, const void* packed, float* out, int rows, int K, hipStream_t s) {
     if (!packed || !out || rows <= 0 || K <= 0) return NOPE_ERR_ARG;
     const unsigned blocks = (unsigned)((rows + 3) / 4);
-    if (dt == NOPE_F32) hipLaunchKernelGGL((rowsum_kernel<float>), dim3(blocks), dim3(NT), 0, s, (const float*)packed, out, rows, K);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((rowsum_kernel<bf16_t>), dim3(blocks), dim3(NT), 0, s, (const bf16_t*)packed, out, rows, K);
-    else return NOPE_ERR_UNSUPPORTED;
+    if (dt == NOPE_BF16X3) { dt = NOPE_BF16; K *= 2; }
+    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((rowsum_kernel<T>), dim3(blocks), dim3(NT), 0, s, (const T*)packed, out, rows, K));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }
@@ -209,9 +213,7 @@ int launch_rowsum(int dt, const void* packed, float* out, int rows, int K, hipSt
 int launch_cast(int dt, const float* in, void* out, size_t n, hipStream_t s) {
     if (!in || !out) return NOPE_ERR_ARG;
     if (n == 0) return NOPE_OK;
-    if (dt == NOPE_F32) hipLaunchKernelGGL((cast_kernel<float>), dim3(grid_for(n)), dim3(NT), 0, s, in, (float*)out, n);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t>), dim3(grid_for(n)), dim3(NT), 0, s, in, (bf16_t*)out, n);
-    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((cast_kernel<T>), dim3(grid_for(n)), dim3(NT), 0, s, in, (T*)out, n));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

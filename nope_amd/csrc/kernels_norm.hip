@@ -261,7 +261,7 @@ __global__ __launch_bounds__(NT) void gn_finalize_kernel(const float* __restrict
 
 int gn_stats_chunks(int HW, int C, int dt) {
     // aim for >= ~32 KB of streaming per workgroup while keeping thousands of workgroups
-    const size_t bytes = (size_t)HW * C * (dt == NOPE_F32 ? 4 : 2);
+    const size_t bytes = (size_t)HW * C * dt_es(dt);
     int n = (int)(bytes / (64 * 1024));
     if (n < 1) n = 1;
     if (n > 16) n = 16;
@@ -271,7 +271,7 @@ int gn_stats_chunks(int HW, int C, int dt) {
 
 int launch_gn_stats(int dt, const void* x, float* partial, int nhyp, int HW, int C, int G, int nchunk, hipStream_t s) {
     if (!x || !partial || nhyp <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G || nchunk < 1) return NOPE_ERR_ARG;
-    const int vec = dt == NOPE_F32 ? 4 : 8;
+    const int vec = dt_vec(dt);
     if (C % vec) return NOPE_ERR_UNSUPPORTED;
     if (G > 64) return NOPE_ERR_UNSUPPORTED;
     const int cpg = C / G;
@@ -279,13 +279,8 @@ int launch_gn_stats(int dt, const void* x, float* partial, int nhyp, int HW, int
     const bool fast = (cpg % vec == 0) && (cvecs <= NT);
     if (!fast && C > 2048) return NOPE_ERR_UNSUPPORTED;
     dim3 grid((unsigned)(nhyp * nchunk)), block(NT);
-    if (dt == NOPE_F32) {
-        if (fast) hipLaunchKernelGGL((gn_stats_kernel<float, true>), grid, block, 0, s, (const float*)x, partial, HW, C, G, nchunk);
-        else hipLaunchKernelGGL((gn_stats_kernel<float, false>), grid, block, 0, s, (const float*)x, partial, HW, C, G, nchunk);
-    } else if (dt == NOPE_BF16) {
-        if (fast) hipLaunchKernelGGL((gn_stats_kernel<bf16_t, true>), grid, block, 0, s, (const bf16_t*)x, partial, HW, C, G, nchunk);
-        else hipLaunchKernelGGL((gn_stats_kernel<bf16_t, false>), grid, block, 0, s, (const bf16_t*)x, partial, HW, C, G, nchunk);
-    } else return NOPE_ERR_UNSUPPORTED;
+    if (fast) NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((gn_stats_kernel<T, true>), grid, block, 0, s, (const T*)x, partial, HW, C, G, nchunk));
+    else NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((gn_stats_kernel<T, false>), grid, block, 0, s, (const T*)x, partial, HW, C, G, nchunk));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }
@@ -298,7 +293,7 @@ int launch_gn_fold(const float* colstats, float* partial, int nhyp, int HW, int 
 }
 
 int gn_apply_blocks(int HW, int C, int dt) {
-    const size_t bytes = (size_t)HW * C * (dt == NOPE_F32 ? 4 : 2);
+    const size_t bytes = (size_t)HW * C * dt_es(dt);
     int bph = (int)(bytes / (32 * 1024));
     if (bph < 1) bph = 1;
     if (bph > 64) bph = 64;
@@ -314,7 +309,7 @@ int launch_gn_finalize(const float* partial, float* ms, int nhyp, int nchunk, fl
 
 int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
     if (!a.x || !a.y || !a.partial || !a.gamma || !a.beta || a.nhyp <= 0 || a.C % a.G) return NOPE_ERR_ARG;
-    const int vec = dt == NOPE_F32 ? 4 : 8;
+    const int vec = dt_vec(dt);
     if (a.C % vec || a.G > 64) return NOPE_ERR_UNSUPPORTED;
     if (a.x_rep < 1 || a.resid_rep < 1) return NOPE_ERR_ARG;
     const int bph = gn_apply_blocks(a.HW, a.C, dt);
@@ -330,6 +325,9 @@ int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
     } else if (dt == NOPE_BF16) {
         if (a.film) NOPE_GN_APPLY(bf16_t, true, false, true);
         else if (a.out_stats) NOPE_GN_APPLY(bf16_t, true, true, false); else NOPE_GN_APPLY(bf16_t, true, false, false);
+    } else if (dt == NOPE_F16) {
+        if (a.film) NOPE_GN_APPLY(f16_t, true, false, true);
+        else if (a.out_stats) NOPE_GN_APPLY(f16_t, true, true, false); else NOPE_GN_APPLY(f16_t, true, false, false);
     } else return NOPE_ERR_UNSUPPORTED;
 #undef NOPE_GN_APPLY
     NOPE_CHECK_LAUNCH();

@@ -14,7 +14,8 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef unsigned short bf16_t;   // raw bfloat16 bits
-typedef _Float16 f16_t;          // IEEE half (bank storage only): hardware v_cvt_f16_f32 / v_cvt_f32_f16, round-to-nearest-even
+typedef _Float16 f16_t;          // IEEE half (bank storage, NOPE_F16 compute mode): hardware v_cvt_f16_f32 / v_cvt_f32_f16, round-to-nearest-even
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 constexpr int kWave = 64;
 
@@ -40,6 +41,15 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     const f32x2_hw_t v = {lo, hi};
     union { bf16x2_hw_t h; unsigned u; } x;
     x.h = __builtin_convertvector(v, bf16x2_hw_t);
+    return x.u;
+}
+
+// Two f32 -> packed f16x2 (round-to-nearest-even; v_cvt_pk_f16_f32 on gfx950)
+typedef _Float16 f16x2_hw_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+    const f32x2_hw_t v = {lo, hi};
+    union { f16x2_hw_t h; unsigned u; } x;
+    x.h = __builtin_convertvector(v, f16x2_hw_t);
     return x.u;
 }
 
@@ -83,6 +93,7 @@ template <> struct Elt<bf16_t> {
         for (int i = 0; i < 4; ++i) v[i] = cvt_pk_bf16(o[2 * i], o[2 * i + 1]);
         return v;
     }
+    static __device__ __forceinline__ unsigned cvt_pk(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
 };
 
 template <> struct Elt<f16_t> {
@@ -96,12 +107,31 @@ template <> struct Elt<f16_t> {
         for (int i = 0; i < 8; ++i) o[i] = (float)x.h[i];
     }
     static __device__ __forceinline__ u32x4 pack(const float* o) {
-        union { u32x4 u; f16_t h[8]; } x;
+        u32x4 v;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x.h[i] = (f16_t)o[i];
-        return x.u;
+        for (int i = 0; i < 4; ++i) v[i] = cvt_pk_f16(o[2 * i], o[2 * i + 1]);
+        return v;
     }
+    static __device__ __forceinline__ unsigned cvt_pk(float lo, float hi) { return cvt_pk_f16(lo, hi); }
 };
+
+// NOPE_BF16X3: activations are plain f32 in memory; the tag type only selects the conv kernels' split-precision MFMA tile
+// (conv_gemm_common.h) and the (hi, lo) weight layout of the pack kernels.  Everything else treats the data as float.
+struct f32s_t { float f; };
+template <> struct Elt<f32s_t> {
+    static constexpr int VEC = 4;
+    static constexpr int DT = NOPE_BF16X3;
+    static __device__ __forceinline__ float ld(const f32s_t* p) { return p->f; }
+    static __device__ __forceinline__ void st(f32s_t* p, float v) { p->f = v; }
+    static __device__ __forceinline__ void unpack(const u32x4& v, float* o) { Elt<float>::unpack(v, o); }
+    static __device__ __forceinline__ u32x4 pack(const float* o) { return Elt<float>::pack(o); }
+};
+
+// dtype code -> bytes per stored element / elements per 16-byte vector / the dtype the non-conv kernels see
+static inline int dt_es(int dt) { return (dt == NOPE_F32 || dt == NOPE_BF16X3) ? 4 : 2; }
+static inline int dt_vec(int dt) { return 16 / dt_es(dt); }
+static inline int dt_storage(int dt) { return dt == NOPE_BF16X3 ? NOPE_F32 : dt; }
+static inline bool dt_is_compute(int dt) { return dt == NOPE_F32 || dt == NOPE_BF16 || dt == NOPE_F16 || dt == NOPE_BF16X3; }
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
@@ -132,6 +162,22 @@ template <bool FAST> __device__ __forceinline__ float silu_f(float x) {
 #ifndef NOPE_OPAQUE_VGPR
 #define NOPE_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 #endif
+
+// Run a statement with T bound to the element type of a STORAGE dtype code (f32 / bf16 / f16); returns NOPE_ERR_UNSUPPORTED
+// from the enclosing function for anything else.
+#define NOPE_DISPATCH_T(dt, T, ...)                                              \
+    do {                                                                         \
+        if ((dt) == NOPE_F32) { typedef float T; __VA_ARGS__; }                  \
+        else if ((dt) == NOPE_BF16) { typedef bf16_t T; __VA_ARGS__; }           \
+        else if ((dt) == NOPE_F16) { typedef f16_t T; __VA_ARGS__; }             \
+        else return NOPE_ERR_UNSUPPORTED;                                        \
+    } while (0)
+// ... and of a weight-pack dtype, which adds NOPE_BF16X3's (hi, lo) layout
+#define NOPE_DISPATCH_W(dt, T, ...)                                              \
+    do {                                                                         \
+        if ((dt) == NOPE_BF16X3) { typedef f32s_t T; __VA_ARGS__; }              \
+        else NOPE_DISPATCH_T(dt, T, __VA_ARGS__);                                \
+    } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

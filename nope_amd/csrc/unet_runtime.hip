@@ -44,7 +44,8 @@ struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, rep = 1; };
 
 struct nope_unet {
     nope_unet_config cfg;
-    int dt = NOPE_F32;
+    int dt = NOPE_F32;      // compute dtype: what the conv kernels and the weight packing see
+    int sdt = NOPE_F32;     // storage dtype of the activations: what every other kernel sees (NOPE_BF16X3 keeps f32 activations)
     std::vector<void*> allocs;
     int dims[9];
     int classes = 0;
@@ -105,7 +106,7 @@ struct Loader {
                                     : convT             ? get(pfx + "weight", {Cin, Cout, 4, 4})
                                                         : get(pfx + "weight", {Cout, Cin, ksz, ksz});
         if (d) {
-            const size_t es = net->dt == NOPE_F32 ? 4 : 2;
+            const size_t es = (size_t)dt_es(net->dt);
             c.w = dmalloc((size_t)Cout * c.ntaps * Cin * es * (mode == NOPE_CONV_UP2P ? 4 : 1));
             if (c.w) { int e = launch_pack_conv_w(net->dt, d->data, c.w, Cout, Cin, convT ? 16 : c.ntaps, mode, s, cin_scale); if (e && err == NOPE_OK) err = e; }
         }
@@ -242,15 +243,15 @@ struct Fwd {
         if (colstats) {
             chk(launch_gn_fold(colstats, gn_partial, nx, HW, nm.C, G, s));
         } else {
-            nch = gn_stats_chunks(HW, nm.C, net->dt);
-            chk(launch_gn_stats(net->dt, x, gn_partial, nx, HW, nm.C, G, nch, s));
+            nch = gn_stats_chunks(HW, nm.C, net->sdt);
+            chk(launch_gn_stats(net->sdt, x, gn_partial, nx, HW, nm.C, G, nch, s));
         }
         GnApplyArgs ga;
         ga.x = x; ga.y = y; ga.partial = gn_partial; ga.nchunk = nch; ga.gamma = nm.gamma; ga.beta = nm.beta;
         ga.nhyp = nhyp; ga.HW = HW; ga.C = nm.C; ga.G = G; ga.act = act;
         if (emb_off >= 0) { ga.emb = emb_all + emb_off; ga.emb_stride = net->emb_total; }
         ga.resid = resid; ga.x_rep = x_rep; ga.resid_rep = resid_rep; ga.out_stats = out_stats;
-        chk(launch_gn_apply(net->dt, ga, s));
+        chk(launch_gn_apply(net->sdt, ga, s));
     }
 
     // ResnetBlock, model_utils.py:271-279.  `a` may be shared by a.rep hypotheses (rep > 1 only
@@ -293,7 +294,7 @@ struct Fwd {
     void qkv_prenorm(const Conv& qkvw, const float* c0, const float* c1, const Act& x, void* qkv) {
         if (!live()) return;
         const int HW = x.H * x.W;
-        chk(launch_gn_finalize(pn_partial, pn_ms, nhyp, gn_apply_blocks(HW, x.C, net->dt), (float)HW * (float)x.C, 1e-5f, s));
+        chk(launch_gn_finalize(pn_partial, pn_ms, nhyp, gn_apply_blocks(HW, x.C, net->sdt), (float)HW * (float)x.C, 1e-5f, s));
         conv(qkvw, x, nullptr, qkv, x.H, x.W, nhyp, 1, 1, nullptr, 0, NOPE_F32, nullptr, c0, c1);
     }
 
@@ -307,7 +308,7 @@ struct Fwd {
         void* qkv = alloc_act(M * 3 * heads * dh);
         void* a = alloc_act(M * heads * dh);
         qkv_prenorm(L.qkv, L.c0, L.c1, x, qkv);
-        if (live()) chk(launch_linattn(net->dt, qkv, a, nhyp, HW, heads, dh, s));
+        if (live()) chk(launch_linattn(net->sdt, qkv, a, nhyp, HW, heads, dh, s));
         Act aa{a, heads * dh, x.H, x.W, 1};
         float* cs = colstats_for(nhyp, HW, L.out.Cout);
         conv(L.out, aa, nullptr, y, x.H, x.W, nhyp, 1, 1, nullptr, 0, NOPE_F32, cs);
@@ -323,7 +324,7 @@ struct Fwd {
         void* qkv = alloc_act(M * 3 * heads * dh);
         void* a = alloc_act(M * heads * dh);
         qkv_prenorm(A.qkv, A.c0, A.c1, x, qkv);
-        if (live()) chk(launch_attn(net->dt, qkv, a, nhyp, HW, heads, dh, s));
+        if (live()) chk(launch_attn(net->sdt, qkv, a, nhyp, HW, heads, dh, s));
         Act aa{a, heads * dh, x.H, x.W, 1};
         conv(A.out, aa, nullptr, out, x.H, x.W, nhyp, 1, 1, /*resid=*/x.p);
         ar.off = mark;
@@ -335,7 +336,7 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
     const nope_unet_config& cfg = net->cfg;
     const int L = cfg.n_levels;
     Fwd f;
-    f.net = net; f.s = s; f.nhyp = n_hyp; f.es = net->dt == NOPE_F32 ? 4 : 2;
+    f.net = net; f.s = s; f.nhyp = n_hyp; f.es = (size_t)dt_es(net->dt);
     f.ar.base = (unsigned char*)ws; f.ar.cap = ws_bytes; f.ar.dry = dry;
     const int HW = H * W;
     const int* dims = net->dims;
@@ -371,7 +372,7 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
 
     // ---- input + pose embedding ----------------------------------------------------------------
     if (f.live()) {
-        f.chk(launch_nchw_to_nhwc(net->dt, x, x_in, n_src, cfg.channels, HW, s));
+        f.chk(launch_nchw_to_nhwc(net->sdt, x, x_in, n_src, cfg.channels, HW, s));
         if (cfg.pose_mlp_layers == 0) f.chk(launch_pos_emb(pose, c0, n_hyp, cfg.pose_dim, net->classes, s));   // u_net.py:73-76
         else f.chk(launch_linear_naive(pose, net->pose_w0, net->pose_b0, c0, n_hyp, net->classes, cfg.pose_dim, 0, net->classes, s));
         const float* c = c0;
@@ -473,7 +474,7 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
                      nope_unet** out) {
     if (!cfg || !tensors || !out || n_tensors <= 0) return NOPE_ERR_ARG;
     if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->groups < 1 || cfg->heads < 1 || cfg->dim_head != 32) return NOPE_ERR_UNSUPPORTED;
-    if (cfg->compute_dtype != NOPE_F32 && cfg->compute_dtype != NOPE_BF16) return NOPE_ERR_UNSUPPORTED;
+    if (!dt_is_compute(cfg->compute_dtype)) return NOPE_ERR_UNSUPPORTED;
     if (cfg->pose_mlp_layers < 0 || cfg->pose_mlp_layers > 2) return NOPE_ERR_UNSUPPORTED;   // 0 = "posEncoding" (no parameters)
     if (cfg->pose_mlp_layers == 0 && (cfg->pose_dim < 1 || (cfg->u_net_dim * 4) % (2 * cfg->pose_dim) || cfg->u_net_dim * 4 / cfg->pose_dim < 4)) return NOPE_ERR_UNSUPPORTED;
     if (cfg->u_net_dim % 8 || cfg->channels % 8 || cfg->u_net_dim % cfg->groups) return NOPE_ERR_UNSUPPORTED;
@@ -481,6 +482,7 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
     nope_unet* net = new nope_unet();
     net->cfg = *cfg;
     net->dt = cfg->compute_dtype;
+    net->sdt = dt_storage(net->dt);
     const int L = cfg->n_levels;
     net->dims[0] = cfg->u_net_dim;
     for (int l = 0; l < L; ++l) net->dims[l + 1] = cfg->u_net_dim * cfg->dim_mults[l];

@@ -12,7 +12,8 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-F32, BF16, F16 = 0, 1, 2      # F16: a bank / output storage type only
+F32, BF16, F16, BF16X3 = 0, 1, 2, 3      # BF16X3: compute mode only (f32 storage, three bf16 MFMA passes per product)
+ABI_VERSION = 2                          # NOPE_ABI_VERSION of include/nope_hip.h these ctypes structs mirror
 CONV_PLAIN, CONV_UP2, CONV_DOWN2, CONV_UP2P, CONV_STRIDE2 = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -97,6 +98,9 @@ class NopeLib:
             fn = getattr(self.dll, name)
             fn.restype = res
             fn.argtypes = args
+        got = self.dll.nope_abi_version()
+        if got != ABI_VERSION:     # a stale build would read the config structs below past their end
+            raise NopeError(f"{path} has ABI version {got}, this binding was written for {ABI_VERSION}: rebuild the library")
 
     def check(self, code: int, what: str):
         if code != 0:
@@ -173,7 +177,13 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def torch_dtype(dt: int) -> torch.dtype:
-    return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[dt]
+    """torch dtype of tensors STORED under dtype code dt (BF16X3 keeps f32 activations)."""
+    return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16, BF16X3: torch.float32}[dt]
+
+
+def storage_code(dt: int) -> int:
+    """dtype code the non-conv operators see for tensors of compute mode dt."""
+    return F32 if dt == BF16X3 else dt
 
 
 def dtype_code(dt) -> int:
@@ -183,6 +193,8 @@ def dtype_code(dt) -> int:
         return BF16
     if dt in (F16, "f16", "fp16", "float16", "half", torch.float16):
         return F16
+    if dt in (BF16X3, "bf16x3"):
+        return BF16X3
     raise NopeError(f"unsupported dtype {dt!r}")
 
 
@@ -497,7 +509,7 @@ def to_nhwc(x: torch.Tensor, dt: int) -> torch.Tensor:
     n, c, h, w = x.shape
     y = torch.empty((n, h, w, c), dtype=torch_dtype(dt), device=x.device)
     l = lib()
-    l.check(l.dll.nope_op_nchw_to_nhwc(dt, _ptr(x), _ptr(y), n, c, h * w, _stream(x)), "nchw_to_nhwc")
+    l.check(l.dll.nope_op_nchw_to_nhwc(storage_code(dt), _ptr(x), _ptr(y), n, c, h * w, _stream(x)), "nchw_to_nhwc")
     return y
 
 
@@ -505,7 +517,7 @@ def to_nchw(y: torch.Tensor, dt: int) -> torch.Tensor:
     n, h, w, c = y.shape
     x = torch.empty((n, c, h, w), dtype=torch.float32, device=y.device)
     l = lib()
-    l.check(l.dll.nope_op_nhwc_to_nchw(dt, _ptr(y), _ptr(x), n, c, h * w, _stream(y)), "nhwc_to_nchw")
+    l.check(l.dll.nope_op_nhwc_to_nchw(storage_code(dt), _ptr(y), _ptr(x), n, c, h * w, _stream(y)), "nhwc_to_nchw")
     return x
 
 
@@ -552,6 +564,7 @@ def op_group_norm(dt: int, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Ten
                   emb: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
     n, h, w, c = x.shape
     l = lib()
+    dt = storage_code(dt)
     nch = l.dll.nope_op_gn_chunks(dt, h * w, c)
     partial = torch.empty((n, nch, groups, 2), dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
@@ -568,7 +581,7 @@ def op_linear_attention(dt: int, qkv: torch.Tensor, heads: int = 4, dim_head: in
     out = torch.empty((n, h, w, heads * dim_head), dtype=qkv.dtype, device=qkv.device)
     l = lib()
     fn = l.dll.nope_op_attention if full else l.dll.nope_op_linear_attention
-    l.check(fn(dt, _ptr(qkv), _ptr(out), n, h * w, heads, dim_head, _stream(qkv)), "nope_op_attention")
+    l.check(fn(storage_code(dt), _ptr(qkv), _ptr(out), n, h * w, heads, dim_head, _stream(qkv)), "nope_op_attention")
     return out
 
 

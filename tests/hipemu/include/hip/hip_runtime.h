@@ -371,6 +371,27 @@ inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x
     }
     return c;
 }
+// v_mfma_f32_32x32x16_f16: same fragment maps as the bf16 form
+typedef __attribute__((ext_vector_type(8))) _Float16 hipemu_f16x8;
+inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x16 c, int, int, int) {
+    struct P { hipemu_f16x8 a, b; } p{a, b};
+    auto s = hipemu::wave_exchange(&p, sizeof(P));
+    int lane = hipemu::lane_id();
+    int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            P pa, pb;
+            memcpy(&pa, s[row + 32 * (k >> 3)], sizeof(P));
+            memcpy(&pb, s[col + 32 * (k >> 3)], sizeof(P));
+            acc = fmaf((float)pa.a[k & 7], (float)pb.b[k & 7], acc);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu_mfma_f32_32x32x16_f16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_f32_16x16x32_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16

@@ -17,11 +17,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_pingpong_kernel_under_adversarial_interpreter(emu):
+    # (compute modes: 1 = bf16, 3 = bf16x3 split precision on f32 data, 0 = f32, 2 = f16)
     envs = [{"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, {"HIPEMU_SHUFFLE": "2"}]
+    dts = ["1,3", "0,2"]
     procs = []
-    for e in envs:
+    for e, dd in zip(envs, dts):
         env = dict(os.environ, HIPEMU_THREADS="4", **e)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pp_emu_case.py"), "--light"], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pp_emu_case.py"), "--light", "--dts", dd], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     for e, pr in zip(envs, procs):
         out, _ = pr.communicate(timeout=1500)

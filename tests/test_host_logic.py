@@ -28,7 +28,7 @@ def test_capi_exports_every_declared_symbol():
     exported = set(re.findall(r"\bT (nope_[a-z0-9_]+)", out))
     assert set(declared) <= exported, set(declared) - exported
     dll = ctypes.CDLL(lib)
-    assert dll.nope_abi_version() == 1
+    assert dll.nope_abi_version() == hip.ABI_VERSION
     dll.nope_strerror.restype = ctypes.c_char_p
     assert dll.nope_strerror(-3) == b"workspace too small"
 
