@@ -19,10 +19,13 @@ of `--templates` templates per GPU in `--bank-dtype` (default: BASELINE configs[
 templates); for N>1 every rank scores its slice, the (B, N/G) scores are all-gathered over RCCL and ranked.
 
 Extra legs on rank 0 at N=1 (outside the timed region):
-  roofline      the dominant kernels of the step, the implicit-GEMM convs (conv3x3_halo_kernel, conv_gemm_pp_kernel,
-                conv_gemm_dma_kernel: the U-Net's 83 launches): multiply-adds x2 those launches EXECUTE (phase convs 4/9 of
-                the nearest-x2 MACs) / their summed duration, measured with HIP events around every launch on the launch
-                stream, vs the 2.5 PFLOP/s dense bf16 peak;
+  roofline      the dominant kernel of the step, conv3x3_halo_kernel (the 3x3 convs: 41 of the U-Net's 83 implicit-GEMM launches,
+                ~half of the step): multiply-adds x2 its launches EXECUTE / their summed duration, measured with HIP events around
+                every launch on the launch stream, vs the 2.5 PFLOP/s dense bf16 / f16 peak; `family` = all implicit-GEMM
+                launches, `classes` = one line per launch shape;
+  parity        the same step in every compute mode against the f32 parity mode of this library (pinned to the reference at
+                1e-4 / bit-exact top-5 by tests/, spot-checked against the CPU oracle here): score error, top-5 / top-1
+                equality and throughput of bf16, f16 and bf16x3 (the split-precision mode that holds the 1e-4 tolerance);
   scoring       the similarity kernel on a 1.07 GB resident bank, vs 8 TB/s HBM;
   cpu_baseline  the oracle (CPU restatement, kind "port") on the host cores, bounded sample.
 """
@@ -81,10 +84,12 @@ def _pick_threads() -> int:
     return best
 
 
-def cpu_baseline(model, size: int, n_templates: int, hyp_sample: int = 16, chunk: int = 8):
+def cpu_baseline(model, size: int, n_templates: int, hyp_sample: int = 16, chunk: int = 8, spot=None):
     """Oracle timed on the host cores: U-Net on `hyp_sample` hypotheses (the reference's loop is
     linear in N, model.py:212-222), scoring on a 64-template bank slice, the encoder once;
-    extrapolated to one full step (hoisted-encoder schedule = the faster CPU schedule)."""
+    extrapolated to one full step (hoisted-encoder schedule = the faster CPU schedule).
+    `spot` = (reference embedding (1,C,h,w), poses (1,N,6), query embedding) of the benchmarked step: the hypotheses the oracle
+    is timed on are then the step's first `hyp_sample`, and their maps / scores are returned for the parity record."""
     from oracle import nope_ref as R
     threads = _pick_threads()
     sd = {k: v.detach().float().cpu() for k, v in model.u_net.own_state_dict().items()}
@@ -94,6 +99,9 @@ def cpu_baseline(model, size: int, n_templates: int, hyp_sample: int = 16, chunk
     img = torch.rand(1, 3, size, size, generator=g) * 2 - 1
     x = torch.randn(1, 8, h, h, generator=g)
     poses = torch.randn(1, hyp_sample, 6, generator=g)
+    q = torch.randn(1, 8, h, h, generator=g)
+    if spot is not None:
+        x, poses, q = spot[0].float().cpu(), spot[1][:, :hyp_sample].float().cpu(), spot[2].float().cpu()
     with torch.no_grad():
         t0 = time.perf_counter()
         R.unet_forward(sd, x.expand(2, -1, -1, -1), poses[0, :2])          # warm-up
@@ -102,25 +110,26 @@ def cpu_baseline(model, size: int, n_templates: int, hyp_sample: int = 16, chunk
             hyp_sample, chunk = 4, 4
             poses = poses[:, :4]
         t0 = time.perf_counter()
-        R.generate_templates(sd, x, poses, chunk=chunk)
+        obank = R.generate_templates(sd, x, poses, chunk=chunk)
         t_unet = (time.perf_counter() - t0) / hyp_sample
         R.encode_image(enc_sd, img)
         t0 = time.perf_counter()
         R.encode_image(enc_sd, img)
         t_enc = time.perf_counter() - t0
         bank = torch.randn(1, 64, 8, h, h, generator=g)
-        q = torch.randn(1, 8, h, h, generator=g)
         R.retrieval(q, bank)
         t0 = time.perf_counter()
         for _ in range(3):
             R.retrieval(q, bank)
         t_score = (time.perf_counter() - t0) / 3 / 64
+        oscore = R.similarity_scores(q, obank)
     step = n_templates * (t_unet + t_score) + 2 * t_enc
-    return {"value": n_templates / step, "unit": "pose-hypotheses/s", "cores": threads, "kind": "port",
-            "host_cpus": _usable_cpus(),
-            "sample": f"oracle fp32, {threads} torch threads (fastest of a small sweep): U-Net on {hyp_sample} hypotheses (batches of "
-                      f"{chunk}) at {h}x{h} latent = {t_unet * 1e3:.0f} ms/hyp, scoring 64 templates = {t_score * 1e6:.0f} us/hyp, "
-                      f"encoder {t_enc * 1e3:.0f} ms/image; extrapolated linearly to {n_templates} templates + 2 encoder passes"}
+    rec = {"value": n_templates / step, "unit": "pose-hypotheses/s", "cores": threads, "kind": "port",
+           "host_cpus": _usable_cpus(),
+           "sample": f"oracle fp32, {threads} torch threads (fastest of a small sweep): U-Net on {hyp_sample} hypotheses (batches of "
+                     f"{chunk}) at {h}x{h} latent = {t_unet * 1e3:.0f} ms/hyp, scoring 64 templates = {t_score * 1e6:.0f} us/hyp, "
+                     f"encoder {t_enc * 1e3:.0f} ms/image; extrapolated linearly to {n_templates} templates + 2 encoder passes"}
+    return rec, obank, oscore
 
 
 def _csrc_sha() -> str:
@@ -159,6 +168,104 @@ def scoring_roofline(dtype: torch.dtype, N: int = 0):
             "hyp_per_s": B * N / med * 1e3}
 
 
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f32": 157.3}   # dense MFMA peak of the instruction each mode issues
+
+
+def conv_roofline(model, step, dtype: str, dev, templates: int, size: int):
+    """HIP events around every implicit-GEMM launch of one step (nope_unet_profile): the dominant kernel on its own, the whole
+    family, and one line per launch shape."""
+    h = model.u_net._get_handle(dev)
+    torch.cuda.synchronize()
+    h.profile(True)
+    step()
+    torch.cuda.synchronize()
+    launches = h.profile_launches()
+    h.profile(False)
+    peak = PEAK_MFMA_TFLOPS[dtype]
+
+    def agg(rows):
+        ms = sum(r["ms"] for r in rows)
+        fl = sum(r["flops"] * r["mfma_passes"] for r in rows)
+        return {"launches": len(rows), "kernel_ms": ms, "mfma_flops": fl, "conv_flops": sum(r["flops"] for r in rows),
+                "algorithmic_bytes": sum(r["bytes"] for r in rows), "tflops": fl / ms / 1e9 if ms > 0 else 0.0}
+    by_kernel = {}
+    for r in launches:
+        by_kernel.setdefault(r["kernel"], []).append(r)
+    dom = max(by_kernel, key=lambda k: sum(r["ms"] for r in by_kernel[k]))
+    d, fam = agg(by_kernel[dom]), agg(launches)
+    classes = {}
+    for r in launches:
+        key = (r["kernel"], r["mode"], r["ntaps"], r["Cin"], r["Cout"], r["Hs"], r["Ws"], r["n_hyp"], r["posmajor"])
+        classes.setdefault(key, []).append(r)
+    table = []
+    for key, rows in classes.items():
+        a = agg(rows)
+        table.append({"kernel": key[0], "mode": key[1], "taps": key[2], "Cin": key[3], "Cout": key[4], "H": key[5], "W": key[6],
+                      "n": key[7], "posmajor": key[8], "launches": a["launches"], "avg_ms": a["kernel_ms"] / a["launches"],
+                      "tflops": a["tflops"], "frac": a["tflops"] / peak})
+    table.sort(key=lambda t: -t["avg_ms"] * t["launches"])
+    # HBM traffic of the dominant kernel from rocprofv3 PMC passes over the same U-Net step (FETCH_SIZE / WRITE_SIZE in their own
+    # runs, tools/gpu_pmc.sh); PMC cannot be read from inside the process, so the figure is loaded from the committed
+    # measurement -- only next to the kernel sources and workload it was taken on, null otherwise.
+    traffic = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if rec.get("dtype") == dtype and rec.get("templates") == templates and rec.get("size") == size and rec.get("csrc_sha") == _csrc_sha():
+            traffic = rec.get("per_kernel", {}).get(dom, {}).get("bytes_per_launch")
+    except Exception:
+        pass
+    passes = by_kernel[dom][0]["mfma_passes"]
+    return {"bound": "mfma", "kernel": f"{dom}<{dtype}>", "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": d["tflops"] / peak,
+            "traffic": traffic, "algorithmic_bytes_per_launch": d["algorithmic_bytes"] / d["launches"], "launches_per_step": d["launches"],
+            "avg_launch_ms": d["kernel_ms"] / d["launches"], "kernel_ms_per_step": d["kernel_ms"], "flops_per_step": d["mfma_flops"],
+            "family": {"kernels": sorted(by_kernel), "launches_per_step": fam["launches"], "kernel_ms_per_step": fam["kernel_ms"],
+                       "achieved": fam["tflops"], "frac": fam["tflops"] / peak, "flops_per_step": fam["mfma_flops"],
+                       "algorithmic_bytes_per_launch": fam["algorithmic_bytes"] / fam["launches"]},
+            "classes": table,
+            "note": "flops = multiply-adds x2 the launches execute (nearest-x2 convs run as four 2x2 phase convs = 4/9 of the reference "
+                    "MACs; position-major launches skip padding taps)" + (f" x {passes} MFMA passes per product (bf16x3)" if passes > 1 else "") +
+                    "; time = HIP events around each launch on the launch stream; achieved / frac are the dominant kernel's own"}
+
+
+def parity_record(a, dev, batch, bench_model, bench_sim, bench_idx, bench_ms, spot_out):
+    """The step of this benchmark in every compute mode, against the f32 parity mode of the library."""
+    from nope_amd.harness import build_model
+    query, reference, poses = batch["query"], batch["reference"], batch["all_relativeR"]
+    hyp = a.batch * a.templates
+
+    def run(model, steps):
+        sim, idx, bank = model.generate_and_retrieve(query, reference, poses)          # warm-up (weights repacked here)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sim, idx, bank = model.generate_and_retrieve(query, reference, poses)
+        torch.cuda.synchronize()
+        return sim, idx, bank, (time.perf_counter() - t0) / steps * 1e3
+    m32 = bench_model if a.dtype == "f32" else build_model(seed=2022, compute_dtype="f32", bank_dtype="f32", device=dev)
+    sim32, idx32, bank32, ms32 = run(m32, 2)
+    scale = float(sim32.abs().max())
+    rec = {"reference": "f32 mode of this library (exact-f32 MFMA; tests/ pin it to the reference PyTorch path at <= 1e-4 on scores with bit-exact "
+                        "top-5, observed 5e-7)", "score_rel_err": "max |score - score_f32| / max |score_f32| over the step's (batch x templates) scores",
+           "modes": {}}
+    spot_out["ref_feat"] = m32.u_net.encoder.encode_image(reference[:1], mode="mode")
+    spot_out["q_feat"] = m32.u_net.encoder.encode_image(query[:1], mode="mode")
+    spot_out["bank32"], spot_out["sim32"] = bank32, sim32
+    for mode in ("bf16", "f16", "bf16x3", "f32"):
+        if mode == "f32":
+            sim, idx, ms = sim32, idx32, ms32
+        elif mode == a.dtype:
+            sim, idx, ms = bench_sim, bench_idx, bench_ms
+        else:
+            m = build_model(seed=2022, compute_dtype=mode, bank_dtype=mode if mode in ("bf16", "f16") else "f32", device=dev)
+            sim, idx, _, ms = run(m, 3)
+            del m
+            torch.cuda.empty_cache()
+        rec["modes"][mode] = {"score_rel_err": float((sim - sim32).abs().max()) / scale, "top5_equal": bool(torch.equal(idx, idx32)),
+                              "top1_equal": int((idx[:, 0] == idx32[:, 0]).sum()), "queries": a.batch, "ms_per_step": ms,
+                              "hyp_per_s": hyp / ms * 1e3, "meets_1e-4": bool(float((sim - sim32).abs().max()) / scale <= 1e-4 and torch.equal(idx, idx32))}
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,7 +274,9 @@ def main():
     ap.add_argument("--templates", type=int, default=512, help="templates per GPU")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "bf16x3", "f32"],
+                    help="compute mode: bf16 (BASELINE configs[1]) | f16 | bf16x3 (f32 storage, split-precision MFMA: the fast mode inside the "
+                         "1e-4 score tolerance) | f32 (exact-f32 MFMA, the parity mode)")
     ap.add_argument("--bank-dtype", default=None, choices=["bf16", "f32", "f16"], help="template-bank storage (default: --dtype; f16 for --scoring-only)")
     ap.add_argument("--scoring-only", action="store_true", help="time scoring + top-5 on a resident bank (SURVEY 8(d) metric (i))")
     ap.add_argument("--skip-extras", action="store_true", help="skip roofline / cpu_baseline legs")
@@ -189,7 +298,7 @@ def main():
     from nope_amd.harness import build_model, synthetic_batch
     if a.scoring_only:
         return scoring_only(a, dev, rank, world)
-    bank_dtype = a.bank_dtype or a.dtype
+    bank_dtype = a.bank_dtype or (a.dtype if a.dtype in ("bf16", "f16") else "f32")
     model = build_model(seed=2022, compute_dtype=a.dtype, bank_dtype=bank_dtype, device=dev, template_parallel=world > 1)
     n_total = a.templates * world
     batch = synthetic_batch(a.batch, n_total, a.size, seed=2022, device=dev)
@@ -234,39 +343,19 @@ def main():
                    "bank_dtype": bank_dtype, "top5": idx[0].tolist()},
     }
     if rank == 0 and world == 1 and not a.skip_extras:
-        h = model.u_net._get_handle(dev)
-        torch.cuda.synchronize()
-        h.profile(True)
-        step()
-        torch.cuda.synchronize()
-        n_launch, ms, flops, abytes = h.profile_read()
-        h.profile(False)
-        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
-        tf = flops / ms / 1e9
-        # HBM traffic of the same kernel from rocprofv3 PMC passes over this command (FETCH_SIZE / WRITE_SIZE in
-        # their own runs, tools/gpu_pmc.sh); PMC cannot be read from inside the process, so the figure is loaded
-        # from the committed measurement and is null when the workload differs from the one it was taken on.
-        traffic = None
-        try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            # only next to the kernel sources it was measured on: a stale figure must not ride along after a kernel changes
-            if (rec.get("dtype") == a.dtype and rec.get("templates") == a.templates and rec.get("size") == a.size
-                    and rec.get("csrc_sha") == _csrc_sha()):
-                traffic = rec["bytes_per_launch"]
-        except Exception:
-            rec = None
-        res["roofline"] = {"bound": "mfma", "kernel": f"implicit-GEMM conv kernels <{a.dtype}>: conv3x3_halo_kernel (tap-resident 3x3, "
-                                                       f"256x192 ping-pong), conv_gemm_pp_kernel, conv_gemm_dma_kernel", "achieved": tf, "peak": peak,
-                           "unit": "TFLOP/s", "frac": tf / peak, "traffic": traffic,
-                           "algorithmic_bytes_per_launch": abytes / max(n_launch, 1), "launches_per_step": n_launch,
-                           "avg_launch_ms": ms / max(n_launch, 1), "kernel_ms_per_step": ms, "flops_per_step": flops,
-                           "note": "flops = executed MACs x2 of all implicit-GEMM launches of one step (the nearest-x2 convs run "
-                                   "as four 2x2 phase convs = 4/9 of the reference MACs; the few 4x4-level launches that stay on the 128x192 kernel in "
-                                   "position-major order skip the taps lying in the zero padding, everything else executes every tap); time = HIP "
-                                   "events around each launch"}
+        res["roofline"] = conv_roofline(model, step, a.dtype, dev, a.templates, a.size)
+        spot = {}
+        res["parity"] = parity_record(a, dev, batch, model, sim, idx, dt / a.steps * 1e3, spot)
         res["scoring_roofline"] = [scoring_roofline(torch.bfloat16), scoring_roofline(torch.float32),
-                                   scoring_roofline(torch.float16, N=1024)]      # BASELINE configs[4]: fp16 bank, 8192 / 8 templates per GPU
-        res["cpu_baseline"] = cpu_baseline(model, a.size, a.templates)
+                                   scoring_roofline(torch.float16, N=1024),     # BASELINE configs[4]: fp16 bank, 8192 / 8 templates per GPU
+                                   scoring_roofline(torch.bfloat16, N=512)]     # BASELINE configs[3]: 32 x 4096 bf16 sharded 8-way -> 512 per GPU
+        res["cpu_baseline"], obank, oscore = cpu_baseline(model, a.size, a.templates, spot=(spot["ref_feat"], poses[:1], spot["q_feat"]))
+        n_o = obank.shape[1]
+        got = spot["bank32"][:1, :n_o].float().cpu()
+        res["parity"]["oracle_spot_check"] = {
+            "hypotheses": n_o, "maps_rel_err": float((got - obank).abs().max() / obank.abs().max()),
+            "score_rel_err": float((spot["sim32"][:1, :n_o].cpu() - oscore).abs().max() / oscore.abs().max()),
+            "note": "f32 mode against the CPU oracle (oracle/nope_ref.py) on the step's first hypotheses -- the ones the cpu_baseline leg times"}
         res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(res))

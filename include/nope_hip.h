@@ -136,6 +136,16 @@ int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep
  * keep it off in timed regions. */
 int nope_unet_profile(nope_unet* net, int enable);
 int nope_unet_profile_read(nope_unet* net, int* n_launches, double* total_ms, double* total_flops, double* total_bytes);
+/* ... and launch by launch, in issue order: which kernel took the launch, its shape, its HIP-event time.  `flops` counts the
+ * convolution's multiply-adds x 2 as executed (NOPE_BF16X3 issues three MFMA passes per product: mfma_passes = 3).  Writes at
+ * most `max` records and the total number of recorded launches to *n. */
+enum { NOPE_CONV_KERNEL_GENERIC = 0, NOPE_CONV_KERNEL_DMA128 = 1, NOPE_CONV_KERNEL_PP256 = 2, NOPE_CONV_KERNEL_HALO256 = 3 };
+typedef struct {
+    double ms, flops, bytes;
+    int kernel;            /* NOPE_CONV_KERNEL_* */
+    int mode, ntaps, Cin, Cout, Hs, Ws, n_hyp, mfma_passes, posmajor;
+} nope_conv_launch_info;
+int nope_unet_profile_launches(nope_unet* net, nope_conv_launch_info* out, int max, int* n);
 
 /* ------------------------------------------------------------------------------------------
  * LDM cross-attention U-Net variant.  Replaces UNetModelPose.__init__/forward,

@@ -542,6 +542,11 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
 // Would launch_conv run this conv in position-major row order?
 bool conv_is_posmajor(int dt, const ConvArgs& a) { return plan_conv(dt, a).posmajor; }
 
+int conv_kernel_kind(int dt, const ConvArgs& a) {
+    const ConvPlan pl = plan_conv(dt, a);
+    return pl.halo ? NOPE_CONV_KERNEL_HALO256 : pl.pp ? NOPE_CONV_KERNEL_PP256 : pl.dma ? NOPE_CONV_KERNEL_DMA128 : NOPE_CONV_KERNEL_GENERIC;
+}
+
 // Multiply-adds x2 the launch actually executes (position-major launches skip the taps that lie in the padding:
 // (3H-2)(3W-2) of the 9 H W tap instances remain).
 double conv_executed_flops(int dt, const ConvArgs& a) {

@@ -219,6 +219,7 @@ struct ConvArgs {
 int launch_conv(int dt, const ConvArgs& a, hipStream_t s);
 int conv_splitk_factor(int dt, const ConvArgs& a);
 bool conv_is_posmajor(int dt, const ConvArgs& a);
+int conv_kernel_kind(int dt, const ConvArgs& a);      // NOPE_CONV_KERNEL_* launch_conv would pick
 double conv_executed_flops(int dt, const ConvArgs& a);
 
 int launch_gn_stats(int dt, const void* x, float* partial, int nhyp, int HW, int C, int G, int nchunk, hipStream_t s);

@@ -57,7 +57,7 @@ struct nope_unet {
     float *emb_w = nullptr, *emb_b = nullptr;
     int emb_total = 0;
     // optional per-launch timing of the implicit-GEMM kernel (bench.py roofline leg)
-    struct Ev { hipEvent_t a, b; double flops, bytes; };
+    struct Ev { hipEvent_t a, b; double flops, bytes; nope_conv_launch_info info; };
     mutable bool profile = false;
     mutable std::vector<Ev> evs;
 };
@@ -214,6 +214,8 @@ struct Fwd {
             // algorithmic HBM bytes: every input, weight and output element exactly once
             ev.bytes = ((double)(n / rep1) * a.H * a.W * a.C + (b ? (double)(n / rep2) * a.H * a.W * b->C : 0.0) +
                         (double)c.Cout * c.ntaps * c.Cin * (c.mode == NOPE_CONV_UP2P ? 4 : 1) + (double)n * Ho * Wo * c.Cout) * (double)es;
+            ev.info = nope_conv_launch_info{0.0, ev.flops, ev.bytes, conv_kernel_kind(net->dt, ca), c.mode, c.ntaps, c.Cin, c.Cout, a.H, a.W, n,
+                                            net->dt == NOPE_BF16X3 ? 3 : 1, conv_is_posmajor(net->dt, ca) ? 1 : 0};
             hipEventRecord(ev.a, s);
             chk(launch_conv(net->dt, ca, s));
             hipEventRecord(ev.b, s);
@@ -583,6 +585,23 @@ int nope_unet_profile_read(nope_unet* net, int* n_launches, double* total_ms, do
         ms += t; fl += e.flops; by += e.bytes;
     }
     *n_launches = (int)net->evs.size(); *total_ms = ms; *total_flops = fl; *total_bytes = by;
+    return NOPE_OK;
+}
+
+int nope_unet_profile_launches(nope_unet* net, nope_conv_launch_info* out, int max, int* n) {
+    if (!net || !n || (max > 0 && !out)) return NOPE_ERR_ARG;
+    int i = 0;
+    for (auto& e : net->evs) {
+        if (i < max) {
+            if (hipEventSynchronize(e.b) != hipSuccess) return NOPE_ERR_LAUNCH;
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) return NOPE_ERR_LAUNCH;
+            out[i] = e.info;
+            out[i].ms = t;
+        }
+        ++i;
+    }
+    *n = i;
     return NOPE_OK;
 }
 

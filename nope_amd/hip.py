@@ -39,6 +39,14 @@ class LdmConfig(C.Structure):
                 ("pose_mlp_layers", _i), ("injecting_condition_twice", _i), ("compute_dtype", _i), ("use_scale_shift_norm", _i)]
 
 
+class ConvLaunchInfo(C.Structure):
+    _fields_ = [("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("kernel", _i), ("mode", _i), ("ntaps", _i), ("Cin", _i),
+                ("Cout", _i), ("Hs", _i), ("Ws", _i), ("n_hyp", _i), ("mfma_passes", _i), ("posmajor", _i)]
+
+
+CONV_KERNEL_NAMES = ("conv_gemm_kernel", "conv_gemm_dma_kernel", "conv_gemm_pp_kernel", "conv3x3_halo_kernel")
+
+
 class EncoderConfig(C.Structure):
     _fields_ = [("descriptor_size", _i), ("compute_dtype", _i), ("bn_eps", C.c_float)]
 
@@ -54,6 +62,7 @@ _PROTOS = {
     "nope_unet_forward": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "nope_unet_profile": (_i, [_vp, _i]),
     "nope_unet_profile_read": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "nope_unet_profile_launches": (_i, [_vp, C.POINTER(ConvLaunchInfo), _i, C.POINTER(_i)]),
     "nope_op_nchw_to_nhwc": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
     "nope_op_nhwc_to_nchw": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
     "nope_op_pack_conv_weight": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -367,6 +376,19 @@ class UNetHandle:
         n, ms, fl, by = _i(0), C.c_double(0), C.c_double(0), C.c_double(0)
         self._l.check(self._l.dll.nope_unet_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "profile_read")
         return n.value, ms.value, fl.value, by.value
+
+    def profile_launches(self):
+        """One dict per conv launch since profile(True), in issue order: kernel name, shape, ms, flops, bytes."""
+        n = _i(0)
+        self._l.check(self._l.dll.nope_unet_profile_launches(self._h, None, 0, C.byref(n)), "profile_launches")
+        buf = (ConvLaunchInfo * max(1, n.value))()
+        self._l.check(self._l.dll.nope_unet_profile_launches(self._h, buf, n.value, C.byref(n)), "profile_launches")
+        out = []
+        for r in buf[:n.value]:
+            d = {k: getattr(r, k) for k, _ in ConvLaunchInfo._fields_}
+            d["kernel"] = CONV_KERNEL_NAMES[r.kernel]
+            out.append(d)
+        return out
 
     def workspace_bytes(self, n_hyp: int, n_src: int, H: int, W: int) -> int:
         return int(self._l.dll.nope_unet_workspace_bytes(self._h, n_hyp, n_src, H, W))

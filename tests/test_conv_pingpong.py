@@ -33,19 +33,19 @@ def test_pingpong_kernel_under_adversarial_interpreter(emu):
 @pytest.mark.gpu
 def test_pingpong_small_shapes_gpu(gpu):
     from tests import pp_emu_case
-    assert pp_emu_case.run(gpu, "cuda") < 1.0
-    e32, e16 = pp_emu_case.run_unet(gpu, "cuda", 64, "f32", n_hyp=5, hw=16), pp_emu_case.run_unet(gpu, "cuda", 64, "bf16", n_hyp=5, hw=16)
-    print(f"U-Net (u_net_dim 64) with every eligible conv on the ping-pong kernel: f32 {e32:.2e}, bf16 {e16:.2e}")
-    assert e32 < 1e-4 and e16 < 6e-2
+    assert pp_emu_case.run(gpu, "cuda", dts=(1, 0, 3, 2)) < 1.0
+    errs = {cdt: pp_emu_case.run_unet(gpu, "cuda", 64, cdt, n_hyp=5, hw=16) for cdt in ("f32", "bf16x3", "f16", "bf16")}
+    print("U-Net (u_net_dim 64) with every eligible conv on the ping-pong kernel: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert errs["f32"] < 1e-4 and errs["bf16x3"] < 1e-4 and errs["f16"] < 8e-3 and errs["bf16"] < 6e-2
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dt", [1, 0])
+@pytest.mark.parametrize("dt", [1, 0, 3, 2])
 def test_pingpong_bit_identical_to_128_tile_kernel(gpu, dt):
     hip = gpu
     g = torch.Generator(device="cuda").manual_seed(5)
     tdt = hip.torch_dtype(dt)
-    n = 512 if dt == 1 else 128          # f32: 16x fewer MFMA flops per second -- keep the test short
+    n = {1: 512, 2: 512, 3: 256, 0: 128}[dt]          # f32: 16x fewer MFMA flops per second -- keep the test short
     shapes = [  # C1, C2, Cout, H, mode, ksize
         (192, 0, 192, 32, hip.CONV_PLAIN, 3), (192, 192, 192, 32, hip.CONV_PLAIN, 3), (384, 192, 384, 16, hip.CONV_PLAIN, 3),
         (768, 0, 768, 8, hip.CONV_PLAIN, 3), (192, 0, 384, 32, hip.CONV_PLAIN, 1), (128, 0, 192, 32, hip.CONV_PLAIN, 1),

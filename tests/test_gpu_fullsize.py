@@ -17,7 +17,7 @@ def model_f32(gpu):
     return build_model(compute_dtype="f32", bank_dtype="f32", device="cuda")
 
 
-@pytest.mark.parametrize("cdt,tol", [("f32", 1e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("cdt,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("f16", 8e-3), ("bf16", 6e-2)])
 def test_mid_unet_dma_path_vs_oracle(gpu, cdt, tol):
     """u_net_dim=64: every conv's channel count is a multiple of the 128-byte K step, so the whole
     network runs on the LDS-DMA implicit-GEMM kernel in both dtypes; checked against the oracle."""
@@ -148,13 +148,13 @@ def test_properties_full_size(model_f32):
     assert rel(sb, s) < 5e-3 and torch.equal(hip.topk(sb, 1)[1], hip.topk(s, 1)[1])
 
 
-@pytest.mark.parametrize("cdt,tol", [("f32", 1e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("cdt,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("f16", 8e-3), ("bf16", 6e-2)])
 def test_bench_batch_vs_oracle(gpu, model_f32, cdt, tol):
     """The benchmark's own launch regime -- ONE batch of 512 pose hypotheses at a 32x32 latent through the full-size U-Net
     (position-major 4x4 level, persistent level-0/1 launches in bf16, fused statistics) -- checked hypothesis by hypothesis
     against the CPU restatement on a spread of 6 of the 512 (the oracle needs ~50 ms per hypothesis)."""
     from nope_amd.harness import build_model
-    m = model_f32 if cdt == "f32" else build_model(compute_dtype="bf16", bank_dtype="f32", device="cuda")
+    m = model_f32 if cdt == "f32" else build_model(compute_dtype=cdt, bank_dtype="f32", device="cuda")
     g = torch.Generator().manual_seed(21)
     feat = torch.randn(1, 8, 32, 32, generator=g)
     poses = torch.randn(1, 512, 6, generator=g)
