@@ -271,7 +271,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--templates", type=int, default=512, help="templates per GPU")
+    ap.add_argument("--templates", type=int, default=512, help="templates per GPU (weak scaling: N_total = templates x GPUs)")
+    ap.add_argument("--templates-total", type=int, default=0,
+                    help="strong scaling: a FIXED bank of this many templates sharded over the GPUs (e.g. 4096 = BASELINE configs[3]); overrides --templates")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL, one rank per GPU (production); gloo = ranks may share a GPU (the 8-rank tests on a 1-GPU box)")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "bf16x3", "f32"],
@@ -288,19 +292,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if a.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from nope_amd.harness import build_model, synthetic_batch
     if a.scoring_only:
         return scoring_only(a, dev, rank, world)
     bank_dtype = a.bank_dtype or (a.dtype if a.dtype in ("bf16", "f16") else "f32")
     model = build_model(seed=2022, compute_dtype=a.dtype, bank_dtype=bank_dtype, device=dev, template_parallel=world > 1)
-    n_total = a.templates * world
+    strong = a.templates_total > 0
+    n_total = a.templates_total if strong else a.templates * world
     batch = synthetic_batch(a.batch, n_total, a.size, seed=2022, device=dev)
     query, reference, poses = batch["query"], batch["reference"], batch["all_relativeR"]
 
@@ -333,12 +343,12 @@ def main():
     res = {
         "metric": "pose-hypotheses/sec (queries x templates), generate_templates + retrieval",
         "value": hyp * a.steps / dt, "unit": "pose-hypotheses/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": f"{a.batch} query {a.size}x{a.size} x {a.templates} viewpoint templates per GPU "
+        "config": {"workload": f"{a.batch} query {a.size}x{a.size} x " + (f"{n_total} viewpoint templates sharded over {world} GPU(s) " if strong else f"{a.templates} viewpoint templates per GPU ") +
                                f"(BASELINE configs[1]); U-Net u_net_dim=192 (305.8M params, random init) at "
                                f"{a.size // 8}x{a.size // 8} latent + ResNet-50 template encoder + l2 scoring + top-5",
-                   "batch": a.batch, "templates_total": n_total, "templates_per_gpu": a.templates, "image": a.size,
+                   "batch": a.batch, "templates_total": n_total, "templates_per_gpu": (n_total + world - 1) // world if strong else a.templates, "image": a.size,
                    "parallelism": f"template-shard x{world} + score all-gather" if world > 1 else "single GPU",
                    "bank_dtype": bank_dtype, "top5": idx[0].tolist()},
     }
@@ -373,8 +383,12 @@ def scoring_only(a, dev, rank, world):
     from tests.util import StubEncoder
     bank_dtype = a.bank_dtype or "f16"
     B = a.batch if a.batch > 1 else 32
+    strong = a.templates_total > 0
     n_local = a.templates if a.templates != 512 else 1024
-    n_total = n_local * world
+    if strong:
+        lo_, hi_ = ndist.shard_range(a.templates_total, rank, world)
+        n_local = hi_ - lo_
+    n_total = a.templates_total if strong else n_local * world
     h = a.size // 8
     g = torch.Generator(device=dev).manual_seed(2022 + rank)
     bank = torch.randn(B, n_local, 8, h, h, device=dev, generator=g).to(hip.torch_dtype(hip.dtype_code(bank_dtype)))
@@ -385,10 +399,10 @@ def scoring_only(a, dev, rank, world):
     model = PoseConditional(UNet(u_net_dim=8, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer"),
                             None, {"similarity_metric": "l2"}, None, bank_dtype=bank_dtype, template_parallel=world > 1)
     lo, hi = ndist.shard_range(n_total, rank, world)
-    bank._nope_shard = (lo, hi, n_total) if world > 1 else None
+    shard = (lo, hi, n_total) if world > 1 else None
 
     def step():
-        return model.retrieval_from_feat(qfeat, bank)
+        return model.retrieval_from_feat(qfeat, bank, shard=shard)
 
     for _ in range(a.warmup):
         sim, idx = step()
@@ -410,7 +424,7 @@ def scoring_only(a, dev, rank, world):
     byts = B * n_local * (8 * h * h * bank.element_size() + 4)
     res = {"metric": "pose-hypotheses/sec (queries x templates), scoring + top-5 on a resident bank", "value": B * n_total * a.steps / dt,
            "unit": "pose-hypotheses/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": bank_dtype, "data": "synthetic",
+           "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": bank_dtype, "data": "synthetic",
            "config": {"workload": f"{B} query embeddings x {n_local} templates per GPU ({bank_dtype} bank, 8 x {h} x {h}), BASELINE configs[4] slice; "
                                   f"template-shard x{world} + score all-gather" if world > 1 else
                                   f"{B} query embeddings x {n_local} templates ({bank_dtype} bank, 8 x {h} x {h}), BASELINE configs[4] per-GPU slice",

@@ -71,9 +71,10 @@ def all_gather_scores(local: torch.Tensor, n_total: int, group=None) -> torch.Te
     else:
         dist.all_gather_into_tensor(recv.view(ws * B, nmax), send, group=group)
     base, extra = divmod(n_total, ws)
-    if extra == 0:
-        return recv.permute(1, 0, 2).reshape(B, n_total)
-    out = local.new_empty((B, n_total))
+    out = local.new_empty((B, n_total))            # always an OWNED tensor: `recv` is a cached buffer the next gather overwrites
+    if extra == 0:                                 # (for B == 1 a reshape of the permuted buffer would be a view of it)
+        out.view(B, ws, nmax).copy_(recv.permute(1, 0, 2))
+        return out
     cut = extra * (base + 1)                       # the first `extra` ranks hold base + 1 columns each
     out[:, :cut].view(B, extra, base + 1).copy_(recv[:extra].permute(1, 0, 2))
     if base > 0:

@@ -93,10 +93,11 @@ class FeatureExtractor(nn.Module):
         self._handle = None
 
     def _weights_version(self):
-        v = 0
-        for t in list(self.backbone.parameters()) + list(self.backbone.buffers()) + list(self.projector.parameters()):
-            v += t._version + (t.data_ptr() & 0xFFFFF)
-        return v
+        # (storage address, version counter) per parameter / BatchNorm buffer, as UNet._weights_version: `.data` writes need invalidate()
+        ts = self.__dict__.get("_own_tensors")
+        if ts is None:
+            ts = self.__dict__["_own_tensors"] = list(self.backbone.parameters()) + list(self.backbone.buffers()) + list(self.projector.parameters())
+        return hash(tuple((t.data_ptr(), t._version) for t in ts))
 
     def _get_handle(self, device) -> "hip.EncoderHandle":
         key = (str(device), self.compute_dtype, self._weights_version())

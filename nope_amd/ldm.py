@@ -142,11 +142,11 @@ class UNetModelPose(nn.Module):
             inv()
 
     def _weights_version(self):
-        v = 0
-        for n, p in self.named_parameters(recurse=True):
-            if not n.startswith("encoder."):
-                v += p._version + (p.data_ptr() & 0xFFFFF)
-        return v
+        # (storage address, version counter) per tensor, as UNet._weights_version: `.data` writes need invalidate()
+        ps = self.__dict__.get("_own_params")
+        if ps is None:
+            ps = self.__dict__["_own_params"] = [p for n, p in self.named_parameters(recurse=True) if not n.startswith("encoder.")]
+        return hash(tuple((p.data_ptr(), p._version) for p in ps))
 
     def _get_handle(self, device) -> "hip.LdmHandle":
         key = (str(device), self.compute_dtype, self._weights_version())

@@ -56,9 +56,11 @@ def _roty180(device, dtype):
 
 
 def _opencv_to_opengl(R: torch.Tensor) -> torch.Tensor:
-    # convert_openCV_to_openGL_torch, poses/utils.py:142-152
-    t = torch.tensor([[1, 0, 0], [0, -1, 0], [0, 0, -1]], device=R.device, dtype=R.dtype)
-    return torch.matmul(t, R[:, :3, :3])
+    # convert_openCV_to_openGL_torch, poses/utils.py:142-152 (same op sequence -- a batched product against the repeated
+    # transform -- so that the unclamped acos of the circular branch sees the reference's bits: an exact match gives a cosine
+    # within one ulp of 1 and acos returns 0 or NaN depending on that ulp; fixture metric_ref.npz holds both outcomes)
+    t = torch.tensor([[1, 0, 0], [0, -1, 0], [0, 0, -1]], device=R.device, dtype=R.dtype).unsqueeze(0).repeat(R.shape[0], 1, 1)
+    return torch.bmm(t, R[:, :3, :3])
 
 
 def so3_relative_angle_with_symmetry(pred: torch.Tensor, gt: torch.Tensor, symmetry: torch.Tensor) -> torch.Tensor:
@@ -79,8 +81,8 @@ def so3_relative_angle_with_symmetry(pred: torch.Tensor, gt: torch.Tensor, symme
     if int(non.sum()) + int(two.sum()) == pred.shape[0]:
         return err
     cir = sym == 2
-    p_gl = _opencv_to_opengl(torch.linalg.inv(pred[cir][:, :3, :3]))       # object pose -> camera pose -> OpenGL axes
-    g_gl = _opencv_to_opengl(torch.linalg.inv(gt[cir][:, :3, :3]))
+    p_gl = _opencv_to_opengl(pred[cir].clone()[:, :3, :3].inverse())       # object pose -> camera pose -> OpenGL axes (loss.py:56-63)
+    g_gl = _opencv_to_opengl(gt[cir].clone()[:, :3, :3].inverse())
     err[cir] = torch.acos(F.cosine_similarity(p_gl[:, 2, :3], g_gl[:, 2, :3]))   # only the viewing (Z) axis matters
     return err
 

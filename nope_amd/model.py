@@ -117,11 +117,11 @@ class PoseConditional(nn.Module):
 
     # ---- model.py:254-266 ----------------------------------------------------------------------------
     @torch.no_grad()
-    def retrieval(self, query, template_feat):
+    def retrieval(self, query, template_feat, shard=None):
         if self.similarity_metric != "l2":
             return None                   # the reference implements only "l2" (model.py:256,266)
         query_feat = self.u_net.encoder.encode_image(query, mode="mode")
-        return self.retrieval_from_feat(query_feat, template_feat)
+        return self.retrieval_from_feat(query_feat, template_feat, shard=shard)
 
     # ---- model.py:313,323 (the two calls eval_geodesic makes back to back) --------------------------------
     @torch.no_grad()
@@ -140,9 +140,19 @@ class PoseConditional(nn.Module):
         return similarity, nearest_idx, bank
 
     @torch.no_grad()
-    def retrieval_from_feat(self, query_feat, template_feat, k=5):
-        sl = getattr(template_feat, "_nope_shard", None)
+    def retrieval_from_feat(self, query_feat, template_feat, k=5, shard=None):
+        """`shard` = (lo, hi, N): this rank's slice [lo, hi) of the N templates; `shard=False`: the bank is COMPLETE on this rank
+        (e.g. loaded from disk on every rank) and is scored locally without a collective.  Banks made by `generate_templates`
+        carry their placement themselves; a bank that went through another op since (`.to()`, a slice, `torch.cat`, save /
+        load) has lost the tag: under `template_parallel` with more than one rank that raises -- scoring only a local slice
+        while the other ranks wait in the collective would return rank-local indices without an error."""
+        sl = getattr(template_feat, "_nope_shard", None) if shard is None else (shard or None)
+        if self.template_parallel and sl is None and shard is None and ndist.world()[1] > 1:
+            raise hip.NopeError("template_parallel: this bank carries no shard placement (it was not made by generate_templates, or was "
+                                "copied / sliced since): pass shard=(lo, hi, n_total), or shard=False for a bank that is complete on every rank")
         if self.template_parallel and sl is not None:
+            if sl[1] - sl[0] != template_feat.shape[1]:
+                raise hip.NopeError(f"shard {tuple(sl)} does not match the bank's {template_feat.shape[1]} local templates")
             B, n_local = query_feat.shape[0], template_feat.shape[1]
             send, _ = ndist.gather_buffers(B, sl[2], query_feat.device)
             if n_local > 0:          # this rank's columns go straight into the collective's send buffer

@@ -146,12 +146,15 @@ class UNet(nn.Module):
             inv()
 
     def _weights_version(self):
-        # in-place writes (optimizer steps, p.copy_, p.data.copy_) bump a tensor's _version; re-assigned storage moves data_ptr
-        v = 0
-        for n, p in self.named_parameters(recurse=True):
-            if not n.startswith("encoder."):
-                v += p._version + (p.data_ptr() & 0xFFFFF)
-        return v
+        """Key of the repacked device copy: (storage address, version counter) of every tensor of the U-Net.  In-place writes through
+        the tensor itself (optimizer steps, `p.copy_`, `p.mul_`) bump `_version`, re-assigned storage moves `data_ptr`; writes
+        through `p.data` have their own counter and are NOT seen -- call `invalidate()` after those (EMA swaps, hand-written
+        checkpoint loaders); `load_state_dict` on this module or any parent invalidates by itself.  The parameter list is
+        cached (the module tree is fixed after __init__), so a forward pays ~40 us for the ~420 tensors, not a named_parameters walk."""
+        ps = self.__dict__.get("_own_params")
+        if ps is None:
+            ps = self.__dict__["_own_params"] = [p for n, p in self.named_parameters(recurse=True) if not n.startswith("encoder.")]
+        return hash(tuple((p.data_ptr(), p._version) for p in ps))
 
     def _get_handle(self, device) -> hip.UNetHandle:
         key = (str(device), self.compute_dtype, self._weights_version())

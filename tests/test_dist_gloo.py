@@ -36,13 +36,22 @@ def _worker(rank, ws, port, emu_path, q, bank, poses, ret):
         m = PoseConditional(u, None, {"similarity_metric": "l2"}, None, template_parallel=True)
         ref_feat = q[:1, :, :8, :8].contiguous()
         b_local, _, _ = m.generate_templates(ref_feat, poses)
+        lo5, hi5 = shard_range(poses.shape[1], rank, ws)
         sim, idx = m.retrieval(ref_feat * 0.5, b_local)
+        keep = sim.clone()
+        m.retrieval(ref_feat * 0.25, b_local)          # a second gather of the same shape must not overwrite the first result (B = 1)
+        assert torch.equal(sim, keep)
         sim2, idx2, _ = m.generate_and_retrieve(ref_feat * 0.5, ref_feat, poses)     # what bench.py --gpus N calls per step
         assert torch.equal(sim2, sim) and torch.equal(idx2, idx)
-        # a caller-supplied bank that happens to have this rank's local size is scored as is, not gathered
+        # a bank that lost its placement tag (any op that makes a new tensor) is an error, not a silent rank-local result
+        # (ADVICE r2); a bank that is complete on every rank is scored locally on request; an explicit shard is honoured
         mine = b_local.clone()
-        s_own, _ = m.retrieval_from_feat(ref_feat * 0.5, torch.cat([mine, mine, mine], 1)[:, :5].contiguous())
+        with pytest.raises(hip.NopeError, match="shard"):
+            m.retrieval_from_feat(ref_feat * 0.5, mine)
+        s_own, _ = m.retrieval_from_feat(ref_feat * 0.5, torch.cat([mine, mine, mine], 1)[:, :5].contiguous(), shard=False)
         assert s_own.shape == (1, 5)
+        s_exp, i_exp = m.retrieval_from_feat(ref_feat * 0.5, mine, shard=(lo5, hi5, 5))
+        assert torch.equal(s_exp, sim) and torch.equal(i_exp, idx)
         # fewer templates than ranks: rank 1 holds an empty shard and still takes part in the gather
         b1, _, _ = m.generate_templates(ref_feat, poses[:, :1])
         assert b1.shape[1] == (1 if rank == 0 else 0)
@@ -165,10 +174,10 @@ def _nccl_worker(rank, ws, port, ret):
 
 @pytest.mark.gpu
 def test_rccl_sharded_path(gpu):
-    """The production backend: "nccl" (= RCCL), one rank per GPU, min(device_count, 2) ranks.  On a 1-GPU box this is a
-    world-size-1 RCCL group (communicator init + one all_gather_into_tensor on device buffers); with two GPUs the
-    sharded generate_and_retrieve must match the unsharded one."""
-    ws = min(torch.cuda.device_count(), 2)
+    """The production backend: "nccl" (= RCCL), one rank per GPU, on EVERY GPU of the box (up to 8).  On a 1-GPU box this is a
+    world-size-1 RCCL group (communicator init + one all_gather_into_tensor on device buffers); with more GPUs the
+    sharded generate_and_retrieve (9 templates over the ranks: uneven, and empty shards beyond 9 ranks) must match the unsharded one."""
+    ws = min(torch.cuda.device_count(), 8)
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 29700 + os.getpid() % 2000
@@ -176,4 +185,5 @@ def test_rccl_sharded_path(gpu):
     for r in range(ws):
         err, same_idx, shard_shape, ok_coll = ret[r]
         assert ok_coll and err < 1e-5 and same_idx, (r, err)
-        assert shard_shape[1] == (9 if ws == 1 else (5 if r == 0 else 4))
+        base, extra = divmod(9, ws)
+        assert shard_shape[1] == base + (1 if r < extra else 0)

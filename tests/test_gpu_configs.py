@@ -160,6 +160,115 @@ def test_per_rank_shapes_of_configs_3_and_4(gpu, n_per_rank, ws, bank_dtype):
     assert bool(torch.isfinite(ret[0]["sim"]).all()) and len(set(ret[0]["idx"][:, 0].tolist())) > 1
 
 
+def _whole_config_worker(rank, ws, port, n_total, cdt, bank_dtype, ret):
+    """One of `ws` gloo ranks sharing GPU 0: the whole BASELINE configuration (32 queries x n_total templates), not its per-rank
+    shape -- sharded template generation, scoring into the collective's send buffer, all-gather, top-5."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        from nope_amd import dist as nd
+        from nope_amd.harness import build_model, synthetic_batch
+        torch.cuda.set_device(0)
+        B = 32
+        b = synthetic_batch(B, n_total, 256, seed=93, device="cuda")
+        m = build_model(compute_dtype=cdt, bank_dtype=bank_dtype, device="cuda", template_parallel=True)
+        tdt = {"bf16": torch.bfloat16, "f16": torch.float16}[bank_dtype]
+        # the query embedding rounded to the bank's storage type, so that a planted copy of it scores exactly -0.0
+        q_feat = m.u_net.encoder.encode_image(b["query"], mode="mode").to(tdt).float()
+        bank, _, _ = m.generate_templates(b["reference"], b["all_relativeR"], None)
+        lo, hi = nd.shard_range(n_total, rank, ws)
+        plant = n_total - 7                                   # a slot of the LAST rank's shard
+        if lo <= plant < hi:
+            bank[:, plant - lo] = q_feat.to(tdt)              # (in place: the bank keeps its shard placement)
+        sim, idx = m.retrieval_from_feat(q_feat, bank)
+        torch.cuda.synchronize()
+        out = {"shape": tuple(bank.shape), "sim": sim.cpu(), "idx": idx.cpu(), "range": (lo, hi)}
+        if rank == 0:
+            # the unsharded call on one rank: same per-launch hypothesis batches (one reference image x 512 poses), so the same bits
+            m.template_parallel = False
+            bank1, _, _ = m.generate_templates(b["reference"], b["all_relativeR"], None)
+            bank1[:, plant] = q_feat.to(tdt)
+            sim1, idx1 = m.retrieval_from_feat(q_feat, bank1)
+            torch.cuda.synchronize()
+            out["sim1"], out["idx1"] = sim1.cpu(), idx1.cpu()
+            # oracle spot check: (b, n) pairs spread over the shards of six different ranks
+            per = n_total // ws
+            pairs = [(0, 1), (0, per + 3), (13, 2 * per + 5), (13, 4 * per + 7), (31, 5 * per + 11), (31, 7 * per + 1)]
+            enc_sd = {k: v.detach().cpu() for k, v in m.u_net.encoder.state_dict().items()}
+            sd = {k: v.detach().cpu() for k, v in m.u_net.own_state_dict().items()}
+            worst = 0.0
+            for bb in sorted({p[0] for p in pairs}):
+                ns = [n for (x, n) in pairs if x == bb]
+                ref_feat = R.encode_image(enc_sd, b["reference"][bb:bb + 1].cpu())
+                want = R.generate_templates(sd, ref_feat, b["all_relativeR"][bb:bb + 1, ns].cpu())
+                s_want = R.similarity_scores(q_feat[bb:bb + 1].cpu(), want)
+                worst = max(worst, float(((sim1[bb, ns].cpu() - s_want[0]).abs() / s_want[0].abs()).max()))
+            out["oracle_pairs"], out["oracle_err"] = pairs, worst
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total,cdt,bank_dtype", [(4096, "bf16", "bf16"), (8192, "f16", "f16")])
+def test_whole_configs_3_and_4_eight_ranks(gpu, n_total, cdt, bank_dtype):
+    """BASELINE configs[3] (batch 32 x 4096 templates sharded 8-way, bf16) and configs[4] (fp16 embeddings, 8192-template bank,
+    8 ranks) WHOLE: eight gloo ranks share this GPU (RCCL needs one device per rank; the 8-GPU run is the driver's).
+    (i) every rank ends up with the same gathered (32, N) similarity and top-5, bit-identical to the unsharded call;
+    (ii) six (b, n) scores from the shards of six different ranks match the CPU oracle; (iii) an exact copy of each query's
+    embedding planted in the LAST rank's shard scores -0.0 and wins on every rank."""
+    ws = 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29900 + os.getpid() % 1000
+    mp.spawn(_whole_config_worker, args=(ws, port, n_total, cdt, bank_dtype, ret), nprocs=ws, join=True)
+    r0 = ret[0]
+    plant = n_total - 7
+    for r in range(ws):
+        o = ret[r]
+        assert o["shape"] == (32, n_total // ws, 8, 32, 32) and o["range"] == (r * n_total // ws, (r + 1) * n_total // ws)
+        assert o["sim"].shape == (32, n_total) and torch.equal(o["sim"], r0["sim"]) and torch.equal(o["idx"], r0["idx"])
+    assert torch.equal(r0["sim"], r0["sim1"]) and torch.equal(r0["idx"], r0["idx1"])                       # (i)
+    print(f"{n_total} templates x 32 queries over 8 ranks ({cdt} compute, {bank_dtype} bank): oracle spot check on {r0['oracle_pairs']}: "
+          f"score rel err {r0['oracle_err']:.3e}")
+    assert r0["oracle_err"] < (5e-2 if cdt == "bf16" else 8e-3)                                            # (ii)
+    assert bool((r0["idx"][:, 0] == plant).all()) and bool((r0["sim"][:, plant] == 0).all())               # (iii)
+    assert bool(torch.signbit(r0["sim"][:, plant]).all())                                                  # ... exactly -0.0
+    assert bool(torch.isfinite(r0["sim"]).all())
+
+
+def test_geodesic_metric_vs_reference_run_on_device(gpu):
+    """Row f2 on the poses' device against outputs of the reference's own loss.py (tests/golden/metric_ref.npz,
+    make_golden_f2f3.py): all three symmetry branches, top-1 and top-k forms, CUDA float64 arithmetic."""
+    from tests.test_host_logic import _check_metric_against_reference
+    _check_metric_against_reference("cuda")
+
+
+def test_crop_warp_on_device_with_reference_geometry(gpu):
+    """Row f3, image side: the four source points the REFERENCE's crop_frame hands to cv2.getPerspectiveTransform (recorded in
+    tests/golden/poses_ref.npz) define the map; the device warp of a coordinate-ramp image must return, at every output pixel
+    whose source lies inside the frame, the source coordinates that map prescribes (bilinear interpolation of a linear
+    function is exact).  OpenCV's fixed-point interpolation itself stays unpinned (cv2 is not installed here)."""
+    import numpy as np
+    from nope_amd import dataset as D
+    w = np.load(os.path.join(ROOT, "tests", "golden", "poses_ref.npz"))
+    H = W = 512
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    ramp = torch.stack([xs, ys], -1).cuda()                                    # (H, W, 2): channel 0 = x, channel 1 = y
+    for row, src, dst in zip(w["crop/in"], w["crop/src"], w["crop/dst"]):
+        pose, inplane, vb, size = row[:16].reshape(4, 4), bool(row[16]), float(row[17]), int(row[18])
+        M = D.get_perspective_transform(src, dst)
+        out = D.crop_frame(ramp, None, w["perspective/K"], pose, size, keep_inplane=inplane, virtual_bbox_size=vb).cpu().numpy()
+        Minv = np.linalg.inv(M)
+        uu, vv = np.meshgrid(np.arange(size), np.arange(size))
+        h = np.stack([uu, vv, np.ones_like(uu)], -1).astype(np.float64) @ Minv.T
+        sx, sy = h[..., 0] / h[..., 2], h[..., 1] / h[..., 2]
+        inside = (sx >= 0) & (sx <= W - 1) & (sy >= 0) & (sy <= H - 1)
+        assert inside.mean() > 0.2
+        assert np.abs(out[0][inside] - sx[inside]).max() < 2e-2 and np.abs(out[1][inside] - sy[inside]).max() < 2e-2
+
+
 def test_geodesic_metric_on_device(gpu):
     """GeodesicError with all three symmetry branches (loss.py:14-115) evaluated on CUDA tensors -- the
     step right behind the hot path, on the poses' device -- equals the host evaluation (float64 branch arithmetic)."""
