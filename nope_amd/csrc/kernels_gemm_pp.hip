@@ -459,6 +459,39 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         a_first = c0 < p.C1;                                       // wave-uniform: a chunk lies inside one source
         a_soff = (unsigned)(a_first ? c0 : c0 - p.C1) * ES;
     };
+    // ---- NOPE_BF16X3: the A stage is split into (hi, lo) bf16 IN LDS, once per element.  A resident stage is read by nine taps and
+    // two waves per row: splitting at the fragment reads (Tile<f32s_t>::prep_step, what the other conv kernels do) costs 96 VALU
+    // per wave and K step, and every VALU instruction of the loading group takes an issue slot from the other group's MFMAs
+    // (measured: 3.3 x the bf16 kernel's time for 3 x its MFMAs).  Instead the wave that issued a piece rewrites it after it
+    // has landed (its own vmcnt(0) at the end of the COMPUTE phase): lane l holds 4 channels (its 16-byte slot); with the
+    // neighbouring slot they form one group of 8 channels whose two slots become [hi x 8 | lo x 8] -- the layout of the packed
+    // weights, so the fragment reads need no conversion at all.  A lane writes its 4 hi values into half of the group's first
+    // logical slot and its 4 lo values into half of the second (two ds_write_b64); the wave's single ds_read_b128 has returned
+    // for all lanes before either write is issued (same wave, in-order LDS queue + data dependence), other waves read the piece
+    // only behind the barrier that ends this LOAD phase.  Zero rows and out-of-range rows are zeros either way.
+    constexpr bool A_SPLIT_LDS = TL::RAW > 1;
+    const int cv_half = (lslot ^ swz_of<RB>(r0)) & 1;                         // which half of its 8-channel group this lane's slot holds
+    auto convert_piece = [&](int i, int stage) __attribute__((always_inline)) {
+        if constexpr (A_SPLIT_LDS) {
+            unsigned char* row = a_dst + stage * A_STAGE + i * 8192 + rsub * RB;
+            const u32x4 v = ld16(row + lslot * 16);
+            unsigned hi[2], lo[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const unsigned u0 = v[2 * e], u1 = v[2 * e + 1];
+                const float x0 = __builtin_bit_cast(float, u0), x1 = __builtin_bit_cast(float, u1);
+                const unsigned h = cvt_pk_bf16(x0, x1);
+                hi[e] = h;
+                lo[e] = cvt_pk_bf16(x0 - __builtin_bit_cast(float, h << 16), x1 - __builtin_bit_cast(float, h & 0xffff0000u));
+            }
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            // (every lane's read precedes every lane's write: one wave instruction each on the hardware; the wave barrier pins the
+            //  compiler's order and is the rendezvous point of tests/hipemu, whose lanes run one after the other)
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<u32x2*>(row + ((lslot ^ cv_half) << 4) + 8 * cv_half) = u32x2{hi[0], hi[1]};
+            *reinterpret_cast<u32x2*>(row + ((lslot ^ cv_half ^ 1) << 4) + 8 * cv_half) = u32x2{lo[0], lo[1]};
+        }
+    };
     // ---- B pieces: 24 rows per wave (group 1: panel rows 0..95, group 0: rows 96..191), as in conv_gemm_pp_kernel
     const int brow0 = 96 * (1 - grp) + 24 * wl;
     unsigned b_off[3];
@@ -548,6 +581,13 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         NOPE_OPAQUE_VGPR(frow);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
+            // (bf16x3: the piece this wave issued in the previous step has landed -- its vmcnt(0) closed that step -- split it in place,
+            //  first thing in the phase, while no fragment register is live; the stage is first read three or more steps from
+            //  now, behind this step's barrier.  The LOAD phase has the slack: it is the shorter one with 36 MFMAs per step.)
+            if (A_SPLIT_LDS && dma_on && tap >= 1 && tap <= 6 && !last && (tap - 1 < 4 || (tap - 1 == 4 ? a_has4 : a_has5))) {
+                convert_piece(tap - 1, par ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // ---- LOAD: DMA pieces first (they fly for the rest of this phase and the whole next one), then the fragments
             if (dma_on) {
                 if (tap < 6 && !last && (tap < 4 || (tap == 4 ? a_has4 : a_has5))) piece_a(tap, par ^ 1);
@@ -573,10 +613,6 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                 for (int i = 0; i < TL::MT; ++i) af[kk / RAW][kk % RAW][i] = ld16(lds + (fa[i] ^ (raw_slot<T>(kk) << 4)) + par * A_STAGE);
 #pragma unroll
                 for (int j = 0; j < TL::NTL; ++j) bfr[kk / RAW][kk % RAW][j] = ld16(lds + fbk[kk] + ((tap % 3) * B_STAGE + j * TL::TM * RB));
-            }
-            if constexpr (RAW > 1) {                       // (bf16x3: hi / lo split of the f32 A values, in the LOAD phase)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) TL::prep_step(af[ks]);
             }
             __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);     // my reads of this step are done: after the barrier the other group may overwrite them
             stamp();
@@ -615,6 +651,11 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         }
     };
     for (int it = 0; it < iters; ++it) {
+        if (A_SPLIT_LDS && dma_on) {                               // the prologue's A pieces have landed (vmcnt(0) above / in the epilogue's drain)
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (i < 4 || (i == 4 ? a_has4 : a_has5)) convert_piece(i, 0);
+        }
         __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);                 // zero rows written / my panel reads of the previous tile done
         __builtin_amdgcn_s_barrier();                              // every wave's prologue pieces have landed (waited by their issuers)
         __builtin_amdgcn_sched_barrier(0);

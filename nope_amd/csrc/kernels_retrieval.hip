@@ -40,6 +40,8 @@ template <bool NTL, int W> __device__ __forceinline__ RawVec<W> ld_stream(const 
     return r;
 }
 
+template <bool V> struct BoolTag { static constexpr bool value = V; };
+
 template <class T, int W> __device__ __forceinline__ void unpack_words(const RawVec<W>& raw, float* t) {
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -76,11 +78,21 @@ __device__ __forceinline__ void accum_quartic(const RawVec<W>& raw, const float*
 // 256 % P == 0.  hpi = 256 / P hypotheses are scored per iteration (thread -> (sub-hypothesis, pixel-vector)).
 // LV = 16 bytes' worth.  (LV = 4 for the 16-bit banks -- 8-byte loads, half the registers, five resident workgroups per CU
 // instead of three -- is kept as tuning variant 8: measured 4-7 % slower, 8-byte loads do not reach the 16-byte rate.)
-template <class T, int CMAX, bool NTL, int LV>
+// CEXACT: C == CMAX (the shipped descriptor size, 8): the per-channel guards fold away (40 branches of the general form).
+// The per-pixel sqrt is the hardware v_sqrt_f32 (1 ulp; sqrt(0) = 0 exactly, so a planted match still scores -0.0): the
+// correctly rounded sqrtf expands to ~12 instructions per pixel, a third of the 16-bit path's VALU work, for a 1e-9
+// relative change of a 1024-term sum.
+// QLDS (16-bit banks, C * HW <= 8192): the query tile of the sample sits in LDS (32 KiB, stored as [channel][4-pixel quad
+// parity][lane] so that both 16-byte reads of a lane's 8 pixels are stride-16 across lanes: conflict-free) instead of 64
+// registers per lane.  A 16-bit hypothesis needs twice the VALU work per byte of an f32 one, and with the query in registers
+// the kernel holds 142-200 VGPRs (2-3 waves per SIMD); with the tile in LDS ~80 (6 waves), for 32 KiB of LDS reads per
+// 16 KiB of bank -- a seventh of the LDS bandwidth at the HBM rate.
+template <class T, int CMAX, bool NTL, int LV, bool CEXACT, bool QLDS = false>
 __global__ __launch_bounds__(NT) void sim_reg_kernel(const float* __restrict__ q, const T* __restrict__ bank, float* __restrict__ scores,
                                                      int N, int C, int HW, long long bank_stride_b, int score_ld, int nsplit) {
     constexpr int W = LV * (int)sizeof(T) / 4;
     __shared__ float s_part[2][NT / 64];
+    __shared__ __attribute__((aligned(16))) float s_q[QLDS ? 8192 : 4];
     const int P = HW / LV;
     const int hpi = NT / P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -92,44 +104,75 @@ __global__ __launch_bounds__(NT) void sim_reg_kernel(const float* __restrict__ q
     const int groups = (N + hpi - 1) / hpi;
     const int g0 = split, g1 = groups, gs = nsplit;
 
-    float qr[CMAX][LV];
+    if constexpr (QLDS) {
+        // element (c, pixel p) -> s_q[c * HW + ((p >> 2) & 1) * (HW / 2) + (p >> 3) * 4 + (p & 3)]   (LV == 8)
+        const float* qb = q + (size_t)b * C * HW;
+        for (int i = tid * 4; i < C * HW; i += NT * 4) {
+            const int c = i / HW, p = i - c * HW;
+            *reinterpret_cast<f32x4*>(&s_q[c * HW + ((p >> 2) & 1) * (HW / 2) + (p >> 3) * 4]) = *reinterpret_cast<const f32x4*>(qb + i);
+        }
+        __syncthreads();
+    }
+    float qr[QLDS ? 1 : CMAX][QLDS ? 1 : LV];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
-        if (c < C) {
+        if (!QLDS && (CEXACT || c < C)) {
             const float* qp = q + ((size_t)b * C + c) * HW + (size_t)pv * LV;
 #pragma unroll
             for (int v4 = 0; v4 < LV / 4; ++v4) {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(qp + 4 * v4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qr[c][4 * v4 + e] = x[e];
+                for (int e = 0; e < 4; ++e) qr[QLDS ? 0 : c][QLDS ? 0 : 4 * v4 + e] = x[e];
             }
         }
     }
     const T* bb = bank + (size_t)b * bank_stride_b;
     const size_t hyp_elems = (size_t)C * HW;
     int buf = 0;
-    // Software pipeline, depth 1: the C plane loads of group g+1 are issued before group g is
-    // reduced, so every workgroup keeps C loads per lane in flight across the reduction + barrier
-    // (without it the memory pipe of a workgroup drains once per hypothesis).
-    RawVec<W> rawA[CMAX], rawB[CMAX];
-    auto fetch = [&](RawVec<W> (&raw)[CMAX], int g) {
+    // Software pipeline, depth 1, in ONE register set: channel plane c of group g + 1 is loaded into raw[c] right after plane c
+    // of group g has been consumed, so every lane keeps C loads in flight across the reduction + barrier (without the
+    // prefetch the memory pipe of a workgroup drains once per hypothesis) and the kernel needs 32 registers less than with
+    // two alternating sets: four resident waves per SIMD for the 16-bit banks instead of three.
+    RawVec<W> raw[CMAX];
+    auto plane_ptr = [&](int g) {
         const int n = g * hpi + sub;
-        const T* tp = bb + (size_t)(n < N ? n : 0) * hyp_elems + (size_t)pv * LV;
+        return bb + (size_t)(n < N ? n : 0) * hyp_elems + (size_t)pv * LV;
+    };
+    if (g0 < g1) {
+        const T* tp = plane_ptr(g0);
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
-            if (c < C) raw[c] = ld_stream<NTL, W>(tp + (size_t)c * HW);
-    };
-    auto reduce = [&](const RawVec<W> (&raw)[CMAX], int g) {
+            if (CEXACT || c < C) raw[c] = ld_stream<NTL, W>(tp + (size_t)c * HW);
+    }
+    // (the last group is peeled: a per-plane `if (more)` around the prefetch makes the compiler keep a second register set)
+    auto body = [&](int g, auto more_tag) __attribute__((always_inline)) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        const T* tn = plane_ptr(MORE ? g + gs : g);
         const int n = g * hpi + sub;
         float acc[LV];
 #pragma unroll
         for (int e = 0; e < LV; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
-            if (c < C) accum_quartic<T, LV, W>(raw[c], qr[c], acc);
+            if (CEXACT || c < C) {
+                if constexpr (QLDS) {
+                    float qv[LV];
+#pragma unroll
+                    for (int h = 0; h < LV / 4; ++h) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(&s_q[c * HW + h * (HW / 2) + pv * 4]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) qv[4 * h + e] = x[e];
+                    }
+                    accum_quartic<T, LV, W>(raw[c], qv, acc);
+                } else {
+                    accum_quartic<T, LV, W>(raw[c], qr[c], acc);
+                }
+                if constexpr (MORE) raw[c] = ld_stream<NTL, W>(tn + (size_t)c * HW);
+                __builtin_amdgcn_sched_barrier(0);      // (one plane at a time: unpacking all C planes ahead costs 30-90 VGPRs)
+            }
         float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < LV; ++e) s += sqrtf(acc[e]);
+        for (int e = 0; e < LV; ++e) s += __builtin_amdgcn_sqrtf(acc[e]);
         // reduce over the P threads of this sub-hypothesis
         if (P >= 64) {
             s = wave_sum(s);
@@ -147,15 +190,9 @@ __global__ __launch_bounds__(NT) void sim_reg_kernel(const float* __restrict__ q
             if (pv == 0 && n < N) scores[(size_t)b * score_ld + n] = -s;
         }
     };
-    if (g0 < g1) fetch(rawA, g0);
-    for (int g = g0; g < g1; g += 2 * gs) {
-        if (g + gs < g1) fetch(rawB, g + gs);
-        reduce(rawA, g);
-        if (g + gs < g1) {
-            if (g + 2 * gs < g1) fetch(rawA, g + 2 * gs);
-            reduce(rawB, g + gs);
-        }
-    }
+    int g = g0;
+    for (; g + gs < g1; g += gs) body(g, BoolTag<true>{});
+    if (g < g1) body(g, BoolTag<false>{});
 }
 
 // Generic shapes: one hypothesis per iteration, query tile in LDS (C*HW*4 <= 64 KiB).
@@ -253,6 +290,7 @@ int launch_similarity(const float* q, const void* bank, int bank_dt, float* scor
     const int vec = bank_dt == NOPE_F32 ? 4 : 8;
     if (HW % vec) return NOPE_ERR_UNSUPPORTED;
     static const int variant = getenv("NOPE_SIM_VARIANT") ? atoi(getenv("NOPE_SIM_VARIANT")) : 1;    // tuning: 1 = non-temporal bank loads (0.69 -> 0.75-0.82 of HBM peak), 2 = one residency round of long workgroups, 8 = 4 pixels per lane for 16-bit banks
+    const bool qlds = !(variant & 16) && (long long)C * HW <= 8192 && HW % 8 == 0;   // tuning: 16 = query tile in registers for the 16-bit banks too
     const int lv = (bank_dt != NOPE_F32 && (variant & 8) && C <= 8 && HW % 4 == 0 && HW / 4 <= NT) ? 4 : vec;
     const int P = HW / lv;
     const bool reg_ok = (P <= NT) && (NT % P == 0) && (C <= 16);
@@ -265,27 +303,29 @@ int launch_similarity(const float* q, const void* bank, int bank_dt, float* scor
         // sizes the grid to exactly one round, CUs x resident workgroups: bf16 +3 %, f32 -9 %, fp16 -6 %, profiles/r02i_sim_bench.txt)
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-#define NOPE_SIM_LAUNCH(T, CM, NTLOAD, LV)                                                                                         \
+#define NOPE_SIM_LAUNCH(T, CM, NTLOAD, LV, EX) NOPE_SIM_LAUNCH_Q(T, CM, NTLOAD, LV, EX, false)
+#define NOPE_SIM_LAUNCH_Q(T, CM, NTLOAD, LV, EX, QL)                                                                                       \
         do {                                                                                                                       \
             static int occ = 0;        /* (per instantiation; a property of the kernel's register count) */                       \
-            if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sim_reg_kernel<T, CM, NTLOAD, LV>, NT, 0) != hipSuccess || occ < 1)) occ = 2; \
+            if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sim_reg_kernel<T, CM, NTLOAD, LV, EX, QL>, NT, 0) != hipSuccess || occ < 1)) occ = 2; \
             nsplit = ((variant & 2) ? cus * occ : 4096) / B;                                                                       \
             if (nsplit > groups) nsplit = groups;                                                                                  \
             if (nsplit < 1) nsplit = 1;                                                                                            \
-            hipLaunchKernelGGL((sim_reg_kernel<T, CM, NTLOAD, LV>), dim3((unsigned)((long long)B * nsplit)), dim3(NT), 0, s, q, (const T*)bank, scores, \
+            hipLaunchKernelGGL((sim_reg_kernel<T, CM, NTLOAD, LV, EX, QL>), dim3((unsigned)((long long)B * nsplit)), dim3(NT), 0, s, q, (const T*)bank, scores, \
                                N, C, HW, bank_stride_b, score_ld, nsplit);                                                         \
         } while (0)
 #define NOPE_SIM_T(T, LVD)                                                                                              \
         do {                                                                                                            \
-            if (lv != LVD) { if (variant & 1) NOPE_SIM_LAUNCH(T, 8, true, 4); else NOPE_SIM_LAUNCH(T, 8, false, 4); }    \
-            else if (variant & 1) { if (C <= 8) NOPE_SIM_LAUNCH(T, 8, true, LVD); else NOPE_SIM_LAUNCH(T, 16, true, LVD); } \
-            else { if (C <= 8) NOPE_SIM_LAUNCH(T, 8, false, LVD); else NOPE_SIM_LAUNCH(T, 16, false, LVD); }             \
+            if (lv != LVD) { if (variant & 1) NOPE_SIM_LAUNCH(T, 8, true, 4, false); else NOPE_SIM_LAUNCH(T, 8, false, 4, false); }    \
+            else if (variant & 1) { if (C == 8 && LVD == 8 && qlds) NOPE_SIM_LAUNCH_Q(T, 8, true, LVD, true, (LVD == 8)); else if (C == 8) NOPE_SIM_LAUNCH(T, 8, true, LVD, true); else if (C < 8) NOPE_SIM_LAUNCH(T, 8, true, LVD, false); else NOPE_SIM_LAUNCH(T, 16, true, LVD, false); } \
+            else { if (C <= 8) NOPE_SIM_LAUNCH(T, 8, false, LVD, false); else NOPE_SIM_LAUNCH(T, 16, false, LVD, false); }             \
         } while (0)
         if (bank_dt == NOPE_F32) NOPE_SIM_T(float, 4);
         else if (bank_dt == NOPE_BF16) NOPE_SIM_T(bf16_t, 8);
         else NOPE_SIM_T(f16_t, 8);
 #undef NOPE_SIM_T
 #undef NOPE_SIM_LAUNCH
+#undef NOPE_SIM_LAUNCH_Q
     } else {
         if ((size_t)C * HW > 16384) return NOPE_ERR_UNSUPPORTED;
         nsplit = cdiv(4096, B);
