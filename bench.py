@@ -9,8 +9,9 @@ One "step" = one pass of the hot path over one batch, inputs resident in HBM:
     retrieval(query, bank)                         encoder(query) + scoring + top-5
 issued as ONE call, PoseConditional.generate_and_retrieve (same values; the query's encoder pass runs on a second HIP
 stream underneath the reference encoder and the first U-Net kernels); --two-calls times the literal two-call sequence.
-Workload at N=1: BASELINE.json configs[1] -- one 256x256 query against 512 viewpoint templates,
-bf16 (bf16 U-Net compute with f32 accumulation/statistics, bf16 bank).  For N>1 the template
+Workload at N=1: BASELINE.json configs[1] -- one 256x256 query against 512 viewpoint templates, 16-bit (f16 U-Net compute with
+f32 accumulation / statistics and an f16 bank by default; --dtype bf16 is the same kernels on bfloat16: same MFMA rate, same
+bytes, 8x the score error -- both, and the two modes inside the 1e-4 tolerance, are timed in the `parity` record).  For N>1 the template
 axis is sharded (weak scaling: 512 templates per GPU, N_total = 512*N) and the per-rank scores
 are all-gathered over RCCL before the top-5, as BASELINE configs[3]/[4] describe.
 
@@ -278,9 +279,11 @@ def main():
                     help="nccl = RCCL, one rank per GPU (production); gloo = ranks may share a GPU (the 8-rank tests on a 1-GPU box)")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "bf16x3", "f32"],
-                    help="compute mode: bf16 (BASELINE configs[1]) | f16 | bf16x3 (f32 storage, split-precision MFMA: the fast mode inside the "
-                         "1e-4 score tolerance) | f32 (exact-f32 MFMA, the parity mode)")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "bf16x3", "f32"],
+                    help="compute mode.  f16 (default) and bf16: 16-bit storage + 16-bit MFMA at the same rate and bytes -- BASELINE configs[1] "
+                         "names bf16; f16 carries 3 more significand bits and is the 16-bit mode whose best template equals the f32 mode's for "
+                         "32 of 32 queries at configs[2] (bf16: 31), so it is the default.  bf16x3: f32 storage, split-precision MFMA -- the fast "
+                         "mode inside the 1e-4 score tolerance.  f32: exact-f32 MFMA, the parity mode.  All four are timed in the `parity` record.")
     ap.add_argument("--bank-dtype", default=None, choices=["bf16", "f32", "f16"], help="template-bank storage (default: --dtype; f16 for --scoring-only)")
     ap.add_argument("--scoring-only", action="store_true", help="time scoring + top-5 on a resident bank (SURVEY 8(d) metric (i))")
     ap.add_argument("--skip-extras", action="store_true", help="skip roofline / cpu_baseline legs")

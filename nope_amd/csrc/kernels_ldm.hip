@@ -298,35 +298,29 @@ unsigned grid_for_ll(long long n) {
 }  // namespace
 
 int launch_layernorm(int dt, const void* x, void* y, const float* gamma, const float* beta, long long M, int C, float eps, hipStream_t s) {
-    const int vec = dt == NOPE_F32 ? 4 : 8;
+    const int vec = dt_vec(dt);
     if (!x || !y || !gamma || !beta || M <= 0 || C <= 0 || C % vec) return NOPE_ERR_ARG;
     const dim3 grid((unsigned)((M + NT / 64 - 1) / (NT / 64)));
-    if (dt == NOPE_F32) hipLaunchKernelGGL((layernorm_kernel<float>), grid, dim3(NT), 0, s, (const float*)x, (float*)y, gamma, beta, M, C, eps);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t>), grid, dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)y, gamma, beta, M, C, eps);
-    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((layernorm_kernel<T>), grid, dim3(NT), 0, s, (const T*)x, (T*)y, gamma, beta, M, C, eps));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }
 
 int launch_geglu(int dt, const void* in, void* out, long long M, int D, hipStream_t s) {
-    const int vec = dt == NOPE_F32 ? 4 : 8;
+    const int vec = dt_vec(dt);
     if (!in || !out || M <= 0 || D <= 0 || D % vec) return NOPE_ERR_ARG;
     const dim3 grid(grid_for_ll(M * (D / vec)));
-    if (dt == NOPE_F32) hipLaunchKernelGGL((geglu_kernel<float>), grid, dim3(NT), 0, s, (const float*)in, (float*)out, M, D);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((geglu_kernel<bf16_t>), grid, dim3(NT), 0, s, (const bf16_t*)in, (bf16_t*)out, M, D);
-    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((geglu_kernel<T>), grid, dim3(NT), 0, s, (const T*)in, (T*)out, M, D));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }
 
 int launch_add_rowvec(int dt, const void* x, void* y, const float* u, long long M, int tokens, int C, hipStream_t s, int u_stride) {
     if (u_stride <= 0) u_stride = C;
-    const int vec = dt == NOPE_F32 ? 4 : 8;
+    const int vec = dt_vec(dt);
     if (!x || !y || !u || M <= 0 || tokens <= 0 || C % vec) return NOPE_ERR_ARG;
     const dim3 grid(grid_for_ll(M * (C / vec)));
-    if (dt == NOPE_F32) hipLaunchKernelGGL((add_rowvec_kernel<float>), grid, dim3(NT), 0, s, (const float*)x, (float*)y, u, M, tokens, C, u_stride);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((add_rowvec_kernel<bf16_t>), grid, dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)y, u, M, tokens, C, u_stride);
-    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((add_rowvec_kernel<T>), grid, dim3(NT), 0, s, (const T*)x, (T*)y, u, M, tokens, C, u_stride));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }
@@ -341,20 +335,16 @@ int launch_token_attention(int dt, const void* qkv, void* out, int nsmp, int N, 
     if (mfma) {
         const dim3 g2((unsigned)cdiv(N, MQ), (unsigned)(C / AD), (unsigned)nsmp);
         hipLaunchKernelGGL(token_attn_mfma_kernel, g2, dim3(NT), 0, s, (const bf16_t*)qkv, (bf16_t*)out, N, C, scale * 1.4426950408889634f);
-    } else if (dt == NOPE_F32) hipLaunchKernelGGL((token_attn_kernel<float>), grid, dim3(NT), 0, s, (const float*)qkv, (float*)out, N, C, scale);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((token_attn_kernel<bf16_t>), grid, dim3(NT), 0, s, (const bf16_t*)qkv, (bf16_t*)out, N, C, scale);
-    else return NOPE_ERR_UNSUPPORTED;
+    } else NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((token_attn_kernel<T>), grid, dim3(NT), 0, s, (const T*)qkv, (T*)out, N, C, scale));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }
 
 int launch_copy_cols(int dt, const void* x, void* y, long long M, int C, int C2, int off, hipStream_t s) {
-    const int vec = dt == NOPE_F32 ? 4 : 8;
+    const int vec = dt_vec(dt);
     if (!x || !y || M <= 0 || C % vec || C2 % vec || off % vec || off + C > C2) return NOPE_ERR_ARG;
     const dim3 grid(grid_for_ll(M * (C / vec)));
-    if (dt == NOPE_F32) hipLaunchKernelGGL((copy_cols_kernel<float>), grid, dim3(NT), 0, s, (const float*)x, (float*)y, M, C, C2, off);
-    else if (dt == NOPE_BF16) hipLaunchKernelGGL((copy_cols_kernel<bf16_t>), grid, dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)y, M, C, C2, off);
-    else return NOPE_ERR_UNSUPPORTED;
+    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((copy_cols_kernel<T>), grid, dim3(NT), 0, s, (const T*)x, (T*)y, M, C, C2, off));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

@@ -22,14 +22,15 @@ template <> __device__ __forceinline__ void st_w<f32s_t>(f32s_t* out, size_t i, 
 }
 
 // (n, C, HW) f32 NCHW -> [n][HW][C] T.  C is small (8 latent channels) at this boundary.
+// (Csrc < C: the source has fewer channels; channels Csrc .. C-1 of the output are zeros -- inputs padded to a whole 16-byte vector)
 template <class T>
-__global__ __launch_bounds__(NT) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int C, int HW, size_t total) {
+__global__ __launch_bounds__(NT) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int C, int HW, size_t total, int Csrc) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
         const int c = (int)(i % C);
         const size_t t = i / C;
         const int p = (int)(t % HW);
         const size_t b = t / HW;
-        Elt<T>::st(y + i, x[(b * C + c) * HW + p]);
+        Elt<T>::st(y + i, c < Csrc ? x[(b * Csrc + c) * HW + p] : 0.f);
     }
 }
 
@@ -51,16 +52,16 @@ __global__ __launch_bounds__(NT) void nhwc_to_nchw_kernel(const T* __restrict__ 
 template <class T>
 __global__ __launch_bounds__(NT) void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ out, int Cin, int ntaps, int mode,
                                                          size_t total, const float* __restrict__ cin_scale,
-                                                         const float* __restrict__ cout_scale) {
+                                                         const float* __restrict__ cout_scale, int Csrc) {
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
         const int c = (int)(i % Cin);
         const size_t t = i / Cin;
         const int tap = (int)(t % ntaps);
         const size_t co = t / ntaps;
         size_t src;
-        if (mode == NOPE_CONV_DOWN2) src = co * ((size_t)Cin * 4) + (size_t)c * 4 + tap;
-        else src = (co * Cin + c) * ntaps + tap;
-        float v = w[src];
+        if (mode == NOPE_CONV_DOWN2) src = co * ((size_t)Csrc * 4) + (size_t)c * 4 + tap;
+        else src = (co * Csrc + c) * ntaps + tap;
+        float v = c < Csrc ? w[src] : 0.f;         // (Csrc < Cin: zero weights for the channels the input was padded with)
         if (cin_scale) v *= cin_scale[c];      // per-input-channel scale (PreNorm gamma)
         if (cout_scale) v *= cout_scale[co];   // per-output-channel scale (folded eval-mode BatchNorm)
         st_w<T>(out, i, Cin, v);
@@ -159,10 +160,11 @@ inline unsigned grid_for(size_t n) {
 
 }  // namespace
 
-int launch_nchw_to_nhwc(int dt, const float* x, void* y, int n, int C, int HW, hipStream_t s) {
-    if (!x || !y || n <= 0 || C <= 0 || HW <= 0) return NOPE_ERR_ARG;
+int launch_nchw_to_nhwc(int dt, const float* x, void* y, int n, int C, int HW, hipStream_t s, int C_src) {
+    if (!x || !y || n <= 0 || C <= 0 || HW <= 0 || C_src < 0 || C_src > C) return NOPE_ERR_ARG;
     const size_t total = (size_t)n * C * HW;
-    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(total)), dim3(NT), 0, s, x, (T*)y, C, HW, total));
+    const int cs = C_src ? C_src : C;
+    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(total)), dim3(NT), 0, s, x, (T*)y, C, HW, total, cs));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }
@@ -176,8 +178,10 @@ int launch_nhwc_to_nchw_f32(int dt, const void* x, float* y, int n, int C, int H
 }
 
 int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s, const float* cin_scale,
-                       const float* cout_scale) {
-    if (!w || !out || Cout <= 0 || Cin <= 0 || ntaps <= 0) return NOPE_ERR_ARG;
+                       const float* cout_scale, int Cin_src) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || ntaps <= 0 || Cin_src < 0 || Cin_src > Cin) return NOPE_ERR_ARG;
+    if (Cin_src && Cin_src != Cin && (mode == NOPE_CONV_UP2P || cin_scale)) return NOPE_ERR_ARG;
+    const int csrc = Cin_src ? Cin_src : Cin;
     if (mode == NOPE_CONV_DOWN2 && ntaps != 4) return NOPE_ERR_ARG;
     if (dt == NOPE_BF16X3 && Cin % 8) return NOPE_ERR_UNSUPPORTED;      // (hi, lo) groups of 8 channels
     if (mode == NOPE_CONV_UP2P && ntaps == 16) {     // source is a ConvTranspose2d(4, 2, 1) weight
@@ -195,7 +199,7 @@ int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int
         return NOPE_OK;
     }
     const size_t total = (size_t)Cout * ntaps * Cin;
-    NOPE_DISPATCH_W(dt, T, hipLaunchKernelGGL((pack_conv_w_kernel<T>), dim3(grid_for(total)), dim3(NT), 0, s, w, (T*)out, Cin, ntaps, mode, total, cin_scale, cout_scale));
+    NOPE_DISPATCH_W(dt, T, hipLaunchKernelGGL((pack_conv_w_kernel<T>), dim3(grid_for(total)), dim3(NT), 0, s, w, (T*)out, Cin, ntaps, mode, total, cin_scale, cout_scale, csrc));
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

@@ -82,11 +82,10 @@ __device__ __forceinline__ void accum_quartic(const RawVec<W>& raw, const float*
 // The per-pixel sqrt is the hardware v_sqrt_f32 (1 ulp; sqrt(0) = 0 exactly, so a planted match still scores -0.0): the
 // correctly rounded sqrtf expands to ~12 instructions per pixel, a third of the 16-bit path's VALU work, for a 1e-9
 // relative change of a 1024-term sum.
-// QLDS (16-bit banks, C * HW <= 8192): the query tile of the sample sits in LDS (32 KiB, stored as [channel][4-pixel quad
-// parity][lane] so that both 16-byte reads of a lane's 8 pixels are stride-16 across lanes: conflict-free) instead of 64
-// registers per lane.  A 16-bit hypothesis needs twice the VALU work per byte of an f32 one, and with the query in registers
-// the kernel holds 142-200 VGPRs (2-3 waves per SIMD); with the tile in LDS ~80 (6 waves), for 32 KiB of LDS reads per
-// 16 KiB of bank -- a seventh of the LDS bandwidth at the HBM rate.
+// QLDS (tuning variant 16; 16-bit banks, C * HW <= 8192): the query tile of the sample sits in LDS (32 KiB, stored as
+// [channel][4-pixel quad parity][lane] so that both 16-byte reads of a lane's 8 pixels are stride-16 across lanes:
+// conflict-free) instead of 64 registers per lane: 91-115 VGPRs instead of 124-150.  Measured slower than the register tile
+// (the extra 16 LDS reads per hypothesis and lane cost more than the occupancy buys): not the default.
 template <class T, int CMAX, bool NTL, int LV, bool CEXACT, bool QLDS = false>
 __global__ __launch_bounds__(NT) void sim_reg_kernel(const float* __restrict__ q, const T* __restrict__ bank, float* __restrict__ scores,
                                                      int N, int C, int HW, long long bank_stride_b, int score_ld, int nsplit) {
@@ -290,7 +289,12 @@ int launch_similarity(const float* q, const void* bank, int bank_dt, float* scor
     const int vec = bank_dt == NOPE_F32 ? 4 : 8;
     if (HW % vec) return NOPE_ERR_UNSUPPORTED;
     static const int variant = getenv("NOPE_SIM_VARIANT") ? atoi(getenv("NOPE_SIM_VARIANT")) : 1;    // tuning: 1 = non-temporal bank loads (0.69 -> 0.75-0.82 of HBM peak), 2 = one residency round of long workgroups, 8 = 4 pixels per lane for 16-bit banks
-    const bool qlds = !(variant & 16) && (long long)C * HW <= 8192 && HW % 8 == 0;   // tuning: 16 = query tile in registers for the 16-bit banks too
+    // tuning: 16 = query tile in LDS for the 16-bit banks (6 instead of 4 waves per SIMD; measured SLOWER than the register tile with the
+    // single-set pipeline: bf16 0.61 / 0.78 of peak at 32 x 512 / 32 x 2048 against 0.72 / 0.84, profiles/r03b_sim_bench.txt)
+    const bool qlds = (variant & 16) && (long long)C * HW <= 8192 && HW % 8 == 0;
+    // workgroups per sample: ~4096 in all, but at least NOPE_SIM_MINGROUPS template groups each (a workgroup's fixed cost is the 32 KiB
+    // query tile: with two groups per workgroup -- 32 x 512 templates -- it is a third of the workgroup's traffic)
+    static const int min_groups = getenv("NOPE_SIM_MINGROUPS") ? atoi(getenv("NOPE_SIM_MINGROUPS")) : 1;
     const int lv = (bank_dt != NOPE_F32 && (variant & 8) && C <= 8 && HW % 4 == 0 && HW / 4 <= NT) ? 4 : vec;
     const int P = HW / lv;
     const bool reg_ok = (P <= NT) && (NT % P == 0) && (C <= 16);
@@ -309,6 +313,7 @@ int launch_similarity(const float* q, const void* bank, int bank_dt, float* scor
             static int occ = 0;        /* (per instantiation; a property of the kernel's register count) */                       \
             if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sim_reg_kernel<T, CM, NTLOAD, LV, EX, QL>, NT, 0) != hipSuccess || occ < 1)) occ = 2; \
             nsplit = ((variant & 2) ? cus * occ : 4096) / B;                                                                       \
+            if (nsplit > groups / min_groups) nsplit = groups / min_groups;                                                        \
             if (nsplit > groups) nsplit = groups;                                                                                  \
             if (nsplit < 1) nsplit = 1;                                                                                            \
             hipLaunchKernelGGL((sim_reg_kernel<T, CM, NTLOAD, LV, EX, QL>), dim3((unsigned)((long long)B * nsplit)), dim3(NT), 0, s, q, (const T*)bank, scores, \

@@ -38,7 +38,8 @@ struct LBlock { bool has_res = false, has_st = false, has_resample = false; LRes
 
 struct nope_ldm {
     nope_ldm_config cfg;
-    int dt = NOPE_F32;
+    int dt = NOPE_F32;      // compute dtype (conv kernels, weight packing)
+    int sdt = NOPE_F32;     // storage dtype of the activations (every other kernel)
     std::vector<void*> allocs;
     LConv conv_in, conv_out;
     LNorm norm_out;
@@ -89,15 +90,18 @@ struct Loader {
         return p;
     }
     // conv (4-d weight) or linear (2-d weight) packed for the implicit-GEMM kernel
-    LConv conv(const std::string& pfx, int Cin, int Cout, int ksz, int mode, bool has_bias, bool linear = false) {
+    // (Cin_pad > Cin: the kernel sees Cin_pad input channels, the last ones zero -- the 4-channel latent of vae_cin_ldm.yaml padded
+    //  to one 16-byte vector of the 16-bit modes)
+    LConv conv(const std::string& pfx, int Cin, int Cout, int ksz, int mode, bool has_bias, bool linear = false, int Cin_pad = 0) {
         LConv c;
-        c.Cin = Cin; c.Cout = Cout; c.mode = mode;
+        const int Ck = Cin_pad > Cin ? Cin_pad : Cin;
+        c.Cin = Ck; c.Cout = Cout; c.mode = mode;
         c.ntaps = mode == NOPE_CONV_UP2P ? 4 : ksz * ksz;
         const nope_tensor_desc* d = linear ? get(pfx + "weight", {Cout, Cin}) : get(pfx + "weight", {Cout, Cin, ksz, ksz});
         if (d) {
-            const size_t es = net->dt == NOPE_F32 ? 4 : 2;
-            c.w = dmalloc((size_t)Cout * c.ntaps * Cin * es * (mode == NOPE_CONV_UP2P ? 4 : 1));
-            if (c.w) chk(launch_pack_conv_w(net->dt, d->data, c.w, Cout, Cin, c.ntaps, mode, s));
+            const size_t es = (size_t)dt_es(net->dt);
+            c.w = dmalloc((size_t)Cout * c.ntaps * Ck * es * (mode == NOPE_CONV_UP2P ? 4 : 1));
+            if (c.w) chk(launch_pack_conv_w(net->dt, d->data, c.w, Cout, Ck, c.ntaps, mode, s, nullptr, nullptr, Cin));
         }
         if (has_bias) c.bias = copy_f32(pfx + "bias", {Cout});
         return c;
@@ -143,7 +147,7 @@ struct Loader {
         t.qkv.Cin = C; t.qkv.Cout = 3 * C; t.qkv.ntaps = 1;
         if (wq && wk && wv) {
             float* cat = (float*)dmalloc((size_t)3 * C * C * 4);
-            const size_t es = net->dt == NOPE_F32 ? 4 : 2;
+            const size_t es = (size_t)dt_es(net->dt);
             t.qkv.w = dmalloc((size_t)3 * C * C * es);
             if (cat && t.qkv.w) {
                 hipMemcpyAsync(cat, wq->data, (size_t)C * C * 4, hipMemcpyDeviceToDevice, s);
@@ -226,13 +230,13 @@ struct Fwd {
     // y = [silu](GroupNorm(32, eps)(x))
     void gn(const LNorm& nm, const void* x, void* y, int HW, int act, float eps, const float* film = nullptr, int film_stride = 0) {
         if (!live()) return;
-        const int nch = gn_stats_chunks(HW, nm.C, net->dt);
-        chk(launch_gn_stats(net->dt, x, gn_partial, nhyp, HW, nm.C, 32, nch, s));
+        const int nch = gn_stats_chunks(HW, nm.C, net->sdt);
+        chk(launch_gn_stats(net->sdt, x, gn_partial, nhyp, HW, nm.C, 32, nch, s));
         GnApplyArgs ga;
         ga.x = x; ga.y = y; ga.partial = gn_partial; ga.nchunk = nch; ga.gamma = nm.gamma; ga.beta = nm.beta;
         ga.nhyp = nhyp; ga.HW = HW; ga.C = nm.C; ga.G = 32; ga.act = act; ga.eps = eps;
         ga.film = film; ga.film_stride = film_stride;
-        chk(launch_gn_apply(net->dt, ga, s));
+        chk(launch_gn_apply(net->sdt, ga, s));
     }
     // ResBlock._forward, openaimodel.py:262-288 (no up/down)
     void res(const LRes& R, const Act& x, void* out) {
@@ -252,7 +256,7 @@ struct Fwd {
             float* e = alloc_f32((size_t)nhyp * ne);
             if (live()) {
                 chk(launch_linear_naive(emb, R.emb_w, R.emb_b, e, nhyp, ne, net->emb_dim, 1, ne, s));
-                if (!film_on) chk(launch_add_rowvec(net->dt, h, h, e, (long long)M, HW, R.Cout, s));
+                if (!film_on) chk(launch_add_rowvec(net->sdt, h, h, e, (long long)M, HW, R.Cout, s));
             }
             if (film_on) { film = e; film_stride = ne; }
         }
@@ -281,19 +285,19 @@ struct Fwd {
         void* qkv = alloc_act((size_t)M * 3 * C);
         void* o = alloc_act((size_t)M * C);
         void* tok1 = alloc_act((size_t)M * C);
-        if (live()) chk(launch_layernorm(net->dt, tok, a, T.ln1.gamma, T.ln1.beta, M, C, 1e-5f, s));
+        if (live()) chk(launch_layernorm(net->sdt, tok, a, T.ln1.gamma, T.ln1.beta, M, C, 1e-5f, s));
         conv(T.qkv, Act{a, C, x.H, x.W}, qkv, x.H, x.W);
-        if (live()) chk(launch_token_attention(net->dt, qkv, o, nhyp, HW, C, 32, s));
+        if (live()) chk(launch_token_attention(net->sdt, qkv, o, nhyp, HW, C, 32, s));
         conv(T.out1, Act{o, C, x.H, x.W}, tok1, x.H, x.W, tok);
         // attn2 against the single pose token: + to_out(to_v(context)) for every token -- this block's slice of u_all
-        if (live()) chk(launch_add_rowvec(net->dt, tok1, tok1, u_all + T.u_off, M, HW, C, s, net->u_total));
+        if (live()) chk(launch_add_rowvec(net->sdt, tok1, tok1, u_all + T.u_off, M, HW, C, s, net->u_total));
         // feed-forward (GEGLU) + residual
         void* f = o;                                     // reuse: LN3(tok1)
-        if (live()) chk(launch_layernorm(net->dt, tok1, f, T.ln3.gamma, T.ln3.beta, M, C, 1e-5f, s));
+        if (live()) chk(launch_layernorm(net->sdt, tok1, f, T.ln3.gamma, T.ln3.beta, M, C, 1e-5f, s));
         void* g = alloc_act((size_t)M * 8 * C);
         void* gg = alloc_act((size_t)M * 4 * C);
         conv(T.ff1, Act{f, C, x.H, x.W}, g, x.H, x.W);
-        if (live()) chk(launch_geglu(net->dt, g, gg, M, 4 * C, s));
+        if (live()) chk(launch_geglu(net->sdt, g, gg, M, 4 * C, s));
         void* tok3 = tok;                                // tok is dead after the attn1 residual
         conv(T.ff2, Act{gg, 4 * C, x.H, x.W}, tok3, x.H, x.W, tok1);
         conv(T.proj_out, Act{tok3, C, x.H, x.W}, out, x.H, x.W, x.p);
@@ -305,10 +309,11 @@ int run_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, const
                 int out_dtype, void* ws, size_t ws_bytes, hipStream_t s, bool dry, size_t* peak) {
     const nope_ldm_config& cfg = net->cfg;
     Fwd f;
-    f.net = net; f.s = s; f.nhyp = n_hyp; f.es = net->dt == NOPE_F32 ? 4 : 2;
+    f.net = net; f.s = s; f.nhyp = n_hyp; f.es = (size_t)dt_es(net->dt);
     f.ar.base = (unsigned char*)ws; f.ar.cap = ws_bytes; f.ar.dry = dry;
     const int HW = H * W;
-    void* x_in = f.alloc_act((size_t)n_src * HW * cfg.in_channels);
+    const int cin_k = net->conv_in.Cin;          // in_channels rounded up to a whole 16-byte vector
+    void* x_in = f.alloc_act((size_t)n_src * HW * cin_k);
     float* ctx = f.alloc_f32((size_t)n_hyp * cfg.context_dim);
     float* ctx2 = f.alloc_f32((size_t)n_hyp * cfg.context_dim);
     float* emb = cfg.injecting_condition_twice ? f.alloc_f32((size_t)n_hyp * net->emb_dim) : nullptr;
@@ -317,7 +322,7 @@ int run_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, const
     f.gn_partial = f.alloc_f32((size_t)n_hyp * 16 * 32 * 2);
     if (f.err) return f.err;
     if (f.live()) {
-        f.chk(launch_nchw_to_nhwc(net->dt, x, x_in, n_src, cfg.in_channels, HW, s));
+        f.chk(launch_nchw_to_nhwc(net->sdt, x, x_in, n_src, cin_k, HW, s, cfg.in_channels));
         // context = pose_mlp(pose), adapt_openaimodel.py:105-116,145
         f.chk(launch_linear_naive(pose, net->pose_w0, net->pose_b0, ctx, n_hyp, cfg.context_dim, cfg.pose_dim, 0, cfg.context_dim, s));
         if (cfg.pose_mlp_layers == 2) {
@@ -337,7 +342,7 @@ int run_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, const
     int curH = H, curW = W;
     // input_blocks[0]: the input conv, evaluated once per hypothesis from the shared latent (source broadcast)
     Act h{f.alloc_act((size_t)n_hyp * HW * net->conv_in.Cout), net->conv_in.Cout, H, W};
-    f.conv(net->conv_in, Act{x_in, cfg.in_channels, H, W}, h.p, H, W, nullptr, 0, NOPE_F32, x_rep);
+    f.conv(net->conv_in, Act{x_in, cin_k, H, W}, h.p, H, W, nullptr, 0, NOPE_F32, x_rep);
     hs.push_back(h);
     for (size_t b = 1; b < net->input_blocks.size(); ++b) {
         const LBlock& B = net->input_blocks[b];
@@ -376,8 +381,8 @@ int run_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, const
         const long long M = (long long)n_hyp * curH * curW;
         Act cat{f.alloc_act((size_t)M * (h.C + sk.C)), h.C + sk.C, curH, curW};
         if (f.live()) {
-            f.chk(launch_copy_cols(net->dt, h.p, cat.p, M, h.C, cat.C, 0, s));
-            f.chk(launch_copy_cols(net->dt, sk.p, cat.p, M, sk.C, cat.C, h.C, s));
+            f.chk(launch_copy_cols(net->sdt, h.p, cat.p, M, h.C, cat.C, 0, s));
+            f.chk(launch_copy_cols(net->sdt, sk.p, cat.p, M, sk.C, cat.C, h.C, s));
         }
         Act r{f.alloc_act((size_t)M * B.res.Cout), B.res.Cout, curH, curW};
         f.res(B.res, cat, r.p);
@@ -418,13 +423,14 @@ extern "C" {
 int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors, int n_tensors, nope_stream_t stream, nope_ldm** out) {
     if (!cfg || !tensors || !out || n_tensors <= 0) return NOPE_ERR_ARG;
     if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->num_res_blocks < 1 || cfg->num_head_channels != 32) return NOPE_ERR_UNSUPPORTED;
-    if (cfg->compute_dtype != NOPE_F32 && cfg->compute_dtype != NOPE_BF16) return NOPE_ERR_UNSUPPORTED;
+    if (!dt_is_compute(cfg->compute_dtype)) return NOPE_ERR_UNSUPPORTED;
     if (cfg->pose_mlp_layers != 1 && cfg->pose_mlp_layers != 2) return NOPE_ERR_UNSUPPORTED;
-    if (cfg->model_channels % 32 || cfg->in_channels % 4 || cfg->context_dim <= 0) return NOPE_ERR_UNSUPPORTED;
+    if (cfg->model_channels % 32 || cfg->in_channels < 1 || cfg->context_dim <= 0) return NOPE_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     nope_ldm* net = new nope_ldm();
     net->cfg = *cfg;
     net->dt = cfg->compute_dtype;
+    net->sdt = dt_storage(net->dt);
     net->emb_dim = cfg->model_channels * 4;
     const int mc = cfg->model_channels;
     Loader ld;
@@ -443,7 +449,7 @@ int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors,
         net->tb = ld.copy_f32("pose_mlp_timesteps.0.bias", {net->emb_dim});
     }
     // openaimodel.py:511-612 -- input blocks
-    net->conv_in = ld.conv("input_blocks.0.0.", cfg->in_channels, mc, 3, NOPE_CONV_PLAIN, true);
+    net->conv_in = ld.conv("input_blocks.0.0.", cfg->in_channels, mc, 3, NOPE_CONV_PLAIN, true, false, (cfg->in_channels + 7) / 8 * 8);
     net->input_blocks.emplace_back();
     std::vector<int> chans{mc};
     int ch = mc, idx = 1;

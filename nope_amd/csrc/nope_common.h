@@ -248,10 +248,10 @@ int launch_gn_fold(const float* colstats, float* partial, int nhyp, int HW, int 
 int launch_linattn(int dt, const void* qkv, void* out, int nhyp, int HW, int heads, int dim_head, hipStream_t s);
 int launch_attn(int dt, const void* qkv, void* out, int nhyp, int HW, int heads, int dim_head, hipStream_t s);
 
-int launch_nchw_to_nhwc(int dt, const float* x, void* y, int n, int C, int HW, hipStream_t s);
+int launch_nchw_to_nhwc(int dt, const float* x, void* y, int n, int C, int HW, hipStream_t s, int C_src = 0);   // C_src < C: zero-padded channels
 int launch_nhwc_to_nchw_f32(int dt, const void* x, float* y, int n, int C, int HW, hipStream_t s);
 int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s,
-                       const float* cin_scale = nullptr, const float* cout_scale = nullptr);
+                       const float* cin_scale = nullptr, const float* cout_scale = nullptr, int Cin_src = 0);   // Cin_src < Cin: zero weights for the padding
 // template encoder (kernels_encoder.hip)
 int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale, float* shift,
                    int C, hipStream_t s);

@@ -42,6 +42,10 @@ struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, rep = 1; };
 
 }  // namespace
 
+// One captured launch sequence of a forward: valid for exactly this (workspace, shape, output type); x, pose and the output are
+// staged through the workspace so that the caller's pointers stay out of the graph.
+struct UGraph { void* ws; size_t ws_bytes; int n_hyp, n_src, H, W, out_dt; hipGraphExec_t exec; };
+
 struct nope_unet {
     nope_unet_config cfg;
     int dt = NOPE_F32;      // compute dtype: what the conv kernels and the weight packing see
@@ -60,6 +64,10 @@ struct nope_unet {
     struct Ev { hipEvent_t a, b; double flops, bytes; nope_conv_launch_info info; };
     mutable bool profile = false;
     mutable std::vector<Ev> evs;
+    // hipGraph cache for SMALL hypothesis batches (the reference evaluates on 26 / 91 / 341 templates, shapeNet.py:252-263): there
+    // a forward is ~150 dependent launches of 5-20 us each and the gaps between them are a visible share of the pass.
+    mutable std::vector<UGraph> graphs;
+    mutable bool graphs_ok = true;           // cleared when capture is unavailable: direct launches from then on
 };
 
 namespace {
@@ -607,6 +615,7 @@ int nope_unet_profile_launches(nope_unet* net, nope_conv_launch_info* out, int m
 
 void nope_unet_destroy(nope_unet* net) {
     if (!net) return;
+    for (const UGraph& g : net->graphs) hipGraphExecDestroy(g.exec);
     for (auto& e : net->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (void* p : net->allocs) hipFree(p);
     delete net;
@@ -620,12 +629,21 @@ static int check_shape(const nope_unet* net, int n_hyp, int n_src, int x_rep, in
     return NOPE_OK;
 }
 
+// Workspace = [staged x | staged pose | staged output (largest element type) | activation arena]
+static size_t unet_stage_bytes(const nope_unet* net, int n_hyp, int n_src, int H, int W, size_t& xb, size_t& pb, size_t& ob) {
+    xb = align_up((size_t)n_src * net->cfg.channels * H * W * 4, 256);
+    pb = align_up((size_t)n_hyp * net->cfg.pose_dim * 4, 256);
+    ob = align_up((size_t)n_hyp * net->cfg.out_dim * H * W * 4, 256);
+    return xb + pb + ob;
+}
+
 size_t nope_unet_workspace_bytes(const nope_unet* net, int n_hyp, int n_src, int H, int W) {
     if (!net || n_src <= 0 || n_hyp % n_src) return 0;
     if (check_shape(net, n_hyp, n_src, n_hyp / n_src, H, W) != NOPE_OK) return 0;
     size_t peak = 0;
     run_forward(net, nullptr, n_src, n_hyp / n_src, nullptr, n_hyp, H, W, nullptr, NOPE_F32, nullptr, 0, nullptr, true, &peak);
-    return align_up(peak, 256) + 256;
+    size_t xb, pb, ob;
+    return unet_stage_bytes(net, n_hyp, n_src, H, W, xb, pb, ob) + align_up(peak, 256) + 256;
 }
 
 int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep, const float* pose, int n_hyp, int H, int W,
@@ -637,8 +655,59 @@ int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep
     unsigned char* base = (unsigned char*)(((uintptr_t)workspace + 255) / 256 * 256);
     const size_t lost = (size_t)(base - (unsigned char*)workspace);
     if (workspace_bytes < lost) return NOPE_ERR_WORKSPACE;
-    return run_forward(net, x, n_src, x_rep, pose, n_hyp, H, W, out, out_dtype, base, workspace_bytes - lost,
-                       (hipStream_t)stream, false, nullptr);
+    hipStream_t s = (hipStream_t)stream;
+    size_t xb, pb, ob;
+    const size_t sb = unet_stage_bytes(net, n_hyp, n_src, H, W, xb, pb, ob);
+    const size_t avail = workspace_bytes - lost;
+    // Small batches replay a captured launch sequence (NOPE_UNET_GRAPH: 0 = never, else the largest n_hyp * H * W that does,
+    // default 160 Ki pixels = 156 hypotheses at a 32 x 32 latent); large ones launch directly -- their kernels are long enough that the
+    // launches run ahead of the GPU, a graph has nothing to harvest there.
+    static const long long graph_max = getenv("NOPE_UNET_GRAPH") ? atoll(getenv("NOPE_UNET_GRAPH")) : 160 * 1024;
+    const bool want_graph = net->graphs_ok && !net->profile && avail > sb && (long long)n_hyp * H * W <= graph_max;
+    if (!want_graph)
+        return run_forward(net, x, n_src, x_rep, pose, n_hyp, H, W, out, out_dtype, base, avail, s, false, nullptr);
+
+    float* x_s = (float*)base;
+    float* pose_s = (float*)(base + xb);
+    void* out_s = base + xb + pb;
+    unsigned char* arena = base + sb;
+    const size_t arena_bytes = avail - sb;
+    const UGraph* hit = nullptr;
+    for (const UGraph& g : net->graphs)
+        if (g.ws == workspace && g.ws_bytes == workspace_bytes && g.n_hyp == n_hyp && g.n_src == n_src && g.H == H && g.W == W && g.out_dt == out_dtype) { hit = &g; break; }
+    if (!hit) {
+        {   // dry pass: fail on a too-small arena BEFORE a capture is open
+            size_t peak = 0;
+            e = run_forward(net, nullptr, n_src, x_rep, nullptr, n_hyp, H, W, nullptr, out_dtype, nullptr, 0, nullptr, true, &peak);
+            if (e) return e;
+            if (align_up(peak, 256) > arena_bytes) return NOPE_ERR_WORKSPACE;
+        }
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            net->graphs_ok = false;
+            return run_forward(net, x, n_src, x_rep, pose, n_hyp, H, W, out, out_dtype, base, avail, s, false, nullptr);
+        }
+        e = run_forward(net, x_s, n_src, x_rep, pose_s, n_hyp, H, W, out_s, out_dtype, arena, arena_bytes, s, false, nullptr);
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(s, &graph);
+        hipGraphExec_t exec = nullptr;
+        if (e != NOPE_OK || ce != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            net->graphs_ok = false;
+            return e != NOPE_OK ? e : run_forward(net, x, n_src, x_rep, pose, n_hyp, H, W, out, out_dtype, base, avail, s, false, nullptr);
+        }
+        hipGraphDestroy(graph);
+        if (net->graphs.size() >= 16) { hipGraphExecDestroy(net->graphs.front().exec); net->graphs.erase(net->graphs.begin()); }
+        net->graphs.push_back(UGraph{workspace, workspace_bytes, n_hyp, n_src, H, W, out_dtype, exec});
+        hit = &net->graphs.back();
+    }
+    const size_t out_bytes = (size_t)n_hyp * net->cfg.out_dim * H * W * (size_t)(out_dtype == NOPE_F32 ? 4 : 2);
+    if (hipMemcpyAsync(x_s, x, (size_t)n_src * net->cfg.channels * H * W * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    if (hipMemcpyAsync(pose_s, pose, (size_t)n_hyp * net->cfg.pose_dim * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    if (hipGraphLaunch(hit->exec, s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    if (hipMemcpyAsync(out, out_s, out_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    return NOPE_OK;
 }
 
 }  // extern "C"

@@ -1,11 +1,12 @@
 """GPU: the BASELINE.json configurations that round 1 left without a test (configs[2], [3], [4]), `PoseConditional.sample`
 and the evaluation harness end to end.
 
-  configs[2]  batch = 32 queries x 512 templates, bf16, one GPU                 test_config2_batch32_x_512_bf16
-  configs[3]  batch = 32 x 4096 templates sharded 8-way -> 512 per rank          test_per_rank_shapes_of_configs_3_and_4[512-bf16]
-  configs[4]  fp16 bank, 8192 templates on 8 GPUs -> 1024 per rank              test_per_rank_shapes_of_configs_3_and_4[1024-f16]
-The sharded configurations run their PER-RANK shape with several ranks sharing the one GPU of the test box (gloo carries
-the score all-gather; 8-GPU RCCL runs are the driver's), and are compared with the unsharded call: same launches, same
+  configs[2]  batch = 32 queries x 512 templates, one GPU, per compute mode       test_config2_batch32_x_512[f16|bf16x3|bf16]
+  configs[3]  batch = 32 x 4096 templates sharded 8-way, WHOLE (8 ranks)          test_whole_configs_3_and_4_eight_ranks[4096-bf16-bf16]
+  configs[4]  fp16 embeddings + 8192-template bank, WHOLE (8 ranks)               test_whole_configs_3_and_4_eight_ranks[8192-f16-f16]
+              (+ their per-rank shapes with 3 / 2 ranks: test_per_rank_shapes_of_configs_3_and_4)
+The sharded configurations run with all their ranks sharing the one GPU of the test box (gloo carries the score all-gather: RCCL
+wants one device per rank; the 8-GPU RCCL run is the driver's) and are compared with the unsharded call: same launches, same
 bits."""
 import os
 import sys
@@ -28,26 +29,26 @@ def model_f32(gpu):
     return build_model(compute_dtype="f32", bank_dtype="f32", device="cuda")
 
 
-@pytest.fixture(scope="module")
-def model_bf16(gpu):
-    from nope_amd.harness import build_model
-    return build_model(compute_dtype="bf16", bank_dtype="bf16", device="cuda")
-
-
-def test_config2_batch32_x_512_bf16(model_bf16, model_f32):
-    """BASELINE configs[2] end to end: 32 queries x 512 templates (16384 pose hypotheses) through encoder, U-Net, scoring
-    and top-5 in the benchmark's bf16 mode.  (i) a spread of (b, n) hypotheses against the CPU restatement, embedding map
-    and score; (ii) per query, the best template of the bf16 run equals the best template of the f32 parity mode wherever
-    the f32 top-1 gap exceeds twice that query's largest bf16 score deviation, for at least 28 of the 32 queries overall,
-    and is always among the f32 top-5."""
-    from nope_amd.harness import synthetic_batch
+@pytest.mark.parametrize("cdt", ["f16", "bf16x3", "bf16"])
+def test_config2_batch32_x_512(model_f32, cdt):
+    """BASELINE configs[2] end to end: 32 queries x 512 templates (16384 pose hypotheses) through encoder, U-Net, scoring and
+    top-5, per compute mode.  (i) a spread of (b, n) hypotheses against the CPU restatement, embedding map and score;
+    (ii) against the f32 parity mode (itself pinned to the reference at configs[0] / configs[1]):
+        f16    -- the benchmark's default 16-bit mode: the best template equals the f32 mode's for ALL 32 queries;
+        bf16x3 -- the fast mode inside north_star's tolerance: scores within 1e-4 relative, top-5 bit-exact for all 32 queries;
+        bf16   -- 8 significand bits: reported; it does NOT meet the top-1 bar (31 of 32 on this input: the smallest f32 top-1 gap,
+                  1.3e-4 of the score scale, is far below its 6e-3 score error), which is why it is not the default mode; its winner
+                  is always inside the f32 top-5."""
+    from nope_amd.harness import build_model, synthetic_batch
+    bank_dt = cdt if cdt in ("f16", "bf16") else "f32"
+    m = build_model(compute_dtype=cdt, bank_dtype=bank_dt, device="cuda")
     b = synthetic_batch(32, 512, 256, seed=77, device="cuda")
-    sim, idx, bank = model_bf16.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
+    sim, idx, bank = m.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
     torch.cuda.synchronize()
     assert sim.shape == (32, 512) and idx.shape == (32, 5) and bank.shape == (32, 512, 8, 32, 32) and bool(torch.isfinite(sim).all())
     # (i) oracle spot check
-    enc_sd = {k: v.detach().cpu() for k, v in model_bf16.u_net.encoder.state_dict().items()}
-    sd = {k: v.detach().cpu() for k, v in model_bf16.u_net.own_state_dict().items()}
+    enc_sd = {k: v.detach().cpu() for k, v in m.u_net.encoder.state_dict().items()}
+    sd = {k: v.detach().cpu() for k, v in m.u_net.own_state_dict().items()}
     pairs = [(0, 0), (0, 511), (7, 130), (16, 255), (31, 1), (31, 511)]
     worst_map = worst_score = 0.0
     for bb in sorted({p[0] for p in pairs}):
@@ -59,22 +60,24 @@ def test_config2_batch32_x_512_bf16(model_bf16, model_f32):
         worst_map = max(worst_map, rel(got, want))
         s_want = R.similarity_scores(q_feat, want)
         worst_score = max(worst_score, float(((sim[bb, ns].cpu() - s_want[0]).abs() / s_want[0].abs()).max()))
-    print(f"configs[2] bf16: embedding maps rel err {worst_map:.3e}, scores rel err {worst_score:.3e} on {pairs}")
-    assert worst_map < 6e-2 and worst_score < 5e-2
-    # (ii) arg-top against the f32 parity mode (itself pinned to the reference at configs[0] / configs[1])
+    print(f"configs[2] {cdt}: embedding maps rel err {worst_map:.3e}, scores rel err {worst_score:.3e} on {pairs}")
+    tol_map, tol_score = {"f16": (8e-3, 5e-3), "bf16x3": (1e-4, 1e-4), "bf16": (6e-2, 5e-2)}[cdt]
+    assert worst_map < tol_map and worst_score < tol_score
+    # (ii) against the f32 parity mode
     sim32, idx32, _ = model_f32.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
-    dev_q = (sim - sim32).abs().max(dim=1).values                # largest bf16 deviation per query
+    err = float((sim - sim32).abs().max()) / float(sim32.abs().max())
+    same1 = int((idx[:, 0] == idx32[:, 0]).sum())
+    same5 = int((idx == idx32).all(dim=1).sum())
     top2 = sim32.topk(2, dim=1).values
-    gap = (top2[:, 0] - top2[:, 1])
-    decided = gap > 2 * dev_q
-    same = idx[:, 0] == idx32[:, 0]
-    print(f"configs[2]: max |bf16 - f32| score {float(dev_q.max()):.3f} (rel {float(dev_q.max()) / float(sim32.abs().max()):.2e}); top-1 equal for "
-          f"{int(same.sum())}/32 queries; {int(decided.sum())} queries have an f32 top-1 gap above twice their bf16 deviation")
-    # the bf16 error is mostly a common shift of a query's scores, so the ranking survives far more often than the worst-case
-    # bound promises: demand the bound where it applies and a large majority overall
-    assert bool(same[decided].all()) and int(same.sum()) >= 28
-    # wherever they differ, the bf16 winner is among the f32 top-5
-    for q in range(32):
+    print(f"configs[2] {cdt} vs f32: score rel err {err:.2e}; top-1 equal for {same1}/32 queries, top-5 (ordered) equal for {same5}/32; smallest "
+          f"f32 top-1 gap {float((top2[:, 0] - top2[:, 1]).min()) / float(sim32.abs().max()):.2e} of the score scale")
+    if cdt == "f16":
+        assert same1 == 32 and err < 5e-3
+    elif cdt == "bf16x3":
+        assert same1 == 32 and same5 == 32 and err < 1e-4
+    else:
+        assert same1 >= 28 and err < 5e-2
+    for q in range(32):                     # wherever a mode's winner differs, it is among the f32 top-5
         assert int(idx[q, 0]) in idx32[q].tolist()
 
 

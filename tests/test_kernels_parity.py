@@ -521,6 +521,29 @@ def test_ldm_unet_vs_reference_golden(be, golden, tag):
             assert rel(yh, want) < tol
 
 
+def test_ldm_shipped_latent_channels(be):
+    """configs/model/vae_cin_ldm.yaml ships in_channels = out_channels = 4: the input conv's K axis is padded to one 16-byte vector
+    at pack time (zero weights against zero-padded input channels), so every compute mode accepts it; checked against the oracle
+    (whose restatement is pinned to the reference class by ldm_tiny.npz)."""
+    hip, dev, name = be
+    from nope_amd.ldm import UNetModelPose
+    from nope_amd.weights import synth_init_
+    from tests.test_oracle_golden import LDM_CASES
+    g = torch.Generator().manual_seed(17)
+    x, pose = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 3, 6, generator=g)
+    sd = None
+    for cdt, tol in (("f32", F32_TOL), ("bf16x3", F32_TOL), ("f16", 1e-2), ("bf16", 8e-2)):
+        if name == "emu" and cdt in ("f16", "bf16x3"):
+            continue      # keep the CPU suite short
+        m = UNetModelPose(encoder=StubEncoder(4), rot_representation_dim=6, image_size=8, in_channels=4, out_channels=4, num_head_channels=32,
+                          use_spatial_transformer=True, transformer_depth=1, compute_dtype=cdt, **LDM_CASES["m32"])
+        synth_init_(m, 2022)
+        sd = sd or {k: v.clone() for k, v in m.own_state_dict().items()}
+        want = R.ldm_forward(sd, x.expand(3, -1, -1, -1), pose[0])
+        y = m.to(dev).forward_hypotheses(x.to(dev), pose.to(dev)).cpu()[0]
+        assert y.shape == (3, 4, 8, 8) and rel(y, want) < tol, (cdt, rel(y, want))
+
+
 def test_dataset_crop_and_sample_assembly(be):
     """SURVEY section 8 row f3, image side: the four-point perspective solve, the device warp (bilinear, zero border, fused
     /255*2-1 + HWC->CHW) against torch.grid_sample, crop_frame's geometry, and the test-split sample dict of
