@@ -4,7 +4,6 @@ and the evaluation harness end to end.
   configs[2]  batch = 32 queries x 512 templates, one GPU, per compute mode       test_config2_batch32_x_512[f16|bf16x3|bf16]
   configs[3]  batch = 32 x 4096 templates sharded 8-way, WHOLE (8 ranks)          test_whole_configs_3_and_4_eight_ranks[4096-bf16-bf16]
   configs[4]  fp16 embeddings + 8192-template bank, WHOLE (8 ranks)               test_whole_configs_3_and_4_eight_ranks[8192-f16-f16]
-              (+ their per-rank shapes with 3 / 2 ranks: test_per_rank_shapes_of_configs_3_and_4)
 The sharded configurations run with all their ranks sharing the one GPU of the test box (gloo carries the score all-gather: RCCL
 wants one device per rank; the 8-GPU RCCL run is the driver's) and are compared with the unsharded call: same launches, same
 bits."""
@@ -17,7 +16,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import nope_ref as R
-from tests.util import rel
+from tests.util import cached_model, rel
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,8 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def model_f32(gpu):
-    from nope_amd.harness import build_model
-    return build_model(compute_dtype="f32", bank_dtype="f32", device="cuda")
+    from tests.util import cached_model
+    return cached_model("f32", "f32")
 
 
 @pytest.mark.parametrize("cdt", ["f16", "bf16x3", "bf16"])
@@ -41,7 +40,7 @@ def test_config2_batch32_x_512(model_f32, cdt):
                   is always inside the f32 top-5."""
     from nope_amd.harness import build_model, synthetic_batch
     bank_dt = cdt if cdt in ("f16", "bf16") else "f32"
-    m = build_model(compute_dtype=cdt, bank_dtype=bank_dt, device="cuda")
+    m = cached_model(cdt, bank_dt)
     b = synthetic_batch(32, 512, 256, seed=77, device="cuda")
     sim, idx, bank = m.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
     torch.cuda.synchronize()
@@ -120,47 +119,6 @@ def test_harness_eval_geodesic_config1(model_f32, golden, tmp_path):
     # the command-line entry point (python -m nope_amd.harness), small shape
     main(["--batch", "2", "--templates", "6", "--size", "64", "--save-dir", str(tmp_path / "run")])
     assert os.path.isdir(tmp_path / "run" / "predictions")
-
-
-def _shard_worker(rank, ws, port, n_per_rank, bank_dtype, ret):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=ws)
-    try:
-        from nope_amd.harness import build_model, synthetic_batch
-        torch.cuda.set_device(0)
-        B, N = 32, n_per_rank * ws
-        b = synthetic_batch(B, N, 256, seed=91, device="cuda")
-        m = build_model(compute_dtype="bf16", bank_dtype=bank_dtype, device="cuda", template_parallel=True)
-        sim, idx, bank = m.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
-        torch.cuda.synchronize()
-        out = {"shape": tuple(bank.shape), "dtype": str(bank.dtype), "sim": sim.cpu(), "idx": idx.cpu()}
-        if rank == 0:          # the unsharded call: same per-launch hypothesis batches (one reference image x 512 poses), so the same bits
-            m.template_parallel = False
-            sim1, idx1, _ = m.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
-            torch.cuda.synchronize()
-            out["sim1"], out["idx1"] = sim1.cpu(), idx1.cpu()
-        ret[rank] = out
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("n_per_rank,ws,bank_dtype", [(512, 3, "bf16"), (1024, 2, "f16")])
-def test_per_rank_shapes_of_configs_3_and_4(gpu, n_per_rank, ws, bank_dtype):
-    """BASELINE configs[3] (32 x 4096 templates, 8-way) and configs[4] (fp16 bank, 8192 templates on 8 GPUs) at their per-rank
-    shapes -- 32 queries x 512 / 1024 templates per rank -- through the template-parallel path, several ranks on this GPU."""
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    port = 29800 + os.getpid() % 1500
-    mp.spawn(_shard_worker, args=(ws, port, n_per_rank, bank_dtype, ret), nprocs=ws, join=True)
-    N = n_per_rank * ws
-    for r in range(ws):
-        o = ret[r]
-        assert o["shape"] == (32, n_per_rank, 8, 32, 32) and o["dtype"] == {"bf16": "torch.bfloat16", "f16": "torch.float16"}[bank_dtype]
-        assert o["sim"].shape == (32, N) and torch.equal(o["sim"], ret[0]["sim"]) and torch.equal(o["idx"], ret[0]["idx"])
-    assert torch.equal(ret[0]["sim"], ret[0]["sim1"]) and torch.equal(ret[0]["idx"], ret[0]["idx1"])
-    assert bool(torch.isfinite(ret[0]["sim"]).all()) and len(set(ret[0]["idx"][:, 0].tolist())) > 1
 
 
 def _whole_config_worker(rank, ws, port, n_total, cdt, bank_dtype, ret):

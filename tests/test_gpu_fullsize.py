@@ -6,15 +6,15 @@ import pytest
 import torch
 
 from oracle import nope_ref as R
-from tests.util import rel
+from tests.util import cached_model, rel
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
 def model_f32(gpu):
-    from nope_amd.harness import build_model
-    return build_model(compute_dtype="f32", bank_dtype="f32", device="cuda")
+    from tests.util import cached_model
+    return cached_model("f32", "f32")
 
 
 @pytest.mark.parametrize("cdt,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("f16", 8e-3), ("bf16", 6e-2)])
@@ -110,7 +110,7 @@ def test_pipeline_config1_other_modes(gpu, golden, cdt):
     precision, best template equal to the reference's, top-5 the same set."""
     from nope_amd.harness import build_model
     g = golden("pipeline_cfg1.npz")
-    m = build_model(compute_dtype=cdt, bank_dtype=cdt if cdt in ("f16", "bf16") else "f32", device="cuda")
+    m = cached_model(cdt, cdt if cdt in ("f16", "bf16") else "f32")
     bank, _, _ = m.generate_templates(g["reference"].cuda(), g["all_relativeR"].cuda(), None)
     sim, idx = m.retrieval(g["query"].cuda(), bank)
     e = rel(sim.cpu(), g["sim"])
@@ -160,7 +160,7 @@ def test_bench_batch_vs_oracle(gpu, model_f32, cdt, tol):
     (position-major 4x4 level, persistent level-0/1 launches in bf16, fused statistics) -- checked hypothesis by hypothesis
     against the CPU restatement on a spread of 6 of the 512 (the oracle needs ~50 ms per hypothesis)."""
     from nope_amd.harness import build_model
-    m = model_f32 if cdt == "f32" else build_model(compute_dtype=cdt, bank_dtype="f32", device="cuda")
+    m = model_f32 if cdt == "f32" else cached_model(cdt, "f32")
     g = torch.Generator().manual_seed(21)
     feat = torch.randn(1, 8, 32, 32, generator=g)
     poses = torch.randn(1, 512, 6, generator=g)
@@ -195,7 +195,7 @@ def test_pipeline_config2_vs_oracle(model_f32, cfg2_oracle, cdt):
     that claim north_star's tolerance: f32 (exact-f32 MFMA) and bf16x3 (f32 storage, three bf16 MFMA passes per product)."""
     from nope_amd.harness import build_model
     b, sim_want, idx_want = cfg2_oracle
-    m = model_f32 if cdt == "f32" else build_model(compute_dtype=cdt, bank_dtype="f32", device="cuda")
+    m = model_f32 if cdt == "f32" else cached_model(cdt, "f32")
     sim, idx, _ = m.generate_and_retrieve(b["query"].cuda(), b["reference"].cuda(), b["all_relativeR"].cuda())
     e = rel(sim.cpu(), sim_want)
     print(f"config-2 (512 templates, 256x256) {cdt} similarity rel err", e, "idx", idx.tolist(), "ref", idx_want.tolist())
@@ -210,7 +210,7 @@ def test_pipeline_config2_16bit_modes_vs_oracle(cfg2_oracle, cdt, tol):
     together than bf16's error, so their order may swap)."""
     from nope_amd.harness import build_model
     b, sim_want, idx_want = cfg2_oracle
-    m = build_model(compute_dtype=cdt, bank_dtype=cdt, device="cuda")
+    m = cached_model(cdt, cdt)
     sim, idx, _ = m.generate_and_retrieve(b["query"].cuda(), b["reference"].cuda(), b["all_relativeR"].cuda())
     e = rel(sim.cpu(), sim_want)
     print(f"config-2 (512 templates, 256x256) {cdt} similarity rel err", e, "idx", idx.tolist(), "ref", idx_want.tolist())
