@@ -47,6 +47,7 @@ struct ConvParams {
     int out_nchw, out_dt;
     int act;                           // 0 none, 1 ReLU (after bias and residual)
     int tiles_m, tiles_n, xcd_map, wide_out;
+    int nchw_staged;                   // out_nchw through the per-wave LDS panels (epilogue_nchw): whole 64-row blocks inside one sample
     int xcd_gn;                        // xcd_map == 2: XCD columns the weight panels are split over (tile_coords)
     int variant;                       // tuning switches (NOPE_CONV_VARIANT), 0 in production
     FastDiv d_hw, d_w, d_rep1, d_rep2; // / (Hm*Wm), / Wm, / rep1, / rep2
@@ -483,6 +484,53 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
         }
         __builtin_amdgcn_wave_barrier();
         stamp();
+    }
+}
+
+// NCHW output (the last conv writes the (hypothesis, C, h, w) template bank directly) through the per-wave panel: the MFMA C/D layout
+// gives a lane one channel x a few pixels, i.e. 2-byte stores scattered over Cout planes (the 8-channel final conv ran at
+// 1.2 TB/s of input); staged, lane r owns pixel r of the wave's 64 and every channel plane receives 64 consecutive
+// pixels per store instruction.  Requires HWo % 64 == 0 and M % 64 == 0 (checked by the launcher), no residual.
+template <class T>
+__device__ __forceinline__ void epilogue_nchw(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL], int m0, int n0,
+                                              int wm, int wn, int lane, unsigned char* lds_wave) {
+    typedef Tile<T> TL;
+    constexpr int PANW = TL::TM == 32 ? 32 : 48;
+    constexpr int TPP = PANW / TL::TM;
+    float* pan = reinterpret_cast<float*>(lds_wave);
+    const int HWo = p.Ho * p.Wo;
+    const int mrow = m0 + wm * 64;
+    if (mrow >= p.M || n0 + wn * 96 >= p.Cout) return;            // (wave-uniform)
+    const int b = mrow / HWo, pix0 = mrow - b * HWo;
+    const size_t base = (size_t)b * p.Cout * HWo + pix0 + lane;
+#pragma unroll
+    for (int pass = 0; pass < 96 / PANW; ++pass) {
+        if (n0 + wn * 96 + pass * PANW >= p.Cout) break;            // (wave-uniform)
+#pragma unroll
+        for (int jj = 0; jj < TPP; ++jj) {
+            const int j = pass * TPP + jj;
+            const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
+            const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                for (int r = 0; r < TL::R; ++r) {
+                    float v = acc[i][j][r] + bv;
+                    if (p.act) v = v > 0.f ? v : 0.f;
+                    pan[(i * TL::TM + TL::out_row(lane, r)) * Ep<T>::LD + jj * TL::TM + TL::out_col(lane)] = v;
+                }
+        }
+        __builtin_amdgcn_wave_barrier();       // same-wave LDS write -> read (in-order LDS queue; rendezvous point of tests/hipemu)
+        for (int cc = 0; cc < PANW; ++cc) {
+            const int n = n0 + wn * 96 + pass * PANW + cc;
+            if (n >= p.Cout) break;
+            const float v = pan[lane * Ep<T>::LD + cc];
+            const size_t o = base + (size_t)n * HWo;
+            if (p.out_dt == NOPE_F32) reinterpret_cast<float*>(p.out)[o] = v;
+            else if (p.out_dt == NOPE_F16) reinterpret_cast<f16_t*>(p.out)[o] = (f16_t)v;
+            else reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(v);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

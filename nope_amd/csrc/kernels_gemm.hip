@@ -212,6 +212,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
         else epilogue<T, true>(p, acc, m0, n0, wm, wn, lane);
     } else {
         if (p.wide_out) epilogue_wide<T, false>(p, acc, m0, n0, wm, wn, lane, lds + wave * Ep<T>::WAVE_BYTES);
+        else if (p.nchw_staged) epilogue_nchw<T>(p, acc, m0, n0, wm, wn, lane, lds + wave * Ep<T>::WAVE_BYTES);
         else epilogue<T, false>(p, acc, m0, n0, wm, wn, lane);
     }
 }
@@ -468,6 +469,9 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
     } else if (p.wide_out) {
         __syncthreads();                       // every wave is done reading the last stage
         epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
+    } else if (!PN && p.nchw_staged) {
+        __syncthreads();
+        epilogue_nchw<T>(p, acc, m0, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
     } else {
         epilogue<T, PN>(p, acc, m0, n0, wm, wn, lane);
     }
@@ -604,6 +608,8 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.out_nchw = a.out_nchw; p.out_dt = a.out_dt;
     p.act = a.act;
     p.wide_out = (!a.out_nchw && a.Cout % vec == 0) ? 1 : 0;
+    p.nchw_staged = (a.out_nchw && !a.resid && !a.pn_ms && M % 64 == 0 && ((long long)a.Ho * a.Wo) % 64 == 0 &&
+                     !(getenv("NOPE_NCHW_STAGED") && atoi(getenv("NOPE_NCHW_STAGED")) == 0)) ? 1 : 0;
     p.colstats = a.colstats;
     p.pn_ms = a.pn_ms; p.pn_c0 = a.pn_c0; p.pn_c1 = a.pn_c1;
     if (a.pn_ms && (!a.pn_c0 || !a.pn_c1 || a.mode != NOPE_CONV_PLAIN || a.ntaps != 1 || a.colstats)) return NOPE_ERR_ARG;

@@ -68,6 +68,17 @@ def test_conv_variants(be, dt):
     assert rel(hip.to_nchw(y, dt).cpu(), R.hard_downsample(q(x1), {"1.weight": q(wd), "1.bias": bd}, "")) < tol
     y = hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(w1), None, out_nchw=True, out_dtype=hip.F32)
     assert rel(y.cpu(), F.conv2d(q(x1), q(w1))) < (tol if dt in (0, 3) else 1e-2)
+    # NCHW output through the LDS panels (whole 64-pixel blocks inside a sample: the path of the U-Net's last conv), 8 and 40 channels,
+    # f32 / f16 planes, against the scattered-store path (NOPE_NCHW_STAGED=0): same values
+    import os
+    x8, w8, b8 = rn(3, 16, 8, 8), rn(8, 16, 1, 1) / 4, rn(8)
+    for wgt, bias, odt in ((w8, b8, hip.F32), (w1, None, hip.F16)):
+        y = hip.op_conv(dt, hip.to_nhwc(d(x8), dt), d(wgt), None if bias is None else d(bias), out_nchw=True, out_dtype=odt)
+        os.environ["NOPE_NCHW_STAGED"] = "0"
+        y0 = hip.op_conv(dt, hip.to_nhwc(d(x8), dt), d(wgt), None if bias is None else d(bias), out_nchw=True, out_dtype=odt)
+        os.environ.pop("NOPE_NCHW_STAGED")
+        assert torch.equal(y, y0)
+        assert rel(y.float().cpu(), F.conv2d(q(x8), q(wgt), bias)) < (tol if dt in (0, 3) and odt == hip.F32 else 1e-2)
     xb, wb = rn(3, 72, 8, 8), rn(200, 72, 3, 3) / 25          # 192 rows -> 2 M tiles (ragged), 2 N tiles
     y = hip.op_conv(dt, hip.to_nhwc(d(xb), dt), d(wb), None)
     assert rel(hip.to_nchw(y, dt).cpu(), F.conv2d(q(xb), q(wb), padding=1)) < tol
@@ -105,6 +116,9 @@ def test_conv_lds_dma_path(be, dt):
     assert rel(hip.to_nchw(y, dt).cpu(), R.hard_downsample(q(x4), {"1.weight": q(wd), "1.bias": bd}, "")) < tol
     y = hip.op_conv(dt, hip.to_nhwc(d(x2), dt), d(w1), None, out_nchw=True, out_dtype=hip.BF16)
     assert rel(y.float().cpu(), F.conv2d(q(x2), q(w1))) < 1e-2
+    x8, w8, b8 = rn(2, C, 16, 8), rn(8, C, 1, 1) / 8, rn(8)            # NCHW through the LDS panels on the LDS-DMA kernel (2 x 128 pixels)
+    y = hip.op_conv(dt, hip.to_nhwc(d(x8), dt), d(w8), d(b8), out_nchw=True, out_dtype=hip.BF16)
+    assert rel(y.float().cpu(), F.conv2d(q(x8), q(w8), b8)) < 1e-2
 
 
 @pytest.mark.parametrize("dt", [0, 1, 2])
