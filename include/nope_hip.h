@@ -246,7 +246,8 @@ int nope_op_linear(const float* in, const float* w, const float* bias, float* ou
 
 /* Dataset-side crop (caller of the hot path): cv2.warpPerspective(img, M, (Wd, Hd)) of crop_frame, src/poses/utils.py:262-270
  * (bilinear, zero border), fused with the loader's image transform (dataloader/shapeNet.py:64-69):
- *   dst[c,y,x] = scale * bilinear(src, Minv (x,y,1)) + shift.   src (Hs,Ws,C) uint8 (src_is_u8) or f32, HWC;
+ *   dst[c,y,x] = scale * bilinear(src, Minv (x,y,1)) + shift.   src (Hs,Ws,C) uint8 (src_is_u8 = 1, or 2: the interpolated value
+ *   is rounded and clamped to [0, 255] first, as cv2's uint8 destination does) or f32 (src_is_u8 = 0), HWC;
  *   minv9_host: HOST pointer to the 3x3 inverse map, row-major; dst (C,Hd,Wd) f32. */
 int nope_op_warp_perspective(const void* src, int src_is_u8, int Hs, int Ws, int C, const float* minv9_host, float* dst_chw, int Hd, int Wd,
                              float scale, float shift, nope_stream_t s);

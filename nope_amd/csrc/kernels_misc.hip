@@ -250,7 +250,10 @@ int launch_pos_emb(const float* pose, float* out, int n, int pose_dim, int class
 //   dst[c, y, x] = scale * bilinear(src, Minv * (x, y, 1)) + shift,   src (Hs, Ws, C) uint8 or f32, dst (C, Hd, Wd) f32.
 // Pixel centres sit on integer coordinates, as in OpenCV; samples outside the source contribute zeros tap by tap.
 struct Mat3 { float m[9]; };
-template <class TIN>
+// ROUND_U8: the interpolated value is rounded to the nearest integer and clamped to [0, 255] before scale / shift, as a uint8
+// destination image does (cv2.warpPerspective on uint8 frames, then ToTensor's / 255): outputs land on the reference loader's
+// k / 255 grid.  OpenCV's own fixed-point interpolation weights (1/32 pixel) are not restated: parity unpinned (cv2 is absent).
+template <class TIN, bool ROUND_U8>
 __global__ __launch_bounds__(NT) void warp_perspective_kernel(const TIN* __restrict__ src, int Hs, int Ws, int C, Mat3 inv, float* __restrict__ dst,
                                                               int Hd, int Wd, float scale, float shift) {
     const int total = Hd * Wd;
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(NT) void warp_perspective_kernel(const TIN* __restr
                 const float wt = ((t & 1) ? ax : 1.f - ax) * ((t >> 1) ? ay : 1.f - ay);
                 if (xx >= 0 && xx < Ws && yy >= 0 && yy < Hs && w != 0.f) v += wt * (float)src[((size_t)yy * Ws + xx) * C + c];
             }
+            if (ROUND_U8) v = fminf(fmaxf(rintf(v), 0.f), 255.f);
             dst[(size_t)c * total + i] = scale * v + shift;
         }
     }
@@ -281,8 +285,9 @@ int launch_warp_perspective(const void* src, int src_u8, int Hs, int Ws, int C, 
     Mat3 m;
     for (int i = 0; i < 9; ++i) m.m[i] = minv9[i];
     const dim3 grid(grid_for((size_t)Hd * Wd));
-    if (src_u8) hipLaunchKernelGGL((warp_perspective_kernel<unsigned char>), grid, dim3(NT), 0, s, (const unsigned char*)src, Hs, Ws, C, m, dst, Hd, Wd, scale, shift);
-    else hipLaunchKernelGGL((warp_perspective_kernel<float>), grid, dim3(NT), 0, s, (const float*)src, Hs, Ws, C, m, dst, Hd, Wd, scale, shift);
+    if (src_u8 == 2) hipLaunchKernelGGL((warp_perspective_kernel<unsigned char, true>), grid, dim3(NT), 0, s, (const unsigned char*)src, Hs, Ws, C, m, dst, Hd, Wd, scale, shift);
+    else if (src_u8) hipLaunchKernelGGL((warp_perspective_kernel<unsigned char, false>), grid, dim3(NT), 0, s, (const unsigned char*)src, Hs, Ws, C, m, dst, Hd, Wd, scale, shift);
+    else hipLaunchKernelGGL((warp_perspective_kernel<float, false>), grid, dim3(NT), 0, s, (const float*)src, Hs, Ws, C, m, dst, Hd, Wd, scale, shift);
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

@@ -71,9 +71,12 @@ def crop_transform(intrinsic: np.ndarray, openCV_pose: np.ndarray, image_size: i
 
 
 def crop_frame(img, mask, intrinsic, openCV_pose, image_size, keep_inplane=False, virtual_bbox_size=0.3,
-               normalize: bool = False):
+               normalize: bool = False, round_u8: bool = False):
     """utils.py:204-272 with the warp on the device.  img (H,W,C) uint8 / f32 tensor (or array) -> (C,S,S) f32 tensor; raw values,
-    or the loader's `/255 * 2 - 1` when `normalize`.  Returns (img, mask) when a mask is given."""
+    or the loader's `/255 * 2 - 1` when `normalize`.  `round_u8` (uint8 frames): the warped value is rounded and clamped to
+    [0, 255] before the transform, as the reference's uint8 `cv2.warpPerspective` output is before `ToTensor` -- the sample then
+    lies on the same k/255 grid as the reference loader's (within one grey level where OpenCV's 1/32-pixel fixed-point weights
+    round the other way: unpinned, cv2 is not installed).  Returns (img, mask) when a mask is given."""
     M = crop_transform(np.asarray(intrinsic, np.float64), np.asarray(openCV_pose, np.float64), image_size, keep_inplane, virtual_bbox_size)
     Minv = np.linalg.inv(M)
     def warp(a, norm):
@@ -83,7 +86,7 @@ def crop_frame(img, mask, intrinsic, openCV_pose, image_size, keep_inplane=False
         if not t.is_cuda and torch.cuda.is_available():
             t = t.cuda()
         sc, sh = ((2.0 / 255.0, -1.0) if t.dtype == torch.uint8 else (2.0, -1.0)) if norm else (1.0, 0.0)
-        return hip.op_warp_perspective(t, Minv, image_size, sc, sh)
+        return hip.op_warp_perspective(t, Minv, image_size, sc, sh, round_u8=round_u8 and t.dtype == torch.uint8)
     out = warp(img, normalize)
     return (out, warp(mask, False)) if mask is not None else out
 
@@ -93,7 +96,7 @@ def process_test_sample(query_img, reference_img, template_imgs: Sequence, query
                         symmetry: int = 0) -> Dict[str, torch.Tensor]:
     """`ShapeNet.process` + `__getitem__` on the test split (shapeNet.py:265-357) for already decoded frames: crops (virtual bbox
     of size 1, shapeNet.py:171-184), image transform, relative poses; keys and shapes as the reference's sample dict."""
-    crop = lambda im, pose: crop_frame(im, None, SHAPENET_INTRINSIC, pose, img_size, virtual_bbox_size=1, normalize=True)
+    crop = lambda im, pose: crop_frame(im, None, SHAPENET_INTRINSIC, pose, img_size, virtual_bbox_size=1, normalize=True, round_u8=True)
     rel, _ = compute_relative_pose(query_pose, ref_pose)
     all_rel = torch.stack([compute_relative_pose(testing_template_poses[i], ref_pose)[0] for i in range(len(template_imgs))])
     return {

@@ -481,8 +481,9 @@ class LdmHandle:
         return out
 
 
-def op_warp_perspective(img: torch.Tensor, minv, size: int, scale: float = 1.0, shift: float = 0.0) -> torch.Tensor:
-    """img (H,W,C) uint8 or f32 on the device, minv 3x3 (host) mapping output pixels to source pixels -> (C,size,size) f32."""
+def op_warp_perspective(img: torch.Tensor, minv, size: int, scale: float = 1.0, shift: float = 0.0, round_u8: bool = False) -> torch.Tensor:
+    """img (H,W,C) uint8 or f32 on the device, minv 3x3 (host) mapping output pixels to source pixels -> (C,size,size) f32.
+    round_u8 (uint8 sources): round + clamp the interpolated value to [0, 255] before scale / shift (a uint8 destination image)."""
     require_device(img)
     img = img.contiguous()
     if img.dtype not in (torch.uint8, torch.float32):
@@ -491,7 +492,7 @@ def op_warp_perspective(img: torch.Tensor, minv, size: int, scale: float = 1.0, 
     out = torch.empty((Cc, size, size), dtype=torch.float32, device=img.device)
     m = (C.c_float * 9)(*[float(v) for v in list(minv.reshape(-1))])
     l = lib()
-    l.check(l.dll.nope_op_warp_perspective(_ptr(img), int(img.dtype == torch.uint8), H, W, Cc, m, _ptr(out), size, size, scale, shift,
+    l.check(l.dll.nope_op_warp_perspective(_ptr(img), (2 if round_u8 else 1) if img.dtype == torch.uint8 else 0, H, W, Cc, m, _ptr(out), size, size, scale, shift,
                                            _stream(img)), "nope_op_warp_perspective")
     return out
 

@@ -220,8 +220,8 @@ def test_tiny_unet_vs_reference_golden(be, golden, tag, dim, mlp):
     x, pose, ref = g[f"{tag}/x"], g[f"{tag}/pose"], g[f"{tag}/out"]
     # bf16x3 (f32 storage, split-precision MFMA) has to hold the f32 tolerance; f16 = 16-bit storage with 11 significand bits
     for cdt, tol in (("f32", F32_TOL), ("bf16x3", F32_TOL), ("bf16", 6e-2), ("f16", 8e-3)):
-        if name == "emu" and ((cdt in ("bf16", "f16") and tag != "d8") or (cdt == "bf16x3" and tag not in ("d8", "d16soft"))):
-            continue      # keep the CPU suite short
+        if name == "emu" and ((cdt == "bf16" and tag != "d8") or (cdt == "bf16x3" and tag != "d8") or cdt == "f16"):
+            continue      # keep the CPU suite short (f16 differs from bf16 in one MFMA builtin: operator tests + pp_emu_case cover it)
         m = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name=mlp, compute_dtype=cdt,
                  use_hard_up_down=tag != "d16soft")
         synth_init_(m, 2022)
@@ -547,8 +547,8 @@ def test_ldm_shipped_latent_channels(be):
     x, pose = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 3, 6, generator=g)
     sd = None
     for cdt, tol in (("f32", F32_TOL), ("bf16x3", F32_TOL), ("f16", 1e-2), ("bf16", 8e-2)):
-        if name == "emu" and cdt in ("f16", "bf16x3"):
-            continue      # keep the CPU suite short
+        if name == "emu" and cdt != "f32":
+            continue      # keep the CPU suite short (the padding is identical in every mode; the other modes run on the GPU)
         m = UNetModelPose(encoder=StubEncoder(4), rot_representation_dim=6, image_size=8, in_channels=4, out_channels=4, num_head_channels=32,
                           use_spatial_transformer=True, transformer_depth=1, compute_dtype=cdt, **LDM_CASES["m32"])
         synth_init_(m, 2022)
@@ -589,6 +589,11 @@ def test_dataset_crop_and_sample_assembly(be):
     out8 = hip.op_warp_perspective(u8.to(dev), Minv, 64, 2.0 / 255.0, -1.0).cpu()
     want8 = F.grid_sample(u8.float().permute(2, 0, 1)[None], grid, mode="bilinear", padding_mode="zeros", align_corners=True)[0] * (2 / 255.0) - 1
     assert float((out8 - want8).abs().max()) < 2e-5
+    # uint8 destination semantics (what cv2.warpPerspective on a uint8 frame hands to ToTensor): interpolated value rounded to the
+    # nearest grey level and clamped, then the loader's /255 * 2 - 1 -- outputs on the k/255 grid, within half a level of the exact one
+    out8r = hip.op_warp_perspective(u8.to(dev), Minv, 64, 2.0 / 255.0, -1.0, round_u8=True).cpu()
+    lv = (out8r + 1) * 127.5
+    assert float((lv - lv.round()).abs().max()) < 1e-3 and float((out8r - want8).abs().max()) <= (0.5 + 1e-3) * 2 / 255
     # crop_frame geometry: the projected virtual bounding box lands on the output corners
     cams, objs = synthesize_grid(0)
     pose = np.linalg.inv(objs[5]) if False else objs[5].copy()

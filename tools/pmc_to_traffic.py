@@ -27,19 +27,24 @@ def parse(path):
 
 
 def base_name(n):
-    m = re.search(r"(?:nope::)?([a-z0-9_]+_kernel)", n)
+    m = re.search(r"(?:nope::|\d+)?([a-z][a-z0-9_]*_kernel)", n)
     return m.group(1) if m else n
+
+
+# element type of a kernel instantiation as the profiler prints it: demangled ("<unsigned short", ...) or, for _Float16 (which the
+# profiler's demangler does not know), the Itanium mangling ("IDF16_")
+TAGS = {"bf16": ("<unsigned short", "kernelIt"), "f16": ("<_Float16", "kernelIDF16_"), "f32": ("<float", "kernelIf"), "bf16x3": ("f32s_t",)}
 
 
 def main(argv):
     path, out = argv[0], argv[1]
     sim = argv[argv.index("--sim") + 1] if "--sim" in argv else None
     dtype = argv[argv.index("--dtype") + 1] if "--dtype" in argv else "bf16"
-    tag = {"bf16": "unsigned short", "f16": "_Float16", "f32": "float", "bf16x3": "f32s_t"}[dtype]
+    tags = TAGS[dtype]
     per, fam = {}, {"launches": 0, "fetch": 0.0, "write": 0.0}
     for name, ctr in parse(path).items():
         b = base_name(name)
-        if b not in CONV or ("<" + tag not in name and "<nope::" + tag not in name) or "FETCH_SIZE" not in ctr or "WRITE_SIZE" not in ctr:
+        if b not in CONV or not any(t in name for t in tags) or "FETCH_SIZE" not in ctr or "WRITE_SIZE" not in ctr:
             continue
         (nf, f), (nw, w) = ctr["FETCH_SIZE"], ctr["WRITE_SIZE"]
         assert nf == nw, (name, nf, nw)
