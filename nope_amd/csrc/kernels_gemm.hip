@@ -527,10 +527,10 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     const long long M = (long long)a.nhyp * (phased ? a.Hs * a.Ws : a.Ho * a.Wo);
     // (short K loops -- the 1x1 convs around the attention blocks, 2-3 K steps per tile -- stay on the 128 x 192 kernel, whose two
     //  workgroups per CU cover each other's prologue and epilogue: measured 193 vs 234 us for 192 -> 384 at 32 x 32)
-    // (long 3x3 launches may take the tap-resident kernel with fewer tiles than CUs -- NOPE_HALO_MIN_TILES, default 256 = off: the
-    //  768 -> 768 convs of the 4 x 4 level at 512 hypotheses have 128 tiles of 108 K steps and otherwise run position-major on the
-    //  128 x 192 kernel, one workgroup per CU)
-    static const int halo_min_tiles = getenv("NOPE_HALO_MIN_TILES") ? atoi(getenv("NOPE_HALO_MIN_TILES")) : 256;
+    // (long 3x3 launches take the tap-resident kernel from 128 tiles on -- NOPE_HALO_MIN_TILES: the 768 -> 768 convs of the 4 x 4
+    //  level at 512 hypotheses have 128 tiles of 108 K steps; on half the CUs they still beat the position-major 128 x 192 launch,
+    //  one workgroup per CU: 20.26 -> 20.19 ms per step, profiles/r03d_defaults_ab.txt)
+    static const int halo_min_tiles = getenv("NOPE_HALO_MIN_TILES") ? atoi(getenv("NOPE_HALO_MIN_TILES")) : 128;
     const long long min_tiles = (a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.ntaps * (Cin / bk) >= 54) ? halo_min_tiles : 256;
     const bool pp_shape = (a.mode == NOPE_CONV_PLAIN || a.mode == NOPE_CONV_DOWN2 || phased) && !a.out_nchw && a.Cout % vec == 0 &&
                           ((pp_mode & 8) || a.ntaps * (Cin / bk) >= 12) &&
