@@ -132,18 +132,25 @@ def _whole_config_worker(rank, ws, port, n_total, cdt, bank_dtype, ret):
         from nope_amd import dist as nd
         from nope_amd.harness import build_model, synthetic_batch
         torch.cuda.set_device(0)
+        torch.set_num_threads(2)                              # eight ranks share the host's cores too
         B = 32
         b = synthetic_batch(B, n_total, 256, seed=93, device="cuda")
         m = build_model(compute_dtype=cdt, bank_dtype=bank_dtype, device="cuda", template_parallel=True)
         tdt = {"bf16": torch.bfloat16, "f16": torch.float16}[bank_dtype]
-        # the query embedding rounded to the bank's storage type, so that a planted copy of it scores exactly -0.0
-        q_feat = m.u_net.encoder.encode_image(b["query"], mode="mode").to(tdt).float()
-        bank, _, _ = m.generate_templates(b["reference"], b["all_relativeR"], None)
         lo, hi = nd.shard_range(n_total, rank, ws)
         plant = n_total - 7                                   # a slot of the LAST rank's shard
-        if lo <= plant < hi:
-            bank[:, plant - lo] = q_feat.to(tdt)              # (in place: the bank keeps its shard placement)
-        sim, idx = m.retrieval_from_feat(q_feat, bank)
+        # The ranks take turns on the one GPU for the heavy part (8 processes time-slicing a device pay a context switch per
+        # kernel: 6 minutes instead of one); on 8 GPUs they would run side by side.  Nothing is exchanged in this phase.
+        for turn in range(ws):
+            if turn == rank:
+                # the query embedding rounded to the bank's storage type, so that a planted copy of it scores exactly -0.0
+                q_feat = m.u_net.encoder.encode_image(b["query"], mode="mode").to(tdt).float()
+                bank, _, _ = m.generate_templates(b["reference"], b["all_relativeR"], None)
+                if lo <= plant < hi:
+                    bank[:, plant - lo] = q_feat.to(tdt)      # (in place: the bank keeps its shard placement)
+                torch.cuda.synchronize()
+            dist.barrier()
+        sim, idx = m.retrieval_from_feat(q_feat, bank)            # scoring into the send buffer + the all-gather + top-5: all ranks at once
         torch.cuda.synchronize()
         out = {"shape": tuple(bank.shape), "sim": sim.cpu(), "idx": idx.cpu(), "range": (lo, hi)}
         if rank == 0:

@@ -340,3 +340,28 @@ def test_poses_and_crop_geometry_against_reference_run(tmp_path):
     assert np.array_equal(rel.numpy(), w["relpose/rel"]) and np.array_equal(inv.numpy(), w["relpose/rel_inv"])
     allr = P.all_relative_poses(w["L0/upper/obj_poses"], w["relpose/ref"])
     assert np.abs(allr.numpy() - w["relpose/all"]).max() < 1e-6
+
+
+def test_abi_version_is_checked_at_load(monkeypatch):
+    """nope_unet_config grew a field and the enums new meanings; a binding written against another header version must
+    fail at load time instead of passing shorter structs (hip.NopeLib compares nope_abi_version() with its own ABI_VERSION)."""
+    from nope_amd import hip
+    from nope_amd.csrc import build
+    lib = build.build()
+    assert hip.NopeLib(lib).dll.nope_abi_version() == hip.ABI_VERSION
+    src = open(os.path.join(ROOT, "include", "nope_hip.h")).read()
+    assert int(re.search(r"#define NOPE_ABI_VERSION (\d+)", src).group(1)) == hip.ABI_VERSION
+    monkeypatch.setattr(hip, "ABI_VERSION", hip.ABI_VERSION + 1)
+    with pytest.raises(hip.NopeError, match="ABI version"):
+        hip.NopeLib(lib)
+
+
+def test_compute_mode_codes():
+    from nope_amd import hip
+    src = open(os.path.join(ROOT, "include", "nope_hip.h")).read()
+    for name, code in (("NOPE_F32", hip.F32), ("NOPE_BF16", hip.BF16), ("NOPE_F16", hip.F16), ("NOPE_BF16X3", hip.BF16X3)):
+        assert re.search(rf"\b{name} = {code}\b", src), name
+    assert [hip.dtype_code(s) for s in ("f32", "bf16", "f16", "bf16x3")] == [0, 1, 2, 3]
+    assert hip.torch_dtype(hip.BF16X3) == torch.float32 and hip.storage_code(hip.BF16X3) == hip.F32 and hip.storage_code(hip.F16) == hip.F16
+    with pytest.raises(hip.NopeError):
+        hip.dtype_code("fp8")

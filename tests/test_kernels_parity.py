@@ -480,7 +480,8 @@ def test_workspace_canary_odd_hypotheses(be, n_hyp):
     ws = torch.full((need + 8192,), 0xAB, dtype=torch.uint8, device=dev)
     out = torch.empty((n_hyp, 8, 8, 8), device=dev)
     l = hip.lib()
-    l.check(l.dll.nope_unet_forward(h._h, x.to(dev).data_ptr(), n_hyp, 1, pose.to(dev).data_ptr(), n_hyp, 8, 8, out.data_ptr(), hip.F32,
+    xd, pd = x.to(dev), pose.to(dev)       # (held until after the call: a temporary's block may be handed to the next allocation)
+    l.check(l.dll.nope_unet_forward(h._h, xd.data_ptr(), n_hyp, 1, pd.data_ptr(), n_hyp, 8, 8, out.data_ptr(), hip.F32,
                                     ws.data_ptr(), need, None if dev == "cpu" else torch.cuda.current_stream().cuda_stream), "fwd")
     if dev != "cpu":
         torch.cuda.synchronize()
