@@ -36,7 +36,7 @@ def _cfg_get(cfg, key, default=None):
 
 class PoseConditional(nn.Module):
     def __init__(self, u_net, optim_config=None, testing_config=None, save_dir=None, bank_dtype="f32",
-                 max_hypotheses_per_launch=512, template_parallel=False, **kwargs):
+                 max_hypotheses_per_launch=512, template_parallel=False, two_stream_below=None, **kwargs):
         super().__init__()
         self.u_net = u_net
         self.save_dir = save_dir
@@ -50,6 +50,11 @@ class PoseConditional(nn.Module):
         self.bank_dtype = bank_dtype
         self.max_hyp = int(max_hypotheses_per_launch)
         self.template_parallel = bool(template_parallel)
+        # Single-query banks of at most this many templates (the reference's 26 / 91-template grids) are generated as two half
+        # batches on two HIP streams: with a few dozen hypotheses most launches of a forward have fewer tiles than the chip has
+        # workgroup slots, and two independent launch sequences fill each other's idle CUs (NOPE_TWO_STREAM_BELOW overrides; 0 = off).
+        env = os.environ.get("NOPE_TWO_STREAM_BELOW")
+        self.two_stream_below = int(env) if env is not None else (int(two_stream_below) if two_stream_below is not None else 0)
         self.global_step = 0
         self.global_rank = ndist.world()[0]
         if save_dir is not None:    # model.py:63-66
@@ -101,6 +106,13 @@ class PoseConditional(nn.Module):
         # never a caller-supplied tensor that merely has the same local size
         bank._nope_shard = (lo, hi, N) if ws > 1 else None
         if n == 0:                  # more ranks than templates: this rank still takes part in the all-gather
+            return bank
+        if B == 1 and 2 <= n <= self.two_stream_below and reference_feat.is_cuda:
+            h = (n + 1) // 2
+            with hip.overlap_stream(reference_feat) as side:
+                self.u_net.forward_hypotheses(reference_feat, poses[:, h:].contiguous(), out=bank[:, h:], out_dtype=self.bank_dtype)
+            self.u_net.forward_hypotheses(reference_feat, poses[:, :h].contiguous(), out=bank[:, :h], out_dtype=self.bank_dtype)
+            side.join(bank)
             return bank
         if n <= self.max_hyp:
             bs = max(1, self.max_hyp // n)
