@@ -251,6 +251,7 @@ def parity_record(a, dev, batch, bench_model, bench_sim, bench_idx, bench_ms, sp
     spot_out["ref_feat"] = m32.u_net.encoder.encode_image(reference[:1], mode="mode")
     spot_out["q_feat"] = m32.u_net.encoder.encode_image(query[:1], mode="mode")
     spot_out["bank32"], spot_out["sim32"] = bank32, sim32
+    kernel_frac = {}
     for mode in ("bf16", "f16", "bf16x3", "f32"):
         if mode == "f32":
             sim, idx, ms = sim32, idx32, ms32
@@ -259,11 +260,16 @@ def parity_record(a, dev, batch, bench_model, bench_sim, bench_idx, bench_ms, sp
         else:
             m = build_model(seed=2022, compute_dtype=mode, bank_dtype=mode if mode in ("bf16", "f16") else "f32", device=dev)
             sim, idx, _, ms = run(m, 3)
+            # the dominant kernel's MFMA fraction in this mode too (same HIP-event measurement as `roofline`)
+            rf = conv_roofline(m, lambda: m.generate_and_retrieve(query, reference, poses), mode, dev, a.templates, a.size)
+            kernel_frac[mode] = {"kernel": rf["kernel"], "frac": rf["frac"], "family_frac": rf["family"]["frac"]}
             del m
             torch.cuda.empty_cache()
         rec["modes"][mode] = {"score_rel_err": float((sim - sim32).abs().max()) / scale, "top5_equal": bool(torch.equal(idx, idx32)),
                               "top1_equal": int((idx[:, 0] == idx32[:, 0]).sum()), "queries": a.batch, "ms_per_step": ms,
                               "hyp_per_s": hyp / ms * 1e3, "meets_1e-4": bool(float((sim - sim32).abs().max()) / scale <= 1e-4 and torch.equal(idx, idx32))}
+        if mode in kernel_frac:
+            rec["modes"][mode]["dominant_kernel"] = kernel_frac[mode]
     return rec
 
 
