@@ -53,7 +53,7 @@ typedef void* nope_stream_t;
 /* Bumped whenever a struct of this header changes layout or an enum gains a meaning (2: nope_unet_config.soft_up_down,
  * NOPE_F16 / NOPE_BF16X3 compute modes, 4x4 STRIDE2).  Callers compare nope_abi_version() against the header they were
  * built with before passing any struct (nope_amd/hip.py does at load time). */
-#define NOPE_ABI_VERSION 2
+#define NOPE_ABI_VERSION 3
 const char* nope_strerror(int code);
 int nope_abi_version(void);
 
@@ -153,12 +153,12 @@ int nope_unet_profile_launches(nope_unet* net, nope_conv_launch_info* out, int m
  * Upsample :93-174; SpatialTransformer / BasicTransformerBlock / CrossAttention / GEGLU, ldm/attention.py:37-277): the variant
  * whose pose conditioning is cross-attention against context = pose_mlp(pose).  Tensor names are UNetModelPose's own
  * state-dict keys ("input_blocks.1.1.transformer_blocks.0.attn2.to_v.weight", "middle_block.0.in_layers.2.weight", ...).
- * Supported: use_spatial_transformer = true with transformer_depth = 1 and num_head_channels = 32 (the shipped
+ * Supported: use_spatial_transformer = true with transformer_depth >= 1 and num_head_channels = 32 (the shipped
  * configs/model/vae_cin_ldm.yaml), conv_resample, ResBlocks with or without use_scale_shift_norm (FiLM, openaimodel.py:277-281),
  * no resblock_updown; pose_mlp "single_layer" / "two_layers"; injecting_condition_twice on or off. */
 typedef struct nope_ldm nope_ldm;
 typedef struct {
-    int in_channels;        /* 4 in vae_cin_ldm.yaml (bf16 compute needs a multiple of 8) */
+    int in_channels;        /* 4 in vae_cin_ldm.yaml (any count: the input conv's K axis is zero-padded to a multiple of 8 at pack time) */
     int model_channels;     /* 256 */
     int out_channels;       /* 4 */
     int num_res_blocks;     /* 2 */
@@ -172,6 +172,7 @@ typedef struct {
     int injecting_condition_twice;   /* 0: timestep embedding is zeros; 1: emb = pose_mlp_timesteps(pose) */
     int compute_dtype;      /* NOPE_F32 | NOPE_BF16, as nope_unet_config */
     int use_scale_shift_norm;        /* 1: ResBlocks apply out_norm(h) * (1 + scale) + shift with (scale, shift) = emb_layers(emb) */
+    int transformer_depth;           /* BasicTransformerBlocks per SpatialTransformer (attention.py:232-262); 1 in vae_cin_ldm.yaml; 0 reads as 1 */
 } nope_ldm_config;
 
 int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors, int n_tensors, nope_stream_t stream, nope_ldm** out);

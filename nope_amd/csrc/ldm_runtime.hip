@@ -31,7 +31,8 @@ namespace {
 struct LConv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; };
 struct LNorm { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct LRes { LNorm n1, n2; LConv c1, c2, skip; bool has_skip = false; float *emb_w = nullptr, *emb_b = nullptr; int Cin = 0, Cout = 0; };
-struct LST { LNorm norm, ln1, ln3; LConv proj_in, qkv, out1, ff1, ff2, proj_out; int u_off = 0; int C = 0; };   // u_off: its slice of nope_ldm::u_w
+struct LTB { LNorm ln1, ln3; LConv qkv, out1, ff1, ff2; int u_off = 0; };         // one BasicTransformerBlock; u_off: its slice of nope_ldm::u_w
+struct LST { LNorm norm; LConv proj_in, proj_out; std::vector<LTB> blocks; int C = 0; };
 struct LBlock { bool has_res = false, has_st = false, has_resample = false; LRes res; LST st; LConv resample; };
 
 }  // namespace
@@ -130,12 +131,15 @@ struct Loader {
         return r;
     }
     LST st(const std::string& p, int C) {
-        LST t;
-        t.C = C;
+        LST T;
+        T.C = C;
         const int ctx = net->cfg.context_dim;
-        t.norm = norm(p + "norm.", C);
-        t.proj_in = conv(p + "proj_in.", C, C, 1, NOPE_CONV_PLAIN, true);
-        const std::string b = p + "transformer_blocks.0.";
+        T.norm = norm(p + "norm.", C);
+        T.proj_in = conv(p + "proj_in.", C, C, 1, NOPE_CONV_PLAIN, true);
+        const int depth = net->cfg.transformer_depth > 0 ? net->cfg.transformer_depth : 1;
+        for (int d = 0; d < depth; ++d) {                      // attention.py:251-258: `depth` blocks in sequence
+        LTB t;
+        const std::string b = p + "transformer_blocks." + std::to_string(d) + ".";
         t.ln1 = norm(b + "norm1.", C);
         t.ln3 = norm(b + "norm3.", C);
         get(b + "norm2.weight", {C}); get(b + "norm2.bias", {C});                     // validated, provably without effect (see header)
@@ -173,8 +177,10 @@ struct Loader {
         }
         t.ff1 = conv(b + "ff.net.0.proj.", C, 8 * C, 1, NOPE_CONV_PLAIN, true, true);
         t.ff2 = conv(b + "ff.net.2.", 4 * C, C, 1, NOPE_CONV_PLAIN, true, true);
-        t.proj_out = conv(p + "proj_out.", C, C, 1, NOPE_CONV_PLAIN, true);
-        return t;
+        T.blocks.push_back(t);
+        }
+        T.proj_out = conv(p + "proj_out.", C, C, 1, NOPE_CONV_PLAIN, true);
+        return T;
     }
 };
 
@@ -271,36 +277,37 @@ struct Fwd {
         conv(R.c2, Act{t2, R.Cout, x.H, x.W}, out, x.H, x.W, resid);
         ar.off = mark;
     }
-    // SpatialTransformer.forward with one BasicTransformerBlock, attention.py:214-277
+    // SpatialTransformer.forward, attention.py:264-277: GroupNorm, proj_in, `depth` BasicTransformerBlocks (:192-212), proj_out + x
     void st(const LST& T, const Act& x, void* out) {
         const int HW = x.H * x.W, C = T.C;
         const long long M = (long long)nhyp * HW;
         const size_t mark = ar.off;
         void* xn = alloc_act((size_t)M * C);
         void* tok = alloc_act((size_t)M * C);
-        gn(T.norm, x.p, xn, HW, 0, 1e-6f);
-        conv(T.proj_in, Act{xn, C, x.H, x.W}, tok, x.H, x.W);
-        // attn1 (self-attention) + residual
-        void* a = xn;                                    // reuse: LN1(tok)
         void* qkv = alloc_act((size_t)M * 3 * C);
         void* o = alloc_act((size_t)M * C);
         void* tok1 = alloc_act((size_t)M * C);
-        if (live()) chk(launch_layernorm(net->sdt, tok, a, T.ln1.gamma, T.ln1.beta, M, C, 1e-5f, s));
-        conv(T.qkv, Act{a, C, x.H, x.W}, qkv, x.H, x.W);
-        if (live()) chk(launch_token_attention(net->sdt, qkv, o, nhyp, HW, C, 32, s));
-        conv(T.out1, Act{o, C, x.H, x.W}, tok1, x.H, x.W, tok);
-        // attn2 against the single pose token: + to_out(to_v(context)) for every token -- this block's slice of u_all
-        if (live()) chk(launch_add_rowvec(net->sdt, tok1, tok1, u_all + T.u_off, M, HW, C, s, net->u_total));
-        // feed-forward (GEGLU) + residual
-        void* f = o;                                     // reuse: LN3(tok1)
-        if (live()) chk(launch_layernorm(net->sdt, tok1, f, T.ln3.gamma, T.ln3.beta, M, C, 1e-5f, s));
         void* g = alloc_act((size_t)M * 8 * C);
         void* gg = alloc_act((size_t)M * 4 * C);
-        conv(T.ff1, Act{f, C, x.H, x.W}, g, x.H, x.W);
-        if (live()) chk(launch_geglu(net->sdt, g, gg, M, 4 * C, s));
-        void* tok3 = tok;                                // tok is dead after the attn1 residual
-        conv(T.ff2, Act{gg, 4 * C, x.H, x.W}, tok3, x.H, x.W, tok1);
-        conv(T.proj_out, Act{tok3, C, x.H, x.W}, out, x.H, x.W, x.p);
+        gn(T.norm, x.p, xn, HW, 0, 1e-6f);
+        conv(T.proj_in, Act{xn, C, x.H, x.W}, tok, x.H, x.W);
+        for (const LTB& B : T.blocks) {
+            // attn1 (self-attention) + residual
+            void* a = xn;                                    // reuse: LN1(tok)
+            if (live()) chk(launch_layernorm(net->sdt, tok, a, B.ln1.gamma, B.ln1.beta, M, C, 1e-5f, s));
+            conv(B.qkv, Act{a, C, x.H, x.W}, qkv, x.H, x.W);
+            if (live()) chk(launch_token_attention(net->sdt, qkv, o, nhyp, HW, C, 32, s));
+            conv(B.out1, Act{o, C, x.H, x.W}, tok1, x.H, x.W, tok);
+            // attn2 against the single pose token: + to_out(to_v(context)) for every token -- this block's slice of u_all
+            if (live()) chk(launch_add_rowvec(net->sdt, tok1, tok1, u_all + B.u_off, M, HW, C, s, net->u_total));
+            // feed-forward (GEGLU) + residual
+            void* f = o;                                     // reuse: LN3(tok1)
+            if (live()) chk(launch_layernorm(net->sdt, tok1, f, B.ln3.gamma, B.ln3.beta, M, C, 1e-5f, s));
+            conv(B.ff1, Act{f, C, x.H, x.W}, g, x.H, x.W);
+            if (live()) chk(launch_geglu(net->sdt, g, gg, M, 4 * C, s));
+            conv(B.ff2, Act{gg, 4 * C, x.H, x.W}, tok, x.H, x.W, tok1);      // (tok is dead after the attn1 residual: the block's output)
+        }
+        conv(T.proj_out, Act{tok, C, x.H, x.W}, out, x.H, x.W, x.p);
         ar.off = mark;
     }
 };
@@ -425,7 +432,7 @@ int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors,
     if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->num_res_blocks < 1 || cfg->num_head_channels != 32) return NOPE_ERR_UNSUPPORTED;
     if (!dt_is_compute(cfg->compute_dtype)) return NOPE_ERR_UNSUPPORTED;
     if (cfg->pose_mlp_layers != 1 && cfg->pose_mlp_layers != 2) return NOPE_ERR_UNSUPPORTED;
-    if (cfg->model_channels % 32 || cfg->in_channels < 1 || cfg->context_dim <= 0) return NOPE_ERR_UNSUPPORTED;
+    if (cfg->model_channels % 32 || cfg->in_channels < 1 || cfg->context_dim <= 0 || cfg->transformer_depth < 0 || cfg->transformer_depth > 16) return NOPE_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     nope_ldm* net = new nope_ldm();
     net->cfg = *cfg;

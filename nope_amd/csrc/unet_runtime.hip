@@ -105,18 +105,22 @@ struct Loader {
         return p;
     }
     // (ksz 4 with UP2P: the weight is a ConvTranspose2d(4, 2, 1)'s, [Cin][Cout][4][4], repacked into the same four phase sets)
-    Conv conv(const std::string& pfx, int Cin, int Cout, int ksz, int mode, bool has_bias, const float* cin_scale = nullptr) {
+    // (Cin_pad > Cin: the kernel sees Cin_pad input channels, the last ones zero -- a latent whose channel count is not a whole 16-byte
+    //  vector, e.g. a 4-channel VAE latent, zero-padded at pack time and in the NHWC input)
+    Conv conv(const std::string& pfx, int Cin, int Cout, int ksz, int mode, bool has_bias, const float* cin_scale = nullptr, int Cin_pad = 0) {
         Conv c;
+        const int Csrc = Cin;
+        if (Cin_pad > Cin) Cin = Cin_pad;
         c.Cin = Cin; c.Cout = Cout; c.mode = mode;
         c.ntaps = (mode == NOPE_CONV_DOWN2 || mode == NOPE_CONV_UP2P) ? 4 : ksz * ksz;
         const bool convT = mode == NOPE_CONV_UP2P && ksz == 4;
         const nope_tensor_desc* d = mode == NOPE_CONV_DOWN2 ? get(pfx + "weight", {Cout, (int64_t)Cin * 4, 1, 1})
                                     : convT             ? get(pfx + "weight", {Cin, Cout, 4, 4})
-                                                        : get(pfx + "weight", {Cout, Cin, ksz, ksz});
+                                                        : get(pfx + "weight", {Cout, Csrc, ksz, ksz});
         if (d) {
             const size_t es = (size_t)dt_es(net->dt);
             c.w = dmalloc((size_t)Cout * c.ntaps * Cin * es * (mode == NOPE_CONV_UP2P ? 4 : 1));
-            if (c.w) { int e = launch_pack_conv_w(net->dt, d->data, c.w, Cout, Cin, convT ? 16 : c.ntaps, mode, s, cin_scale); if (e && err == NOPE_OK) err = e; }
+            if (c.w) { int e = launch_pack_conv_w(net->dt, d->data, c.w, Cout, Cin, convT ? 16 : c.ntaps, mode, s, cin_scale, nullptr, Csrc); if (e && err == NOPE_OK) err = e; }
         }
         if (has_bias) c.bias = copy_f32(pfx + "bias", {Cout});
         return c;
@@ -352,7 +356,8 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
     const int* dims = net->dims;
 
     // ---- persistent buffers ------------------------------------------------------------------
-    void* x_in = f.alloc_act((size_t)n_src * HW * cfg.channels);
+    const int cin_k = net->init_conv.Cin;         // latent channels rounded up to 8
+    void* x_in = f.alloc_act((size_t)n_src * HW * cin_k);
     void* x0 = f.alloc_act((size_t)n_src * HW * dims[0]);
     float* c0 = (float*)f.ar.alloc((size_t)n_hyp * net->classes * 4);
     float* c1 = (float*)f.ar.alloc((size_t)n_hyp * net->classes * 4);
@@ -382,7 +387,7 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
 
     // ---- input + pose embedding ----------------------------------------------------------------
     if (f.live()) {
-        f.chk(launch_nchw_to_nhwc(net->sdt, x, x_in, n_src, cfg.channels, HW, s));
+        f.chk(launch_nchw_to_nhwc(net->sdt, x, x_in, n_src, cin_k, HW, s, cfg.channels));
         if (cfg.pose_mlp_layers == 0) f.chk(launch_pos_emb(pose, c0, n_hyp, cfg.pose_dim, net->classes, s));   // u_net.py:73-76
         else f.chk(launch_linear_naive(pose, net->pose_w0, net->pose_b0, c0, n_hyp, net->classes, cfg.pose_dim, 0, net->classes, s));
         const float* c = c0;
@@ -397,7 +402,7 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
         ea.Cout = net->emb_total; ea.nhyp = n_hyp;
         f.chk(launch_conv(NOPE_F32, ea, s));
     }
-    Act xin{x_in, cfg.channels, H, W, 1};
+    Act xin{x_in, cin_k, H, W, 1};
     {
         Fwd g = f;   // init_conv runs over the n_src reference samples only
         g.nhyp = n_src;
@@ -487,7 +492,7 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
     if (!dt_is_compute(cfg->compute_dtype)) return NOPE_ERR_UNSUPPORTED;
     if (cfg->pose_mlp_layers < 0 || cfg->pose_mlp_layers > 2) return NOPE_ERR_UNSUPPORTED;   // 0 = "posEncoding" (no parameters)
     if (cfg->pose_mlp_layers == 0 && (cfg->pose_dim < 1 || (cfg->u_net_dim * 4) % (2 * cfg->pose_dim) || cfg->u_net_dim * 4 / cfg->pose_dim < 4)) return NOPE_ERR_UNSUPPORTED;
-    if (cfg->u_net_dim % 8 || cfg->channels % 8 || cfg->u_net_dim % cfg->groups) return NOPE_ERR_UNSUPPORTED;
+    if (cfg->u_net_dim % 8 || cfg->channels < 1 || cfg->out_dim < 1 || cfg->u_net_dim % cfg->groups) return NOPE_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     nope_unet* net = new nope_unet();
     net->cfg = *cfg;
@@ -514,7 +519,7 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
         net->pose_w2 = ld.copy_f32("pose_mlp.2.weight", {net->classes, net->classes});
         net->pose_b2 = ld.copy_f32("pose_mlp.2.bias", {net->classes});
     }
-    net->init_conv = ld.conv("init_conv.", cfg->channels, dims[0], 3, NOPE_CONV_PLAIN, true);
+    net->init_conv = ld.conv("init_conv.", cfg->channels, dims[0], 3, NOPE_CONV_PLAIN, true, nullptr, (cfg->channels + 7) / 8 * 8);
     auto linattn = [&](const std::string& p, int C) {
         LinAttn a;
         ld.prenorm_qkv(p, C, 3 * HD, a.pre, a.qkv, a.c0, a.c1);

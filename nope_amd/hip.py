@@ -13,7 +13,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3      # BF16X3: compute mode only (f32 storage, three bf16 MFMA passes per product)
-ABI_VERSION = 2                          # NOPE_ABI_VERSION of include/nope_hip.h these ctypes structs mirror
+ABI_VERSION = 3                          # NOPE_ABI_VERSION of include/nope_hip.h these ctypes structs mirror
 CONV_PLAIN, CONV_UP2, CONV_DOWN2, CONV_UP2P, CONV_STRIDE2 = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -36,7 +36,8 @@ class UNetConfig(C.Structure):
 class LdmConfig(C.Structure):
     _fields_ = [("in_channels", _i), ("model_channels", _i), ("out_channels", _i), ("num_res_blocks", _i), ("n_levels", _i),
                 ("channel_mult", _i * 8), ("attn_levels", _i * 8), ("num_head_channels", _i), ("context_dim", _i), ("pose_dim", _i),
-                ("pose_mlp_layers", _i), ("injecting_condition_twice", _i), ("compute_dtype", _i), ("use_scale_shift_norm", _i)]
+                ("pose_mlp_layers", _i), ("injecting_condition_twice", _i), ("compute_dtype", _i), ("use_scale_shift_norm", _i),
+                ("transformer_depth", _i)]
 
 
 class ConvLaunchInfo(C.Structure):
@@ -441,6 +442,7 @@ class LdmHandle:
             c.attn_levels[i] = int(cfg["attn_levels"][i])
         c.compute_dtype = dtype_code(compute_dtype)
         c.use_scale_shift_norm = int(cfg.get("use_scale_shift_norm", 0))
+        c.transformer_depth = int(cfg.get("transformer_depth", 1))
         self.in_channels, self.out_channels, self.pose_dim = c.in_channels, c.out_channels, c.pose_dim
         descs, keep, dev = _tensor_descs(state_dict)
         self.device = dev

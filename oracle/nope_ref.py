@@ -318,17 +318,20 @@ def _ldm_cross_attention(x: Tensor, ctx: Tensor, sd: SD, p: str, d_head: int = 3
 
 
 def _ldm_transformer(x: Tensor, ctx: Tensor, sd: SD, p: str) -> Tensor:
-    """SpatialTransformer.forward with one BasicTransformerBlock, ldm/attention.py:214-277."""
+    """SpatialTransformer.forward, ldm/attention.py:264-277, with its `depth` BasicTransformerBlocks (:192-212, :251-258) in sequence."""
     B, C, H, W = x.shape
     t = F.conv2d(F.group_norm(x, 32, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6), sd[p + "proj_in.weight"], sd[p + "proj_in.bias"])
     t = t.reshape(B, C, H * W).permute(0, 2, 1)
-    b = p + "transformer_blocks.0."
-    ln = lambda y, n: F.layer_norm(y, (C,), sd[b + n + ".weight"], sd[b + n + ".bias"], 1e-5)
-    y = ln(t, "norm1")
-    t = _ldm_cross_attention(y, y, sd, b + "attn1.") + t
-    t = _ldm_cross_attention(ln(t, "norm2"), ctx, sd, b + "attn2.") + t
-    a, gate = F.linear(ln(t, "norm3"), sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"]).chunk(2, dim=-1)
-    t = F.linear(a * F.gelu(gate), sd[b + "ff.net.2.weight"], sd[b + "ff.net.2.bias"]) + t
+    d = 0
+    while f"{p}transformer_blocks.{d}.norm1.weight" in sd:
+        b = f"{p}transformer_blocks.{d}."
+        ln = lambda y, n: F.layer_norm(y, (C,), sd[b + n + ".weight"], sd[b + n + ".bias"], 1e-5)
+        y = ln(t, "norm1")
+        t = _ldm_cross_attention(y, y, sd, b + "attn1.") + t
+        t = _ldm_cross_attention(ln(t, "norm2"), ctx, sd, b + "attn2.") + t
+        a, gate = F.linear(ln(t, "norm3"), sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"]).chunk(2, dim=-1)
+        t = F.linear(a * F.gelu(gate), sd[b + "ff.net.2.weight"], sd[b + "ff.net.2.bias"]) + t
+        d += 1
     t = t.permute(0, 2, 1).reshape(B, C, H, W)
     return F.conv2d(t, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"]) + x
 

@@ -187,9 +187,13 @@ def ldm():
                         ("m32film", dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[1, 2], context_dim=24,
                                          pose_mlp_name="single_layer", injecting_condition_twice=False, use_scale_shift_norm=True), 8),
                         ("m64film", dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[2], context_dim=40,
-                                         pose_mlp_name="single_layer", injecting_condition_twice=True, use_scale_shift_norm=True), 8)):
+                                         pose_mlp_name="single_layer", injecting_condition_twice=True, use_scale_shift_norm=True), 8),
+                        # two BasicTransformerBlocks per SpatialTransformer (transformer_depth = 2, attention.py:251-258)
+                        ("m32d2", dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[1, 2], context_dim=24,
+                                       pose_mlp_name="single_layer", injecting_condition_twice=False, transformer_depth=2), 8)):
         common = dict(rot_representation_dim=6, image_size=hw, in_channels=8, out_channels=8, num_head_channels=32,
-                      use_spatial_transformer=True, transformer_depth=1, **kw)
+                      use_spatial_transformer=True, transformer_depth=1)
+        common.update(kw)
         mine = UNetModelPose(encoder=RI.StubEncoder(8), **common)
         synth_init_(mine, SEED)
         ref = RefLdm(encoder=RI.StubEncoder(8), **common)

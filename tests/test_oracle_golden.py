@@ -97,20 +97,24 @@ LDM_CASES = {"m32": dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=
              "m32film": dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[1, 2], context_dim=24,
                              pose_mlp_name="single_layer", injecting_condition_twice=False, use_scale_shift_norm=True),
              "m64film": dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[2], context_dim=40,
-                             pose_mlp_name="single_layer", injecting_condition_twice=True, use_scale_shift_norm=True)}
+                             pose_mlp_name="single_layer", injecting_condition_twice=True, use_scale_shift_norm=True),
+             "m32d2": dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=[1, 2], context_dim=24,
+                           pose_mlp_name="single_layer", injecting_condition_twice=False, transformer_depth=2)}
 
 
 def build_ldm(tag, compute_dtype="f32"):
     from nope_amd.ldm import UNetModelPose
     from nope_amd.weights import synth_init_
     from tests.util import StubEncoder
+    kw = dict(transformer_depth=1)
+    kw.update(LDM_CASES[tag])
     m = UNetModelPose(encoder=StubEncoder(8), rot_representation_dim=6, image_size=8, in_channels=8, out_channels=8, num_head_channels=32,
-                      use_spatial_transformer=True, transformer_depth=1, compute_dtype=compute_dtype, **LDM_CASES[tag])
+                      use_spatial_transformer=True, compute_dtype=compute_dtype, **kw)
     synth_init_(m, 2022)
     return m
 
 
-@pytest.mark.parametrize("tag", ["m32", "m64two", "m32film", "m64film"])
+@pytest.mark.parametrize("tag", ["m32", "m64two", "m32film", "m64film", "m32d2"])
 def test_ldm_variant(golden, tag):
     """The LDM cross-attention variant (UNetModelPose, adapt_openaimodel.py:130-158): the oracle's restatement against outputs
     recorded from the reference class (tests/golden/make_golden.py ldm), same synthesised weights."""
