@@ -20,7 +20,7 @@ of `--templates` templates per GPU in `--bank-dtype` (default: BASELINE configs[
 templates); for N>1 every rank scores its slice, the (B, N/G) scores are all-gathered over RCCL and ranked.
 
 Extra legs on rank 0 at N=1 (outside the timed region):
-  roofline      the dominant kernel of the step, conv3x3_halo_kernel (the 3x3 convs: 41 of the U-Net's 83 implicit-GEMM launches,
+  roofline      the dominant kernel of the step, conv3x3_halo_kernel (the 3x3 convs: 45 of the U-Net's 83 implicit-GEMM launches,
                 ~half of the step): multiply-adds x2 its launches EXECUTE / their summed duration, measured with HIP events around
                 every launch on the launch stream, vs the 2.5 PFLOP/s dense bf16 / f16 peak; `family` = all implicit-GEMM
                 launches, `classes` = one line per launch shape;
