@@ -282,7 +282,7 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const typename Til
                 if (p.out_nchw) {
                     const size_t o = nchw_base + (size_t)n * HWo;
                     if (p.out_dt == NOPE_F32) reinterpret_cast<float*>(p.out)[o] = v;
-                    else if (p.out_dt == NOPE_F16) reinterpret_cast<f16_t*>(p.out)[o] = (f16_t)v;
+                    else if (p.out_dt == NOPE_F16) reinterpret_cast<f16_t*>(p.out)[o] = f32_to_f16_sat(v);
                     else reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(v);
                 } else {
                     Elt<T>::st(out + mo * p.Cout + n, v);
@@ -527,7 +527,7 @@ __device__ __forceinline__ void epilogue_nchw(const ConvParams& p, const typenam
             const float v = pan[lane * Ep<T>::LD + cc];
             const size_t o = base + (size_t)n * HWo;
             if (p.out_dt == NOPE_F32) reinterpret_cast<float*>(p.out)[o] = v;
-            else if (p.out_dt == NOPE_F16) reinterpret_cast<f16_t*>(p.out)[o] = (f16_t)v;
+            else if (p.out_dt == NOPE_F16) reinterpret_cast<f16_t*>(p.out)[o] = f32_to_f16_sat(v);
             else reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(v);
         }
         __builtin_amdgcn_wave_barrier();

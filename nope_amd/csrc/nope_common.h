@@ -44,10 +44,17 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     return x.u;
 }
 
-// Two f32 -> packed f16x2 (round-to-nearest-even; v_cvt_pk_f16_f32 on gfx950)
+// f32 -> f16 SATURATES: values beyond the format's range become +-65504 instead of +-inf (one v_med3_f32 per element).  The f16
+// compute mode stores every activation through these two functions; an overflowing conv output (possible with real checkpoints:
+// nothing bounds a pre-GroupNorm activation) then costs precision on that element instead of turning the sample's GroupNorm
+// statistics, and with them the whole embedding map, into NaN.  NaN stays NaN.
+constexpr float kF16Max = 65504.0f;
+__device__ __forceinline__ float sat_f16(float v) { return __builtin_amdgcn_fmed3f(v, -kF16Max, kF16Max); }
+__device__ __forceinline__ _Float16 f32_to_f16_sat(float v) { return (_Float16)sat_f16(v); }
+// Two f32 -> packed f16x2 (saturating, round-to-nearest-even; v_cvt_pk_f16_f32 on gfx950)
 typedef _Float16 f16x2_hw_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
-    const f32x2_hw_t v = {lo, hi};
+    const f32x2_hw_t v = {sat_f16(lo), sat_f16(hi)};
     union { f16x2_hw_t h; unsigned u; } x;
     x.h = __builtin_convertvector(v, f16x2_hw_t);
     return x.u;
@@ -100,7 +107,7 @@ template <> struct Elt<f16_t> {
     static constexpr int VEC = 8;
     static constexpr int DT = NOPE_F16;
     static __device__ __forceinline__ float ld(const f16_t* p) { return (float)*p; }
-    static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
+    static __device__ __forceinline__ void st(f16_t* p, float v) { *p = f32_to_f16_sat(v); }
     static __device__ __forceinline__ void unpack(const u32x4& v, float* o) {
         union { u32x4 u; f16_t h[8]; } x; x.u = v;
 #pragma unroll

@@ -439,6 +439,8 @@ inline void hipemu_buffer_load_lds(hipemu_rsrc r, P ldsptr, unsigned size, unsig
 #define __builtin_amdgcn_make_buffer_rsrc hipemu_make_rsrc
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds hipemu_buffer_load_lds
 
+inline float hipemu_fmed3f(float a, float b, float c) { return a != a ? a : fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }   // v_med3_f32 (NaN in: NaN out)
+#define __builtin_amdgcn_fmed3f hipemu_fmed3f
 inline float __expf(float x) { return expf(x); }
 inline float hipemu_rcpf(float x) { return 1.0f / x; }
 #define __builtin_amdgcn_rcpf hipemu_rcpf

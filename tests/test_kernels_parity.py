@@ -121,6 +121,43 @@ def test_conv_lds_dma_path(be, dt):
     assert rel(y.float().cpu(), F.conv2d(q(x8), q(w8), b8)) < 1e-2
 
 
+def test_f16_mode_saturates_instead_of_overflowing(be):
+    """f16 compute mode: a value beyond the format's range is stored as +-65504, never +-inf (one inf would turn a sample's
+    GroupNorm statistics, and with them its whole embedding map, into NaN).  Every f32 -> f16 store site: layout conversion,
+    the conv epilogue (packed NHWC rows on the generic and the LDS-DMA kernels, scattered and LDS-staged NCHW planes),
+    GroupNorm-apply, the attention core's 4-wide store.  NaN stays NaN."""
+    hip, dev, _ = be
+    dt, big = hip.F16, 65504.0
+    g = torch.Generator().manual_seed(3)
+    for C in (16, 64):                                                       # generic kernel / LDS-DMA kernel
+        x = torch.randn(2, C, 8, 8, generator=g) * 3
+        w = torch.randn(24, C, 1, 1, generator=g) * 8e3
+        ref = F.conv2d(_q(x, dt, hip), _q(w, dt, hip)).clamp(-big, big)
+        assert (ref.abs() == big).float().mean() > 0.3 and (ref.abs() < big).any()
+        y = hip.to_nchw(hip.op_conv(dt, hip.to_nhwc(x.to(dev), dt), w.to(dev), None), dt).cpu()
+        assert torch.isfinite(y).all() and rel(y, ref) < OP_TOL[dt]
+        assert torch.equal(y.abs() == big, ref.abs() == big) or ((y.abs() == big) != (ref.abs() == big)).float().mean() < 0.01
+        for staged in ("1", "0"):
+            import os
+            os.environ["NOPE_NCHW_STAGED"] = staged
+            y = hip.op_conv(dt, hip.to_nhwc(x.to(dev), dt), w[:8].to(dev), None, out_nchw=True, out_dtype=hip.F16).float().cpu()
+            os.environ.pop("NOPE_NCHW_STAGED")
+            assert torch.isfinite(y).all() and rel(y, ref[:, :8]) < OP_TOL[dt], (C, staged)
+    xin = torch.tensor([1e6, -1e6, 7e4, -65520.0, 65519.0, 3.0, float("nan"), float("inf")]).view(1, 8, 1, 1).expand(1, 8, 2, 2).contiguous()
+    y = hip.to_nchw(hip.to_nhwc(xin.to(dev), dt), dt).cpu()[0, :, 0, 0]
+    assert y[:6].tolist() == [big, -big, big, -big, big, 3.0] and torch.isnan(y[6]) and y[7] == big
+    x = torch.randn(2, 16, 4, 4, generator=g)
+    ga, be_ = torch.full((16,), 5e4), torch.zeros(16)
+    y = hip.to_nchw(hip.op_group_norm(dt, hip.to_nhwc(x.to(dev), dt), ga.to(dev), be_.to(dev), 8), dt).cpu()
+    ref = F.group_norm(_q(x, dt, hip), 8, ga, be_).clamp(-big, big)
+    assert torch.isfinite(y).all() and (y.abs() == big).any() and rel(y, ref) < OP_TOL[dt]
+    qkv = torch.randn(1, 3 * 128, 4, 4, generator=g)
+    qkv[:, 256:] *= 6e4                                                      # v beyond the range: out = softmax(..) @ v
+    for full in (False, True):
+        y = hip.to_nchw(hip.op_linear_attention(dt, hip.to_nhwc(qkv.to(dev), dt), full=full), dt).cpu()
+        assert torch.isfinite(y).all(), full
+
+
 @pytest.mark.parametrize("dt", [0, 1, 2])
 def test_group_norm_variants(be, dt):
     hip, dev, _ = be
