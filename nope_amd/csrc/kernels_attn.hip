@@ -75,11 +75,21 @@ __global__ __launch_bounds__(NT, 4) void linattn_kernel(const T* __restrict__ qk
         float m[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) m[e] = -3.0e38f;
-        for (int p = pp; p < n; p += PT) {
-            float kv[VEC];
-            Elt<T>::unpack(ld16(kp + (size_t)p * ldq + cg * VEC), kv);
+        // (four independent loads in flight per thread: the sweep is latency-bound, 16 dependent iterations at n = 1024 before)
+        for (int p = pp; p < n; p += 4 * PT) {
+            u32x4 raw[4];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], kv[e]);
+            for (int u = 0; u < 4; ++u) {
+                const int pu = p + u * PT < n ? p + u * PT : p;      // (a repeat of the first pixel past the end: max is idempotent)
+                raw[u] = ld16(kp + (size_t)pu * ldq + cg * VEC);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float kv[VEC];
+                Elt<T>::unpack(raw[u], kv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], kv[e]);
+            }
         }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) s_a[pp][cg * VEC + e] = m[e];
@@ -104,18 +114,22 @@ __global__ __launch_bounds__(NT, 4) void linattn_kernel(const T* __restrict__ qk
     float kmx[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) kmx[e] = s_kmax[cg * VEC + e];
+    // the next tile's k / v vectors are requested before this tile's products: one HBM / L2 round trip per 64 pixels was exposed
+    u32x4 kraw = {0u, 0u, 0u, 0u}, vraw = {0u, 0u, 0u, 0u};
+    if (pp < n) { kraw = ld16(kp + (size_t)pp * ldq + cg * VEC); vraw = ld16(vp + (size_t)pp * ldq + cg * VEC); }
     for (int t0 = 0; t0 < n; t0 += PT) {
         const int p = t0 + pp;
         float ek[VEC], vv[VEC];
         if (p < n) {
-            Elt<T>::unpack(ld16(kp + (size_t)p * ldq + cg * VEC), ek);
-            Elt<T>::unpack(ld16(vp + (size_t)p * ldq + cg * VEC), vv);
+            Elt<T>::unpack(kraw, ek);
+            Elt<T>::unpack(vraw, vv);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) ek[e] = fexp<FASTM>(ek[e] - kmx[e]);
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { ek[e] = 0.f; vv[e] = 0.f; }
         }
+        if (p + PT < n) { kraw = ld16(kp + (size_t)(p + PT) * ldq + cg * VEC); vraw = ld16(vp + (size_t)(p + PT) * ldq + cg * VEC); }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { s_a[pp][cg * VEC + e] = ek[e]; s_v[pp][cg * VEC + e] = vv[e]; }
         __syncthreads();
@@ -162,16 +176,20 @@ __global__ __launch_bounds__(NT, 4) void linattn_kernel(const T* __restrict__ qk
 #pragma unroll
             for (int j = 0; j < 8; ++j) cf[mt][j] = s_ctx[kg * 8 + j][mt * 16 + pr];
         const int groups = (n + 15) >> 4;
+        constexpr int QL = 8 / VEC;                      // 16-byte loads per lane and pixel (1 for the 16-bit types, 2 for f32)
+        u32x4 qraw[QL];
+        auto fetch_q = [&](int g) {
+            const int p = g * 16 + pr;
+#pragma unroll
+            for (int c = 0; c < QL; ++c) qraw[c] = p < n ? ld16(qp + (size_t)p * ldq + kg * 8 + c * VEC) : u32x4{0u, 0u, 0u, 0u};
+        };
+        if (wave < groups) fetch_q(wave);
         for (int g = wave; g < groups; g += NT / 64) {
             const int p = g * 16 + pr;
             float qv[8];
-            if (p < n) {
 #pragma unroll
-                for (int c = 0; c < 8 / VEC; ++c) Elt<T>::unpack(ld16(qp + (size_t)p * ldq + kg * 8 + c * VEC), &qv[c * VEC]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) qv[j] = 0.f;
-            }
+            for (int c = 0; c < QL; ++c) Elt<T>::unpack(qraw[c], &qv[c * VEC]);      // (pixels past the end: zeros, never stored)
+            if (g + NT / 64 < groups) fetch_q(g + NT / 64);                          // next group's q while this one is reduced
             float m = qv[0];
 #pragma unroll
             for (int j = 1; j < 8; ++j) m = fmaxf(m, qv[j]);

@@ -124,13 +124,32 @@ __global__ __launch_bounds__(NT) void gn_fold_kernel(const float* __restrict__ c
     }
 }
 
-template <class T, bool FAST, bool OS, bool FILM>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// SiLU of two values in the 16-bit storage modes: v_pk_mul, 2 x v_exp_f32, v_pk_add, 2 x v_rcp_f32, v_pk_mul (the transcendentals
+// are quarter rate: 8 of the ~14 issue slots an element costs).  The f32 mode keeps expf and a true division (parity bar 1e-6).
+template <bool FAST> __device__ __forceinline__ f32x2 silu2(f32x2 t) {
+    if (FAST) {
+        const f32x2 a = t * -1.4426950408889634f;
+        f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+        e = e + 1.0f;
+        const f32x2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+        return t * r;
+    }
+    return f32x2{silu_f<false>(t.x), silu_f<false>(t.y)};
+}
+
+// ACT / RES are template parameters and the arithmetic is written on float pairs: the body is VALU-bound before it is HBM-bound
+// (per 16-bit element: unpack, fma, SiLU = 2 quarter-rate transcendentals + 3, adds, clamp, pack), so runtime `if (act)` /
+// `if (resid)` selects, the unpack of an absent residual and unpaired adds were 40 % of its issue slots (193 -> 117 VALU per
+// two pixels).  U = pixels in flight per thread.
+template <class T, bool FAST, bool OS, bool FILM, bool ACT, bool RES, int U>
 __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ partial,
                                                       int nchunk, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      int HW, int C, int G, int act, const float* __restrict__ emb, int emb_stride,
+                                                      int HW, int C, int G, const float* __restrict__ emb, int emb_stride,
                                                       const T* __restrict__ resid, float eps, int blocks_per_hyp, int x_rep, int resid_rep,
                                                       float* __restrict__ out_stats, const float* __restrict__ film, int film_stride) {
-    constexpr int VEC = Elt<T>::VEC;
+    constexpr int VEC = Elt<T>::VEC, V2 = VEC / 2;
     __shared__ float s_mean[64];
     __shared__ float s_rstd[64];
     __shared__ float s_os[NT / 64], s_oq[NT / 64];
@@ -160,7 +179,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
     const int p1 = p0 + pper < HW ? p0 + pper : HW;
     const T* xb = x + (size_t)xs * HW * C;
     T* yb = y + (size_t)hyp * HW * C;
-    const T* rb = resid ? resid + (size_t)(hyp / resid_rep) * HW * C : nullptr;
+    const T* rb = RES ? resid + (size_t)(hyp / resid_rep) * HW * C : nullptr;
     const float* eb = emb ? emb + (size_t)hyp * emb_stride : nullptr;
     // FiLM: [scale (C) | shift (C)] of this hypothesis.  Its own instantiation: compiled into the common kernel it cost 16 VGPRs
     // = one resident wave per SIMD, +7 % on every GroupNorm of the default U-Net.
@@ -169,68 +188,70 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
     const int tpr = cvecs < NT ? cvecs : NT;
     const int rows = NT / tpr;
     const int row = tid / tpr, lc = tid - row * tpr;
-    float os = 0.f, oq = 0.f;      // sum / sum of squares of this thread's OUTPUT values (optional out_stats)
+    const bool one_group = cpg % VEC == 0;     // a 16-byte vector never straddles two groups (every GroupNorm of the shipped networks)
+    f32x2 os2 = {0.f, 0.f}, oq2 = {0.f, 0.f};  // sum / sum of squares of this thread's OUTPUT values (optional out_stats)
     for (int cv = lc; cv < cvecs && row < rows; cv += tpr) {
-        float sc[VEC], sh[VEC], ev[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
+        f32x2 sc[V2], sh[V2], ev[V2];
+        auto coeff = [&](int e, int g) {
             const int c = cv * VEC + e;
-            const int g = c / cpg;
-            const float a = s_rstd[g] * gamma[c];
-            sc[e] = a;
-            sh[e] = beta[c] - s_mean[g] * a;
+            float a = s_rstd[g] * gamma[c];
+            float b = beta[c] - s_mean[g] * a;
             if (FILM) {                                // norm(x) * (1 + scale) + shift: still one fma per element
                 const float f = 1.0f + fb[c];
-                sc[e] = a * f;
-                sh[e] = sh[e] * f + fb[C + c];
+                a = a * f;
+                b = b * f + fb[C + c];
             }
-            ev[e] = eb ? eb[c] : 0.f;
+            sc[e >> 1][e & 1] = a;
+            sh[e >> 1][e & 1] = b;
+            ev[e >> 1][e & 1] = eb ? eb[c] : 0.f;
+        };
+        if (one_group) {                               // (a real branch: written as a select, the compiler kept the eight divisions)
+            const int g0 = cv * VEC / cpg;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) coeff(e, g0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) coeff(e, (cv * VEC + e) / cpg);
         }
+        auto apply = [&](const u32x4 xa, const u32x4 xr) -> u32x4 {
+            float v[VEC], r[VEC];
+            Elt<T>::unpack(xa, v);
+            if (RES) Elt<T>::unpack(xr, r);
+#pragma unroll
+            for (int q = 0; q < V2; ++q) {
+                f32x2 t = f32x2{v[2 * q], v[2 * q + 1]} * sc[q] + sh[q];
+                if (ACT) t = silu2<FAST>(t);
+                t += ev[q];
+                if (RES) t += f32x2{r[2 * q], r[2 * q + 1]};
+                v[2 * q] = t.x; v[2 * q + 1] = t.y;
+                if (OS) { os2 += t; oq2 += t * t; }
+            }
+            return Elt<T>::pack(v);
+        };
         const size_t coff = (size_t)cv * VEC;
         int pix = p0 + row;
-        for (; pix + rows < p1; pix += 2 * rows) {       // two pixels in flight per thread
-            const size_t o0 = (size_t)pix * C + coff, o1 = (size_t)(pix + rows) * C + coff;
-            float v0[VEC], v1[VEC], r0[VEC], r1[VEC];
-            const u32x4 a0 = ld16(xb + o0), a1 = ld16(xb + o1);
-            u32x4 b0 = a0, b1 = a1;
-            if (rb) { b0 = ld16(rb + o0); b1 = ld16(rb + o1); }
-            Elt<T>::unpack(a0, v0); Elt<T>::unpack(a1, v1);
-            Elt<T>::unpack(b0, r0); Elt<T>::unpack(b1, r1);
+        for (; pix + (U - 1) * rows < p1; pix += U * rows) {       // U pixels in flight per thread
+            u32x4 xa[U], xr[U];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                float t0 = v0[e] * sc[e] + sh[e], t1 = v1[e] * sc[e] + sh[e];
-                if (act) { t0 = silu_f<FAST>(t0); t1 = silu_f<FAST>(t1); }
-                t0 += ev[e]; t1 += ev[e];
-                if (rb) { t0 += r0[e]; t1 += r1[e]; }
-                v0[e] = t0; v1[e] = t1;
-                if (OS) { os += t0 + t1; oq += t0 * t0 + t1 * t1; }
+            for (int u = 0; u < U; ++u) {
+                const size_t o = (size_t)(pix + u * rows) * C + coff;
+                xa[u] = ld16(xb + o);
+                xr[u] = RES ? ld16(rb + o) : xa[u];
             }
-            st16(yb + o0, Elt<T>::pack(v0));
-            st16(yb + o1, Elt<T>::pack(v1));
+#pragma unroll
+            for (int u = 0; u < U; ++u) st16(yb + (size_t)(pix + u * rows) * C + coff, apply(xa[u], xr[u]));
         }
         for (; pix < p1; pix += rows) {
-            const size_t o0 = (size_t)pix * C + coff;
-            float v0[VEC], r0[VEC];
-            const u32x4 a0 = ld16(xb + o0);
-            u32x4 b0 = a0;
-            if (rb) b0 = ld16(rb + o0);
-            Elt<T>::unpack(a0, v0); Elt<T>::unpack(b0, r0);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                float t0 = v0[e] * sc[e] + sh[e];
-                if (act) t0 = silu_f<FAST>(t0);
-                t0 += ev[e];
-                if (rb) t0 += r0[e];
-                v0[e] = t0;
-                if (OS) { os += t0; oq += t0 * t0; }
-            }
-            st16(yb + o0, Elt<T>::pack(v0));
+            const size_t o = (size_t)pix * C + coff;
+            const u32x4 xa = ld16(xb + o);
+            const u32x4 xr = RES ? ld16(rb + o) : xa;
+            st16(yb + o, apply(xa, xr));
         }
     }
     if (OS) {
         // per-block (sum, sum of squares) of what was just written: the GroupNorm(1) statistics of the NEXT op
         // (PreNorm of the attention that follows a ResnetBlock) without another pass over the tensor.
-        os = wave_sum(os); oq = wave_sum(oq);
+        const float os = wave_sum(os2.x + os2.y), oq = wave_sum(oq2.x + oq2.y);
         if ((tid & 63) == 0) { s_os[tid >> 6] = os; s_oq[tid >> 6] = oq; }
         __syncthreads();
         if (tid == 0) {
@@ -293,8 +314,12 @@ int launch_gn_fold(const float* colstats, float* partial, int nhyp, int HW, int 
 }
 
 int gn_apply_blocks(int HW, int C, int dt) {
+    // Streaming bytes per workgroup.  Every workgroup first rebuilds (mean, rstd) and its per-channel coefficients (a barrier and
+    // ~25 dependent loads): at 32 KiB that set-up was a third of a workgroup's instructions; 16 / 32 / 64 / 128 KiB measured
+    // 198 / 143 / 124 / 121 us per statistics + apply pass over 512 x 32 x 32 x 192 f16 (profiles/r03k_gn_apply_ab.txt).
+    static const int block_kb = getenv("NOPE_GN_BLOCK_KB") ? atoi(getenv("NOPE_GN_BLOCK_KB")) : 64;
     const size_t bytes = (size_t)HW * C * dt_es(dt);
-    int bph = (int)(bytes / (32 * 1024));
+    int bph = (int)(bytes / ((size_t)(block_kb > 0 ? block_kb : 64) * 1024));
     if (bph < 1) bph = 1;
     if (bph > 64) bph = 64;
     return bph;
@@ -314,10 +339,17 @@ int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
     if (a.x_rep < 1 || a.resid_rep < 1) return NOPE_ERR_ARG;
     const int bph = gn_apply_blocks(a.HW, a.C, dt);
     dim3 grid((unsigned)(a.nhyp * bph)), block(NT);
-#define NOPE_GN_APPLY(T, FAST, OS, FILM)                                                                                        \
-    hipLaunchKernelGGL((gn_apply_kernel<T, FAST, OS, FILM>), grid, block, 0, s, (const T*)a.x, (T*)a.y, a.partial, a.nchunk, a.gamma,  \
-                       a.beta, a.HW, a.C, a.G, a.act, a.emb, a.emb_stride, (const T*)a.resid, a.eps, bph, a.x_rep, a.resid_rep,   \
-                       a.out_stats, a.film, a.film_stride)
+    const bool act = a.act != 0, res = a.resid != nullptr;
+#define NOPE_GN_APPLY_U(T, FAST, OS, FILM, ACT, RES, U)                                                                          \
+    hipLaunchKernelGGL((gn_apply_kernel<T, FAST, OS, FILM, ACT, RES, U>), grid, block, 0, s, (const T*)a.x, (T*)a.y, a.partial,  \
+                       a.nchunk, a.gamma, a.beta, a.HW, a.C, a.G, a.emb, a.emb_stride, (const T*)a.resid, a.eps, bph, a.x_rep,   \
+                       a.resid_rep, a.out_stats, a.film, a.film_stride)
+#define NOPE_GN_APPLY_AR(T, FAST, OS, FILM, ACT, RES) NOPE_GN_APPLY_U(T, FAST, OS, FILM, ACT, RES, 2)   /* (4 in flight: +-0) */
+#define NOPE_GN_APPLY(T, FAST, OS, FILM)                                                                                         \
+    do {                                                                                                                         \
+        if (act) { if (res) NOPE_GN_APPLY_AR(T, FAST, OS, FILM, true, true); else NOPE_GN_APPLY_AR(T, FAST, OS, FILM, true, false); }   \
+        else     { if (res) NOPE_GN_APPLY_AR(T, FAST, OS, FILM, false, true); else NOPE_GN_APPLY_AR(T, FAST, OS, FILM, false, false); } \
+    } while (0)
     if (a.film && a.out_stats) return NOPE_ERR_UNSUPPORTED;
     if (dt == NOPE_F32) {
         if (a.film) NOPE_GN_APPLY(float, false, false, true);
@@ -330,6 +362,8 @@ int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
         else if (a.out_stats) NOPE_GN_APPLY(f16_t, true, true, false); else NOPE_GN_APPLY(f16_t, true, false, false);
     } else return NOPE_ERR_UNSUPPORTED;
 #undef NOPE_GN_APPLY
+#undef NOPE_GN_APPLY_AR
+#undef NOPE_GN_APPLY_U
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

@@ -47,7 +47,8 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 // f32 -> f16 SATURATES: values beyond the format's range become +-65504 instead of +-inf (one v_med3_f32 per element).  The f16
 // compute mode stores every activation through these two functions; an overflowing conv output (possible with real checkpoints:
 // nothing bounds a pre-GroupNorm activation) then costs precision on that element instead of turning the sample's GroupNorm
-// statistics, and with them the whole embedding map, into NaN.  NaN stays NaN.
+// statistics, and with them the whole embedding map, into NaN.  v_med3_f32 returns MIN3 when an operand is NaN, so a NaN is stored as
+// -65504: the f16 mode does not carry NaN inputs through (the f32 / bf16x3 / bf16 modes do).
 constexpr float kF16Max = 65504.0f;
 __device__ __forceinline__ float sat_f16(float v) { return __builtin_amdgcn_fmed3f(v, -kF16Max, kF16Max); }
 __device__ __forceinline__ _Float16 f32_to_f16_sat(float v) { return (_Float16)sat_f16(v); }

@@ -439,7 +439,11 @@ inline void hipemu_buffer_load_lds(hipemu_rsrc r, P ldsptr, unsigned size, unsig
 #define __builtin_amdgcn_make_buffer_rsrc hipemu_make_rsrc
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds hipemu_buffer_load_lds
 
-inline float hipemu_fmed3f(float a, float b, float c) { return a != a ? a : fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }   // v_med3_f32 (NaN in: NaN out)
+// v_med3_f32: with a NaN among the operands the hardware returns MIN3 of them (IEEE minNum: the NaN is ignored), else the median
+inline float hipemu_fmed3f(float a, float b, float c) {
+    if (a != a || b != b || c != c) return fminf(fminf(a, b), c);
+    return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+}
 #define __builtin_amdgcn_fmed3f hipemu_fmed3f
 inline float __expf(float x) { return expf(x); }
 inline float hipemu_rcpf(float x) { return 1.0f / x; }

@@ -17,20 +17,23 @@ def main():
     ap.add_argument("--emb", type=int, default=0)
     ap.add_argument("--resid", type=int, default=0)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16"])
     a = ap.parse_args()
     g = torch.Generator(device="cuda").manual_seed(3)
-    for (h, c) in ((32, 192), (16, 192), (8, 384), (4, 768), (4, 1536)):
-        x = torch.randn(512, h, h, c, device="cuda", generator=g).bfloat16()
+    dt = hip.F16 if a.dtype == "f16" else hip.BF16
+    td = hip.torch_dtype(dt)
+    for (h, c) in ((32, 192), (16, 384), (8, 768), (4, 1536)):      # the U-Net's four levels at 512 hypotheses
+        x = torch.randn(512, h, h, c, device="cuda", generator=g).to(td)
         gamma, beta = torch.randn(c, device="cuda", generator=g), torch.randn(c, device="cuda", generator=g)
         emb = torch.randn(512, c, device="cuda", generator=g) if a.emb else None
-        res = torch.randn(512, h, h, c, device="cuda", generator=g).bfloat16() if a.resid else None
+        res = torch.randn(512, h, h, c, device="cuda", generator=g).to(td) if a.resid else None
         for _ in range(3):
-            hip.op_group_norm(1, x, gamma, beta, 8, bool(a.act), emb, res)
+            hip.op_group_norm(dt, x, gamma, beta, 8, bool(a.act), emb, res)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.reps):
-            hip.op_group_norm(1, x, gamma, beta, 8, bool(a.act), emb, res)
+            hip.op_group_norm(dt, x, gamma, beta, 8, bool(a.act), emb, res)
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1000 / a.reps
         mb = x.numel() * 2 / 1e6
