@@ -325,6 +325,9 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
         const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
         bvj[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
     }
+    bool inrange[TL::NTL];              // f16 storage: this lane's values of column tile j are known to lie inside the format's range
+#pragma unroll
+    for (int j = 0; j < TL::NTL; ++j) inrange[j] = false;
     if (p.colstats) {
         // GroupNorm statistics of the conv output, fused: per column (sum, sum of squares) over this wave's 64
         // rows, straight from the accumulators (f32, before the rounding to T): a lane adds up the rows it
@@ -335,11 +338,18 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
         for (int j = 0; j < TL::NTL; ++j) {
             const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
             const float bv = bvj[j];
-            float s = 0.f, q = 0.f;
+            // (on float pairs -- v_pk_add / v_pk_add / v_pk_fma per two values: the epilogue is VALU-issue-bound with two waves per SIMD)
+            f32x2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
-                for (int r = 0; r < TL::R; ++r) { const float v = acc[i][j][r] + bv; s += v; q += v * v; }
+                for (int r = 0; r < TL::R; r += 2) {
+                    const f32x2_t v = f32x2_t{acc[i][j][r], acc[i][j][r + 1]} + bv;
+                    s2 += v; q2 += v * v;
+                }
+            float s = s2.x + s2.y, q = q2.x + q2.y;
+            // q bounds the lane's 32 values of this column: q <= 65504^2 means none of them needs the f16 clamp (free overflow test)
+            if (Elt<T>::SATURATES) inrange[j] = q <= kF16Max * kF16Max;
 #pragma unroll
             for (int o = TL::TM; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
             // (M % 128 == 64: the second wave row of the last tile lies beyond M -- it owns no row block)
@@ -357,22 +367,44 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
             // store side splits 8 dwords (8 columns x 2 rows) into the two rows' 16-byte chunks.
             constexpr int PLD = 36;                                   // dwords per row pair (32 columns + pad)
             unsigned* pk = reinterpret_cast<unsigned*>(lds_wave);
+            // The four rows a lane stores (two row pairs) are the same in every pass: their offsets -- out_row() is a chain of
+            // uniform branches around divisions for the position-major / 2x2-phase launches -- are taken once, not per store.
+            const int ch = lane & 3;
+            size_t ro[2][2];
+            bool ok[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int m = m0 + wm * 64 + 2 * ((lane >> 2) + 16 * t) + h;
+                    ok[t][h] = m < p.M;
+                    ro[t][h] = ok[t][h] ? out_row(p, m) * p.Cout : 0;
+                }
+            const bool relu = p.act != 0;                             // (encoder convs; a real branch around the whole fill)
 #pragma unroll
             for (int pass = 0; pass < TL::NTL; ++pass) {
                 const float bv = bvj[pass];
+                auto fill = [&](auto relu_tag, auto sat_tag) {
 #pragma unroll
-                for (int i = 0; i < TL::MT; ++i)
+                    for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
-                    for (int r = 0; r < TL::R; r += 2) {
-                        float v0 = acc[i][pass][r] + bv, v1 = acc[i][pass][r + 1] + bv;
-                        if (p.act) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-                        pk[((i * TL::TM + TL::out_row(lane, r)) >> 1) * PLD + TL::out_col(lane)] = Elt<T>::cvt_pk(v0, v1);
-                    }
+                        for (int r = 0; r < TL::R; r += 2) {
+                            f32x2_t v = f32x2_t{acc[i][pass][r], acc[i][pass][r + 1]} + bv;
+                            if (decltype(relu_tag)::value) v = f32x2_t{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)};
+                            pk[((i * TL::TM + TL::out_row(lane, r)) >> 1) * PLD + TL::out_col(lane)] =
+                                decltype(sat_tag)::value ? Elt<T>::cvt_pk(v.x, v.y) : Elt<T>::cvt_pk_raw(v.x, v.y);
+                        }
+                };
+                // f16: the clamp (one v_med3_f32 per value, half of this loop's VALU) is skipped when the column statistics
+                // above have shown every value of the wave's tile column in range (wave-uniform vote)
+                const bool sat = Elt<T>::SATURATES && !__all(inrange[pass]);
+                if (relu) fill(BoolTag<true>(), BoolTag<true>());
+                else if (sat) fill(BoolTag<false>(), BoolTag<true>());
+                else fill(BoolTag<false>(), BoolTag<false>());
                 __builtin_amdgcn_wave_barrier();                      // (same-wave LDS write -> read, see below)
                 stamp();
                 if (DRAIN && pass == 0) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
                 stamp();
-                const int ch = lane & 3;
                 const int n = n0 + wn * 96 + pass * TL::TM + ch * 8;
                 u32x4 d[2][2];
 #pragma unroll
@@ -383,7 +415,6 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int m = m0 + wm * 64 + 2 * ((lane >> 2) + 16 * t);
                     u32x4 lo, hi;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -392,8 +423,8 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                         hi[k] = (e >> 16) | (o & 0xffff0000u);
                     }
                     if (n < p.Cout) {
-                        if (m < p.M) st16(out + out_row(p, m) * p.Cout + n, lo);
-                        if (m + 1 < p.M) st16(out + out_row(p, m + 1) * p.Cout + n, hi);
+                        if (ok[t][0]) st16(out + ro[t][0] + n, lo);
+                        if (ok[t][1]) st16(out + ro[t][1] + n, hi);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NT) void gn_fold_kernel(const float* __restrict__ c
     }
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x2_t f32x2;
 
 // SiLU of two values in the 16-bit storage modes: v_pk_mul, 2 x v_exp_f32, v_pk_add, 2 x v_rcp_f32, v_pk_mul (the transcendentals
 // are quarter rate: 8 of the ~14 issue slots an element costs).  The f32 mode keeps expf and a true division (parity bar 1e-6).

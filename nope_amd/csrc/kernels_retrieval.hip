@@ -40,7 +40,6 @@ template <bool NTL, int W> __device__ __forceinline__ RawVec<W> ld_stream(const 
     return r;
 }
 
-template <bool V> struct BoolTag { static constexpr bool value = V; };
 
 template <class T, int W> __device__ __forceinline__ void unpack_words(const RawVec<W>& raw, float* t) {
     if constexpr (sizeof(T) == 4) {

@@ -37,6 +37,7 @@ __device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) {
 // Two f32 -> packed bf16x2 in one v_cvt_pk_bf16_f32 (gfx950 hardware RNE; same results as f32_to_bf16).
 typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_hw_t __attribute__((ext_vector_type(2)));
+typedef f32x2_hw_t f32x2_t;       // float pairs: arithmetic on them compiles to v_pk_add / v_pk_mul / v_pk_fma_f32
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     const f32x2_hw_t v = {lo, hi};
     union { bf16x2_hw_t h; unsigned u; } x;
@@ -54,18 +55,23 @@ __device__ __forceinline__ float sat_f16(float v) { return __builtin_amdgcn_fmed
 __device__ __forceinline__ _Float16 f32_to_f16_sat(float v) { return (_Float16)sat_f16(v); }
 // Two f32 -> packed f16x2 (saturating, round-to-nearest-even; v_cvt_pk_f16_f32 on gfx950)
 typedef _Float16 f16x2_hw_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
-    const f32x2_hw_t v = {sat_f16(lo), sat_f16(hi)};
+__device__ __forceinline__ unsigned cvt_pk_f16_raw(float lo, float hi) {      // no clamp: the caller knows |lo|, |hi| <= 65504
+    const f32x2_hw_t v = {lo, hi};
     union { f16x2_hw_t h; unsigned u; } x;
     x.h = __builtin_convertvector(v, f16x2_hw_t);
     return x.u;
 }
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) { return cvt_pk_f16_raw(sat_f16(lo), sat_f16(hi)); }
+
+// compile-time flag passed by value to a generic lambda (decltype(tag)::value)
+template <bool V> struct BoolTag { static constexpr bool value = V; };
 
 // Element traits: VEC = elements per 16-byte vector.
 template <class T> struct Elt;
 template <> struct Elt<float> {
     static constexpr int VEC = 4;
     static constexpr int DT = NOPE_F32;
+    static constexpr bool SATURATES = false;
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
     static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
     static __device__ __forceinline__ void unpack(const u32x4& v, float* o) {
@@ -102,6 +108,8 @@ template <> struct Elt<bf16_t> {
         return v;
     }
     static __device__ __forceinline__ unsigned cvt_pk(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
+    static constexpr bool SATURATES = false;     // (bf16 has f32's exponent range)
+    static __device__ __forceinline__ unsigned cvt_pk_raw(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
 };
 
 template <> struct Elt<f16_t> {
@@ -121,6 +129,8 @@ template <> struct Elt<f16_t> {
         return v;
     }
     static __device__ __forceinline__ unsigned cvt_pk(float lo, float hi) { return cvt_pk_f16(lo, hi); }
+    static constexpr bool SATURATES = true;      // cvt_pk clamps; cvt_pk_raw is for values known to be in range
+    static __device__ __forceinline__ unsigned cvt_pk_raw(float lo, float hi) { return cvt_pk_f16_raw(lo, hi); }
 };
 
 // NOPE_BF16X3: activations are plain f32 in memory; the tag type only selects the conv kernels' split-precision MFMA tile
@@ -129,6 +139,7 @@ struct f32s_t { float f; };
 template <> struct Elt<f32s_t> {
     static constexpr int VEC = 4;
     static constexpr int DT = NOPE_BF16X3;
+    static constexpr bool SATURATES = false;
     static __device__ __forceinline__ float ld(const f32s_t* p) { return p->f; }
     static __device__ __forceinline__ void st(f32s_t* p, float v) { p->f = v; }
     static __device__ __forceinline__ void unpack(const u32x4& v, float* o) { Elt<float>::unpack(v, o); }

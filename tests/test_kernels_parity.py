@@ -159,6 +159,27 @@ def test_f16_mode_saturates_instead_of_overflowing(be):
         assert torch.isfinite(y).all(), full
 
 
+@pytest.mark.gpu
+def test_f16_unet_survives_an_overflowing_conv(gpu):
+    """The conv epilogue skips the f16 clamp for a tile column whose fused GroupNorm statistics show every value in range
+    (sum of squares <= 65504^2) and clamps otherwise.  A U-Net whose first ResnetBlock conv is scaled by 1e5 overflows f16 in that
+    conv: GroupNorm renormalises, so the f32 mode's output barely moves; the f16 mode must stay finite (before the clamp: one inf
+    -> NaN statistics -> NaN map) and in the neighbourhood of the f32 result (the clamp flattens that one activation's tails)."""
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    g = torch.Generator().manual_seed(31)
+    x, pose = torch.randn(1, 8, 8, 8, generator=g), torch.randn(1, 4, 6, generator=g)
+    outs = {}
+    for cdt in ("f32", "f16"):
+        u = UNet(u_net_dim=64, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype=cdt)
+        synth_init_(u, 2022)
+        with torch.no_grad():
+            u.downs[0][0].block1.proj.weight.mul_(1e5)        # |conv output| ~ 1e5: beyond 65504 for a good part of every map
+        outs[cdt] = u.to("cuda").forward_hypotheses(x.cuda(), pose.cuda()).float().cpu()[0]
+    assert torch.isfinite(outs["f32"]).all() and torch.isfinite(outs["f16"]).all()
+    assert rel(outs["f16"], outs["f32"]) < 0.5
+
+
 @pytest.mark.parametrize("dt", [0, 1, 2])
 def test_group_norm_variants(be, dt):
     hip, dev, _ = be
