@@ -27,4 +27,4 @@ for h in (32, 16, 8, 4):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1000 / a.reps
     mb = qkv.numel() * qkv.element_size() * (4 / 3) / 1e6        # q, k, v in + out (a third of qkv)
-    print(f"linattn {h}x{h} x 512 {a.dtype}: {us:7.1f} us  {mb:.0f} MB algorithmic = {mb / us / 1e3 * 1e3 / 1e3:.2f} TB/s")
+    print(f"linattn {h}x{h} x 512 {a.dtype}: {us:7.1f} us  {mb:.0f} MB algorithmic = {mb / us:.2f} TB/s")
