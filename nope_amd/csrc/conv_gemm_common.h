@@ -359,9 +359,23 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
             }
         }
     }
-    if constexpr (sizeof(T) == 2 && TL::TM == 32 && !PN) {
-        if (!resid) {
-            // bf16 without a residual: the values are final before they leave the registers, so the panel holds them ROUNDED,
+    if constexpr (sizeof(T) == 2 && TL::TM == 32) {
+        // (fused PreNorm: with HW % 64 == 0 the wave's 64 rows are one sample, so rstd * (acc - mean c1[n]) + c0[n] + bias[n] is
+        //  acc * rstd + off[n] with one constant per lane and pass -- the same fill loop with an fma in place of the add)
+        const bool pn_uniform = PN && ((p.Hm * p.Wm) % 64 == 0);
+        if (!resid && (!PN || pn_uniform)) {
+            float pn_scale = 1.f;
+            if (PN) {
+                const int b = (m0 + wm * 64 < p.M ? m0 + wm * 64 : 0) / (p.Hm * p.Wm);
+                const float mean = p.pn_ms[2 * b];
+                pn_scale = p.pn_ms[2 * b + 1];
+#pragma unroll
+                for (int j = 0; j < TL::NTL; ++j) {
+                    const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
+                    if (n < p.Cout) bvj[j] += p.pn_c0[n] - pn_scale * mean * p.pn_c1[n];
+                }
+            }
+            // 16-bit without a residual: the values are final before they leave the registers, so the panel holds them ROUNDED,
             // two rows per dword (a lane's accumulator registers r, r + 1 are rows 2q, 2q + 1 of one column): half the LDS
             // stores of the f32 panel -- the LDS store path (64 B/clk) is what bounds the fill -- and half the reads; the
             // store side splits 8 dwords (8 columns x 2 rows) into the two rows' 16-byte chunks.
@@ -389,7 +403,8 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                     for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
                         for (int r = 0; r < TL::R; r += 2) {
-                            f32x2_t v = f32x2_t{acc[i][pass][r], acc[i][pass][r + 1]} + bv;
+                            f32x2_t v = f32x2_t{acc[i][pass][r], acc[i][pass][r + 1]};
+                            if (PN) v = v * pn_scale + bv; else v = v + bv;
                             if (decltype(relu_tag)::value) v = f32x2_t{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)};
                             pk[((i * TL::TM + TL::out_row(lane, r)) >> 1) * PLD + TL::out_col(lane)] =
                                 decltype(sat_tag)::value ? Elt<T>::cvt_pk(v.x, v.y) : Elt<T>::cvt_pk_raw(v.x, v.y);
@@ -454,7 +469,9 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
         // Fused PreNorm operands, hoisted out of the chunk loop where they are loop-invariant: with 64 % CH == 0
         // a lane keeps the same column chunk for the whole pass, and with HW % 64 == 0 the wave's 64 rows are
         // one sample (one mean / rstd).
-        constexpr bool PN_COLS_FIXED = PN && (64 % CH == 0);
+        // (16-bit types reach this loop with PN only on maps whose samples do not fill whole 64-row blocks -- the 4 x 4 level; the
+        //  hoisted operands stay out of that instantiation: next to the packed path above they pushed the kernel into scratch)
+        constexpr bool PN_COLS_FIXED = PN && (64 % CH == 0) && !(sizeof(T) == 2 && TL::TM == 32);
         float pc0[VEC], pc1[VEC];
         float pmean = 0.f, prstd = 1.f;
         const bool pn_row_uniform = PN && ((p.Hm * p.Wm) % 64 == 0);

@@ -134,6 +134,14 @@ def run_unet(hip, dev, dim, cdt, n_hyp=2, hw=8):
 
 if __name__ == "__main__":
     hip._set_library_for_testing(hip.NopeLib(build_emu.build()))
+    if "--unet16" in sys.argv:
+        # 16-bit storage needs 64-channel K steps for the LDS-DMA kernels: u_net_dim 64 on an 8 x 8 map (level 0: whole 64-row blocks
+        # per sample -> fused GroupNorm statistics with the range test, fused PreNorm through the packed epilogue panel)
+        e = run_unet(hip, "cpu", 64, "f16", n_hyp=1, hw=8)
+        assert e < 8e-3, e
+        print(f"unet f16 (u_net_dim 64) on the LDS-DMA / ping-pong kernels: rel err {e:.2e}")
+        print("pp_emu_case OK")
+        sys.exit(0)
     dts = tuple(int(v) for v in sys.argv[sys.argv.index("--dts") + 1].split(",")) if "--dts" in sys.argv else (1, 0)
     w = run(hip, "cpu", dts=dts, light="--light" in sys.argv)
     if "--unet" in sys.argv:

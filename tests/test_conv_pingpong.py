@@ -25,6 +25,10 @@ def test_pingpong_kernel_under_adversarial_interpreter(emu):
         env = dict(os.environ, HIPEMU_THREADS="4", **e)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pp_emu_case.py"), "--light", "--dts", dd], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    # third process: a whole 16-bit U-Net schedule (fused statistics / PreNorm epilogues of the 16-bit types)
+    envs.append({"HIPEMU_SHUFFLE": "1"})
+    procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pp_emu_case.py"), "--unet16"], env=dict(os.environ, HIPEMU_THREADS="4", **envs[-1]),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     for e, pr in zip(envs, procs):
         out, _ = pr.communicate(timeout=1500)
         assert pr.returncode == 0 and "pp_emu_case OK" in out, (e, out[-2000:])
