@@ -29,7 +29,7 @@ extern "C" {
 enum { NOPE_F32 = 0, NOPE_BF16 = 1,
        NOPE_F16 = 2,   /* IEEE half: storage type of the template bank (nope_similarity's bank_dtype, nope_unet_forward's out_dtype,
                           BASELINE configs[4]) and a compute mode of the networks: f16 storage + f16 MFMA, f32 accumulate / statistics
-                          -- the MFMA rate of NOPE_BF16 with 3 more mantissa bits (values beyond +-65504 overflow) */
+                          -- the MFMA rate of NOPE_BF16 with 3 more mantissa bits; stores saturate at +-65504 (no inf; a NaN is stored as -65504) */
        NOPE_BF16X3 = 3 /* compute mode only: f32 storage, every conv / linear as three bf16 MFMA passes over (hi, lo) bf16 splits of
                           both operands (hi*hi + hi*lo + lo*hi, f32 accumulate): ~2^-17 relative per product instead of bf16's 2^-9
                           at 3/16 of the exact-f32 MFMA cost -- the fast mode that meets the 1e-4 score tolerance */ };
