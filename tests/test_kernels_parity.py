@@ -193,6 +193,23 @@ def test_group_norm_variants(be, dt):
                               resid=hip.to_nhwc(rs.to(dev), dt))
         ref = F.silu(F.group_norm(_q(x, dt, hip), G, ga, be_)) + emb[:, :, None, None] + _q(rs, dt, hip)
         assert rel(hip.to_nchw(y, dt).cpu(), ref) < tol, (C, G)
+    # the apply kernel is instantiated per (activation, residual) pair: every combination, with and without the embedding row
+    C, G = 48, 8
+    x = torch.randn(2, C, 5, 4, generator=g) * 2 + 0.5
+    ga, be_, emb, rs = torch.randn(C, generator=g), torch.randn(C, generator=g), torch.randn(2, C, generator=g), torch.randn(2, C, 5, 4, generator=g)
+    for act in (False, True):
+        for use_rs in (False, True):
+            for use_emb in (False, True):
+                y = hip.op_group_norm(dt, hip.to_nhwc(x.to(dev), dt), ga.to(dev), be_.to(dev), G, act_silu=act,
+                                      emb=emb.to(dev) if use_emb else None, resid=hip.to_nhwc(rs.to(dev), dt) if use_rs else None)
+                ref = F.group_norm(_q(x, dt, hip), G, ga, be_)
+                if act:
+                    ref = F.silu(ref)
+                if use_emb:
+                    ref = ref + emb[:, :, None, None]
+                if use_rs:
+                    ref = ref + _q(rs, dt, hip)
+                assert rel(hip.to_nchw(y, dt).cpu(), ref) < tol, (act, use_rs, use_emb)
 
 
 @pytest.mark.parametrize("dt", [0, 1, 2])
