@@ -309,7 +309,17 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "gloo":
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): keep stdout to the one JSON line
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
