@@ -50,10 +50,11 @@ enum {
 
 typedef void* nope_stream_t;
 
-/* Bumped whenever a struct of this header changes layout or an enum gains a meaning (2: nope_unet_config.soft_up_down,
- * NOPE_F16 / NOPE_BF16X3 compute modes, 4x4 STRIDE2).  Callers compare nope_abi_version() against the header they were
+/* Bumped whenever a struct of this header changes layout or an enum gains a meaning (2: nope_unet_config.soft_up_down;
+ * 3: NOPE_F16 / NOPE_BF16X3 compute modes, 4x4 STRIDE2, nope_ldm_config.transformer_depth;
+ * 4: nope_op_geodesic, nope_unet_graph_limit -- hipGraph replay became opt-in).  Callers compare nope_abi_version() against the header they were
  * built with before passing any struct (nope_amd/hip.py does at load time). */
-#define NOPE_ABI_VERSION 3
+#define NOPE_ABI_VERSION 4
 const char* nope_strerror(int code);
 int nope_abi_version(void);
 
@@ -76,6 +77,19 @@ int nope_similarity(const float* q, const void* bank, int bank_dtype, float* sco
  *   idx   (B,k) int64;  vals (B,k) f32 or NULL.   1 <= k <= 16, k <= N. */
 int nope_topk(const float* scores, int64_t* idx, float* vals, int B, int N, int k, int score_ld,
               nope_stream_t stream);
+
+/* Geodesic error of the retrieved poses against the ground truth (row f2).  Replaces `pred_R = template_poses[nearest_idx]`,
+ * src/model/model.py:352-354, and GeodesicError's per-element arithmetic, src/model/loss.py:14-75 (so3_relative_angle_with_symmetry:
+ * symmetry 0 = none, 1 = 180 degrees about Y, 2 = circular) with pytorch3d's so3_relative_angle(eps = 1e-2) restated from its
+ * published formula (acos_linear_extrapolation, bound 1 - 1e-4).  float64 throughout, as loss.py:87,103 casts.
+ *   poses     (B, N, 3, 3) f64, sample stride `pose_stride_b` elements (0 = one grid shared by every query)
+ *   idx       (B, k) int64 rows of `poses` to score (nope_topk's output), or NULL: score poses[b, 0..k)
+ *   gt        (B, 3, 3) f64;  symmetry (B) int32 in {0, 1, 2} or NULL (all 0)
+ *   err_rad   (B, k) f64 radians
+ *   status    one device int: bit 0 = a trace left [-1 - eps, 3 + eps] (pytorch3d raises ValueError there: the caller must),
+ *             bit 1 = an index outside [0, N). */
+int nope_op_geodesic(const double* poses, int64_t pose_stride_b, int N, const int64_t* idx, const double* gt, const int* symmetry,
+                     double* err_rad, int* status, int B, int k, nope_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pose-conditioned U-Net.  Replaces UNet.__init__/forward,
@@ -128,6 +142,15 @@ int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep
                       int H, int W, void* out, int out_dtype, void* workspace, size_t workspace_bytes,
                       nope_stream_t stream);
 
+/* hipGraph replay of SMALL forwards, opt-in (no reference counterpart): with max_hyp_pixels > 0, forwards of at most that many
+ * n_hyp * H * W replay a captured launch sequence (x, pose and the output are staged through the head of the workspace so the
+ * caller's pointers stay out of the graph; one graph per (workspace, shape, out_dtype), cache guarded by a mutex).  0 (the default;
+ * NOPE_UNET_GRAPH in the environment at create time overrides) = always launch directly.  Results are bit-identical either way
+ * (tests/test_gpu_configs.py::test_unet_graph_replay_matches_direct); a 64-hypothesis pass measured +-0 on MI355X, which is why it is
+ * off.  nope_unet_graph_replays: forwards served by a replay since create. */
+int nope_unet_graph_limit(nope_unet* net, long long max_hyp_pixels);
+int nope_unet_graph_replays(const nope_unet* net);
+
 /* Measurement aid (bench.py roofline leg, no reference counterpart): while enabled, every
  * launch of the implicit-GEMM conv kernel made by nope_unet_forward is bracketed by HIP events on
  * the caller's stream; _read synchronises them and returns the launch count, the summed kernel
@@ -139,7 +162,7 @@ int nope_unet_profile_read(nope_unet* net, int* n_launches, double* total_ms, do
 /* ... and launch by launch, in issue order: which kernel took the launch, its shape, its HIP-event time.  `flops` counts the
  * convolution's multiply-adds x 2 as executed (NOPE_BF16X3 issues three MFMA passes per product: mfma_passes = 3).  Writes at
  * most `max` records and the total number of recorded launches to *n. */
-enum { NOPE_CONV_KERNEL_GENERIC = 0, NOPE_CONV_KERNEL_DMA128 = 1, NOPE_CONV_KERNEL_PP256 = 2, NOPE_CONV_KERNEL_HALO256 = 3 };
+enum { NOPE_CONV_KERNEL_GENERIC = 0, NOPE_CONV_KERNEL_DMA128 = 1, NOPE_CONV_KERNEL_PP256 = 2, NOPE_CONV_KERNEL_HALO256 = 3, NOPE_CONV_KERNEL_SMALL = 4 };
 typedef struct {
     double ms, flops, bytes;
     int kernel;            /* NOPE_CONV_KERNEL_* */
@@ -170,7 +193,7 @@ typedef struct {
     int pose_dim;           /* rot_representation_dim, 6 */
     int pose_mlp_layers;    /* 1 = "single_layer", 2 = "two_layers" */
     int injecting_condition_twice;   /* 0: timestep embedding is zeros; 1: emb = pose_mlp_timesteps(pose) */
-    int compute_dtype;      /* NOPE_F32 | NOPE_BF16, as nope_unet_config */
+    int compute_dtype;      /* NOPE_F32 | NOPE_BF16 | NOPE_F16 | NOPE_BF16X3, as nope_unet_config */
     int use_scale_shift_norm;        /* 1: ResBlocks apply out_norm(h) * (1 + scale) + shift with (scale, shift) = emb_layers(emb) */
     int transformer_depth;           /* BasicTransformerBlocks per SpatialTransformer (attention.py:232-262); 1 in vae_cin_ldm.yaml; 0 reads as 1 */
 } nope_ldm_config;

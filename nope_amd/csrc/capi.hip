@@ -31,6 +31,11 @@ int nope_topk(const float* scores, int64_t* idx, float* vals, int B, int N, int 
     return launch_topk(scores, (long long*)idx, vals, B, N, k, score_ld, (hipStream_t)stream);
 }
 
+int nope_op_geodesic(const double* poses, int64_t pose_stride_b, int N, const int64_t* idx, const double* gt, const int* symmetry,
+                     double* err_rad, int* status, int B, int k, nope_stream_t stream) {
+    return launch_geodesic(poses, (long long)pose_stride_b, N, (const long long*)idx, gt, symmetry, err_rad, status, B, k, (hipStream_t)stream);
+}
+
 int nope_op_nchw_to_nhwc(int dtype, const float* x, void* y, int n, int C, int HW, nope_stream_t s) {
     return launch_nchw_to_nhwc(dtype, x, y, n, C, HW, (hipStream_t)s);
 }

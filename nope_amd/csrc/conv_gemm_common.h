@@ -63,7 +63,8 @@ struct ConvParams {
     float* split_out;                  // [splits][M][Cout]
     int Hm, Wm;                        // grid the GEMM rows enumerate: output grid, or the SOURCE grid for UP2P
     unsigned w_phase_bytes;            // UP2P: byte stride between the 4 phase weight sets
-    float* colstats;                   // optional [M/64][Cout][2]: per 64-row block column sum / sum of squares
+    float* colstats;                   // optional [M/stat_rows][Cout][2]: per row block column sum / sum of squares
+    int stat_rows;                     // 64 (every kernel), 16 / 32 (small-tile kernel only)
     const float* pn_ms; const float* pn_c0; const float* pn_c1;   // optional fused PreNorm (see ConvArgs)
     unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
 };

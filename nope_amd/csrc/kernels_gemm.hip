@@ -494,6 +494,7 @@ void launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
 constexpr int POSMAJOR_MAX_HW = 64;
 
 void launch_conv_pp(int dt, const void* params, dim3 grid, hipStream_t s);   // kernels_gemm_pp.hip
+void launch_conv_small(int dt, const void* params, int tile, dim3 grid, hipStream_t s);   // kernels_gemm_small.hip
 void launch_conv_halo(int dt, const void* params, dim3 grid, hipStream_t s);
 int conv_halo_max_width();
 
@@ -503,13 +504,30 @@ int conv_halo_max_width();
 // 1536 -> 1536 at 4 x 4 x 512 although it executes the 31 % of MACs the position-major order skips), bit 2 = those run position-major on the
 // ping-pong kernel (needs nhyp % 256 == 0), bit 3 = no minimum tile count (tests: small shapes on the ping-pong kernel),
 // bit 4 = 3x3 convs per tap on the ping-pong kernel instead of the tap-resident (halo) kernel.
-struct ConvPlan { bool dma, pp, posmajor, halo; };
+struct ConvPlan { bool dma, pp, posmajor, halo; int small; };      // small: -1, or the tile of conv_gemm_small_kernel (0 = 64 x 64, 1 = 128 x 128, 2 = 64 x 64 / 4-stage ring)
+
+// Launches that cannot give every CU a 128 x 192 tile take the small-tile kernel (kernels_gemm_small.hip): fewer than
+// NOPE_SMALL_MAX_TILES (default 320) tiles of 128 x 192.  NOPE_CONV_SMALL: 0 = never, 1 = that policy (default), 2 = whenever the
+// kernel applies (tests); NOPE_SMALL_TILE forces the tile.
+static int plan_small(int dt, const ConvArgs& a, bool dma) {
+    const int mode_env = getenv("NOPE_CONV_SMALL") ? atoi(getenv("NOPE_CONV_SMALL")) : 1;
+    if (!dma || mode_env == 0 || a.mode == NOPE_CONV_UP2 || a.ntaps == 16 || a.force_generic) return -1;
+    const bool phased = a.mode == NOPE_CONV_UP2P;
+    const long long M = (long long)a.nhyp * (phased ? a.Hs * a.Ws : a.Ho * a.Wo);
+    const long long tiles128 = (long long)cdiv((int)M, BM) * cdiv(a.Cout, BN) * (phased ? 4 : 1);
+    static const int max_tiles = getenv("NOPE_SMALL_MAX_TILES") ? atoi(getenv("NOPE_SMALL_MAX_TILES")) : 320;
+    if (mode_env == 1 && tiles128 >= max_tiles) return -1;
+    if (const char* t = getenv("NOPE_SMALL_TILE")) return atoi(t) < 0 || atoi(t) > 2 ? 0 : atoi(t);
+    const long long tiles64 = (long long)cdiv((int)M, 64) * cdiv(a.Cout, 64) * (phased ? 4 : 1);
+    return tiles64 > 1536 ? 1 : 0;
+}
+
 static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     // (read per launch: the tests toggle it.  f32 -- the parity mode -- stays on the 128 x 192 kernel unless asked: its MFMA phase is
     //  16x longer per K step, loads were never its bound, and two workgroups per CU beat one: 126 vs 135 ms per 512-template step)
     const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : (dt != NOPE_F32 ? 3 : 0);
     static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
-    ConvPlan pl{false, false, false, false};
+    ConvPlan pl{false, false, false, false, -1};
     const int vec = dt_vec(dt), es = dt_es(dt), bk = 8 * vec;
     const int Cin = a.C1 + a.C2;
     const unsigned long long lim = 0x7fffffffULL;
@@ -521,6 +539,8 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     // (the 4x4 stride-2 conv of the non-default soft downsampling runs on the generic kernel: its tap geometry is not a 3x3 mask)
     pl.dma = !a.force_generic && a.ntaps != 16 && Cin % bk == 0 && (a.C2 == 0 || (a.C1 % bk == 0 && a.mode == NOPE_CONV_PLAIN)) && b1 < lim && b2 < lim && bw < lim;
     if (!pl.dma) return pl;
+    pl.small = plan_small(dt, a, pl.dma);
+    if (pl.small >= 0) return pl;
     const bool small3x3 = a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && !a.colstats && !a.pn_ms && !a.out_nchw && !a.splitk_ws &&
                           a.Hs * a.Ws <= POSMAJOR_MAX_HW;
     const bool posmajor128 = small3x3 && a.nhyp % BM == 0 && !(variant & 8) && variant != 4;
@@ -551,9 +571,22 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
 // Would launch_conv run this conv in position-major row order?
 bool conv_is_posmajor(int dt, const ConvArgs& a) { return plan_conv(dt, a).posmajor; }
 
+// Fused GroupNorm column statistics: every kernel emits them per 64-row block (64-row blocks must not straddle samples); the
+// small-tile kernel also per 16 / 32 rows, which covers the 4 x 4 level (16 pixels per sample) and removes its gn_stats pass.
+int conv_stat_rows(int dt, const ConvArgs& a) {
+    const int vec = dt_vec(dt);
+    if (a.mode == NOPE_CONV_UP2P || a.resid || a.out_nchw || a.Cout % vec || a.Cout > 2048) return 0;
+    const long long HW = (long long)a.Ho * a.Wo, M = (long long)a.nhyp * HW;
+    if (HW % 64 == 0) return 64;
+    ConvArgs b = a;
+    b.colstats = nullptr;
+    if ((HW == 16 || HW == 32) && M % HW == 0 && plan_conv(dt, b).small >= 0) return (int)HW;
+    return 0;
+}
+
 int conv_kernel_kind(int dt, const ConvArgs& a) {
     const ConvPlan pl = plan_conv(dt, a);
-    return pl.halo ? NOPE_CONV_KERNEL_HALO256 : pl.pp ? NOPE_CONV_KERNEL_PP256 : pl.dma ? NOPE_CONV_KERNEL_DMA128 : NOPE_CONV_KERNEL_GENERIC;
+    return pl.small >= 0 ? NOPE_CONV_KERNEL_SMALL : pl.halo ? NOPE_CONV_KERNEL_HALO256 : pl.pp ? NOPE_CONV_KERNEL_PP256 : pl.dma ? NOPE_CONV_KERNEL_DMA128 : NOPE_CONV_KERNEL_GENERIC;
 }
 
 // Multiply-adds x2 the launch actually executes (position-major launches skip the taps that lie in the padding:
@@ -569,6 +602,7 @@ int conv_splitk_factor(int dt, const ConvArgs& a) {
     const int vec = dt_vec(dt);
     const int Cin = a.C1 + a.C2;
     if (Cin % (8 * vec)) return 1;
+    if (plan_conv(dt, a).small >= 0) return 1;        // the small-tile kernel has enough workgroups without splitting K
     const long long M = (long long)a.nhyp * a.Ho * a.Wo;
     const long long tiles = (long long)cdiv((int)M, BM) * cdiv(a.Cout, BN);
     const int nk = a.ntaps * (Cin / (8 * vec));
@@ -616,9 +650,10 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.nchw_staged = (a.out_nchw && !a.resid && !a.pn_ms && M % 64 == 0 && ((long long)a.Ho * a.Wo) % 64 == 0 &&
                      !(getenv("NOPE_NCHW_STAGED") && atoi(getenv("NOPE_NCHW_STAGED")) == 0)) ? 1 : 0;
     p.colstats = a.colstats;
+    p.stat_rows = a.stat_rows;
     p.pn_ms = a.pn_ms; p.pn_c0 = a.pn_c0; p.pn_c1 = a.pn_c1;
     if (a.pn_ms && (!a.pn_c0 || !a.pn_c1 || a.mode != NOPE_CONV_PLAIN || a.ntaps != 1 || a.colstats)) return NOPE_ERR_ARG;
-    if (a.colstats && (!p.wide_out || M % 64 != 0 || phased || a.resid)) return NOPE_ERR_ARG;
+    if (a.colstats && (!p.wide_out || phased || a.resid || a.stat_rows != conv_stat_rows(dt, a))) return NOPE_ERR_ARG;
     const int es = dt_es(dt);
     const int Cin = a.C1 + a.C2;
     const unsigned long long b1 = (unsigned long long)cdiv(a.nhyp, a.rep1) * a.Hs * a.Ws * a.C1 * es;
@@ -634,10 +669,12 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.variant = variant;
     p.d_hw = make_fastdiv((unsigned)(p.Hm * p.Wm)); p.d_w = make_fastdiv((unsigned)p.Wm);
     p.d_rep1 = make_fastdiv((unsigned)p.rep1); p.d_rep2 = make_fastdiv((unsigned)p.rep2);
-    const int bm = (plan.pp || (dma && variant == 4 && M >= 256 * 256 && (dt == NOPE_F32 || dt == NOPE_BF16))) ? 256 : BM;
-    p.tiles_m = cdiv((int)M, bm); p.tiles_n = cdiv(a.Cout, BN);
+    const int bm = plan.small >= 0 ? (plan.small == 1 ? 128 : 64)
+                   : (plan.pp || (dma && variant == 4 && M >= 256 * 256 && (dt == NOPE_F32 || dt == NOPE_BF16))) ? 256 : BM;
+    const int bn = plan.small >= 0 ? (plan.small == 1 ? 128 : 64) : BN;
+    p.tiles_m = cdiv((int)M, bm); p.tiles_n = cdiv(a.Cout, bn);
     const int tn = p.tiles_n;
-    p.xcd_map = (tn == 1 || tn == 2 || tn == 4 || tn == 8) && (p.tiles_m % (8 / tn) == 0) ? 1 : 0;
+    p.xcd_map = plan.small < 0 && (tn == 1 || tn == 2 || tn == 4 || tn == 8) && (p.tiles_m % (8 / tn) == 0) ? 1 : 0;
     const long long nblocks = (long long)p.tiles_m * p.tiles_n;
     if (nblocks > 0x7fffffffLL) return NOPE_ERR_UNSUPPORTED;
     p.splits = 1; p.split_out = nullptr;
@@ -666,7 +703,17 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     // so that the bytes crossing the fabric, gn x activations + (8 / gn) x weights, are fewest (tile_coords, map 2).
     // NOPE_XCD_MAP=1 keeps one panel per XCD (gn = tiles_n).
     p.xcd_gn = tn;
-    if (dma && p.xcd_map && tn > 1 && !(getenv("NOPE_XCD_MAP") && atoi(getenv("NOPE_XCD_MAP")) == 1)) {
+    if (plan.small >= 0) {
+        // small tiles: an (8 / gn) x gn XCD grid over (runs of M tiles) x (groups of weight panels), gn chosen like below; at small
+        // M the weights are most of the bytes, so they usually cross the fabric once (gn = 8) and the activations 8 times
+        const double abytes = (double)b1 + (double)b2, wbytes = (double)bw * (phased ? 4 : 1);
+        double best = -1.0;
+        for (int gn = 1; gn <= 8; gn *= 2)
+            if (p.tiles_m % (8 / gn) == 0 && p.tiles_n % gn == 0 && (best < 0 || gn * abytes + (8 / gn) * wbytes < best)) {
+                best = gn * abytes + (8 / gn) * wbytes; p.xcd_gn = gn; p.xcd_map = 3;
+            }
+    }
+    if (dma && p.xcd_map && p.xcd_map != 3 && tn > 1 && !(getenv("NOPE_XCD_MAP") && atoi(getenv("NOPE_XCD_MAP")) == 1)) {
         const double abytes = (double)b1 + (double)b2, wbytes = (double)bw * (phased ? 4 : 1);
         double best = tn * abytes + (8 / tn) * wbytes;
         for (int gn = 1; gn < tn; gn *= 2)
@@ -685,7 +732,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         const long long hw = (long long)a.Hs * a.Ws;
         static const int persist_on = getenv("NOPE_CONV_PERSIST") ? atoi(getenv("NOPE_CONV_PERSIST")) : 1;
         const int span = p.xcd_map == 2 ? tn / p.xcd_gn : 1;
-        if (persist_on && dma && bm == BM && dt != NOPE_F32 && a.mode == NOPE_CONV_PLAIN && !p.posmajor && p.splits == 1 && p.xcd_map &&
+        if (persist_on && dma && plan.small < 0 && bm == BM && dt != NOPE_F32 && a.mode == NOPE_CONV_PLAIN && !p.posmajor && p.splits == 1 && p.xcd_map &&
             p.wide_out && a.rep1 == 1 && a.rep2 == 1 && M % BM == 0 && nblocks > 512 && nblocks % 512 == 0 && 64 % span == 0 &&
             ((64ll / span) * BM) % hw == 0 && !(variant & 2)) {
             p.persist_iters = (int)(nblocks / 512);
@@ -709,10 +756,14 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     }
     const dim3 grid(gx, phased ? 4u : 1u, (unsigned)p.splits), block(NT);
     static const bool trace = getenv("NOPE_CONV_TRACE") != nullptr;     // tuning aid: one line per launch
-    if (trace) fprintf(stderr, "conv %s mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u posmajor %d persist %d xcd %d/%d\n",
+    if (trace && plan.small >= 0) fprintf(stderr, "conv small%d mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u xcd %d/%d\n", plan.small, a.mode, a.ntaps, Cin, a.Cout, M,
+                                        p.tiles_m, p.tiles_n, grid.x, grid.y, grid.z, p.xcd_map, p.xcd_gn);
+    else if (trace) fprintf(stderr, "conv %s mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u posmajor %d persist %d xcd %d/%d\n",
                        plan.halo ? "halo256" : plan.pp ? "pp256" : dma ? "dma128" : "generic", a.mode, a.ntaps, Cin, a.Cout, M, p.tiles_m, p.tiles_n, grid.x, grid.y, grid.z,
                        p.posmajor, p.persist_iters, p.xcd_map, p.xcd_gn);
-    if (plan.pp) {
+    if (plan.small >= 0) {
+        launch_conv_small(dt, &p, plan.small, grid, s);
+    } else if (plan.pp) {
         if (const char* v = getenv("NOPE_PP_VARIANT")) p.variant = atoi(v);      // tuning ablations of the ping-pong kernel
         if (plan.halo) launch_conv_halo(dt, &p, grid, s);
         else launch_conv_pp(dt, &p, grid, s);

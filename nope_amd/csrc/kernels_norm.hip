@@ -143,7 +143,10 @@ template <bool FAST> __device__ __forceinline__ f32x2 silu2(f32x2 t) {
 // (per 16-bit element: unpack, fma, SiLU = 2 quarter-rate transcendentals + 3, adds, clamp, pack), so runtime `if (act)` /
 // `if (resid)` selects, the unpack of an absent residual and unpaired adds were 40 % of its issue slots (193 -> 117 VALU per
 // two pixels).  U = pixels in flight per thread.
-template <class T, bool FAST, bool OS, bool FILM, bool ACT, bool RES, int U>
+// FOLD: `partial` holds the producing conv's column statistics [x sample][nchunk row blocks][C][2] and every workgroup folds its
+// sample's itself, in gn_fold_kernel's order (same bits) -- for small batches, where a separate fold launch costs more than the
+// few KiB every workgroup re-reads.
+template <class T, bool FAST, bool OS, bool FILM, bool ACT, bool RES, int U, bool FOLD>
 __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ partial,
                                                       int nchunk, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       int HW, int C, int G, const float* __restrict__ emb, int emb_stride,
@@ -157,6 +160,38 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
     const int tid = threadIdx.x;
     const int cpg = C / G;
     const int xs = hyp / x_rep;
+    if constexpr (FOLD) {
+        __shared__ float ch_s[2048];
+        __shared__ float ch_q[2048];
+        const float* base = partial + (size_t)xs * nchunk * C * 2;
+        for (int c = tid; c < C; c += NT) {
+            float s = 0.f, q = 0.f;
+            int b = 0;
+            for (; b + 8 <= nchunk; b += 8) {
+                f32x2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x2*>(base + ((size_t)(b + u) * C + c) * 2);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s += v[u][0]; q += v[u][1]; }
+            }
+            for (; b < nchunk; ++b) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(base + ((size_t)b * C + c) * 2);
+                s += v[0]; q += v[1];
+            }
+            ch_s[c] = s; ch_q[c] = q;
+        }
+        __syncthreads();
+        for (int g = tid; g < G; g += NT) {
+            float S = 0.f, Q = 0.f;
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { S += ch_s[c]; Q += ch_q[c]; }
+            const float cnt = (float)cpg * (float)HW;
+            const float mean = S / cnt;
+            float var = Q / cnt - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            s_mean[g] = mean;
+            s_rstd[g] = 1.0f / sqrtf(var + eps);
+        }
+    } else
     for (int g = tid; g < G; g += NT) {
         float S = 0.f, Q = 0.f;
         for (int k = 0; k < nchunk; ++k) {
@@ -306,9 +341,9 @@ int launch_gn_stats(int dt, const void* x, float* partial, int nhyp, int HW, int
     return NOPE_OK;
 }
 
-int launch_gn_fold(const float* colstats, float* partial, int nhyp, int HW, int C, int G, hipStream_t s) {
-    if (!colstats || !partial || nhyp <= 0 || HW % 64 || C % G || C > 2048 || G > 64) return NOPE_ERR_ARG;
-    hipLaunchKernelGGL(gn_fold_kernel, dim3((unsigned)nhyp), dim3(NT), 0, s, colstats, partial, HW / 64, C, G);
+int launch_gn_fold(const float* colstats, float* partial, int nhyp, int blocks, int C, int G, hipStream_t s) {
+    if (!colstats || !partial || nhyp <= 0 || blocks < 1 || C % G || C > 2048 || G > 64) return NOPE_ERR_ARG;
+    hipLaunchKernelGGL(gn_fold_kernel, dim3((unsigned)nhyp), dim3(NT), 0, s, colstats, partial, blocks, C, G);
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }
@@ -333,17 +368,21 @@ int launch_gn_finalize(const float* partial, float* ms, int nhyp, int nchunk, fl
 }
 
 int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
-    if (!a.x || !a.y || !a.partial || !a.gamma || !a.beta || a.nhyp <= 0 || a.C % a.G) return NOPE_ERR_ARG;
+    const bool fold = a.colstats != nullptr;
+    if (!a.x || !a.y || (!a.partial && !fold) || !a.gamma || !a.beta || a.nhyp <= 0 || a.C % a.G) return NOPE_ERR_ARG;
+    if (fold && (a.stat_blocks < 1 || a.C > 2048 || a.film)) return NOPE_ERR_ARG;
     const int vec = dt_vec(dt);
     if (a.C % vec || a.G > 64) return NOPE_ERR_UNSUPPORTED;
     if (a.x_rep < 1 || a.resid_rep < 1) return NOPE_ERR_ARG;
     const int bph = gn_apply_blocks(a.HW, a.C, dt);
     dim3 grid((unsigned)(a.nhyp * bph)), block(NT);
     const bool act = a.act != 0, res = a.resid != nullptr;
+#define NOPE_GN_APPLY_F(T, FAST, OS, FILM, ACT, RES, U, FOLD)                                                                    \
+    hipLaunchKernelGGL((gn_apply_kernel<T, FAST, OS, FILM, ACT, RES, U, FOLD>), grid, block, 0, s, (const T*)a.x, (T*)a.y,       \
+                       FOLD ? a.colstats : a.partial, FOLD ? a.stat_blocks : a.nchunk, a.gamma, a.beta, a.HW, a.C, a.G, a.emb,   \
+                       a.emb_stride, (const T*)a.resid, a.eps, bph, a.x_rep, a.resid_rep, a.out_stats, a.film, a.film_stride)
 #define NOPE_GN_APPLY_U(T, FAST, OS, FILM, ACT, RES, U)                                                                          \
-    hipLaunchKernelGGL((gn_apply_kernel<T, FAST, OS, FILM, ACT, RES, U>), grid, block, 0, s, (const T*)a.x, (T*)a.y, a.partial,  \
-                       a.nchunk, a.gamma, a.beta, a.HW, a.C, a.G, a.emb, a.emb_stride, (const T*)a.resid, a.eps, bph, a.x_rep,   \
-                       a.resid_rep, a.out_stats, a.film, a.film_stride)
+    do { if (!FILM && fold) NOPE_GN_APPLY_F(T, FAST, OS, false, ACT, RES, U, true); else NOPE_GN_APPLY_F(T, FAST, OS, FILM, ACT, RES, U, false); } while (0)
 #define NOPE_GN_APPLY_AR(T, FAST, OS, FILM, ACT, RES) NOPE_GN_APPLY_U(T, FAST, OS, FILM, ACT, RES, 2)   /* (4 in flight: +-0) */
 #define NOPE_GN_APPLY(T, FAST, OS, FILM)                                                                                         \
     do {                                                                                                                         \
@@ -364,6 +403,7 @@ int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
 #undef NOPE_GN_APPLY
 #undef NOPE_GN_APPLY_AR
 #undef NOPE_GN_APPLY_U
+#undef NOPE_GN_APPLY_F
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NT) void sim_reg_kernel(const float* __restrict__ q
             }
         float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < LV; ++e) s += __builtin_amdgcn_sqrtf(acc[e]);
+        for (int e = 0; e < LV; ++e) s += sizeof(T) == 4 ? sqrtf(acc[e]) : __builtin_amdgcn_sqrtf(acc[e]);   // f32 banks (the parity path): correctly rounded
         // reduce over the P threads of this sub-hypothesis
         if (P >= 64) {
             s = wave_sum(s);
@@ -304,8 +304,11 @@ int launch_similarity(const float* q, const void* bank, int bank_dt, float* scor
         // nsplit workgroups per sample, ~4096 in all (several residency rounds: the workgroups drift out of phase, which the
         // memory system likes better than one round of long workgroups running load / reduce in lockstep -- NOPE_SIM_VARIANT & 2
         // sizes the grid to exactly one round, CUs x resident workgroups: bf16 +3 %, f32 -9 %, fp16 -6 %, profiles/r02i_sim_bench.txt)
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        int cus = 256;                 // (only the tuning variant sizes its grid by the CU count: no device query on the default path)
+        if (variant & 2) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        }
 #define NOPE_SIM_LAUNCH(T, CM, NTLOAD, LV, EX) NOPE_SIM_LAUNCH_Q(T, CM, NTLOAD, LV, EX, false)
 #define NOPE_SIM_LAUNCH_Q(T, CM, NTLOAD, LV, EX, QL)                                                                                       \
         do {                                                                                                                       \

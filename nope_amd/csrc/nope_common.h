@@ -228,7 +228,8 @@ struct ConvArgs {
     void* splitk_ws = nullptr;   // optional f32 scratch [splits][M][Cout]: allows a deterministic split-K launch for
     size_t splitk_bytes = 0;     //   small-M / long-K problems (conv_splitk_factor); ignored when too small
     int force_generic = 0;       // tests: take the register-staged kernel even when the LDS-DMA one applies
-    float* colstats = nullptr;   // optional fused GroupNorm statistics: [M/64][Cout][2] (needs M % 64 == 0, NHWC out)
+    float* colstats = nullptr;   // optional fused GroupNorm statistics: [M/stat_rows][Cout][2] (needs M % stat_rows == 0, NHWC out)
+    int stat_rows = 64;          // rows per statistics block: 64, or 16 / 32 on the small-tile kernel (maps of 16 / 32 pixels: conv_stat_rows)
     // optional fused PreNorm (GroupNorm(1) in front of a 1x1 conv whose weights already carry gamma):
     //   out[m,n] = rstd[b] * (acc[m,n] - mean[b] * pn_c1[n]) + pn_c0[n],  b = sample of row m
     const float* pn_ms = nullptr;   // [nhyp][2] (mean, rstd)
@@ -239,12 +240,15 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s);
 int conv_splitk_factor(int dt, const ConvArgs& a);
 bool conv_is_posmajor(int dt, const ConvArgs& a);
 int conv_kernel_kind(int dt, const ConvArgs& a);      // NOPE_CONV_KERNEL_* launch_conv would pick
+int conv_stat_rows(int dt, const ConvArgs& a);        // rows per block of the fused column statistics this conv can emit (0: none)
 double conv_executed_flops(int dt, const ConvArgs& a);
 
 int launch_gn_stats(int dt, const void* x, float* partial, int nhyp, int HW, int C, int G, int nchunk, hipStream_t s);
 struct GnApplyArgs {
     const void* x = nullptr; void* y = nullptr;
     const float* partial = nullptr; int nchunk = 1;
+    const float* colstats = nullptr; int stat_blocks = 0;   // instead of `partial`: the producing conv's column statistics [x sample][stat_blocks][C][2],
+                                                            // folded by every workgroup itself (small batches: no gn_fold launch)
     const float* gamma = nullptr; const float* beta = nullptr;
     int nhyp = 0, HW = 0, C = 0, G = 1;
     int act = 0;                       // 1 = SiLU
@@ -261,8 +265,8 @@ int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s);
 int gn_apply_blocks(int HW, int C, int dt);      // workgroups per hypothesis of launch_gn_apply (= chunks of out_stats)
 int launch_gn_finalize(const float* partial, float* ms, int nhyp, int nchunk, float count, float eps, hipStream_t s);
 int gn_stats_chunks(int HW, int C, int dt);
-// fold the conv epilogue's per-64-row-block column statistics into per-(hypothesis, group) partials (nchunk = 1)
-int launch_gn_fold(const float* colstats, float* partial, int nhyp, int HW, int C, int G, hipStream_t s);
+// fold the conv epilogue's per-row-block column statistics [nhyp][blocks][C][2] into per-(hypothesis, group) partials (nchunk = 1)
+int launch_gn_fold(const float* colstats, float* partial, int nhyp, int blocks, int C, int G, hipStream_t s);
 
 int launch_linattn(int dt, const void* qkv, void* out, int nhyp, int HW, int heads, int dim_head, hipStream_t s);
 int launch_attn(int dt, const void* qkv, void* out, int nhyp, int HW, int heads, int dim_head, hipStream_t s);
@@ -296,5 +300,7 @@ int launch_copy_cols(int dt, const void* x, void* y, long long M, int C, int C2,
 int launch_similarity(const float* q, const void* bank, int bank_dt, float* scores, int B, int N, int C, int HW,
                       long long bank_stride_b, int score_ld, hipStream_t s);
 int launch_topk(const float* scores, long long* idx, float* vals, int B, int N, int k, int ld, hipStream_t s);
+int launch_geodesic(const double* poses, long long stride_b, int N, const long long* idx, const double* gt, const int* symmetry,
+                    double* err, int* status, int B, int k, hipStream_t s);
 
 }  // namespace nope

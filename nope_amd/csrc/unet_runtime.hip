@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <initializer_list>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -66,8 +67,15 @@ struct nope_unet {
     mutable std::vector<Ev> evs;
     // hipGraph cache for SMALL hypothesis batches (the reference evaluates on 26 / 91 / 341 templates, shapeNet.py:252-263): there
     // a forward is ~150 dependent launches of 5-20 us each and the gaps between them are a visible share of the pass.
+    // OPT-IN (nope_unet_graph_limit, or NOPE_UNET_GRAPH read once at create time; default 0 = never): measured +-0 against direct launches
+    // (profiles/r03c_small_banks.txt -- a 64-hypothesis pass is GPU-bound, not launch-bound), and a cached graph freezes the launch plan
+    // it was captured with (the NOPE_* tuning variables are not part of the key).  The cache is guarded by a mutex: ctypes callers
+    // have released the GIL.
     mutable std::vector<UGraph> graphs;
     mutable bool graphs_ok = true;           // cleared when capture is unavailable: direct launches from then on
+    mutable std::mutex graph_mu;
+    mutable int graph_replays = 0;           // forwards served by a graph replay since create (tests assert the path really ran)
+    long long graph_max = 0;                 // largest n_hyp * H * W that replays a graph; 0 = off
 };
 
 namespace {
@@ -172,6 +180,10 @@ struct Arena {
     }
 };
 
+// Fused GroupNorm statistics of a conv output: [n][blocks][C][2] column sums per row block (null: the conv cannot emit them --
+// the GroupNorm takes its own statistics pass)
+struct Stats { float* cs = nullptr; int blocks = 0; };
+
 struct Fwd {
     const nope_unet* net;
     hipStream_t s;
@@ -192,13 +204,14 @@ struct Fwd {
     }
     bool live() const { return !ar.dry && err == NOPE_OK; }
 
-    // out = conv(a [cat b]) (+bias) (+resid);  n = number of samples computed (nhyp or fewer)
+    // out = conv(a [cat b]) (+bias) (+resid);  n = number of samples computed (nhyp or fewer).  `stats`: also emit the column
+    // statistics of the output when this launch can (conv_stat_rows: whole 64-row blocks per sample on every kernel, 16 / 32-pixel
+    // maps on the small-tile kernel); the scratch comes from the arena and lives until the caller's release.
     void conv(const Conv& c, const Act& a, const Act* b, void* out, int Ho, int Wo, int n, int rep1, int rep2,
-              const void* resid = nullptr, int out_nchw = 0, int out_dt = NOPE_F32, float* colstats = nullptr,
+              const void* resid = nullptr, int out_nchw = 0, int out_dt = NOPE_F32, Stats* stats = nullptr,
               const float* pn_c0 = nullptr, const float* pn_c1 = nullptr) {
         if (err != NOPE_OK) return;
         ConvArgs ca;
-        ca.colstats = colstats;
         if (pn_c0) { ca.pn_ms = pn_ms; ca.pn_c0 = pn_c0; ca.pn_c1 = pn_c1; }
         ca.src1 = a.p; ca.C1 = a.C; ca.rep1 = rep1;
         if (b) { ca.src2 = b->p; ca.C2 = b->C; ca.rep2 = rep2; }
@@ -206,6 +219,17 @@ struct Fwd {
         ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.bias = c.bias; ca.resid = resid;
         ca.out = out; ca.Cout = c.Cout; ca.nhyp = n; ca.out_nchw = out_nchw; ca.out_dt = out_dt;
         if (a.C + (b ? b->C : 0) != c.Cin) { chk(NOPE_ERR_ARG); return; }
+        float* colstats = nullptr;
+        if (stats) {
+            const int sr = conv_stat_rows(net->dt, ca);
+            if (sr > 0) {
+                const int HWo = Ho * Wo;
+                colstats = (float*)ar.alloc((size_t)n * (HWo / sr) * c.Cout * 2 * sizeof(float));
+                if (!colstats) { chk(NOPE_ERR_WORKSPACE); return; }
+                ca.colstats = colstats; ca.stat_rows = sr;
+                stats->cs = colstats; stats->blocks = HWo / sr;
+            }
+        }
         // few output tiles + long K (small hypothesis batches at the 4x4 level): deterministic split-K through a
         // scratch taken from the arena for the duration of the launch
         const size_t sk_mark = ar.off;
@@ -236,31 +260,26 @@ struct Fwd {
             chk(launch_conv(net->dt, ca, s));
         }
     }
-    // Can the conv that produces a [n][HW][C] tensor also emit its GroupNorm statistics?  (64-row blocks
-    // must not straddle samples; the wide epilogue needs C % VEC == 0.)  Returns the scratch it needs.
-    // `conv3x3`: the producer is a 3x3 conv; on maps of <= posmajor_hw pixels with a multiple of 128 samples it runs
-    // in position-major row order (padding taps skipped, kernels_gemm.hip), which cannot emit per-sample column
-    // statistics -- the GroupNorm then takes its own statistics pass over the (small) tensor.
-    float* colstats_for(int n, int HW, int C, bool conv3x3 = false) {
-        static const int posmajor_hw = getenv("NOPE_POSMAJOR_HW") ? atoi(getenv("NOPE_POSMAJOR_HW")) : 16;
-        if (conv3x3 && HW <= posmajor_hw && n % 128 == 0) return nullptr;
-        if (HW % 64 || C % 8 || C > 2048) return nullptr;
-        return (float*)ar.alloc((size_t)n * (HW / 64) * C * 2 * sizeof(float));
-    }
     // y = act(GN(x)) [+emb] [+resid]; x holds n_x = nhyp / x_rep samples; `colstats` != null: statistics were
     // produced by the conv epilogue and only need folding.
     void gn(const Norm& nm, int G, const void* x, int x_rep, void* y, int HW, int act, int emb_off, const void* resid,
-            int resid_rep, const float* colstats = nullptr, float* out_stats = nullptr) {
+            int resid_rep, const Stats& st = Stats(), float* out_stats = nullptr) {
         if (!live()) return;
         const int nx = nhyp / x_rep;
         int nch = 1;
-        if (colstats) {
-            chk(launch_gn_fold(colstats, gn_partial, nx, HW, nm.C, G, s));
+        GnApplyArgs ga;
+        if (st.cs) {
+            // Small batches: every gn_apply workgroup folds its sample's column statistics itself (the fold is st.blocks * C * 8 bytes
+            // per workgroup out of L2; a separate launch costs ~8 us).  Large ones keep the fold launch: at 512 hypotheses the six
+            // workgroups of a level-0 sample would each repeat a 24 KiB fold (+0.25 ms per step, measured in round 2).
+            static const long long fold_inline_max = getenv("NOPE_GN_FOLD_INLINE") ? atoll(getenv("NOPE_GN_FOLD_INLINE")) : 16ll << 20;
+            const long long refold = (long long)nhyp * gn_apply_blocks(HW, nm.C, net->sdt) * st.blocks * nm.C * 8;
+            if (refold <= fold_inline_max) { ga.colstats = st.cs; ga.stat_blocks = st.blocks; }
+            else chk(launch_gn_fold(st.cs, gn_partial, nx, st.blocks, nm.C, G, s));
         } else {
             nch = gn_stats_chunks(HW, nm.C, net->sdt);
             chk(launch_gn_stats(net->sdt, x, gn_partial, nx, HW, nm.C, G, nch, s));
         }
-        GnApplyArgs ga;
         ga.x = x; ga.y = y; ga.partial = gn_partial; ga.nchunk = nch; ga.gamma = nm.gamma; ga.beta = nm.beta;
         ga.nhyp = nhyp; ga.HW = HW; ga.C = nm.C; ga.G = G; ga.act = act;
         if (emb_off >= 0) { ga.emb = emb_all + emb_off; ga.emb_stride = net->emb_total; }
@@ -281,17 +300,17 @@ struct Fwd {
             // pose-independent prefix: conv + GN statistics once per reference sample
             const int ns = nhyp / a.rep;
             void* t1s = alloc_act((size_t)ns * HW * R.c1.Cout);
-            float* cs = colstats_for(ns, HW, R.c1.Cout, true);
-            conv(R.c1, a, nullptr, t1s, a.H, a.W, ns, 1, 1, nullptr, 0, NOPE_F32, cs);
+            Stats cs;
+            conv(R.c1, a, nullptr, t1s, a.H, a.W, ns, 1, 1, nullptr, 0, NOPE_F32, &cs);
             gn(R.n1, G, t1s, a.rep, t1, HW, 1, emb_off, nullptr, 1, cs);
         } else {
-            float* cs = colstats_for(nhyp, HW, R.c1.Cout, true);
-            conv(R.c1, a, b, t1, a.H, a.W, nhyp, a.rep, b ? b->rep : 1, nullptr, 0, NOPE_F32, cs);
+            Stats cs;
+            conv(R.c1, a, b, t1, a.H, a.W, nhyp, a.rep, b ? b->rep : 1, nullptr, 0, NOPE_F32, &cs);
             gn(R.n1, G, t1, 1, t1, HW, 1, emb_off, nullptr, 1, cs);
         }
         Act h{t1, R.c1.Cout, a.H, a.W, 1};
-        float* cs2 = colstats_for(nhyp, HW, R.c2.Cout, true);
-        conv(R.c2, h, nullptr, out, a.H, a.W, nhyp, 1, 1, nullptr, 0, NOPE_F32, cs2);
+        Stats cs2;
+        conv(R.c2, h, nullptr, out, a.H, a.W, nhyp, 1, 1, nullptr, 0, NOPE_F32, &cs2);
         const void* resid = a.p;
         int resid_rep = a.rep;
         if (R.has_res) {
@@ -324,8 +343,8 @@ struct Fwd {
         qkv_prenorm(L.qkv, L.c0, L.c1, x, qkv);
         if (live()) chk(launch_linattn(net->sdt, qkv, a, nhyp, HW, heads, dh, s));
         Act aa{a, heads * dh, x.H, x.W, 1};
-        float* cs = colstats_for(nhyp, HW, L.out.Cout);
-        conv(L.out, aa, nullptr, y, x.H, x.W, nhyp, 1, 1, nullptr, 0, NOPE_F32, cs);
+        Stats cs;
+        conv(L.out, aa, nullptr, y, x.H, x.W, nhyp, 1, 1, nullptr, 0, NOPE_F32, &cs);
         gn(L.post, 1, y, 1, out, HW, 0, -1, x.p, 1, cs);
         ar.off = mark;
     }
@@ -502,6 +521,7 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
     net->dims[0] = cfg->u_net_dim;
     for (int l = 0; l < L; ++l) net->dims[l + 1] = cfg->u_net_dim * cfg->dim_mults[l];
     net->classes = cfg->u_net_dim * 4;
+    net->graph_max = getenv("NOPE_UNET_GRAPH") ? atoll(getenv("NOPE_UNET_GRAPH")) : 0;
     const int* dims = net->dims;
     const int HD = cfg->heads * cfg->dim_head;
 
@@ -618,6 +638,19 @@ int nope_unet_profile_launches(nope_unet* net, nope_conv_launch_info* out, int m
     return NOPE_OK;
 }
 
+int nope_unet_graph_limit(nope_unet* net, long long max_hyp_pixels) {
+    if (!net || max_hyp_pixels < 0) return NOPE_ERR_ARG;
+    std::lock_guard<std::mutex> lock(net->graph_mu);
+    net->graph_max = max_hyp_pixels;
+    return NOPE_OK;
+}
+
+int nope_unet_graph_replays(const nope_unet* net) {
+    if (!net) return NOPE_ERR_ARG;
+    std::lock_guard<std::mutex> lock(net->graph_mu);
+    return net->graph_replays;
+}
+
 void nope_unet_destroy(nope_unet* net) {
     if (!net) return;
     for (const UGraph& g : net->graphs) hipGraphExecDestroy(g.exec);
@@ -664,13 +697,12 @@ int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep
     size_t xb, pb, ob;
     const size_t sb = unet_stage_bytes(net, n_hyp, n_src, H, W, xb, pb, ob);
     const size_t avail = workspace_bytes - lost;
-    // Small batches replay a captured launch sequence (NOPE_UNET_GRAPH: 0 = never, else the largest n_hyp * H * W that does,
-    // default 160 Ki pixels = 156 hypotheses at a 32 x 32 latent); large ones launch directly -- their kernels are long enough that the
-    // launches run ahead of the GPU, a graph has nothing to harvest there.
-    static const long long graph_max = getenv("NOPE_UNET_GRAPH") ? atoll(getenv("NOPE_UNET_GRAPH")) : 160 * 1024;
-    const bool want_graph = net->graphs_ok && !net->profile && avail > sb && (long long)n_hyp * H * W <= graph_max;
+    // Opt-in (net->graph_max > 0): batches of at most that many hypothesis-pixels replay a captured launch sequence; everything else
+    // launches directly.
+    const bool want_graph = net->graph_max > 0 && net->graphs_ok && !net->profile && avail > sb && (long long)n_hyp * H * W <= net->graph_max;
     if (!want_graph)
         return run_forward(net, x, n_src, x_rep, pose, n_hyp, H, W, out, out_dtype, base, avail, s, false, nullptr);
+    std::lock_guard<std::mutex> lock(net->graph_mu);
 
     float* x_s = (float*)base;
     float* pose_s = (float*)(base + xb);
@@ -711,6 +743,7 @@ int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep
     if (hipMemcpyAsync(x_s, x, (size_t)n_src * net->cfg.channels * H * W * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return NOPE_ERR_LAUNCH;
     if (hipMemcpyAsync(pose_s, pose, (size_t)n_hyp * net->cfg.pose_dim * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return NOPE_ERR_LAUNCH;
     if (hipGraphLaunch(hit->exec, s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    ++net->graph_replays;
     if (hipMemcpyAsync(out, out_s, out_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return NOPE_ERR_LAUNCH;
     return NOPE_OK;
 }

@@ -17,6 +17,28 @@ import torch
 import torch.distributed as dist
 
 
+class ShardedBank(torch.Tensor):
+    """This rank's slice [lo, hi) of the template axis of a (B, n_total, C, h, w) bank: what `PoseConditional.generate_templates`
+    returns under `template_parallel` with more than one rank.  An ordinary tensor of the local slice (same storage: kernels
+    write into it, views and `data_ptr()` work) that carries its placement as part of its TYPE -- any torch op on it returns a
+    plain `torch.Tensor` (torch-function dispatch is disabled for the subclass), i.e. a copy, a slice or a concatenation is no
+    longer a placed shard and `retrieval` refuses it unless told where it sits (`shard=`)."""
+
+    @staticmethod
+    def __new__(cls, local: torch.Tensor, lo: int, hi: int, n_total: int):
+        if local.dim() != 5 or local.shape[1] != hi - lo or not (0 <= lo <= hi <= n_total):
+            raise ValueError(f"shard [{lo}, {hi}) of {n_total} does not describe a local bank of shape {tuple(local.shape)}")
+        t = torch.Tensor._make_subclass(cls, local, False)
+        t.lo, t.hi, t.n_total = int(lo), int(hi), int(n_total)
+        return t
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @property
+    def shard(self) -> Tuple[int, int, int]:
+        return self.lo, self.hi, self.n_total
+
+
 def world(group=None) -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)

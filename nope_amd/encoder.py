@@ -91,6 +91,7 @@ class FeatureExtractor(nn.Module):
     def invalidate(self):
         """Drop the folded / repacked device weights; the next device call rebuilds them."""
         self._handle = None
+        self.__dict__.pop("_own_tensors", None)      # the cached tensor list: parameters may have been re-assigned (load_state_dict(assign=True))
 
     def _weights_version(self):
         # (storage address, version counter) per parameter / BatchNorm buffer, as UNet._weights_version: `.data` writes need invalidate()

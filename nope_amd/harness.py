@@ -32,6 +32,21 @@ TEMPLATE_BASE = dict(          # configs/model/template_base.yaml
 )
 
 
+class StubEncoder(torch.nn.Module):
+    """An encoder that hands embeddings through unchanged: exactly what UNet / PoseConditional read from an encoder (`latent_dim`, `name`,
+    `encode_image`, u_net.py:44-46, model.py:107-108) and nothing else.  Scoring-only runs and operator-level checks build a U-Net
+    around it when the images are already embeddings."""
+
+    def __init__(self, latent_dim=8):
+        super().__init__()
+        self.latent_dim = latent_dim
+        self.name = "template"
+
+    @torch.no_grad()
+    def encode_image(self, image, mode=None):
+        return image
+
+
 def random_rotations(n: int, gen: torch.Generator) -> torch.Tensor:
     """Haar-distributed rotations, float64 (n,3,3): QR of a Gaussian with sign fix."""
     a = torch.randn(n, 3, 3, generator=gen, dtype=torch.float64)
@@ -110,10 +125,10 @@ def eval_geodesic(model, batch: Dict[str, torch.Tensor], thresholds=(15, 30), sa
     """The body of PoseConditional.eval_geodesic (model.py:268-376) without visualisation."""
     loss = model.forward(batch["query"], batch["reference"], batch["gt_relativeR"])
     similarity, nearest_idx, _ = model.generate_and_retrieve(batch["query"], batch["reference"], batch["all_relativeR"])
-    template_poses = batch["template_poses"][0]                 # model.py:352
-    predR = template_poses[nearest_idx]                         # (B,5,3,3)
-    sym = batch.get("symmetry", torch.zeros(predR.shape[0], 1, dtype=torch.long, device=predR.device))
-    _, metric = GeodesicError(list(thresholds))(predR, batch["query_pose"], sym)      # model.py:354-358, loss.py:78-115
+    sym = batch.get("symmetry", torch.zeros(nearest_idx.shape[0], 1, dtype=torch.long, device=nearest_idx.device))
+    # pred_R = template_poses[0][nearest_idx] -> GeodesicError (model.py:352-358, loss.py:78-115): gather + angle + symmetry branches as
+    # one device launch (nope_op_geodesic); the grid of the first sample serves every query, as model.py:352 indexes it
+    _, metric = GeodesicError(list(thresholds)).from_indices(batch["template_poses"][:1], nearest_idx, batch["query_pose"], sym)
     res = {"loss": float(loss)}
     res.update({k: float(v) for k, v in metric.items()})
     if save_path:

@@ -13,7 +13,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3      # BF16X3: compute mode only (f32 storage, three bf16 MFMA passes per product)
-ABI_VERSION = 3                          # NOPE_ABI_VERSION of include/nope_hip.h these ctypes structs mirror
+ABI_VERSION = 4                          # NOPE_ABI_VERSION of include/nope_hip.h these ctypes structs mirror
 CONV_PLAIN, CONV_UP2, CONV_DOWN2, CONV_UP2P, CONV_STRIDE2 = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -45,7 +45,7 @@ class ConvLaunchInfo(C.Structure):
                 ("Cout", _i), ("Hs", _i), ("Ws", _i), ("n_hyp", _i), ("mfma_passes", _i), ("posmajor", _i)]
 
 
-CONV_KERNEL_NAMES = ("conv_gemm_kernel", "conv_gemm_dma_kernel", "conv_gemm_pp_kernel", "conv3x3_halo_kernel")
+CONV_KERNEL_NAMES = ("conv_gemm_kernel", "conv_gemm_dma_kernel", "conv_gemm_pp_kernel", "conv3x3_halo_kernel", "conv_gemm_small_kernel")
 
 
 class EncoderConfig(C.Structure):
@@ -57,10 +57,13 @@ _PROTOS = {
     "nope_abi_version": (_i, []),
     "nope_similarity": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp]),
     "nope_topk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "nope_op_geodesic": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "nope_unet_create": (_i, [C.POINTER(UNetConfig), C.POINTER(TensorDesc), _i, _vp, C.POINTER(_vp)]),
     "nope_unet_destroy": (None, [_vp]),
     "nope_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "nope_unet_forward": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "nope_unet_graph_limit": (_i, [_vp, C.c_longlong]),
+    "nope_unet_graph_replays": (_i, [_vp]),
     "nope_unet_profile": (_i, [_vp, _i]),
     "nope_unet_profile_read": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nope_unet_profile_launches": (_i, [_vp, C.POINTER(ConvLaunchInfo), _i, C.POINTER(_i)]),
@@ -172,8 +175,9 @@ class overlap_stream:
     def join(self, *tensors):
         if self.dev is not None:
             self.cur.wait_stream(self.side)
-            for t in tensors:
+            for t in tensors:          # used on both streams, whichever of them it was allocated on
                 t.record_stream(self.cur)
+                t.record_stream(self.side)
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -254,6 +258,40 @@ def topk(scores: torch.Tensor, k: int = 5) -> Tuple[torch.Tensor, torch.Tensor]:
     l = lib()
     l.check(l.dll.nope_topk(_ptr(scores), _ptr(idx), _ptr(vals), B, N, k, N, _stream(scores)), "nope_topk")
     return vals, idx
+
+
+def op_geodesic(poses: torch.Tensor, gt: torch.Tensor, symmetry: Optional[torch.Tensor] = None,
+                idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Geodesic error (radians, f64) of poses[b, idx[b, j]] (or poses[b, j] without `idx`) against gt[b], with the reference's
+    symmetry handling (loss.py:14-75).  poses (B|1, N, 3, 3), gt (B, 3, 3), symmetry (B,) / (B, 1) in {0, 1, 2}, idx (B, k) int64.
+    Raises ValueError where pytorch3d's so3_rotation_angle does (trace outside [-1 - eps, 3 + eps])."""
+    require_device(poses)
+    gt = gt.to(torch.float64).contiguous()
+    poses = poses.to(device=gt.device, dtype=torch.float64).contiguous()
+    B = gt.shape[0]
+    if poses.dim() != 4 or tuple(poses.shape[2:]) != (3, 3) or poses.shape[0] not in (1, B) or tuple(gt.shape[1:]) != (3, 3):
+        raise NopeError(f"poses {tuple(poses.shape)} / gt {tuple(gt.shape)}: expected (B|1, N, 3, 3) and (B, 3, 3)")
+    N = poses.shape[1]
+    if idx is not None:
+        idx = idx.to(device=gt.device, dtype=torch.int64).contiguous()
+        k = idx.shape[1]
+    else:
+        k = N
+    sym = None if symmetry is None else symmetry.reshape(-1).to(device=gt.device, dtype=torch.int32).contiguous()
+    err = torch.empty((B, k), dtype=torch.float64, device=gt.device)
+    if B == 0 or k == 0:
+        return err
+    status = torch.empty(1, dtype=torch.int32, device=gt.device)
+    stride_b = 0 if (poses.shape[0] == 1 and B > 1) else N * 9
+    l = lib()
+    l.check(l.dll.nope_op_geodesic(_ptr(poses), stride_b, N, _ptr(idx), _ptr(gt), _ptr(sym), _ptr(err), _ptr(status), B, k, _stream(gt)),
+            "nope_op_geodesic")
+    st = int(status.item())
+    if st & 2:
+        raise NopeError("nope_op_geodesic: an index lies outside the pose grid")
+    if st & 1:
+        raise ValueError("A matrix has trace outside valid range [-1-eps,3+eps].")      # pytorch3d so3_rotation_angle's message
+    return err
 
 
 def _tensor_descs(state_dict: Dict[str, torch.Tensor]):
@@ -371,6 +409,13 @@ class UNetHandle:
 
     def profile(self, enable: bool):
         self._l.check(self._l.dll.nope_unet_profile(self._h, int(enable)), "nope_unet_profile")
+
+    def graph_limit(self, max_hyp_pixels: int):
+        """Opt in to hipGraph replay for forwards of at most this many n_hyp * H * W (0 = off, the default)."""
+        self._l.check(self._l.dll.nope_unet_graph_limit(self._h, int(max_hyp_pixels)), "nope_unet_graph_limit")
+
+    def graph_replays(self) -> int:
+        return int(self._l.dll.nope_unet_graph_replays(self._h))
 
     def profile_read(self):
         """(n_launches, total_ms, total_flops, total_bytes) of the conv-GEMM launches since profile(True)."""

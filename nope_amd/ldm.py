@@ -140,6 +140,7 @@ class UNetModelPose(nn.Module):
 
     def invalidate(self):
         self._handle = None
+        self.__dict__.pop("_own_params", None)      # the cached tensor list: parameters may have been re-assigned (load_state_dict(assign=True))
         inv = getattr(self.encoder, "invalidate", None)
         if callable(inv):
             inv()

@@ -1,4 +1,9 @@
-"""`GeodesicError` -- the metric applied right after the hot path (src/model/loss.py:14-115), host-side.
+"""`GeodesicError` -- the metric applied right after the hot path (src/model/loss.py:14-115).
+
+Device tensors go through the C ABI: ONE launch of `nope_op_geodesic` (csrc/kernels_metric.hip) evaluates the angle with the
+reference's three symmetry branches for all (B, k) retrieved poses -- `geodesic_from_indices` gathers `template_poses[nearest_idx]`
+(model.py:352-354) inside that launch.  Host tensors (the CPU tests, the fixtures recorded from the reference's own loss.py) take
+the torch restatement below; both are pinned to the same hand-computed known answers of pytorch3d's published formula.
 
 The reference delegates the angle to `pytorch3d.transforms.so3_relative_angle(pred, gt, eps=1e-2)`, an
 un-vendored and unpinned dependency that is not installed here: **parity unpinned**.
@@ -26,8 +31,8 @@ _COS_BOUND = 1e-4            # pytorch3d default `cos_bound`
 
 def acos_linear_extrapolation(x: torch.Tensor, bound: float = 1.0 - _COS_BOUND) -> torch.Tensor:
     """acos inside [-bound, bound], first-order Taylor extrapolation outside (pytorch3d transforms/math.py)."""
-    def ext(v, b):
-        return math.acos(b) - (v - b) / math.sqrt(1.0 - b * b)
+    def ext(v, b):      # pytorch3d's `_acos_linear_approximation`: (x - x0) * dacos_dx(x0) + acos(x0), dacos_dx(x) = -1 / sqrt(1 - x^2)
+        return (v - b) * (-1.0 / math.sqrt(1.0 - b * b)) + math.acos(b)
     out = torch.empty_like(x)
     hi, lo = x >= bound, x <= -bound
     mid = ~(hi | lo)
@@ -63,8 +68,18 @@ def _opencv_to_opengl(R: torch.Tensor) -> torch.Tensor:
     return torch.bmm(t, R[:, :3, :3])
 
 
+def geodesic_from_indices(template_poses: torch.Tensor, nearest_idx: torch.Tensor, gt: torch.Tensor, symmetry: torch.Tensor) -> torch.Tensor:
+    """model.py:352-357 in one device launch: error (radians, float64, (B, k)) of `template_poses[b, nearest_idx[b, j]]` against `gt[b]`
+    with the reference's symmetry handling.  template_poses (B|1, N, 3, 3), nearest_idx (B, k) int64 (PoseConditional.retrieval's)."""
+    from . import hip
+    return hip.op_geodesic(template_poses, gt, symmetry, idx=nearest_idx)
+
+
 def so3_relative_angle_with_symmetry(pred: torch.Tensor, gt: torch.Tensor, symmetry: torch.Tensor) -> torch.Tensor:
     """loss.py:14-75.  pred, gt (B,3,3); symmetry (B,) or (B,1) in {0,1,2}.  Radians."""
+    if pred.is_cuda:                  # the HIP kernel: one thread per pose, float64
+        from . import hip
+        return hip.op_geodesic(pred[:, None].to(torch.float64), gt, symmetry)[:, 0].to(pred.dtype)
     sym = symmetry.reshape(-1).to(pred.device)
     non = sym == 0
     e_non = so3_relative_angle(pred[non], gt[non], eps=1e-2)
@@ -101,11 +116,26 @@ class GeodesicError(torch.nn.Module):
             res = {f"top1, accuracy_{t}": (error <= t).float().mean() * 100 for t in self.thresholds}
             res["top1, median"] = error.median()
             return error, res
+        if predR.is_cuda:             # all k ranks in ONE launch instead of k passes over the symmetry branches
+            from . import hip
+            rad = hip.op_geodesic(predR.to(torch.float64), gtR, symmetry)
+        else:
+            rad = torch.stack([so3_relative_angle_with_symmetry(predR[:, k].to(torch.float64), gtR.to(torch.float64), symmetry)
+                               for k in range(predR.shape[1])], 1)
+        return self._topk_result(rad)
+
+    @torch.no_grad()
+    def from_indices(self, template_poses: torch.Tensor, nearest_idx: torch.Tensor, gtR: torch.Tensor, symmetry: torch.Tensor):
+        """`GeodesicError(template_poses[nearest_idx], gtR, symmetry)` (model.py:352-357) with the gather inside the metric launch:
+        template_poses (B|1, N, 3, 3) on the device, nearest_idx (B, k) as PoseConditional.retrieval returns it."""
+        return self._topk_result(geodesic_from_indices(template_poses, nearest_idx, gtR, symmetry))
+
+    def _topk_result(self, rad: torch.Tensor):
+        """loss.py:97-115 from the (B, k) angles in radians (float64)."""
         res: Dict[str, torch.Tensor] = {}
-        errors = torch.zeros((predR.shape[0], predR.shape[1]), device=predR.device)     # f32, as loss.py:101
-        for k in range(predR.shape[1]):
-            e = so3_relative_angle_with_symmetry(predR[:, k].to(torch.float64), gtR.to(torch.float64), symmetry)
-            errors[:, k] = torch.rad2deg(e.to(errors.dtype))
+        errors = torch.zeros(tuple(rad.shape), device=rad.device)     # f32, as loss.py:101
+        for k in range(rad.shape[1]):
+            errors[:, k] = torch.rad2deg(rad[:, k].to(errors.dtype))
             if k in (0, 2, 4):
                 top = errors[:, :k + 1].min(dim=1).values
                 for t in self.thresholds:

@@ -102,18 +102,22 @@ class PoseConditional(nn.Module):
         C, h, w = self.u_net.channels, reference_feat.shape[2], reference_feat.shape[3]   # latent_dim, model.py:207-210
         bank = torch.empty((B, n, C, h, w), dtype=hip.torch_dtype(hip.dtype_code(self.bank_dtype)),
                            device=reference_feat.device)
-        # a sharded bank carries its own placement (lo, hi, N): retrieval gathers exactly the banks made here,
-        # never a caller-supplied tensor that merely has the same local size
-        bank._nope_shard = (lo, hi, N) if ws > 1 else None
+        out = bank
+        if ws > 1:
+            # a sharded bank is a ShardedBank: it carries its placement (lo, hi, N) in its type, so retrieval gathers exactly the banks
+            # made here, never a caller-supplied tensor that merely has the same local size
+            out = ndist.ShardedBank(bank, lo, hi, N)
         if n == 0:                  # more ranks than templates: this rank still takes part in the all-gather
-            return bank
+            return out
         if B == 1 and 2 <= n <= self.two_stream_below and reference_feat.is_cuda:
-            h = (n + 1) // 2
+            # (off by default.  Splitting n changes the GEMM row count and with it the launch plan: the halves agree with the
+            #  single-batch result to rounding, not bit for bit -- tests/test_gpu_configs.py::test_two_stream_split_close_to_single_batch)
+            n_first = (n + 1) // 2
             with hip.overlap_stream(reference_feat) as side:
-                self.u_net.forward_hypotheses(reference_feat, poses[:, h:].contiguous(), out=bank[:, h:], out_dtype=self.bank_dtype)
-            self.u_net.forward_hypotheses(reference_feat, poses[:, :h].contiguous(), out=bank[:, :h], out_dtype=self.bank_dtype)
+                self.u_net.forward_hypotheses(reference_feat, poses[:, n_first:].contiguous(), out=bank[:, n_first:], out_dtype=self.bank_dtype)
+            self.u_net.forward_hypotheses(reference_feat, poses[:, :n_first].contiguous(), out=bank[:, :n_first], out_dtype=self.bank_dtype)
             side.join(bank)
-            return bank
+            return out
         if n <= self.max_hyp:
             bs = max(1, self.max_hyp // n)
             for b0 in range(0, B, bs):
@@ -125,7 +129,7 @@ class PoseConditional(nn.Module):
                     e = min(n, s + self.max_hyp)
                     self.u_net.forward_hypotheses(reference_feat[b:b + 1], poses[b:b + 1, s:e],
                                                   out=bank[b:b + 1, s:e], out_dtype=self.bank_dtype)
-        return bank
+        return out
 
     # ---- model.py:254-266 ----------------------------------------------------------------------------
     @torch.no_grad()
@@ -155,12 +159,12 @@ class PoseConditional(nn.Module):
     def retrieval_from_feat(self, query_feat, template_feat, k=5, shard=None):
         """`shard` = (lo, hi, N): this rank's slice [lo, hi) of the N templates; `shard=False`: the bank is COMPLETE on this rank
         (e.g. loaded from disk on every rank) and is scored locally without a collective.  Banks made by `generate_templates`
-        carry their placement themselves; a bank that went through another op since (`.to()`, a slice, `torch.cat`, save /
-        load) has lost the tag: under `template_parallel` with more than one rank that raises -- scoring only a local slice
-        while the other ranks wait in the collective would return rank-local indices without an error."""
-        sl = getattr(template_feat, "_nope_shard", None) if shard is None else (shard or None)
+        are `nope_amd.dist.ShardedBank`s and carry their placement themselves; a bank that went through another op since (`.to()`,
+        a slice, `torch.cat`, save / load) is a plain tensor again: under `template_parallel` with more than one rank that raises --
+        scoring only a local slice while the other ranks wait in the collective would return rank-local indices without an error."""
+        sl = (template_feat.shard if isinstance(template_feat, ndist.ShardedBank) else None) if shard is None else (shard or None)
         if self.template_parallel and sl is None and shard is None and ndist.world()[1] > 1:
-            raise hip.NopeError("template_parallel: this bank carries no shard placement (it was not made by generate_templates, or was "
+            raise hip.NopeError("template_parallel: this bank is a plain tensor, not a ShardedBank with a shard placement (it was not made by generate_templates, or was "
                                 "copied / sliced since): pass shard=(lo, hi, n_total), or shard=False for a bank that is complete on every rank")
         if self.template_parallel and sl is not None:
             if sl[1] - sl[0] != template_feat.shape[1]:

@@ -143,6 +143,7 @@ class UNet(nn.Module):
         """Drop the repacked device weights (also the encoder's); the next forward repacks them.  Called
         automatically after any load_state_dict that reaches this module and when a parameter was modified in place."""
         self._handle = None
+        self.__dict__.pop("_own_params", None)      # the cached tensor list: parameters may have been re-assigned (load_state_dict(assign=True))
         inv = getattr(self.encoder, "invalidate", None)
         if callable(inv):
             inv()

@@ -458,6 +458,8 @@ inline float atomicAdd(float* p, float v) {
     return old;
 }
 
+inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+
 // ---- runtime API shims --------------------------------------------------------------------
 inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }

@@ -1,0 +1,124 @@
+"""Runs the small-tile conv kernel (kernels_gemm_small.hip) on small shapes under tests/hipemu and checks it against torch
+convolutions and, bit for bit, against the 128 x 192 kernel.  Executed as a subprocess by tests/test_conv_small.py with different
+interpreter settings (HIPEMU_DMA=late: LDS-DMA lands at the covering wait -- the counted vmcnt waits of the ring are what this
+exercises; HIPEMU_SHUFFLE: wave scheduling order)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+import torch
+import torch.nn.functional as F
+
+import build_emu
+from nope_amd import hip
+from oracle import nope_ref as R
+from tests.util import rel
+
+
+def run(hip, dev, dts=(1, 0), tiles=(0, 1, 2), light=False):
+    g = torch.Generator().manual_seed(177)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    d = lambda x: x.to(dev)
+    worst = 0.0
+    for dt in dts:
+        q = lambda x: x.to(hip.torch_dtype(dt)).float()
+        tol = {0: 2e-5, 1: 4e-2, 2: 5e-3, 3: 3e-5}[dt]      # f32, bf16, f16, bf16x3
+        C = 32 if dt in (0, 3) else 64           # one 128-byte K step per tap and source
+
+        def both(fn, what, ref, t=tol, bit_equal=True):
+            """fn() on the small-tile kernel (every tile variant) and on the 128 x 192 kernel: all against `ref`, and equal bits."""
+            nonlocal worst
+            os.environ["NOPE_CONV_SMALL"] = "0"
+            os.environ["NOPE_CONV_PP"] = "0"
+            y_big = fn()
+            os.environ.pop("NOPE_CONV_PP")
+            for tile in tiles:
+                os.environ["NOPE_CONV_SMALL"] = "2"
+                os.environ["NOPE_SMALL_TILE"] = str(tile)
+                y = fn()
+                os.environ.pop("NOPE_SMALL_TILE")
+                yy = hip.to_nchw(y, dt).cpu() if y.dim() == 4 and y.shape[-1] != ref.shape[-1] or (y.dtype != torch.float32) else y.cpu().float()
+                if yy.shape != ref.shape:
+                    yy = hip.to_nchw(y, dt).cpu()
+                e = rel(yy, ref)
+                worst = max(worst, e / t)
+                assert e < t, (what, dt, tile, e)
+                if bit_equal:
+                    assert torch.equal(y, y_big), (what, dt, tile, "small-tile kernel differs from the 128 x 192 kernel")
+            os.environ.pop("NOPE_CONV_SMALL")
+
+        # 3x3 over a virtual concat (broadcast first source), ragged M (270 rows), Cout = 200 (4 tiles of 64, the last one ragged), bias
+        x1, x2 = rn(1, C, 10, 9), rn(3, C, 10, 9)
+        w, b = rn(200, 2 * C, 3, 3) / 30, rn(200)
+        both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x1), dt), d(w), d(b), src2=hip.to_nhwc(d(x2), dt), rep1=3, rep2=1, n_hyp=3),
+             "3x3 concat", F.conv2d(torch.cat((q(x1).expand(3, -1, -1, -1), q(x2)), 1), q(w), b, padding=1))
+        # 4x4 maps, many samples per tile, ReLU
+        xs, ws_, bs = rn(40, C, 4, 4), rn(24, C, 3, 3) / (3 * C ** 0.5), rn(24)
+        both(lambda: hip.op_conv(dt, hip.to_nhwc(d(xs), dt), d(ws_), d(bs), act_relu=True), "3x3 4x4 relu", F.relu(F.conv2d(q(xs), q(ws_), bs, padding=1)))
+        # 1x1 with one, two, three and five K steps (the ring wraps), residual
+        for nkc in (1, 2, 3, 5):
+            x3, w3, r3 = rn(2, nkc * C, 12, 11), rn(72, nkc * C, 1, 1) / (nkc * C) ** 0.5, rn(2, 72, 12, 11)
+            both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x3), dt), d(w3), None, resid=hip.to_nhwc(d(r3), dt)), f"1x1 nk={nkc}", F.conv2d(q(x3), q(w3)) + q(r3))
+        # NCHW f32 output with a channel count that is no whole vector (the U-Net's last conv: 8 channels)
+        x6, w6, b6 = rn(3, C, 8, 8), rn(8, C, 1, 1) / C ** 0.5, rn(8)
+        both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x6), dt), d(w6), d(b6), out_nchw=True, out_dtype=0), "1x1 nchw", F.conv2d(q(x6), q(w6), b6))
+        if light:
+            continue
+        # nearest-x2 + 3x3 as four 2x2 phase convs; space-to-depth + 1x1; stride-2 3x3 and 1x1 (encoder)
+        wu, bu = rn(40, C, 3, 3) / 24, rn(40)
+        both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x2), dt), d(wu), d(bu), mode=hip.CONV_UP2P), "up2p",
+             R.hard_upsample(q(x2), {"1.weight": wu, "1.bias": bu}, ""), {0: tol, 1: 6e-2, 2: 8e-3, 3: tol}[dt])
+        x4 = rn(5, C, 12, 10)
+        wd, bd = rn(72, 4 * C, 1, 1) / 16, rn(72)
+        both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x4), dt), d(wd), d(bd), mode=hip.CONV_DOWN2), "down2", R.hard_downsample(q(x4), {"1.weight": q(wd), "1.bias": bd}, ""))
+        ws2, bs2 = rn(48, C, 3, 3) / (3 * C ** 0.5), rn(48)
+        both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x4), dt), d(ws2), d(bs2), mode=hip.CONV_STRIDE2, act_relu=True), "stride2 3x3",
+             F.relu(F.conv2d(q(x4), q(ws2), bs2, stride=2, padding=1)))
+        ws1 = rn(48, C, 1, 1) / C ** 0.5
+        both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x4), dt), d(ws1), None, mode=hip.CONV_STRIDE2), "stride2 1x1", F.conv2d(q(x4), q(ws1), stride=2))
+    return worst
+
+
+def run_unet(hip, dev, dim, cdt, n_hyp=2, hw=8, tile=0):
+    """Whole U-Net schedule with every eligible conv on the small-tile kernel (fused GroupNorm statistics, fused PreNorm, concat
+    sources, phase convs, space-to-depth, NCHW bank output) against the oracle."""
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    from tests.util import StubEncoder
+    os.environ["NOPE_CONV_SMALL"] = "2"
+    os.environ["NOPE_SMALL_TILE"] = str(tile)
+    try:
+        u = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype=cdt)
+        synth_init_(u, 2022)
+        sd = {k: v.clone() for k, v in u.own_state_dict().items()}
+        u = u.to(dev)
+        g = torch.Generator().manual_seed(23)
+        x, pose = torch.randn(1, 8, hw, hw, generator=g), torch.randn(1, n_hyp, 6, generator=g)
+        y = u.forward_hypotheses(x.to(dev), pose.to(dev)).cpu()[0]
+        want = R.unet_forward(sd, x.expand(n_hyp, -1, -1, -1), pose[0])
+        return rel(y, want)
+    finally:
+        os.environ.pop("NOPE_CONV_SMALL")
+        os.environ.pop("NOPE_SMALL_TILE")
+
+
+if __name__ == "__main__":
+    hip._set_library_for_testing(hip.NopeLib(build_emu.build()))
+    if "--unet16" in sys.argv:
+        e = run_unet(hip, "cpu", 64, "f16", n_hyp=1, hw=8)
+        assert e < 8e-3, e
+        print(f"unet f16 (u_net_dim 64) on the small-tile kernel: rel err {e:.2e}")
+        print("small_emu_case OK")
+        sys.exit(0)
+    if "--unet32" in sys.argv:
+        e = run_unet(hip, "cpu", 32, "f32", n_hyp=2, hw=8, tile=1)
+        assert e < 1e-4, e
+        print(f"unet f32 (u_net_dim 32) on the small-tile kernel, 128 x 128 tiles: rel err {e:.2e}")
+        print("small_emu_case OK")
+        sys.exit(0)
+    dts = tuple(int(v) for v in sys.argv[sys.argv.index("--dts") + 1].split(",")) if "--dts" in sys.argv else (1, 0)
+    tiles = tuple(int(v) for v in sys.argv[sys.argv.index("--tiles") + 1].split(",")) if "--tiles" in sys.argv else (0, 1, 2)
+    w = run(hip, "cpu", dts=dts, tiles=tiles, light="--light" in sys.argv)
+    print(f"small_emu_case OK worst/tol {w:.3f}")

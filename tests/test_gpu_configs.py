@@ -237,6 +237,66 @@ def test_crop_warp_on_device_with_reference_geometry(gpu):
         assert np.abs(out[0][inside] - sx[inside]).max() < 2e-2 and np.abs(out[1][inside] - sy[inside]).max() < 2e-2
 
 
+def test_unet_graph_replay_matches_direct(gpu):
+    """hipGraph replay of small forwards is opt-in (nope_unet_graph_limit): on a NON-default stream a graph must really be
+    instantiated and replayed, and its output must equal the direct launches' bit for bit -- in f32, bf16x3 and f16, into a different
+    output tensor, and after the workspace was regrown (a new capture)."""
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    from tests.util import StubEncoder
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(1, 8, 16, 16, generator=g).cuda()
+    poses = torch.randn(1, 9, 6, generator=g).cuda()
+    for cdt in ("f32", "bf16x3", "f16"):
+        u = UNet(u_net_dim=64, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype=cdt)
+        synth_init_(u, 2022)
+        u = u.cuda()
+        direct5 = u.forward_hypotheses(x, poses[:, :5].contiguous())
+        direct9 = u.forward_hypotheses(x, poses)
+        h = u._get_handle(x.device)
+        assert h.graph_replays() == 0                       # off by default
+        h.graph_limit(1 << 20)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            y1 = u.forward_hypotheses(x, poses[:, :5].contiguous())
+            y2 = u.forward_hypotheses(x, poses[:, :5].contiguous(), out=torch.empty_like(y1))      # another output pointer, same graph
+            y3 = u.forward_hypotheses(x, poses)                                                     # bigger batch: the workspace regrows
+            y4 = u.forward_hypotheses(x, poses[:, :5].contiguous())                                 # ... so this shape is captured afresh
+        side.synchronize()
+        assert h.graph_replays() == 4, (cdt, h.graph_replays())
+        assert torch.equal(y1, direct5) and torch.equal(y2, direct5) and torch.equal(y4, direct5) and torch.equal(y3, direct9), cdt
+        h.graph_limit(0)
+        assert torch.equal(u.forward_hypotheses(x, poses[:, :5].contiguous()), direct5) and h.graph_replays() == 4
+
+
+def test_two_stream_split_close_to_single_batch(gpu):
+    """`two_stream_below` (off by default): the two half batches on two HIP streams agree with the single batch to rounding -- not bit
+    for bit, the halves have other GEMM row counts and so other launch plans -- and the bank is complete when the call returns."""
+    from nope_amd.model import PoseConditional
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    from tests.util import StubEncoder
+    g = torch.Generator().manual_seed(32)
+    feat = torch.randn(1, 8, 16, 16, generator=g).cuda()
+    poses = torch.randn(1, 27, 6, generator=g).cuda()
+    u = UNet(u_net_dim=64, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype="f32")
+    synth_init_(u, 2022)
+    one = PoseConditional(u, None, {"similarity_metric": "l2"}, None).cuda()
+    two = PoseConditional(u, None, {"similarity_metric": "l2"}, None, two_stream_below=64)
+    b1 = one.generate_templates_from_feat(feat, poses)
+    b2 = two.generate_templates_from_feat(feat, poses)
+    torch.cuda.synchronize()
+    assert b2.shape == b1.shape and rel(b2, b1) < 1e-5
+
+
+def test_geodesic_kernel_known_answers(gpu):
+    """Row f2 on the device: `nope_op_geodesic` against hand-computed answers of pytorch3d's published formula, the ValueError, the
+    gather form against the host restatement (tests/test_host_logic.py::_check_geodesic_kernel)."""
+    from tests.test_host_logic import _check_geodesic_kernel
+    _check_geodesic_kernel(gpu, "cuda")
+
+
 def test_geodesic_metric_on_device(gpu):
     """GeodesicError with all three symmetry branches (loss.py:14-115) evaluated on CUDA tensors -- the
     step right behind the hot path, on the poses' device -- equals the host evaluation (float64 branch arithmetic)."""

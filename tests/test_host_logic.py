@@ -191,6 +191,69 @@ def test_geodesic_error_metric():
     assert set(res) == {f"top{k}, {m}" for k in (1, 3, 5) for m in ("accuracy_15", "median")}
 
 
+def test_geodesic_known_answers_host():
+    """Row f2, the angle itself: the torch restatement against hand-computed answers of pytorch3d's published formula (tests/util.py);
+    the device kernel is held to the same table in tests/test_gpu_configs.py."""
+    from nope_amd.metrics import GeodesicError, so3_relative_angle_with_symmetry
+    from tests.util import geodesic_known_answers
+    for name, p, g, sym, want in geodesic_known_answers():
+        if want == "raises":
+            with pytest.raises(ValueError):
+                so3_relative_angle_with_symmetry(p[None], g[None], torch.tensor([sym]))
+            continue
+        got = float(so3_relative_angle_with_symmetry(p[None], g[None], torch.tensor([sym]))[0])
+        assert abs(got - want) < (2e-6 if sym == 1 else 1e-12), (name, got, want)
+    # the module on the same table: degrees, top-1 form
+    rows = [k for k in geodesic_known_answers() if k[4] != "raises"]
+    P, G = torch.stack([k[1] for k in rows]), torch.stack([k[2] for k in rows])
+    err, _ = GeodesicError([15])(P, G, torch.tensor([k[3] for k in rows]).view(-1, 1))
+    want = torch.rad2deg(torch.tensor([k[4] for k in rows], dtype=torch.float64))
+    assert float((err - want).abs().max()) < 1e-4
+
+
+def _check_geodesic_kernel(hip, dev):
+    """`nope_op_geodesic` (csrc/kernels_metric.hip) against the hand-computed answers of pytorch3d's published formula (identity -> the
+    extrapolated 7.07e-3, NOT 0; 180 degrees about each axis -> pi - 7.07e-3; the extrapolation branches either side of the bound; a
+    trace outside [-1 - eps, 3 + eps] -> ValueError; the two symmetric branches), then the gather form (`template_poses[nearest_idx]`
+    inside the launch, model.py:352-354) against the torch restatement on the host."""
+    from nope_amd.harness import random_rotations
+    from nope_amd.metrics import GeodesicError, geodesic_from_indices, so3_relative_angle_with_symmetry
+    from tests.util import geodesic_known_answers
+    rows = [k for k in geodesic_known_answers() if k[4] != "raises"]
+    P, G = torch.stack([k[1] for k in rows]).to(dev), torch.stack([k[2] for k in rows]).to(dev)
+    sym = torch.tensor([k[3] for k in rows]).to(dev)
+    got = hip.op_geodesic(P[:, None], G, sym)[:, 0].cpu()
+    for (name, _, _, s_, want), e in zip(rows, got.tolist()):
+        assert abs(e - want) < (2e-6 if s_ == 1 else 1e-12), (name, e, want)
+    for name, p, g_, s_, want in geodesic_known_answers():
+        if want == "raises":
+            with pytest.raises(ValueError):
+                hip.op_geodesic(p[None, None].to(dev), g_[None].to(dev), torch.tensor([s_]).to(dev))
+    # gather form, every symmetry, shared and per-query grids, against the host restatement
+    g = torch.Generator().manual_seed(11)
+    B, N, k = 7, 26, 5
+    grid = random_rotations(N, g)
+    gt = random_rotations(B, g)
+    idx = torch.stack([torch.randperm(N, generator=g)[:k] for _ in range(B)])
+    symm = torch.tensor([0, 1, 2, 0, 1, 2, 0])
+    want = torch.stack([so3_relative_angle_with_symmetry(grid[idx[:, j]], gt, symm) for j in range(k)], 1)
+    got = geodesic_from_indices(grid[None].to(dev), idx.to(dev), gt.to(dev), symm.to(dev)).cpu()
+    assert float((got - want).abs().max()) < 1e-6
+    per_query = grid[None].repeat(B, 1, 1, 1).contiguous()
+    assert torch.equal(geodesic_from_indices(per_query.to(dev), idx.to(dev), gt.to(dev), symm.to(dev)).cpu(), got)
+    e1, r1 = GeodesicError([15, 30]).from_indices(grid[None].to(dev), idx.to(dev), gt.to(dev), symm.to(dev))
+    e2, r2 = GeodesicError([15, 30])(grid[idx], gt, symm)
+    assert float((e1.cpu() - e2).abs().max()) < 1e-4 and sorted(r1) == sorted(r2)
+    assert all(abs(float(r1[k_]) - float(r2[k_])) < 1e-3 for k_ in r1)
+    with pytest.raises(hip.NopeError):           # an index outside the grid is an error, not a read past the buffer
+        geodesic_from_indices(grid[None].to(dev), torch.full((B, k), N, dtype=torch.int64).to(dev), gt.to(dev), symm.to(dev))
+
+
+def test_geodesic_kernel_known_answers_emu(emu):
+    """The device kernel's source (csrc/kernels_metric.hip) under the CPU interpreter, same table as on the GPU."""
+    _check_geodesic_kernel(emu, "cpu")
+
+
 def test_pose_grids_and_relative_poses(tmp_path):
     """nope_amd.poses (utils.py:72-125, shapeNet.py:243-251): synthesised icosphere grids have the reference's camera
     positions (level-0 fixture, as a set) and its upper-hemisphere counts at every level; reading the reference's files

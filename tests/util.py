@@ -2,17 +2,7 @@ import torch
 from torch import nn
 
 
-class StubEncoder(nn.Module):
-    """What UNet/PoseConditional read from an encoder (u_net.py:44-46, model.py:107-108)."""
-
-    def __init__(self, latent_dim=8):
-        super().__init__()
-        self.latent_dim = latent_dim
-        self.name = "template"
-
-    @torch.no_grad()
-    def encode_image(self, image, mode=None):
-        return image
+from nope_amd.harness import StubEncoder  # noqa: F401  (re-exported: the tests' historical import path)
 
 
 def rel(a, b):
@@ -31,3 +21,49 @@ def cached_model(compute_dtype="f32", bank_dtype="f32"):
     if base is None:
         base = _MODELS[compute_dtype] = build_model(compute_dtype=compute_dtype, bank_dtype="f32", device="cuda")
     return PoseConditional(base.u_net, TEMPLATE_BASE["optim_config"], TEMPLATE_BASE["testing_config"], None, bank_dtype=bank_dtype).eval()
+
+
+def geodesic_known_answers():
+    """Hand-computable known answers of the pose-error metric, written from pytorch3d's PUBLISHED formula --
+    `so3_relative_angle(R1, R2, eps=1e-2)` = `acos_linear_extrapolation((trace(R1 R2^T) - 1) / 2, bounds=(-1 + 1e-4, 1 - 1e-4))` with
+    `_acos_linear_approximation(x, x0) = (x - x0) * (-1 / sqrt(1 - x0^2)) + acos(x0)` and a ValueError for a trace outside
+    [-1 - eps, 3 + eps] -- and from loss.py:14-75 for the symmetry branches.  pytorch3d itself is not installed anywhere the tests
+    run: these pin the restatement (torch on the host, `nope_op_geodesic` on the device) to the formula, not to pytorch3d's binary.
+    Returns [(name, pred (3,3), gt (3,3), symmetry, expected radians | "raises")]; the symmetry-1 answers hold to ~1e-6 (the flipped
+    pose is an f32 product, loss.py:36-43), everything else to 1e-12."""
+    import math
+
+    def rot(axis, deg):
+        a = math.radians(deg)
+        c, s = math.cos(a), math.sin(a)
+        m = {"x": [[1, 0, 0], [0, c, -s], [0, s, c]], "y": [[c, 0, s], [0, 1, 0], [-s, 0, c]], "z": [[c, -s, 0], [s, c, 0], [0, 0, 1]]}[axis]
+        return torch.tensor(m, dtype=torch.float64)
+
+    b = 1.0 - 1e-4
+    slope = -1.0 / math.sqrt(1.0 - b * b)
+    at_one = (1.0 - b) * slope + math.acos(b)            # cos = 1 lies beyond the bound: NOT 0 but acos(b) - 1e-4 / sqrt(1 - b^2) = 7.0710e-3
+    at_minus_one = (-1.0 + b) * slope + math.acos(-b)    # cos = -1: pi - 7.0710e-3, NOT pi
+    eye = torch.eye(3, dtype=torch.float64)
+    G = rot("z", 33.0) @ rot("x", -71.0) @ rot("y", 12.0)          # an arbitrary ground-truth pose
+    kats = [("identity", eye, eye, 0, at_one), ("same pose", G, G, 0, at_one)]
+    for ax in "xyz":
+        kats.append((f"180 about {ax}", rot(ax, 180.0), eye, 0, at_minus_one))
+        kats.append((f"180 about {ax} of a pose", rot(ax, 180.0) @ G, G, 0, at_minus_one))
+    kats += [("90 about z", rot("z", 90.0), eye, 0, math.pi / 2), ("60 about x", rot("x", 60.0) @ G, G, 0, math.acos(0.5)),
+             ("170 about y", rot("y", 170.0), eye, 0, math.radians(170.0)), ("1 degree: inside the bound", rot("x", 1.0), eye, 0, math.radians(1.0))]
+    half = 0.5                                                  # 0.5 degrees: cos = 0.99996 > b -> the extrapolated branch
+    kats.append(("0.5 degrees: extrapolated", rot("y", half), eye, 0, (math.cos(math.radians(half)) - b) * slope + math.acos(b)))
+    kats.append(("179.5 degrees: extrapolated", rot("y", 180.0 - half), eye, 0, (math.cos(math.radians(180.0 - half)) + b) * slope + math.acos(-b)))
+    kats.append(("trace 3.006 is inside eps = 1e-2", 1.002 * eye, eye, 0, (1.003 - b) * slope + math.acos(b)))      # (negative: the formula is the formula)
+    kats.append(("trace 9 raises", 3.0 * eye, eye, 0, "raises"))
+    bad = rot("x", 180.0).clone()
+    bad[1, 1] -= 0.03; bad[2, 2] -= 0.03                        # trace -1.06 < -1 - eps
+    kats.append(("trace -1.06 raises", bad, eye, 0, "raises"))
+    # symmetry 1 (loss.py:29-48): the ground truth turned by 180 degrees about Y counts as the ground truth (min of the two angles)
+    kats.append(("symmetry 1: flipped about Y", rot("y", 180.0) @ G, G, 1, at_one))
+    kats.append(("symmetry 1: 60 about x stays 60", rot("x", 60.0) @ G, G, 1, math.acos(0.5)))
+    # symmetry 2 (loss.py:55-73): only the camera's viewing axis counts -- an object spun about its own Z axis has a different pose and the
+    # same axis; a 40 degree turn about X tilts the axis by 40 degrees
+    kats.append(("symmetry 2: 40 about x", G @ rot("x", 40.0), G, 2, math.radians(40.0)))
+    kats.append(("symmetry 2: spin 77 about z + 25 about x", G @ rot("z", 77.0) @ rot("x", 25.0), G, 2, math.radians(25.0)))
+    return kats
