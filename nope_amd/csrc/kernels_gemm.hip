@@ -515,7 +515,7 @@ static int plan_small(int dt, const ConvArgs& a, bool dma) {
     const bool phased = a.mode == NOPE_CONV_UP2P;
     const long long M = (long long)a.nhyp * (phased ? a.Hs * a.Ws : a.Ho * a.Wo);
     const long long tiles128 = (long long)cdiv((int)M, BM) * cdiv(a.Cout, BN) * (phased ? 4 : 1);
-    static const int max_tiles = getenv("NOPE_SMALL_MAX_TILES") ? atoi(getenv("NOPE_SMALL_MAX_TILES")) : 320;
+    const int max_tiles = getenv("NOPE_SMALL_MAX_TILES") ? atoi(getenv("NOPE_SMALL_MAX_TILES")) : 320;      // (read per launch: the tuning sweep toggles it)
     if (mode_env == 1 && tiles128 >= max_tiles) return -1;
     if (const char* t = getenv("NOPE_SMALL_TILE")) return atoi(t) < 0 || atoi(t) > 2 ? 0 : atoi(t);
     const long long tiles64 = (long long)cdiv((int)M, 64) * cdiv(a.Cout, 64) * (phased ? 4 : 1);

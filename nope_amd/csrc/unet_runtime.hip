@@ -272,7 +272,7 @@ struct Fwd {
             // Small batches: every gn_apply workgroup folds its sample's column statistics itself (the fold is st.blocks * C * 8 bytes
             // per workgroup out of L2; a separate launch costs ~8 us).  Large ones keep the fold launch: at 512 hypotheses the six
             // workgroups of a level-0 sample would each repeat a 24 KiB fold (+0.25 ms per step, measured in round 2).
-            static const long long fold_inline_max = getenv("NOPE_GN_FOLD_INLINE") ? atoll(getenv("NOPE_GN_FOLD_INLINE")) : 16ll << 20;
+            const long long fold_inline_max = getenv("NOPE_GN_FOLD_INLINE") ? atoll(getenv("NOPE_GN_FOLD_INLINE")) : 16ll << 20;
             const long long refold = (long long)nhyp * gn_apply_blocks(HW, nm.C, net->sdt) * st.blocks * nm.C * 8;
             if (refold <= fold_inline_max) { ga.colstats = st.cs; ga.stat_blocks = st.blocks; }
             else chk(launch_gn_fold(st.cs, gn_partial, nx, st.blocks, nm.C, G, s));
