@@ -246,6 +246,12 @@ int nope_op_pack_conv_weight(int dtype, const float* w, void* packed, int Cout, 
 int nope_op_conv(int dtype, const void* src1, int C1, int rep1, const void* src2, int C2, int rep2, int Hs, int Ws,
                  int mode, int ntaps, const void* w_packed, const float* bias, const void* resid, void* out,
                  int Cout, int n_hyp, int out_nchw, int out_dtype, int act_relu, nope_stream_t s);
+/* ... with a scratch for a deterministic split-K launch (f32 partials + fixed-order reduce) when the launcher wants one for the shape:
+ * nope_op_conv_splitk_bytes returns the bytes it would use (0: this shape is never split); a smaller or NULL scratch = no split. */
+size_t nope_op_conv_splitk_bytes(int dtype, int C1, int C2, int rep1, int Hs, int Ws, int mode, int ntaps, int Cout, int n_hyp);
+int nope_op_conv_ws(int dtype, const void* src1, int C1, int rep1, const void* src2, int C2, int rep2, int Hs, int Ws,
+                    int mode, int ntaps, const void* w_packed, const float* bias, const void* resid, void* out,
+                    int Cout, int n_hyp, int out_nchw, int out_dtype, int act_relu, void* splitk_ws, size_t splitk_bytes, nope_stream_t s);
 /* conv1 of the encoder trunk: 7x7 / stride 2 / pad 3 on an NCHW f32 image, + per-channel scale (folded into the
  * weights) and shift + ReLU -> NHWC (n_img, H/2, W/2, 64).  w (64,3,7,7), scale/shift (64). */
 int nope_op_stem_conv(int dtype, const float* image, const float* w, const float* scale, const float* shift, float* w_scratch,

@@ -46,21 +46,44 @@ int nope_op_pack_conv_weight(int dtype, const float* w, void* packed, int Cout, 
     return launch_pack_conv_w(dtype, w, packed, Cout, Cin, ntaps, mode, (hipStream_t)s);
 }
 
-int nope_op_conv(int dtype, const void* src1, int C1, int rep1, const void* src2, int C2, int rep2, int Hs, int Ws, int mode,
-                 int ntaps, const void* w_packed, const float* bias, const void* resid, void* out, int Cout, int n_hyp,
-                 int out_nchw, int out_dtype, int act_relu, nope_stream_t s) {
-    ConvArgs a;
+static void fill_conv_args(ConvArgs& a, const void* src1, int C1, int rep1, const void* src2, int C2, int rep2, int Hs, int Ws, int mode, int ntaps,
+                           const void* w_packed, const float* bias, const void* resid, void* out, int Cout, int n_hyp, int out_nchw,
+                           int out_dtype, int act_relu) {
     a.src1 = src1; a.C1 = C1; a.rep1 = rep1; a.src2 = src2; a.C2 = C2; a.rep2 = rep2 > 0 ? rep2 : 1;
     a.Hs = Hs; a.Ws = Ws; a.mode = mode; a.ntaps = ntaps;
     const bool up = mode == NOPE_CONV_UP2 || mode == NOPE_CONV_UP2P;
     const bool half = mode == NOPE_CONV_DOWN2 || mode == NOPE_CONV_STRIDE2;
     a.Ho = up ? 2 * Hs : (half ? Hs / 2 : Hs);
     a.Wo = up ? 2 * Ws : (half ? Ws / 2 : Ws);
-    if (half && ((Hs | Ws) & 1)) return NOPE_ERR_ARG;
     a.act = act_relu ? 1 : 0;
     a.w = w_packed; a.bias = bias; a.resid = resid; a.out = out; a.Cout = Cout; a.nhyp = n_hyp;
     a.out_nchw = out_nchw; a.out_dt = out_dtype;
+}
+
+int nope_op_conv_ws(int dtype, const void* src1, int C1, int rep1, const void* src2, int C2, int rep2, int Hs, int Ws, int mode,
+                    int ntaps, const void* w_packed, const float* bias, const void* resid, void* out, int Cout, int n_hyp,
+                    int out_nchw, int out_dtype, int act_relu, void* splitk_ws, size_t splitk_bytes, nope_stream_t s) {
+    ConvArgs a;
+    fill_conv_args(a, src1, C1, rep1, src2, C2, rep2, Hs, Ws, mode, ntaps, w_packed, bias, resid, out, Cout, n_hyp, out_nchw, out_dtype, act_relu);
+    if ((mode == NOPE_CONV_DOWN2 || mode == NOPE_CONV_STRIDE2) && ((Hs | Ws) & 1)) return NOPE_ERR_ARG;
+    a.splitk_ws = splitk_ws; a.splitk_bytes = splitk_ws ? splitk_bytes : 0;
     return launch_conv(dtype, a, (hipStream_t)s);
+}
+
+int nope_op_conv(int dtype, const void* src1, int C1, int rep1, const void* src2, int C2, int rep2, int Hs, int Ws, int mode,
+                 int ntaps, const void* w_packed, const float* bias, const void* resid, void* out, int Cout, int n_hyp,
+                 int out_nchw, int out_dtype, int act_relu, nope_stream_t s) {
+    return nope_op_conv_ws(dtype, src1, C1, rep1, src2, C2, rep2, Hs, Ws, mode, ntaps, w_packed, bias, resid, out, Cout, n_hyp, out_nchw,
+                           out_dtype, act_relu, nullptr, 0, s);
+}
+
+size_t nope_op_conv_splitk_bytes(int dtype, int C1, int C2, int rep1, int Hs, int Ws, int mode, int ntaps, int Cout, int n_hyp) {
+    ConvArgs a;
+    static const int dummy = 0;
+    fill_conv_args(a, &dummy, C1, rep1, C2 ? &dummy : nullptr, C2, 1, Hs, Ws, mode, ntaps, &dummy, nullptr, nullptr, (void*)&dummy, Cout, n_hyp, 0, NOPE_F32, 0);
+    if (!dt_is_compute(dtype)) return 0;
+    const int S = conv_splitk_factor(dtype, a);
+    return S > 1 ? (size_t)S * (size_t)n_hyp * a.Ho * a.Wo * Cout * 4 : 0;
 }
 
 int nope_op_stem_conv(int dtype, const float* image, const float* w, const float* scale, const float* shift, float* w_scratch,

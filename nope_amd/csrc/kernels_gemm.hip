@@ -504,7 +504,7 @@ int conv_halo_max_width();
 // 1536 -> 1536 at 4 x 4 x 512 although it executes the 31 % of MACs the position-major order skips), bit 2 = those run position-major on the
 // ping-pong kernel (needs nhyp % 256 == 0), bit 3 = no minimum tile count (tests: small shapes on the ping-pong kernel),
 // bit 4 = 3x3 convs per tap on the ping-pong kernel instead of the tap-resident (halo) kernel.
-struct ConvPlan { bool dma, pp, posmajor, halo; int small; };      // small: -1, or the tile of conv_gemm_small_kernel (0 = 64 x 64, 1 = 128 x 128, 2 = 64 x 64 / 4-stage ring)
+struct ConvPlan { bool dma, pp, posmajor, halo; int small; int hsplit; };      // hsplit > 1: tap-resident kernel with that many K splits      // small: -1, or the tile of conv_gemm_small_kernel (0 = 64 x 64, 1 = 128 x 128, 2 = 64 x 64 / 4-stage ring)
 
 // Launches that cannot give every CU a 128 x 192 tile take the small-tile kernel (kernels_gemm_small.hip): fewer than
 // NOPE_SMALL_MAX_TILES (default 320) tiles of 128 x 192.  NOPE_CONV_SMALL: 0 = never, 1 = that policy (default), 2 = whenever the
@@ -517,9 +517,35 @@ static int plan_small(int dt, const ConvArgs& a, bool dma) {
     const long long tiles128 = (long long)cdiv((int)M, BM) * cdiv(a.Cout, BN) * (phased ? 4 : 1);
     const int max_tiles = getenv("NOPE_SMALL_MAX_TILES") ? atoi(getenv("NOPE_SMALL_MAX_TILES")) : 320;      // (read per launch: the tuning sweep toggles it)
     if (mode_env == 1 && tiles128 >= max_tiles) return -1;
+    if (mode_env == 1 && dt != NOPE_F32 && a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.Ws <= conv_halo_max_width() && a.rep1 == 1 && !a.out_nchw &&
+        !a.pn_ms && a.Cout % dt_vec(dt) == 0 && 9 * ((a.C1 + a.C2) / (8 * dt_vec(dt))) >= 54 && (long long)cdiv((int)M, 256) * cdiv(a.Cout, BN) >= 128)
+        return -1;       // the tap-resident kernel has its 128 tiles of 256 rows (measured at 16 x 16 x 64: 60.6 / 83 us against 83 / 116 us on 64 x 64 tiles)
     if (const char* t = getenv("NOPE_SMALL_TILE")) return atoi(t) < 0 || atoi(t) > 2 ? 0 : atoi(t);
     const long long tiles64 = (long long)cdiv((int)M, 64) * cdiv(a.Cout, 64) * (phased ? 4 : 1);
     return tiles64 > 1536 ? 1 : 0;
+}
+
+// 3x3 convs with FEW 256 x 192 tiles and a LONG K (the 4 x 4 / 8 x 8 levels of the U-Net at a few dozen pose hypotheses: 16-64 tiles
+// of 100-200 K steps) run on the tap-resident kernel with the channel chunks split over blockIdx.z (f32 partials + the fixed-order
+// reduce): its 256-row tiles move a third of the L2 -> LDS bytes per flop of the 128 x 192 kernel, which is what bounds these
+// launches (profiles/r04b: 51 us for 1536 -> 1536 at 4 x 4 x 64 on the 128 x 192 kernel split 8 ways = 1.9 us per K step, 111 us on 64 x 64
+// tiles).  Returns the number of splits (1: does not apply).  NOPE_HALO_SPLIT=0 turns it off.
+static int halo_split_factor(int dt, const ConvArgs& a) {
+    if (getenv("NOPE_HALO_SPLIT") && atoi(getenv("NOPE_HALO_SPLIT")) == 0) return 1;
+    const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : (dt != NOPE_F32 ? 3 : 0);
+    if (!(pp_mode & 1) || (pp_mode & 16)) return 1;
+    const int vec = dt_vec(dt), bk = 8 * vec, Cin = a.C1 + a.C2;
+    if (a.mode != NOPE_CONV_PLAIN || a.ntaps != 9 || a.Ws > conv_halo_max_width() || a.rep1 != 1 || a.out_nchw || a.pn_ms || a.colstats ||
+        a.force_generic || a.Cout % vec || Cin % bk || (a.C2 && a.C1 % bk)) return 1;
+    const long long M = (long long)a.nhyp * a.Ho * a.Wo;
+    const int nchunks = Cin / bk;
+    const long long tiles = (long long)cdiv((int)M, 256) * cdiv(a.Cout, BN);
+    const int min_chunks = getenv("NOPE_HALO_SPLIT_MIN_CHUNKS") ? atoi(getenv("NOPE_HALO_SPLIT_MIN_CHUNKS")) : 12;
+    if (tiles >= 128 || nchunks < min_chunks) return 1;
+    int S = (int)((256 + tiles - 1) / tiles);
+    if (S > nchunks) S = nchunks;
+    if (S > 16) S = 16;
+    return S < 2 ? 1 : S;
 }
 
 static ConvPlan plan_conv(int dt, const ConvArgs& a) {
@@ -527,7 +553,7 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     //  16x longer per K step, loads were never its bound, and two workgroups per CU beat one: 126 vs 135 ms per 512-template step)
     const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : (dt != NOPE_F32 ? 3 : 0);
     static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
-    ConvPlan pl{false, false, false, false, -1};
+    ConvPlan pl{false, false, false, false, -1, 1};
     const int vec = dt_vec(dt), es = dt_es(dt), bk = 8 * vec;
     const int Cin = a.C1 + a.C2;
     const unsigned long long lim = 0x7fffffffULL;
@@ -539,6 +565,11 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     // (the 4x4 stride-2 conv of the non-default soft downsampling runs on the generic kernel: its tap geometry is not a 3x3 mask)
     pl.dma = !a.force_generic && a.ntaps != 16 && Cin % bk == 0 && (a.C2 == 0 || (a.C1 % bk == 0 && a.mode == NOPE_CONV_PLAIN)) && b1 < lim && b2 < lim && bw < lim;
     if (!pl.dma) return pl;
+    if (a.splitk_ws) {
+        const int hs = halo_split_factor(dt, a);
+        const long long Mr = (long long)a.nhyp * a.Ho * a.Wo;
+        if (hs > 1 && (size_t)hs * (size_t)Mr * a.Cout * 4 <= a.splitk_bytes) { pl.pp = pl.halo = true; pl.hsplit = hs; return pl; }
+    }
     pl.small = plan_small(dt, a, pl.dma);
     if (pl.small >= 0) return pl;
     const bool small3x3 = a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && !a.colstats && !a.pn_ms && !a.out_nchw && !a.splitk_ws &&
@@ -577,9 +608,10 @@ int conv_stat_rows(int dt, const ConvArgs& a) {
     const int vec = dt_vec(dt);
     if (a.mode == NOPE_CONV_UP2P || a.resid || a.out_nchw || a.Cout % vec || a.Cout > 2048) return 0;
     const long long HW = (long long)a.Ho * a.Wo, M = (long long)a.nhyp * HW;
-    if (HW % 64 == 0) return 64;
     ConvArgs b = a;
     b.colstats = nullptr;
+    if (halo_split_factor(dt, b) > 1) return 0;       // split-K partials carry no statistics: the GroupNorm takes its own pass
+    if (HW % 64 == 0) return 64;
     if ((HW == 16 || HW == 32) && M % HW == 0 && plan_conv(dt, b).small >= 0) return (int)HW;
     return 0;
 }
@@ -602,6 +634,10 @@ int conv_splitk_factor(int dt, const ConvArgs& a) {
     const int vec = dt_vec(dt);
     const int Cin = a.C1 + a.C2;
     if (Cin % (8 * vec)) return 1;
+    {
+        const int hs = halo_split_factor(dt, a);      // long 3x3 convs with few tiles: split-K on the tap-resident kernel
+        if (hs > 1) return hs;
+    }
     if (plan_conv(dt, a).small >= 0) return 1;        // the small-tile kernel has enough workgroups without splitting K
     const long long M = (long long)a.nhyp * a.Ho * a.Wo;
     const long long tiles = (long long)cdiv((int)M, BM) * cdiv(a.Cout, BN);
@@ -694,7 +730,10 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
                 const unsigned char tmp = p.pos_order[j]; p.pos_order[j] = p.pos_order[j - 1]; p.pos_order[j - 1] = tmp;
             }
     }
-    if (dma && !plan.pp && a.splitk_ws) {
+    if (plan.hsplit > 1) {
+        p.splits = plan.hsplit;
+        p.split_out = (float*)a.splitk_ws;
+    } else if (dma && !plan.pp && a.splitk_ws) {
         p.splits = conv_splitk_factor(dt, a);
         if ((size_t)p.splits * (size_t)M * a.Cout * 4 > a.splitk_bytes) p.splits = 1;
         if (p.splits > 1) p.split_out = (float*)a.splitk_ws;

@@ -351,7 +351,9 @@ constexpr int HALO_MAX_W = 32;
 
 constexpr int TIMELINE_STAMPS = 720;  // per group; 5 per K step (tuning instantiation only)
 
-template <class T, bool TIMELINE = false>
+// SPLIT: the split-K instantiation (chunk range from blockIdx.z, raw f32 partials out) -- its own kernel so that the main one keeps
+// its register allocation (256 VGPRs, no spill: one more live scalar pair spilled it).
+template <class T, bool TIMELINE = false, bool SPLIT = false>
 __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvParams p) {
     typedef Tile<T> TL;
     constexpr int VEC = Elt<T>::VEC;
@@ -541,16 +543,23 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
 #pragma unroll
             for (int r = 0; r < TL::R; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = Cin / BK;
+    // Split-K (p.splits > 1; few tiles, long K -- the 4 x 4 / 8 x 8 levels at a few dozen hypotheses): blockIdx.z owns the channel
+    // chunks [c_lo, nchunks) of the tile and writes raw f32 partial sums; splitk_reduce_kernel adds them in a fixed order.
+    int c_lo = 0, nchunks = Cin / BK;
+    if constexpr (SPLIT) {
+        const int tot = nchunks, z = (int)blockIdx.z;
+        c_lo = (int)((long long)z * tot / p.splits);
+        nchunks = (int)((long long)(z + 1) * tot / p.splits);
+    }
     const unsigned wrap_inc = (unsigned)BK * ES - 8u * cin_es;     // K offset step from tap 8 of a chunk to tap 0 of the next
 
     // ---- prologue of a tile: the whole A stage of chunk 0, this group's half of B(0), and (group 1) its half of B(1)
     auto tile_prologue = [&]() __attribute__((always_inline)) {
-        set_chunk(0);
+        set_chunk(c_lo);
 #pragma unroll
         for (int i = 0; i < 6; ++i)
             if (i < 4 || (i == 4 ? a_has4 : a_has5)) piece_a(i, 0);
-        bkofs = 0;
+        bkofs = (unsigned)(c_lo * BK) * ES;
         issue_b(0); bkofs += cin_es;
         if (grp == 1) { issue_b(1); bkofs += cin_es; }             // (nk >= 9 > 2)
     };
@@ -664,7 +673,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp();
-        for (int chunk = 0; chunk < nchunks; chunk += 2) {
+        for (int chunk = c_lo; chunk < nchunks; chunk += 2) {
             chunk_steps(chunk, 0);
             if (chunk + 1 < nchunks) chunk_steps(chunk + 1, 1);
         }
@@ -684,7 +693,21 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             NOPE_HALO_SET_OFF2();
             if (dma_on) tile_prologue();
         }
-        if constexpr (TIMELINE) epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel, stamp);
+        if constexpr (SPLIT) {                         // (never with a tile walk: iters == 1)
+            float* so = p.split_out + (size_t)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+            for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                for (int r = 0; r < TL::R; ++r) {
+                    const int m = m_this + wm * 64 + i * TL::TM + TL::out_row(lane, r);
+#pragma unroll
+                    for (int j = 0; j < TL::NTL; ++j) {
+                        const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
+                        if (m < p.M && n < p.Cout) so[(size_t)m * p.Cout + n] = acc[i][j][r];
+                    }
+                }
+            return;
+        } else if constexpr (TIMELINE) epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel, stamp);
         else epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel);
         if (more) {
 #pragma unroll
@@ -747,6 +770,13 @@ void launch_conv_halo(int dt, const void* params, dim3 grid, hipStream_t s) {
                 }
                 fclose(f);
             }
+        return;
+    }
+    if (p.splits > 1) {
+        if (dt == NOPE_F32) hipLaunchKernelGGL((conv3x3_halo_kernel<float, false, true>), grid, block, 0, s, p);
+        else if (dt == NOPE_BF16X3) hipLaunchKernelGGL((conv3x3_halo_kernel<f32s_t, false, true>), grid, block, 0, s, p);
+        else if (dt == NOPE_F16) hipLaunchKernelGGL((conv3x3_halo_kernel<f16_t, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<bf16_t, false, true>), grid, block, 0, s, p);
         return;
     }
     if (dt == NOPE_F32) hipLaunchKernelGGL((conv3x3_halo_kernel<float>), grid, block, 0, s, p);

@@ -340,6 +340,17 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
     const T* resid = reinterpret_cast<const T*>(p.resid);
     constexpr int CH = BNS / VEC;
     if (p.wide_out) {
+        // per-column constants of the tile, once: out = acc * sc_row + off[n] (bias; fused PreNorm: off = c0 + bias, and -mean * rstd * c1[n]
+        // per row) -- read from LDS in the row loop instead of three global loads per element
+        float* cbias = pan + BMS * LDP;            // [BNS] bias (+ c0), [BNS] c1   (the statistics scratch is free again)
+        if (p.colstats) __syncthreads();
+        for (int c = tid; c < BNS; c += 256) {
+            const int n = n0 + c;
+            const bool okc = n < p.Cout;
+            cbias[c] = (okc && p.bias ? p.bias[n] : 0.f) + (PN && okc ? p.pn_c0[n] : 0.f);
+            if (PN) cbias[BNS + c] = okc ? p.pn_c1[n] : 0.f;
+        }
+        __syncthreads();
         for (int idx = tid; idx < BMS * CH; idx += 256) {
             const int row = idx / CH, ch = idx - row * CH;
             const int m = m0 + row, n = n0 + ch * VEC;
@@ -348,17 +359,19 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
 #pragma unroll
             for (int q = 0; q < VEC / 4; ++q) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(&pan[row * LDP + ch * VEC + q * 4]);
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(&cbias[ch * VEC + q * 4]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[q * 4 + e] = t[e];
+                if (!PN) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[q * 4 + e] += bq[e];
+                }
             }
             if (PN) {       // fused PreNorm: rstd_b * (acc - mean_b * c1[n]) + c0[n] (+ bias)
                 const int b = m / HWo;
                 const float mean = p.pn_ms[2 * b], rstd = p.pn_ms[2 * b + 1];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] = rstd * (v[e] - mean * p.pn_c1[n + e]) + p.pn_c0[n + e] + (p.bias ? p.bias[n + e] : 0.f);
-            } else if (p.bias) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] += p.bias[n + e];
+                for (int e = 0; e < VEC; ++e) v[e] = rstd * (v[e] - mean * cbias[BNS + ch * VEC + e]) + cbias[ch * VEC + e];
             }
             const size_t o = out_row(p, m) * p.Cout + n;
             if (resid) {

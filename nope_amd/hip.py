@@ -75,6 +75,8 @@ _PROTOS = {
     "nope_encoder_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "nope_encoder_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "nope_op_conv": (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nope_op_conv_ws": (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "nope_op_conv_splitk_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "nope_op_stem_conv": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "nope_op_gn_chunks": (_i, [_i, _i, _i]),
     "nope_op_group_norm": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
@@ -609,8 +611,9 @@ def pack_conv_weight(w: torch.Tensor, dt: int, mode: int = CONV_PLAIN) -> Tuple[
 def op_conv(dt: int, src1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
             src2: Optional[torch.Tensor] = None, mode: int = CONV_PLAIN, rep1: int = 1, rep2: int = 1,
             resid: Optional[torch.Tensor] = None, n_hyp: Optional[int] = None, out_nchw: bool = False,
-            out_dtype: int = F32, act_relu: bool = False) -> torch.Tensor:
-    """src* NHWC tensors of dtype dt; w torch Conv2d weight (f32).  Returns NHWC (or NCHW)."""
+            out_dtype: int = F32, act_relu: bool = False, split_k: bool = False) -> torch.Tensor:
+    """src* NHWC tensors of dtype dt; w torch Conv2d weight (f32).  Returns NHWC (or NCHW).  split_k: hand the launcher the scratch it
+    asks for (as the U-Net / encoder runtimes do), so shapes it would split along K (few tiles, long K) are."""
     pw, cin, ntaps = pack_conv_weight(w, dt, mode)
     n1, hs, ws, c1 = src1.shape
     c2 = 0 if src2 is None else src2.shape[3]
@@ -624,9 +627,14 @@ def op_conv(dt: int, src1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.T
         out = torch.empty((n_hyp, ho, wo, cout), dtype=torch_dtype(dt), device=src1.device)
     b = None if bias is None else _f32c(bias)
     l = lib()
-    l.check(l.dll.nope_op_conv(dt, _ptr(src1), c1, rep1, _ptr(src2), c2, rep2, hs, ws, mode, ntaps, _ptr(pw), _ptr(b),
-                               _ptr(resid), _ptr(out), cout, n_hyp, int(out_nchw), out_dtype, int(act_relu), _stream(src1)),
-            "nope_op_conv")
+    scratch, sk = None, 0
+    if split_k:
+        sk = int(l.dll.nope_op_conv_splitk_bytes(dt, c1, c2, rep1, hs, ws, mode, ntaps, cout, n_hyp))
+        if sk:
+            scratch = torch.empty(sk, dtype=torch.uint8, device=src1.device)
+    l.check(l.dll.nope_op_conv_ws(dt, _ptr(src1), c1, rep1, _ptr(src2), c2, rep2, hs, ws, mode, ntaps, _ptr(pw), _ptr(b),
+                                  _ptr(resid), _ptr(out), cout, n_hyp, int(out_nchw), out_dtype, int(act_relu), _ptr(scratch), sk,
+                                  _stream(src1)), "nope_op_conv")
     return out
 
 

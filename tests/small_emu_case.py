@@ -64,6 +64,22 @@ def run(hip, dev, dts=(1, 0), tiles=(0, 1, 2), light=False):
         # NCHW f32 output with a channel count that is no whole vector (the U-Net's last conv: 8 channels)
         x6, w6, b6 = rn(3, C, 8, 8), rn(8, C, 1, 1) / C ** 0.5, rn(8)
         both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x6), dt), d(w6), d(b6), out_nchw=True, out_dtype=0), "1x1 nchw", F.conv2d(q(x6), q(w6), b6))
+        # split-K on the tap-resident kernel (few 256-row tiles, long K): 20 channel chunks over 16 splits (one or two chunks each: both A
+        # stage parities), 4 chunks over 4 splits; deterministic, and equal to the unsplit result up to the association of the partials
+        os.environ["NOPE_HALO_SPLIT_MIN_CHUNKS"] = "2"
+        if dt in (0, 3):
+            os.environ["NOPE_CONV_PP"] = "3"        # (the f32 modes stay off the ping-pong kernels unless asked)
+        for nch in (20, 4):
+            xk, wk, bk_ = rn(40, nch * C, 4, 4), rn(24, nch * C, 3, 3) / (3 * (nch * C) ** 0.5), rn(24)
+            rk = rn(40, 24, 4, 4)
+            f = lambda: hip.op_conv(dt, hip.to_nhwc(d(xk), dt), d(wk), d(bk_), resid=hip.to_nhwc(d(rk), dt), act_relu=True, split_k=True)
+            y = f()
+            assert torch.equal(y, f()), "split-K launch is not reproducible"
+            e = rel(hip.to_nchw(y, dt).cpu(), F.relu(F.conv2d(q(xk), q(wk), bk_, padding=1) + q(rk)))
+            worst = max(worst, e / tol)
+            assert e < tol, ("halo split-K", dt, nch, e)
+        os.environ.pop("NOPE_HALO_SPLIT_MIN_CHUNKS")
+        os.environ.pop("NOPE_CONV_PP", None)
         if light:
             continue
         # nearest-x2 + 3x3 as four 2x2 phase convs; space-to-depth + 1x1; stride-2 3x3 and 1x1 (encoder)
