@@ -536,6 +536,36 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
     }
 }
 
+// Split-K partials: this workgroup's raw f32 sums to split_out[blockIdx.z][m][n], through the per-wave panel as 16-byte rows.  Written
+// straight from the MFMA C/D layout they are 96 four-byte store instructions per wave (measured on the tap-resident kernel at
+// 4 x 4 x 64 hypotheses: ~25 of the 45 us of a 27-step workgroup); staged, 24 sixteen-byte ones.  Cout % 4 == 0 (checked by the launcher:
+// Cout % VEC).  Bias, residual and activation are applied by splitk_reduce_kernel, which adds the partials in a fixed order.
+template <class T>
+__device__ __forceinline__ void epilogue_split_wide(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL], int m0, int n0,
+                                                    int wm, int wn, int lane, unsigned char* lds_wave) {
+    typedef Tile<T> TL;
+    constexpr int PANW = TL::TM == 32 ? 32 : 48, TPP = PANW / TL::TM, LD = Ep<T>::LD, CH = PANW / 4;
+    float* pan = reinterpret_cast<float*>(lds_wave);
+    float* so = p.split_out + (size_t)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+    for (int pass = 0; pass < 96 / PANW; ++pass) {
+#pragma unroll
+        for (int jj = 0; jj < TPP; ++jj)
+#pragma unroll
+            for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                for (int r = 0; r < TL::R; ++r)
+                    pan[(i * TL::TM + TL::out_row(lane, r)) * LD + jj * TL::TM + TL::out_col(lane)] = acc[i][pass * TPP + jj][r];
+        __builtin_amdgcn_wave_barrier();       // same-wave LDS write -> read (in-order LDS queue; rendezvous point of tests/hipemu)
+        for (int idx = lane; idx < 64 * CH; idx += 64) {
+            const int row = idx / CH, ch = idx - row * CH;
+            const int m = m0 + wm * 64 + row, n = n0 + wn * 96 + pass * PANW + ch * 4;
+            if (m < p.M && n < p.Cout) *reinterpret_cast<f32x4*>(so + (size_t)m * p.Cout + n) = *reinterpret_cast<const f32x4*>(&pan[row * LD + ch * 4]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // NCHW output (the last conv writes the (hypothesis, C, h, w) template bank directly) through the per-wave panel: the MFMA C/D layout
 // gives a lane one channel x a few pixels, i.e. 2-byte stores scattered over Cout planes (the 8-channel final conv ran at
 // 1.2 TB/s of input); staged, lane r owns pixel r of the wave's 64 and every channel plane receives 64 consecutive

@@ -84,6 +84,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// The same reduction for NHWC outputs that feed a GroupNorm: one thread per column walks the `rows` rows of a statistics block
+// (rows = min(H W, 64): whole samples or 64-row blocks of one sample), so the (sum, sum of squares) of what it writes -- f32, before the
+// rounding to T, like the conv epilogues' -- come for free: colstats[M / rows][Cout][2], one writer per entry.  Grid (M / rows, Cout / 256).
+template <class T>
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ part, int splits, int M, int Cout,
+                                                                  const float* __restrict__ bias, int act, T* __restrict__ out,
+                                                                  float* __restrict__ colstats, int rows) {
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    if (n >= Cout) return;
+    const size_t MN = (size_t)M * Cout;
+    const int m0 = blockIdx.x * rows;
+    const float bv = bias ? bias[n] : 0.f;
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        const size_t i = (size_t)(m0 + r) * Cout + n;
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += part[(size_t)z * MN + i];
+        v += bv;
+        if (act) v = v > 0.f ? v : 0.f;
+        Elt<T>::st(out + i, v);
+        s += v; q += v * v;
+    }
+    float* cs = colstats + ((size_t)blockIdx.x * Cout + n) * 2;
+    cs[0] = s; cs[1] = q;
+}
+
 // Source pixel of output pixel (oy, ox) under tap (dy, dx); false = zero padding / beyond M.
 __device__ __forceinline__ bool tap_pixel(const ConvParams& p, int oy, int ox, int dy, int dx, int& iy, int& ix) {
     if (p.mode == NOPE_CONV_DOWN2) { iy = 2 * oy + dy; ix = 2 * ox + dx; return oy >= 0; }
@@ -465,7 +491,10 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
     if (p.variant & 64) {                      // tuning only: no epilogue (keeps the accumulators live)
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;
     } else if (p.splits > 1) {
-        epilogue_split<T>(p, acc, m0, n0, wm, wn, lane);
+        if (p.Cout % 4 == 0) {
+            __syncthreads();                   // every wave is done reading the last stage: the panels reuse it
+            epilogue_split_wide<T>(p, acc, m0, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
+        } else epilogue_split<T>(p, acc, m0, n0, wm, wn, lane);
     } else if (p.wide_out) {
         __syncthreads();                       // every wave is done reading the last stage
         epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
@@ -535,7 +564,7 @@ static int halo_split_factor(int dt, const ConvArgs& a) {
     const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : (dt != NOPE_F32 ? 3 : 0);
     if (!(pp_mode & 1) || (pp_mode & 16)) return 1;
     const int vec = dt_vec(dt), bk = 8 * vec, Cin = a.C1 + a.C2;
-    if (a.mode != NOPE_CONV_PLAIN || a.ntaps != 9 || a.Ws > conv_halo_max_width() || a.rep1 != 1 || a.out_nchw || a.pn_ms || a.colstats ||
+    if (a.mode != NOPE_CONV_PLAIN || a.ntaps != 9 || a.Ws > conv_halo_max_width() || a.rep1 != 1 || a.out_nchw || a.pn_ms ||
         a.force_generic || a.Cout % vec || Cin % bk || (a.C2 && a.C1 % bk)) return 1;
     const long long M = (long long)a.nhyp * a.Ho * a.Wo;
     const int nchunks = Cin / bk;
@@ -610,7 +639,8 @@ int conv_stat_rows(int dt, const ConvArgs& a) {
     const long long HW = (long long)a.Ho * a.Wo, M = (long long)a.nhyp * HW;
     ConvArgs b = a;
     b.colstats = nullptr;
-    if (halo_split_factor(dt, b) > 1) return 0;       // split-K partials carry no statistics: the GroupNorm takes its own pass
+    if (halo_split_factor(dt, b) > 1)                 // split-K on the tap-resident kernel: the reduce kernel emits the statistics, per sample
+        return HW % 64 == 0 ? 64 : ((HW == 16 || HW == 32) && M % HW == 0 ? (int)HW : 0);      // or 64-row block
     if (HW % 64 == 0) return 64;
     if ((HW == 16 || HW == 32) && M % HW == 0 && plan_conv(dt, b).small >= 0) return (int)HW;
     return 0;
@@ -630,14 +660,14 @@ double conv_executed_flops(int dt, const ConvArgs& a) {
 }
 
 int conv_splitk_factor(int dt, const ConvArgs& a) {
+    {
+        const int hs = halo_split_factor(dt, a);      // long 3x3 convs with few tiles: split-K on the tap-resident kernel (its reduce kernel
+        if (hs > 1) return hs;                        // also serves a colstats request)
+    }
     if (a.colstats || a.pn_ms || a.mode == NOPE_CONV_UP2P || a.mode == NOPE_CONV_UP2) return 1;
     const int vec = dt_vec(dt);
     const int Cin = a.C1 + a.C2;
     if (Cin % (8 * vec)) return 1;
-    {
-        const int hs = halo_split_factor(dt, a);      // long 3x3 convs with few tiles: split-K on the tap-resident kernel
-        if (hs > 1) return hs;
-    }
     if (plan_conv(dt, a).small >= 0) return 1;        // the small-tile kernel has enough workgroups without splitting K
     const long long M = (long long)a.nhyp * a.Ho * a.Wo;
     const long long tiles = (long long)cdiv((int)M, BM) * cdiv(a.Cout, BN);
@@ -698,6 +728,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.w_phase_bytes = phased ? (unsigned)bw : 0u;
     const ConvPlan plan = plan_conv(dt, a);
     const bool dma = plan.dma;
+    if (a.colstats && a.stat_rows != 64 && plan.small < 0 && plan.hsplit <= 1) return NOPE_ERR_ARG;   // 16 / 32-row blocks: small-tile kernel or split-K reduce only
     p.bytes1 = (unsigned)(dma ? b1 : 0); p.bytes2 = (unsigned)(dma ? b2 : 0); p.bytesw = (unsigned)(dma ? bw : 0);
     // NOPE_CONV_VARIANT=4 selects the 256x192 / 8-wave tile (measured on par with the default 128x192 / 4-wave
     // tile in round 1; kept for tuning, see DESIGN.md section 4 for the other variants that were tried).
@@ -827,7 +858,13 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((conv_gemm_kernel<bf16_t, false>), grid, block, 0, s, p);
     }
     NOPE_CHECK_LAUNCH();
-    if (p.splits > 1) {
+    if (p.splits > 1 && a.colstats) {          // (tap-resident split-K only: plan.hsplit)
+        const dim3 rg((unsigned)(M / a.stat_rows), (unsigned)cdiv(a.Cout, 256));
+        if (dt_es(dt) == 4) hipLaunchKernelGGL((splitk_reduce_stats_kernel<float>), rg, dim3(256), 0, s, p.split_out, p.splits, (int)M, a.Cout, a.bias, a.act, (float*)a.out, a.colstats, a.stat_rows);
+        else if (dt == NOPE_F16) hipLaunchKernelGGL((splitk_reduce_stats_kernel<f16_t>), rg, dim3(256), 0, s, p.split_out, p.splits, (int)M, a.Cout, a.bias, a.act, (f16_t*)a.out, a.colstats, a.stat_rows);
+        else hipLaunchKernelGGL((splitk_reduce_stats_kernel<bf16_t>), rg, dim3(256), 0, s, p.split_out, p.splits, (int)M, a.Cout, a.bias, a.act, (bf16_t*)a.out, a.colstats, a.stat_rows);
+        NOPE_CHECK_LAUNCH();
+    } else if (p.splits > 1) {
         const size_t MN = (size_t)M * a.Cout;
         const unsigned rb = (unsigned)((MN + 255) / 256 < 4096 ? (MN + 255) / 256 : 4096);
         if (dt_es(dt) == 4) hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(rb), dim3(256), 0, s, p.split_out, p.splits, (int)M, a.Cout,

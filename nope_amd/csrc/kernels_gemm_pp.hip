@@ -694,18 +694,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             if (dma_on) tile_prologue();
         }
         if constexpr (SPLIT) {                         // (never with a tile walk: iters == 1)
-            float* so = p.split_out + (size_t)blockIdx.z * p.M * p.Cout;
-#pragma unroll
-            for (int i = 0; i < TL::MT; ++i)
-#pragma unroll
-                for (int r = 0; r < TL::R; ++r) {
-                    const int m = m_this + wm * 64 + i * TL::TM + TL::out_row(lane, r);
-#pragma unroll
-                    for (int j = 0; j < TL::NTL; ++j) {
-                        const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
-                        if (m < p.M && n < p.Cout) so[(size_t)m * p.Cout + n] = acc[i][j][r];
-                    }
-                }
+            epilogue_split_wide<T>(p, acc, m_this, n0, wm, wn, lane, lds_panel);
             return;
         } else if constexpr (TIMELINE) epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel, stamp);
         else epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel);

@@ -348,7 +348,7 @@ int launch_gn_fold(const float* colstats, float* partial, int nhyp, int blocks, 
     return NOPE_OK;
 }
 
-int gn_apply_blocks(int HW, int C, int dt) {
+int gn_apply_blocks(int HW, int C, int dt, int nhyp) {
     // Streaming bytes per workgroup.  Every workgroup first rebuilds (mean, rstd) and its per-channel coefficients (a barrier and
     // ~25 dependent loads): at 32 KiB that set-up was a third of a workgroup's instructions; 16 / 32 / 64 / 128 KiB measured
     // 198 / 143 / 124 / 121 us per statistics + apply pass over 512 x 32 x 32 x 192 f16 (profiles/r03k_gn_apply_ab.txt).
@@ -356,6 +356,15 @@ int gn_apply_blocks(int HW, int C, int dt) {
     const size_t bytes = (size_t)HW * C * dt_es(dt);
     int bph = (int)(bytes / ((size_t)(block_kb > 0 ? block_kb : 64) * 1024));
     if (bph < 1) bph = 1;
+    // Small batches (the reference's 26 / 91-template banks, a 64-template shard): one 64 KiB workgroup per sample leaves 64 workgroups
+    // on 256 CUs, each streaming its sample serially (11 us for a 3 MB tensor): spread a sample over more workgroups until the grid
+    // has ~512 of them, at least 8 pixels each.  NOPE_GN_MIN_GRID=0 keeps the byte rule alone.
+    static const int min_grid = getenv("NOPE_GN_MIN_GRID") ? atoi(getenv("NOPE_GN_MIN_GRID")) : 512;
+    if (nhyp > 0 && (long long)nhyp * bph < min_grid) {
+        int want = (min_grid + nhyp - 1) / nhyp;
+        if (want > HW / 8) want = HW / 8;
+        if (want > bph) bph = want;
+    }
     if (bph > 64) bph = 64;
     return bph;
 }
@@ -374,7 +383,7 @@ int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
     const int vec = dt_vec(dt);
     if (a.C % vec || a.G > 64) return NOPE_ERR_UNSUPPORTED;
     if (a.x_rep < 1 || a.resid_rep < 1) return NOPE_ERR_ARG;
-    const int bph = gn_apply_blocks(a.HW, a.C, dt);
+    const int bph = gn_apply_blocks(a.HW, a.C, dt, a.nhyp);
     dim3 grid((unsigned)(a.nhyp * bph)), block(NT);
     const bool act = a.act != 0, res = a.resid != nullptr;
 #define NOPE_GN_APPLY_F(T, FAST, OS, FILM, ACT, RES, U, FOLD)                                                                    \

@@ -262,7 +262,7 @@ struct GnApplyArgs {
     float eps = 1e-5f;
 };
 int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s);
-int gn_apply_blocks(int HW, int C, int dt);      // workgroups per hypothesis of launch_gn_apply (= chunks of out_stats)
+int gn_apply_blocks(int HW, int C, int dt, int nhyp);      // workgroups per hypothesis of launch_gn_apply over nhyp samples (= chunks of out_stats)
 int launch_gn_finalize(const float* partial, float* ms, int nhyp, int nchunk, float count, float eps, hipStream_t s);
 int gn_stats_chunks(int HW, int C, int dt);
 // fold the conv epilogue's per-row-block column statistics [nhyp][blocks][C][2] into per-(hypothesis, group) partials (nchunk = 1)

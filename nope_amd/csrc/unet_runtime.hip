@@ -233,8 +233,8 @@ struct Fwd {
         // few output tiles + long K (small hypothesis batches at the 4x4 level): deterministic split-K through a
         // scratch taken from the arena for the duration of the launch
         const size_t sk_mark = ar.off;
-        if (!colstats && !pn_c0 && !out_nchw) {
-            const int S = conv_splitk_factor(net->dt, ca);
+        if (!pn_c0 && !out_nchw) {
+            const int S = conv_splitk_factor(net->dt, ca);      // (1 for a conv that emits its statistics itself)
             if (S > 1) {
                 ca.splitk_bytes = (size_t)S * n * Ho * Wo * c.Cout * 4;
                 ca.splitk_ws = ar.alloc(ca.splitk_bytes);
@@ -273,7 +273,7 @@ struct Fwd {
             // per workgroup out of L2; a separate launch costs ~8 us).  Large ones keep the fold launch: at 512 hypotheses the six
             // workgroups of a level-0 sample would each repeat a 24 KiB fold (+0.25 ms per step, measured in round 2).
             const long long fold_inline_max = getenv("NOPE_GN_FOLD_INLINE") ? atoll(getenv("NOPE_GN_FOLD_INLINE")) : 16ll << 20;
-            const long long refold = (long long)nhyp * gn_apply_blocks(HW, nm.C, net->sdt) * st.blocks * nm.C * 8;
+            const long long refold = (long long)nhyp * gn_apply_blocks(HW, nm.C, net->sdt, nhyp) * st.blocks * nm.C * 8;
             if (refold <= fold_inline_max) { ga.colstats = st.cs; ga.stat_blocks = st.blocks; }
             else chk(launch_gn_fold(st.cs, gn_partial, nx, st.blocks, nm.C, G, s));
         } else {
@@ -327,7 +327,7 @@ struct Fwd {
     void qkv_prenorm(const Conv& qkvw, const float* c0, const float* c1, const Act& x, void* qkv) {
         if (!live()) return;
         const int HW = x.H * x.W;
-        chk(launch_gn_finalize(pn_partial, pn_ms, nhyp, gn_apply_blocks(HW, x.C, net->sdt), (float)HW * (float)x.C, 1e-5f, s));
+        chk(launch_gn_finalize(pn_partial, pn_ms, nhyp, gn_apply_blocks(HW, x.C, net->sdt, nhyp), (float)HW * (float)x.C, 1e-5f, s));
         conv(qkvw, x, nullptr, qkv, x.H, x.W, nhyp, 1, 1, nullptr, 0, NOPE_F32, nullptr, c0, c1);
     }
 

@@ -128,6 +128,15 @@ if __name__ == "__main__":
         print(f"unet f16 (u_net_dim 64) on the small-tile kernel: rel err {e:.2e}")
         print("small_emu_case OK")
         sys.exit(0)
+    if "--unet16split" in sys.argv:
+        # every 3x3 conv with >= 2 channel chunks as a split-K launch of the tap-resident kernel: raw partials through the per-wave panels,
+        # the reduce kernel that also emits the GroupNorm statistics (per sample at 4 x 4, per 64-row block at 8 x 8)
+        os.environ["NOPE_HALO_SPLIT_MIN_CHUNKS"] = "2"
+        e = run_unet(hip, "cpu", 64, "f16", n_hyp=2, hw=8)
+        assert e < 8e-3, e
+        print(f"unet f16 (u_net_dim 64) with split-K on the tap-resident kernel: rel err {e:.2e}")
+        print("small_emu_case OK")
+        sys.exit(0)
     if "--unet32" in sys.argv:
         e = run_unet(hip, "cpu", 32, "f32", n_hyp=2, hw=8, tile=1)
         assert e < 1e-4, e

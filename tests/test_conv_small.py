@@ -20,7 +20,8 @@ def test_small_tile_kernel_under_adversarial_interpreter(emu):
     # (compute modes: 1 = bf16, 3 = bf16x3 split precision on f32 data, 0 = f32, 2 = f16; tiles: 0 = 64 x 64 / 3 stages, 1 = 128 x 128, 2 = 64 x 64 / 4 stages)
     runs = [({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--dts", "1,0", "--tiles", "0,1,2"]),
             ({"HIPEMU_SHUFFLE": "2"}, ["--dts", "3,2", "--tiles", "0,2", "--light"]),
-            ({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "3"}, ["--unet16"])]      # a whole f16 U-Net schedule: fused statistics per 16 / 64 rows, fused PreNorm, NCHW bank
+            ({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "3"}, ["--unet16"]),      # a whole f16 U-Net schedule: fused statistics per 16 / 64 rows, fused PreNorm, NCHW bank
+            ({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--unet16split"])]  # ... with its 3x3 convs split along K on the tap-resident kernel
     procs = []
     for e, args in runs:
         env = dict(os.environ, HIPEMU_THREADS="3", **e)
