@@ -91,23 +91,40 @@ template <class T>
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ part, int splits, int M, int Cout,
                                                                   const float* __restrict__ bias, int act, T* __restrict__ out,
                                                                   float* __restrict__ colstats, int rows) {
-    const int n = blockIdx.y * 256 + threadIdx.x;
-    if (n >= Cout) return;
+    // 64 columns x 4 row quarters per workgroup; a thread adds the partials of its rows / 4 rows (all split loads of a row in flight
+    // at once), the four quarters of a column are then added in row order by its first thread.  Grid (M / rows, Cout / 64).
+    __shared__ float s_s[4][64], s_q[4][64];
+    const int c = threadIdx.x & 63, rq = threadIdx.x >> 6;
+    const int n = blockIdx.y * 64 + c;
     const size_t MN = (size_t)M * Cout;
-    const int m0 = blockIdx.x * rows;
-    const float bv = bias ? bias[n] : 0.f;
+    const int rper = rows >> 2;
+    const int m0 = blockIdx.x * rows + rq * rper;
     float s = 0.f, q = 0.f;
-    for (int r = 0; r < rows; ++r) {
-        const size_t i = (size_t)(m0 + r) * Cout + n;
-        float v = 0.f;
-        for (int z = 0; z < splits; ++z) v += part[(size_t)z * MN + i];
-        v += bv;
-        if (act) v = v > 0.f ? v : 0.f;
-        Elt<T>::st(out + i, v);
-        s += v; q += v * v;
+    if (n < Cout) {
+        const float bv = bias ? bias[n] : 0.f;
+        for (int r = 0; r < rper; ++r) {
+            const size_t i = (size_t)(m0 + r) * Cout + n;
+            float pv[16];
+#pragma unroll
+            for (int z = 0; z < 16; ++z) pv[z] = z < splits ? part[(size_t)z * MN + i] : 0.f;
+            float v = 0.f;
+#pragma unroll
+            for (int z = 0; z < 16; ++z) if (z < splits) v += pv[z];
+            v += bv;
+            if (act) v = v > 0.f ? v : 0.f;
+            Elt<T>::st(out + i, v);
+            s += v; q += v * v;
+        }
     }
-    float* cs = colstats + ((size_t)blockIdx.x * Cout + n) * 2;
-    cs[0] = s; cs[1] = q;
+    s_s[rq][c] = s; s_q[rq][c] = q;
+    __syncthreads();
+    if (rq == 0 && n < Cout) {
+        float S = 0.f, Q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { S += s_s[k][c]; Q += s_q[k][c]; }
+        float* cs = colstats + ((size_t)blockIdx.x * Cout + n) * 2;
+        cs[0] = S; cs[1] = Q;
+    }
 }
 
 // Source pixel of output pixel (oy, ox) under tap (dy, dx); false = zero padding / beyond M.
@@ -533,7 +550,7 @@ int conv_halo_max_width();
 // 1536 -> 1536 at 4 x 4 x 512 although it executes the 31 % of MACs the position-major order skips), bit 2 = those run position-major on the
 // ping-pong kernel (needs nhyp % 256 == 0), bit 3 = no minimum tile count (tests: small shapes on the ping-pong kernel),
 // bit 4 = 3x3 convs per tap on the ping-pong kernel instead of the tap-resident (halo) kernel.
-struct ConvPlan { bool dma, pp, posmajor, halo; int small; int hsplit; };      // hsplit > 1: tap-resident kernel with that many K splits      // small: -1, or the tile of conv_gemm_small_kernel (0 = 64 x 64, 1 = 128 x 128, 2 = 64 x 64 / 4-stage ring)
+struct ConvPlan { bool dma, pp, posmajor, halo; int small; int hsplit; };      // hsplit > 1: tap-resident kernel with that many K splits      // small: -1, or the tile of conv_gemm_small_kernel (0 = 64 x 64, 1 = 128 x 128, 2 = 64 x 64 / 6-stage ring)
 
 // Launches that cannot give every CU a 128 x 192 tile take the small-tile kernel (kernels_gemm_small.hip): fewer than
 // NOPE_SMALL_MAX_TILES (default 320) tiles of 128 x 192.  NOPE_CONV_SMALL: 0 = never, 1 = that policy (default), 2 = whenever the
@@ -551,7 +568,11 @@ static int plan_small(int dt, const ConvArgs& a, bool dma) {
         return -1;       // the tap-resident kernel has its 128 tiles of 256 rows (measured at 16 x 16 x 64: 60.6 / 83 us against 83 / 116 us on 64 x 64 tiles)
     if (const char* t = getenv("NOPE_SMALL_TILE")) return atoi(t) < 0 || atoi(t) > 2 ? 0 : atoi(t);
     const long long tiles64 = (long long)cdiv((int)M, 64) * cdiv(a.Cout, 64) * (phased ? 4 : 1);
-    return tiles64 > 1536 ? 1 : 0;
+    if (tiles64 > 1536) return 1;
+    // at most two workgroups per CU and a K loop of >= 8 steps: the deep ring (a tile's time is its chain of memory round trips)
+    const int nk = a.ntaps * ((a.C1 + a.C2) / (8 * dt_vec(dt)));
+    const int deep_max = getenv("NOPE_SMALL_DEEP_MAX") ? atoi(getenv("NOPE_SMALL_DEEP_MAX")) : 512;
+    return (tiles64 <= deep_max && nk >= 8) ? 2 : 0;
 }
 
 // 3x3 convs with FEW 256 x 192 tiles and a LONG K (the 4 x 4 / 8 x 8 levels of the U-Net at a few dozen pose hypotheses: 16-64 tiles
@@ -859,7 +880,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     }
     NOPE_CHECK_LAUNCH();
     if (p.splits > 1 && a.colstats) {          // (tap-resident split-K only: plan.hsplit)
-        const dim3 rg((unsigned)(M / a.stat_rows), (unsigned)cdiv(a.Cout, 256));
+        const dim3 rg((unsigned)(M / a.stat_rows), (unsigned)cdiv(a.Cout, 64));      // (splits <= 16, stat_rows in {16, 32, 64})
         if (dt_es(dt) == 4) hipLaunchKernelGGL((splitk_reduce_stats_kernel<float>), rg, dim3(256), 0, s, p.split_out, p.splits, (int)M, a.Cout, a.bias, a.act, (float*)a.out, a.colstats, a.stat_rows);
         else if (dt == NOPE_F16) hipLaunchKernelGGL((splitk_reduce_stats_kernel<f16_t>), rg, dim3(256), 0, s, p.split_out, p.splits, (int)M, a.Cout, a.bias, a.act, (f16_t*)a.out, a.colstats, a.stat_rows);
         else hipLaunchKernelGGL((splitk_reduce_stats_kernel<bf16_t>), rg, dim3(256), 0, s, p.split_out, p.splits, (int)M, a.Cout, a.bias, a.act, (bf16_t*)a.out, a.colstats, a.stat_rows);

@@ -576,6 +576,31 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     const int iters = TL::TM == 32 && p.persist_iters > 1 ? p.persist_iters : 1;
     const int walk_rows = (int)(gridDim.x >> 3) / (p.xcd_map == 2 ? p.tiles_n / p.xcd_gn : 1) * PP_BM;
     tile_prologue();
+    // Split-K launches stream their weights COLD: at 64 hypotheses every weight byte is used by four workgroups at once and never again,
+    // so each K step's B pieces (issued 1-2 steps ahead) come from HBM, not from L2 as in the launches that fill the chip: 1.6 us per K
+    // step instead of 0.6 (profiles/r04d).  The workgroup therefore touches its whole weight stream up front -- one 4-byte load per
+    // 128-byte weight row segment, PFN per thread, after the prologue's DMA pieces (which are older and land first: loads return in
+    // order) -- so the lines are on their way into this XCD's L2 while the first K steps run.  The values are kept live to the end of
+    // the kernel (a VGPR reused before its load returns would be overwritten by it).  NOPE_PP_VARIANT & 2048 = off.
+    constexpr int PFN = 16;
+    unsigned pfv[SPLIT ? PFN : 1];
+    bool prefetched = false;
+    if constexpr (SPLIT) {
+        prefetched = !(p.variant & 2048);
+        if (prefetched) {
+            const int nlines = 9 * (nchunks - c_lo) * BN;
+#pragma unroll
+            for (int k = 0; k < PFN; ++k) {
+                int li = tid + k * (PP_WAVES * 64);
+                li = li < nlines ? li : nlines - 1;
+                const int st = li / BN, row = li - st * BN;
+                const int ch = c_lo + st / 9, tap = st - (st / 9) * 9;
+                const int n = n0 + row < p.Cout ? n0 + row : p.Cout - 1;
+                pfv[k] = *reinterpret_cast<const unsigned*>(p.w + ((size_t)n * 9u * Cin + (size_t)tap * Cin + (size_t)ch * BK) * ES);
+            }
+            NOPE_WAIT_VMCNT_KEEP_LOADS(PFN);           // vmcnt(PFN): the prologue's DMA pieces have landed
+        } else __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
+    } else
     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                       // DMA landed
     const bool dma_on = !(p.variant & 16);                         // (tuning: 16 = no DMA stream)
 
@@ -695,6 +720,10 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         }
         if constexpr (SPLIT) {                         // (never with a tile walk: iters == 1)
             epilogue_split_wide<T>(p, acc, m_this, n0, wm, wn, lane, lds_panel);
+            if (prefetched) {
+#pragma unroll
+                for (int k = 0; k < PFN; ++k) NOPE_KEEP_VGPR(pfv[k]);
+            }
             return;
         } else if constexpr (TIMELINE) epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel, stamp);
         else epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel);

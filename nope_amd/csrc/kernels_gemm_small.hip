@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
     constexpr int LDP = BNS + 4;                                    // f32 panel row stride (words)
     constexpr int RING = NS * STAGE, PANEL = BMS * LDP * 4 + 4 * BNS * 2 * 4;
     constexpr int LDS_BYTES = RING > PANEL ? RING : PANEL;
-    static_assert(NS >= 2 && NS <= 4 && (NS - 2) * L <= 63, "vmcnt field");
+    static_assert(NS >= 2 && NS <= 6 && (NS - 2) * L <= 63, "vmcnt field");
     static_assert(MODE != NOPE_CONV_UP2, "the nearest-x2 + 3x3 form runs as four phase convs");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -234,7 +234,9 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
     for (int ks = 0; ks < nk; ++ks) {
         // Stage ks is this wave's OLDEST outstanding group; min(NS - 2, nk - 1 - ks) younger groups may stay in flight.
         const int younger = nk - 1 - ks;
-        if (NS >= 4 && younger >= 2) wait_vmcnt<2 * L>();
+        if (NS >= 6 && younger >= 4) wait_vmcnt<(NS >= 6 ? 4 * L : 0)>();
+        else if (NS >= 5 && younger >= 3) wait_vmcnt<(NS >= 5 ? 3 * L : 0)>();
+        else if (NS >= 4 && younger >= 2) wait_vmcnt<(NS >= 4 ? 2 * L : 0)>();
         else if (NS >= 3 && younger >= 1) wait_vmcnt<(NS >= 3 ? L : 0)>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();              // every wave's pieces of stage ks have landed; everyone is done with stage ks - 1
@@ -416,13 +418,15 @@ void launch_small_t(const ConvParams& p, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
-// tile: 0 = 64 x 64 (3-stage ring, 48 KiB: three workgroups per CU), 1 = 128 x 128 (3 stages, 96 KiB), 2 = 64 x 64 with a 4-stage ring
+// tile: 0 = 64 x 64 (3-stage ring, 48 KiB: three workgroups per CU), 1 = 128 x 128 (3 stages, 96 KiB), 2 = 64 x 64 with a 6-stage ring
+// (96 KiB: four K steps in flight per workgroup -- launches with at most a workgroup or two per CU and a long K, where a tile's time
+// is its chain of memory round trips: the one-image encoder's 3x3 convs ran 0.45 us per K step on the 3-stage ring)
 void launch_conv_small(int dt, const void* params, int tile, dim3 grid, hipStream_t s) {
     const ConvParams& p = *reinterpret_cast<const ConvParams*>(params);
 #define NOPE_SMALL_T(T)                                                        \
     do {                                                                       \
         if (tile == 1) launch_small_t<T, 2, 2, 3>(p, grid, s);                 \
-        else if (tile == 2) launch_small_t<T, 1, 1, 4>(p, grid, s);            \
+        else if (tile == 2) launch_small_t<T, 1, 1, 6>(p, grid, s);            \
         else launch_small_t<T, 1, 1, 3>(p, grid, s);                           \
     } while (0)
     if (dt == NOPE_F32) NOPE_SMALL_T(float);

@@ -91,6 +91,21 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, f
     }
 }
 
+// Per-group sums of per-channel (sum, sum of squares) held in LDS: wave w takes groups w, w + 4, ..., a lane adds every 64th channel
+// of the group in channel order and the 64 lane sums are folded by the fixed butterfly of wave_sum -- deterministic, and for the
+// single 1536-channel group of a GroupNorm(1) not a 1536-step chain of dependent LDS reads by ONE thread (50 us at 4 x 4 x 64
+// hypotheses, profiles/r04d).  Every thread of the workgroup must call it (wave-collective).
+template <class Emit>
+__device__ __forceinline__ void group_sums(const float* ch_s, const float* ch_q, int cpg, int G, int tid, Emit emit) {
+    const int lane = tid & 63;
+    for (int g = tid >> 6; g < G; g += NT / 64) {
+        float S = 0.f, Q = 0.f;
+        for (int c = lane; c < cpg; c += 64) { S += ch_s[g * cpg + c]; Q += ch_q[g * cpg + c]; }
+        S = wave_sum(S); Q = wave_sum(Q);
+        if (lane == 0) emit(g, S, Q);
+    }
+}
+
 // Fold [HW/64 row blocks][C][2] column statistics (written by the conv epilogue) of one hypothesis into
 // [G][2] group sums.  Fixed summation order -> deterministic.
 __global__ __launch_bounds__(NT) void gn_fold_kernel(const float* __restrict__ colstats, float* __restrict__ partial, int nb, int C, int G) {
@@ -115,13 +130,10 @@ __global__ __launch_bounds__(NT) void gn_fold_kernel(const float* __restrict__ c
         ch_s[c] = s; ch_q[c] = q;
     }
     __syncthreads();
-    const int cpg = C / G;
-    for (int g = tid; g < G; g += NT) {
-        float S = 0.f, Q = 0.f;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { S += ch_s[c]; Q += ch_q[c]; }
+    group_sums(ch_s, ch_q, C / G, G, tid, [&](int g, float S, float Q) {
         partial[((size_t)hyp * G + g) * 2] = S;
         partial[((size_t)hyp * G + g) * 2 + 1] = Q;
-    }
+    });
 }
 
 typedef f32x2_t f32x2;
@@ -181,16 +193,14 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
             ch_s[c] = s; ch_q[c] = q;
         }
         __syncthreads();
-        for (int g = tid; g < G; g += NT) {
-            float S = 0.f, Q = 0.f;
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { S += ch_s[c]; Q += ch_q[c]; }
+        group_sums(ch_s, ch_q, cpg, G, tid, [&](int g, float S, float Q) {
             const float cnt = (float)cpg * (float)HW;
             const float mean = S / cnt;
             float var = Q / cnt - mean * mean;
             var = var > 0.f ? var : 0.f;
             s_mean[g] = mean;
             s_rstd[g] = 1.0f / sqrtf(var + eps);
-        }
+        });
     } else
     for (int g = tid; g < G; g += NT) {
         float S = 0.f, Q = 0.f;
@@ -359,10 +369,15 @@ int gn_apply_blocks(int HW, int C, int dt, int nhyp) {
     // Small batches (the reference's 26 / 91-template banks, a 64-template shard): one 64 KiB workgroup per sample leaves 64 workgroups
     // on 256 CUs, each streaming its sample serially (11 us for a 3 MB tensor): spread a sample over more workgroups until the grid
     // has ~512 of them, at least 8 pixels each.  NOPE_GN_MIN_GRID=0 keeps the byte rule alone.
-    static const int min_grid = getenv("NOPE_GN_MIN_GRID") ? atoi(getenv("NOPE_GN_MIN_GRID")) : 512;
+    static const int min_grid = getenv("NOPE_GN_MIN_GRID") ? atoi(getenv("NOPE_GN_MIN_GRID")) : 1024;
     if (nhyp > 0 && (long long)nhyp * bph < min_grid) {
+        // (a thread walks its pixels serially, two loads in flight: on a 16-pixel map with 1536 channels one workgroup per sample is eight
+        //  dependent memory round trips -- 17 us for 3 MB, profiles/r04d -- so: down to one round trip per thread)
+        const int cvecs = C / dt_vec(dt), tpr = cvecs < NT ? cvecs : NT, rows = NT / tpr;
+        int max_bph = HW / (2 * rows);
+        if (max_bph < 1) max_bph = 1;
         int want = (min_grid + nhyp - 1) / nhyp;
-        if (want > HW / 8) want = HW / 8;
+        if (want > max_bph) want = max_bph;
         if (want > bph) bph = want;
     }
     if (bph > 64) bph = 64;

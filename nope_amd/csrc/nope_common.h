@@ -182,6 +182,14 @@ template <bool FAST> __device__ __forceinline__ float silu_f(float x) {
 #define NOPE_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 #endif
 
+// s_waitcnt vmcnt(n) where the n youngest outstanding operations are PLAIN loads (issued after the LDS-DMA pieces being waited for).
+// tests/hipemu executes plain loads synchronously and does not count them: there the wait is vmcnt(0).
+#ifdef HIPEMU
+#define NOPE_WAIT_VMCNT_KEEP_LOADS(n) __builtin_amdgcn_s_waitcnt(0x0F70)
+#else
+#define NOPE_WAIT_VMCNT_KEEP_LOADS(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+#endif
+
 // Run a statement with T bound to the element type of a STORAGE dtype code (f32 / bf16 / f16); returns NOPE_ERR_UNSUPPORTED
 // from the enclosing function for anything else.
 #define NOPE_DISPATCH_T(dt, T, ...)                                              \

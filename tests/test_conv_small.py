@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_small_tile_kernel_under_adversarial_interpreter(emu):
-    # (compute modes: 1 = bf16, 3 = bf16x3 split precision on f32 data, 0 = f32, 2 = f16; tiles: 0 = 64 x 64 / 3 stages, 1 = 128 x 128, 2 = 64 x 64 / 4 stages)
+    # (compute modes: 1 = bf16, 3 = bf16x3 split precision on f32 data, 0 = f32, 2 = f16; tiles: 0 = 64 x 64 / 3 stages, 1 = 128 x 128, 2 = 64 x 64 / 6 stages)
     runs = [({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--dts", "1,0", "--tiles", "0,1,2"]),
             ({"HIPEMU_SHUFFLE": "2"}, ["--dts", "3,2", "--tiles", "0,2", "--light"]),
             ({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "3"}, ["--unet16"]),      # a whole f16 U-Net schedule: fused statistics per 16 / 64 rows, fused PreNorm, NCHW bank
