@@ -569,9 +569,11 @@ static int plan_small(int dt, const ConvArgs& a, bool dma) {
     if (const char* t = getenv("NOPE_SMALL_TILE")) return atoi(t) < 0 || atoi(t) > 2 ? 0 : atoi(t);
     const long long tiles64 = (long long)cdiv((int)M, 64) * cdiv(a.Cout, 64) * (phased ? 4 : 1);
     if (tiles64 > 1536) return 1;
-    // at most two workgroups per CU and a K loop of >= 8 steps: the deep ring (a tile's time is its chain of memory round trips)
+    // (tile 2, the 6-stage ring, for launches of at most NOPE_SMALL_DEEP_MAX tiles with a K loop of >= 8 steps: with 512 -- launches that
+    //  the 48 KiB ring runs two workgroups per CU -- measured SLOWER than the 3-stage ring, 26 / 64 templates 4.16 / 4.95 ms against
+    //  4.04 / 4.81, profiles/r04e_small_bank_sweep.txt; off by default)
     const int nk = a.ntaps * ((a.C1 + a.C2) / (8 * dt_vec(dt)));
-    const int deep_max = getenv("NOPE_SMALL_DEEP_MAX") ? atoi(getenv("NOPE_SMALL_DEEP_MAX")) : 512;
+    const int deep_max = getenv("NOPE_SMALL_DEEP_MAX") ? atoi(getenv("NOPE_SMALL_DEEP_MAX")) : 0;
     return (tiles64 <= deep_max && nk >= 8) ? 2 : 0;
 }
 
@@ -592,7 +594,9 @@ static int halo_split_factor(int dt, const ConvArgs& a) {
     const long long tiles = (long long)cdiv((int)M, 256) * cdiv(a.Cout, BN);
     const int min_chunks = getenv("NOPE_HALO_SPLIT_MIN_CHUNKS") ? atoi(getenv("NOPE_HALO_SPLIT_MIN_CHUNKS")) : 12;
     if (tiles >= 128 || nchunks < min_chunks) return 1;
-    int S = (int)((256 + tiles - 1) / tiles);
+    // as many splits as fit ONE round of 256 workgroups (one per CU: 158 KiB of LDS each): 88 tiles x 3 = 264 would run a second
+    // round for 8 of them
+    int S = (int)(256 / tiles);
     if (S > nchunks) S = nchunks;
     if (S > 16) S = 16;
     return S < 2 ? 1 : S;

@@ -576,17 +576,18 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     const int iters = TL::TM == 32 && p.persist_iters > 1 ? p.persist_iters : 1;
     const int walk_rows = (int)(gridDim.x >> 3) / (p.xcd_map == 2 ? p.tiles_n / p.xcd_gn : 1) * PP_BM;
     tile_prologue();
-    // Split-K launches stream their weights COLD: at 64 hypotheses every weight byte is used by four workgroups at once and never again,
-    // so each K step's B pieces (issued 1-2 steps ahead) come from HBM, not from L2 as in the launches that fill the chip: 1.6 us per K
-    // step instead of 0.6 (profiles/r04d).  The workgroup therefore touches its whole weight stream up front -- one 4-byte load per
-    // 128-byte weight row segment, PFN per thread, after the prologue's DMA pieces (which are older and land first: loads return in
-    // order) -- so the lines are on their way into this XCD's L2 while the first K steps run.  The values are kept live to the end of
-    // the kernel (a VGPR reused before its load returns would be overwritten by it).  NOPE_PP_VARIANT & 2048 = off.
+    // Tuning only (NOPE_PP_VARIANT & 2048): touch the workgroup's whole weight stream up front -- one 4-byte load per 128-byte weight row
+    // segment, PFN per thread, after the prologue's DMA pieces (older: they land first) -- to pull it towards this XCD's L2 while the
+    // first K steps run.  Measured and NOT adopted (profiles/r04e_conv_split_bench.txt): a split-K launch at 64 hypotheses takes 1.2-1.6 us
+    // per K step against 0.6 in the launches that fill the chip because every B piece misses L2 (each weight byte is used by four
+    // workgroups at once and never again) with only ~1.5 steps of look-ahead in the 3-stage B ring; but an XCD's share of the
+    // weights (5.3 MB of 42.5) does not fit its 4 MB L2 next to the partials, so the prefetched lines are gone before their step:
+    // 63.6 us with, 57.8 us without (warm or cold weights alike: the Infinity Cache holds them either way).
     constexpr int PFN = 16;
     unsigned pfv[SPLIT ? PFN : 1];
     bool prefetched = false;
     if constexpr (SPLIT) {
-        prefetched = !(p.variant & 2048);
+        prefetched = (p.variant & 2048) != 0;
         if (prefetched) {
             const int nlines = 9 * (nchunks - c_lo) * BN;
 #pragma unroll
