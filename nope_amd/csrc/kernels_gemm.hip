@@ -562,6 +562,12 @@ static int plan_small(int dt, const ConvArgs& a, bool dma) {
     const long long M = (long long)a.nhyp * (phased ? a.Hs * a.Ws : a.Ho * a.Wo);
     const long long tiles128 = (long long)cdiv((int)M, BM) * cdiv(a.Cout, BN) * (phased ? 4 : 1);
     const int max_tiles = getenv("NOPE_SMALL_MAX_TILES") ? atoi(getenv("NOPE_SMALL_MAX_TILES")) : 320;      // (read per launch: the tuning sweep toggles it)
+    // Short-K 1x1 convs of ANY size (NOPE_SMALL_1X1_MAXK = K steps, default 0 = off): their 128 x 192 launches are bound by the epilogue
+    // of a three-K-step tile, not by HBM (192 -> 384 at 32 x 32 x 512: 604 MB in 221 us = 2.7 TB/s); the 128 x 128 small tile has a one-pass
+    // epilogue.
+    const int maxk_1x1 = getenv("NOPE_SMALL_1X1_MAXK") ? atoi(getenv("NOPE_SMALL_1X1_MAXK")) : 0;
+    if (mode_env == 1 && a.mode == NOPE_CONV_PLAIN && a.ntaps == 1 && !a.out_nchw && (a.C1 + a.C2) / (8 * dt_vec(dt)) <= maxk_1x1 && tiles128 >= max_tiles)
+        return getenv("NOPE_SMALL_TILE") ? atoi(getenv("NOPE_SMALL_TILE")) : 1;
     if (mode_env == 1 && tiles128 >= max_tiles) return -1;
     if (mode_env == 1 && dt != NOPE_F32 && a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.Ws <= conv_halo_max_width() && a.rep1 == 1 && !a.out_nchw &&
         !a.pn_ms && a.Cout % dt_vec(dt) == 0 && 9 * ((a.C1 + a.C2) / (8 * dt_vec(dt))) >= 54 && (long long)cdiv((int)M, 256) * cdiv(a.Cout, BN) >= 128)
