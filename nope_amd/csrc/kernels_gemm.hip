@@ -550,7 +550,7 @@ int conv_halo_max_width();
 // 1536 -> 1536 at 4 x 4 x 512 although it executes the 31 % of MACs the position-major order skips), bit 2 = those run position-major on the
 // ping-pong kernel (needs nhyp % 256 == 0), bit 3 = no minimum tile count (tests: small shapes on the ping-pong kernel),
 // bit 4 = 3x3 convs per tap on the ping-pong kernel instead of the tap-resident (halo) kernel.
-struct ConvPlan { bool dma, pp, posmajor, halo; int small; int hsplit; };      // hsplit > 1: tap-resident kernel with that many K splits      // small: -1, or the tile of conv_gemm_small_kernel (0 = 64 x 64, 1 = 128 x 128, 2 = 64 x 64 / 6-stage ring)
+struct ConvPlan { bool dma, pp, posmajor, halo; int small; int hsplit; };      // hsplit > 1: tap-resident kernel with that many K splits      // small: -1, or the tile of conv_gemm_small_kernel (0 = 64 x 64, 1 = 128 x 128, 2 = 64 x 64 / 6-stage ring, 3 = 64 x 64 by two K groups)
 
 // Launches that cannot give every CU a 128 x 192 tile take the small-tile kernel (kernels_gemm_small.hip): fewer than
 // NOPE_SMALL_MAX_TILES (default 320) tiles of 128 x 192.  NOPE_CONV_SMALL: 0 = never, 1 = that policy (default), 2 = whenever the
@@ -572,7 +572,7 @@ static int plan_small(int dt, const ConvArgs& a, bool dma) {
     if (mode_env == 1 && dt != NOPE_F32 && a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.Ws <= conv_halo_max_width() && a.rep1 == 1 && !a.out_nchw &&
         !a.pn_ms && a.Cout % dt_vec(dt) == 0 && 9 * ((a.C1 + a.C2) / (8 * dt_vec(dt))) >= 54 && (long long)cdiv((int)M, 256) * cdiv(a.Cout, BN) >= 128)
         return -1;       // the tap-resident kernel has its 128 tiles of 256 rows (measured at 16 x 16 x 64: 60.6 / 83 us against 83 / 116 us on 64 x 64 tiles)
-    if (const char* t = getenv("NOPE_SMALL_TILE")) return atoi(t) < 0 || atoi(t) > 2 ? 0 : atoi(t);
+    if (const char* t = getenv("NOPE_SMALL_TILE")) return atoi(t) < 0 || atoi(t) > 3 ? 0 : atoi(t);
     const long long tiles64 = (long long)cdiv((int)M, 64) * cdiv(a.Cout, 64) * (phased ? 4 : 1);
     if (tiles64 > 1536) return 1;
     // (tile 2, the 6-stage ring, for launches of at most NOPE_SMALL_DEEP_MAX tiles with a K loop of >= 8 steps: with 512 -- launches that
@@ -580,7 +580,10 @@ static int plan_small(int dt, const ConvArgs& a, bool dma) {
     //  4.04 / 4.81, profiles/r04e_small_bank_sweep.txt; off by default)
     const int nk = a.ntaps * ((a.C1 + a.C2) / (8 * dt_vec(dt)));
     const int deep_max = getenv("NOPE_SMALL_DEEP_MAX") ? atoi(getenv("NOPE_SMALL_DEEP_MAX")) : 0;
-    return (tiles64 <= deep_max && nk >= 8) ? 2 : 0;
+    if (tiles64 <= deep_max && nk >= 8) return 2;
+    // at most one workgroup per CU and a long K: two wave groups per tile on alternate K steps (tile 3)
+    const int kg2_max = getenv("NOPE_SMALL_KG2_MAX") ? atoi(getenv("NOPE_SMALL_KG2_MAX")) : 256;
+    return (tiles64 <= kg2_max && nk >= 12) ? 3 : 0;
 }
 
 // 3x3 convs with FEW 256 x 192 tiles and a LONG K (the 4 x 4 / 8 x 8 levels of the U-Net at a few dozen pose hypotheses: 16-64 tiles

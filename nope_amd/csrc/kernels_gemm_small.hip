@@ -79,8 +79,14 @@ constexpr int S_WAIT_LGKMCNT0 = 0xC07F;
 template <int N> __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
 
 // WMT x WNT: 32 x 32 blocks per wave (waves 2 x 2): tile = 64 WMT x 64 WNT.  NS: ring stages of (64 WMT + 64 WNT) x 128 B.
-template <class T, int MODE, int WMT, int WNT, int NS, bool PN>
-__global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
+// KG = 2: TWO wave groups (512 threads) share the tile and take alternate K steps, each through its own ring; their f32 sums are added
+// (group 0 + group 1, a fixed order) in the epilogue panel.  For launches with at most one workgroup per CU and a long K -- the
+// one-image encoder's 3x3 convs: 64-128 workgroups of 36-72 K steps, 0.45 us per step -- where a wave's K step is a serial chain
+// (wait, barrier, issue four DMA pieces at ~100 cycles each, eight ds_reads, four MFMAs): a deeper ring does not shorten that chain
+// (measured: the 6-stage ring is no faster), a second group halves the number of links.  Not bit-identical to the other kernels
+// (the sum over K is associated as (even steps) + (odd steps)); deterministic.
+template <class T, int MODE, int WMT, int WNT, int NS, bool PN, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void conv_gemm_small_kernel(ConvParams p) {
     typedef Tile<T> TL;
     constexpr int VEC = Elt<T>::VEC;
     constexpr unsigned ES = (unsigned)sizeof(T);
@@ -92,15 +98,19 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
     constexpr int KS = RB / 16 / TL::STEP_SLOTS, RAW = TL::RAW;
     constexpr int LDP = BNS + 4;                                    // f32 panel row stride (words)
     constexpr int RING = NS * STAGE, PANEL = BMS * LDP * 4 + 4 * BNS * 2 * 4;
-    constexpr int LDS_BYTES = RING > PANEL ? RING : PANEL;
+    constexpr int NTH = 256 * KG;
+    static_assert(KG == 1 || (KG == 2 && RING >= BMS * LDP * 4), "the second group's panel sits in its own ring");
+    constexpr int LDS_BYTES = KG * RING > PANEL ? KG * RING : PANEL;
     static_assert(NS >= 2 && NS <= 6 && (NS - 2) * L <= 63, "vmcnt field");
     static_assert(MODE != NOPE_CONV_UP2, "the nearest-x2 + 3x3 form runs as four phase convs");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = KG > 1 ? wave8 >> 2 : 0, wave = wave8 & 3;          // K group, wave inside the group
     const int wm = wave >> 1, wn = wave & 1;
+    unsigned char* const ring = lds + grp * RING;                       // this group's ring
     int tile_m, tile_n;
     {
         const int g = blockIdx.x;
@@ -180,11 +190,14 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
         ks0 = (int)((long long)z * tot / p.splits);
         nk = (int)((long long)(z + 1) * tot / p.splits) - ks0;
     }
+    // KG = 2: group g takes steps ks0 + g, ks0 + g + 2, ...
+    const int nk_all = nk;
+    if (KG > 1) { ks0 += grp; nk = (nk_all - grp + 1) >> 1; }
     int ld_kc = ks0 / p.ntaps, ld_tap = ks0 - (ks0 / p.ntaps) * p.ntaps;
     // K order: channel chunk outer, tap inner (as the other kernels: the sum order over K is identical)
     auto issue = [&](int stage) {
-        unsigned char* dA = lds + stage * STAGE + (AI * wave) * 1024;
-        unsigned char* dB = lds + stage * STAGE + BMS * RB + (BI * wave) * 1024;
+        unsigned char* dA = ring + stage * STAGE + (AI * wave) * 1024;
+        unsigned char* dB = ring + stage * STAGE + BMS * RB + (BI * wave) * 1024;
         const int c0 = ld_kc * BK;
         const bool first = c0 < p.C1;                   // wave-uniform: a K step lies inside one source
         const int Cs = first ? p.C1 : p.C2;
@@ -209,7 +222,9 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < BI; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(dB + j * 1024), 16, b_off[j] + kofs, 0, 0, 0);
-        if (++ld_tap == p.ntaps) { ld_tap = 0; ++ld_kc; }
+#pragma unroll
+        for (int adv = 0; adv < KG; ++adv)
+            if (++ld_tap == p.ntaps) { ld_tap = 0; ++ld_kc; }
     };
 
     typename TL::acc_t acc[MT][NTL];
@@ -231,7 +246,13 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s);
     int st = 0;                                     // ring slot of K step ks
-    for (int ks = 0; ks < nk; ++ks) {
+    const int nloop = KG > 1 ? (nk_all + 1) >> 1 : nk;     // (both groups pass the same barriers; group 1 may have one step less)
+    for (int ks = 0; ks < nloop; ++ks) {
+        if (KG > 1 && ks >= nk) {                   // group 1's missing last step: only the rendezvous
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+        }
         // Stage ks is this wave's OLDEST outstanding group; min(NS - 2, nk - 1 - ks) younger groups may stay in flight.
         const int younger = nk - 1 - ks;
         if (NS >= 6 && younger >= 4) wait_vmcnt<(NS >= 6 ? 4 * L : 0)>();
@@ -242,7 +263,7 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
         __builtin_amdgcn_s_barrier();              // every wave's pieces of stage ks have landed; everyone is done with stage ks - 1
         __builtin_amdgcn_sched_barrier(0);
         if (ks + NS - 1 < nk) issue(st == 0 ? NS - 1 : st - 1);     // into the slot of stage ks - 1
-        const unsigned char* base = lds + st * STAGE;
+        const unsigned char* base = ring + st * STAGE;
 #pragma unroll
         for (int kq = 0; kq < KS; ++kq) {
             u32x4 af[MT][RAW], bfr[NTL][RAW];
@@ -270,18 +291,30 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
 
     // ---- epilogue: the tile's f32 accumulators through ONE panel, then rows out
     float* pan = reinterpret_cast<float*>(lds);
+    {
+        float* mine = reinterpret_cast<float*>(ring);          // (group 0: the panel itself)
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NTL; ++j)
+            for (int j = 0; j < NTL; ++j)
 #pragma unroll
-            for (int r = 0; r < TL::R; ++r)
-                pan[(wm * 32 * WMT + i * TL::TM + TL::out_row(lane, r)) * LDP + wn * 32 * WNT + j * TL::TM + TL::out_col(lane)] = acc[i][j][r];
+                for (int r = 0; r < TL::R; ++r)
+                    mine[(wm * 32 * WMT + i * TL::TM + TL::out_row(lane, r)) * LDP + wn * 32 * WNT + j * TL::TM + TL::out_col(lane)] = acc[i][j][r];
+    }
     __syncthreads();
+    if (KG > 1) {                                  // sum of the two K groups, group 0 first
+        const float* other = reinterpret_cast<const float*>(lds + RING);
+        for (int idx = tid; idx < BMS * (BNS / 4); idx += NTH) {
+            const int row = idx / (BNS / 4), ch = idx - row * (BNS / 4);
+            f32x4* d = reinterpret_cast<f32x4*>(&pan[row * LDP + ch * 4]);
+            *d = *d + *reinterpret_cast<const f32x4*>(&other[row * LDP + ch * 4]);
+        }
+        __syncthreads();
+    }
 
     if (p.splits > 1) {                            // raw f32 partial sums; splitk_reduce_kernel finishes (bias, residual, activation)
         float* so = p.split_out + (size_t)blockIdx.z * p.M * p.Cout;
-        for (int idx = tid; idx < BMS * (BNS / 4); idx += 256) {
+        for (int idx = tid; idx < BMS * (BNS / 4); idx += NTH) {
             const int row = idx / (BNS / 4), ch = idx - row * (BNS / 4);
             const int m = m0 + row, n = n0 + ch * 4;
             if (m >= p.M || n >= p.Cout) continue;
@@ -298,7 +331,7 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
         float* part = pan + BMS * LDP;             // [4][BNS][2]
         const int qpb = p.stat_rows >> 4;          // 16-row quarters per statistics block: 1, 2 or 4
         for (int blk = 0; blk < WMT; ++blk) {
-            for (int c = tid & 63; c < BNS; c += 64) {
+            for (int c = tid & 63; c < BNS && tid < 256; c += 64) {        // (the first four waves: one 16-row quarter each)
                 const int q = tid >> 6;
                 const int n = n0 + c;
                 const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
@@ -308,7 +341,7 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
                 part[(q * BNS + c) * 2] = s; part[(q * BNS + c) * 2 + 1] = sq;
             }
             __syncthreads();
-            for (int idx = tid; idx < BNS * (4 / qpb); idx += 256) {
+            for (int idx = tid; idx < BNS * (4 / qpb); idx += NTH) {
                 const int c = idx % BNS, ob = idx / BNS;
                 const int n = n0 + c, mrow = m0 + blk * 64 + ob * p.stat_rows;
                 if (n < p.Cout && mrow < p.M) {
@@ -324,7 +357,7 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
     if (p.out_nchw) {
         // (hypothesis, Cout, Ho, Wo) planes: consecutive threads take consecutive pixels of one channel
         const int ncols = p.Cout - n0 < BNS ? p.Cout - n0 : BNS;
-        for (int idx = tid; idx < BMS * ncols; idx += 256) {
+        for (int idx = tid; idx < BMS * ncols; idx += NTH) {
             const int c = idx / BMS, row = idx - c * BMS;
             const int m = m0 + row, n = n0 + c;
             if (m >= p.M) continue;
@@ -346,14 +379,14 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
         // per row) -- read from LDS in the row loop instead of three global loads per element
         float* cbias = pan + BMS * LDP;            // [BNS] bias (+ c0), [BNS] c1   (the statistics scratch is free again)
         if (p.colstats) __syncthreads();
-        for (int c = tid; c < BNS; c += 256) {
+        for (int c = tid; c < BNS; c += NTH) {
             const int n = n0 + c;
             const bool okc = n < p.Cout;
             cbias[c] = (okc && p.bias ? p.bias[n] : 0.f) + (PN && okc ? p.pn_c0[n] : 0.f);
             if (PN) cbias[BNS + c] = okc ? p.pn_c1[n] : 0.f;
         }
         __syncthreads();
-        for (int idx = tid; idx < BMS * CH; idx += 256) {
+        for (int idx = tid; idx < BMS * CH; idx += NTH) {
             const int row = idx / CH, ch = idx - row * CH;
             const int m = m0 + row, n = n0 + ch * VEC;
             if (m >= p.M || n >= p.Cout) continue;          // (Cout % VEC == 0: whole chunks)
@@ -392,7 +425,7 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
     }
     // any Cout (not a whole number of 16-byte vectors): one element per thread and step
     const int ncols = p.Cout - n0 < BNS ? p.Cout - n0 : BNS;
-    for (int idx = tid; idx < BMS * ncols; idx += 256) {
+    for (int idx = tid; idx < BMS * ncols; idx += NTH) {
         const int row = idx / ncols, c = idx - row * ncols;
         const int m = m0 + row, n = n0 + c;
         if (m >= p.M) continue;
@@ -406,19 +439,20 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvParams p) {
     }
 }
 
-template <class T, int WMT, int WNT, int NS>
+template <class T, int WMT, int WNT, int NS, int KG = 1>
 void launch_small_t(const ConvParams& p, dim3 grid, hipStream_t s) {
-    const dim3 block(256);
-    if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_small_kernel<T, NOPE_CONV_PLAIN, WMT, WNT, NS, true>), grid, block, 0, s, p);
-    else if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_small_kernel<T, NOPE_CONV_PLAIN, WMT, WNT, NS, false>), grid, block, 0, s, p);
-    else if (p.mode == NOPE_CONV_UP2P) hipLaunchKernelGGL((conv_gemm_small_kernel<T, NOPE_CONV_UP2P, WMT, WNT, NS, false>), grid, block, 0, s, p);
-    else if (p.mode == NOPE_CONV_STRIDE2) hipLaunchKernelGGL((conv_gemm_small_kernel<T, NOPE_CONV_STRIDE2, WMT, WNT, NS, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((conv_gemm_small_kernel<T, NOPE_CONV_DOWN2, WMT, WNT, NS, false>), grid, block, 0, s, p);
+    const dim3 block(256 * KG);
+    if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_small_kernel<T, NOPE_CONV_PLAIN, WMT, WNT, NS, true, KG>), grid, block, 0, s, p);
+    else if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_small_kernel<T, NOPE_CONV_PLAIN, WMT, WNT, NS, false, KG>), grid, block, 0, s, p);
+    else if (p.mode == NOPE_CONV_UP2P) hipLaunchKernelGGL((conv_gemm_small_kernel<T, NOPE_CONV_UP2P, WMT, WNT, NS, false, KG>), grid, block, 0, s, p);
+    else if (p.mode == NOPE_CONV_STRIDE2) hipLaunchKernelGGL((conv_gemm_small_kernel<T, NOPE_CONV_STRIDE2, WMT, WNT, NS, false, KG>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv_gemm_small_kernel<T, NOPE_CONV_DOWN2, WMT, WNT, NS, false, KG>), grid, block, 0, s, p);
 }
 
 }  // namespace
 
-// tile: 0 = 64 x 64 (3-stage ring, 48 KiB: three workgroups per CU), 1 = 128 x 128 (3 stages, 96 KiB), 2 = 64 x 64 with a 6-stage ring
+// tile: 0 = 64 x 64 (3-stage ring, 48 KiB: three workgroups per CU), 1 = 128 x 128 (3 stages, 96 KiB), 3 = 64 x 64 by two K groups (512
+// threads, two 3-stage rings), 2 = 64 x 64 with a 6-stage ring
 // (96 KiB: four K steps in flight per workgroup -- launches with at most a workgroup or two per CU and a long K, where a tile's time
 // is its chain of memory round trips: the one-image encoder's 3x3 convs ran 0.45 us per K step on the 3-stage ring)
 void launch_conv_small(int dt, const void* params, int tile, dim3 grid, hipStream_t s) {
@@ -426,6 +460,7 @@ void launch_conv_small(int dt, const void* params, int tile, dim3 grid, hipStrea
 #define NOPE_SMALL_T(T)                                                        \
     do {                                                                       \
         if (tile == 1) launch_small_t<T, 2, 2, 3>(p, grid, s);                 \
+        else if (tile == 3) launch_small_t<T, 1, 1, 3, 2>(p, grid, s);         \
         else if (tile == 2) launch_small_t<T, 1, 1, 6>(p, grid, s);            \
         else launch_small_t<T, 1, 1, 3>(p, grid, s);                           \
     } while (0)

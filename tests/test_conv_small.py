@@ -17,9 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_small_tile_kernel_under_adversarial_interpreter(emu):
-    # (compute modes: 1 = bf16, 3 = bf16x3 split precision on f32 data, 0 = f32, 2 = f16; tiles: 0 = 64 x 64 / 3 stages, 1 = 128 x 128, 2 = 64 x 64 / 6 stages)
-    runs = [({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--dts", "1,0", "--tiles", "0,1,2"]),
-            ({"HIPEMU_SHUFFLE": "2"}, ["--dts", "3,2", "--tiles", "0,2", "--light"]),
+    # (compute modes: 1 = bf16, 3 = bf16x3 split precision on f32 data, 0 = f32, 2 = f16; tiles: 0 = 64 x 64 / 3 stages, 1 = 128 x 128, 2 = 64 x 64 / 6 stages, 3 = 64 x 64 by two K groups)
+    runs = [({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--dts", "1,0", "--tiles", "0,1,3"]),
+            ({"HIPEMU_SHUFFLE": "2"}, ["--dts", "3,2", "--tiles", "2,3", "--light"]),
             ({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "3"}, ["--unet16"]),      # a whole f16 U-Net schedule: fused statistics per 16 / 64 rows, fused PreNorm, NCHW bank
             ({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--unet16split"])]  # ... with its 3x3 convs split along K on the tap-resident kernel
     procs = []
@@ -36,7 +36,7 @@ def test_small_tile_kernel_under_adversarial_interpreter(emu):
 def test_small_tile_small_shapes_gpu(gpu):
     from tests import small_emu_case
     assert small_emu_case.run(gpu, "cuda", dts=(1, 0, 3, 2)) < 1.0
-    errs = {cdt: small_emu_case.run_unet(gpu, "cuda", 64, cdt, n_hyp=5, hw=16, tile=t) for cdt, t in (("f32", 0), ("bf16x3", 1), ("f16", 0), ("bf16", 2))}
+    errs = {cdt: small_emu_case.run_unet(gpu, "cuda", 64, cdt, n_hyp=5, hw=16, tile=t) for cdt, t in (("f32", 3), ("bf16x3", 1), ("f16", 0), ("bf16", 3))}
     print("U-Net (u_net_dim 64) with every eligible conv on the small-tile kernel: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     assert errs["f32"] < 1e-4 and errs["bf16x3"] < 1e-4 and errs["f16"] < 8e-3 and errs["bf16"] < 6e-2
 
