@@ -287,13 +287,13 @@ int launch_similarity(const float* q, const void* bank, int bank_dt, float* scor
     if (bank_dt != NOPE_F32 && bank_dt != NOPE_BF16 && bank_dt != NOPE_F16) return NOPE_ERR_UNSUPPORTED;
     const int vec = bank_dt == NOPE_F32 ? 4 : 8;
     if (HW % vec) return NOPE_ERR_UNSUPPORTED;
-    static const int variant = getenv("NOPE_SIM_VARIANT") ? atoi(getenv("NOPE_SIM_VARIANT")) : 1;    // tuning: 1 = non-temporal bank loads (0.69 -> 0.75-0.82 of HBM peak), 2 = one residency round of long workgroups, 8 = 4 pixels per lane for 16-bit banks
+    const int variant = getenv("NOPE_SIM_VARIANT") ? atoi(getenv("NOPE_SIM_VARIANT")) : 1;          // (read per launch: no state is kept between calls)    // tuning: 1 = non-temporal bank loads (0.69 -> 0.75-0.82 of HBM peak), 2 = one residency round of long workgroups, 8 = 4 pixels per lane for 16-bit banks
     // tuning: 16 = query tile in LDS for the 16-bit banks (6 instead of 4 waves per SIMD; measured SLOWER than the register tile with the
     // single-set pipeline: bf16 0.61 / 0.78 of peak at 32 x 512 / 32 x 2048 against 0.72 / 0.84, profiles/r03b_sim_bench.txt)
     const bool qlds = (variant & 16) && (long long)C * HW <= 8192 && HW % 8 == 0;
     // workgroups per sample: ~4096 in all, but at least NOPE_SIM_MINGROUPS template groups each (a workgroup's fixed cost is the 32 KiB
     // query tile: with two groups per workgroup -- 32 x 512 templates -- it is a third of the workgroup's traffic)
-    static const int min_groups = getenv("NOPE_SIM_MINGROUPS") ? atoi(getenv("NOPE_SIM_MINGROUPS")) : 1;
+    const int min_groups = getenv("NOPE_SIM_MINGROUPS") ? atoi(getenv("NOPE_SIM_MINGROUPS")) : 1;
     const int lv = (bank_dt != NOPE_F32 && (variant & 8) && C <= 8 && HW % 4 == 0 && HW / 4 <= NT) ? 4 : vec;
     const int P = HW / lv;
     const bool reg_ok = (P <= NT) && (NT % P == 0) && (C <= 16);

@@ -9,7 +9,7 @@ import os
 import re
 import sys
 
-CONV = ("conv_gemm_kernel", "conv_gemm_dma_kernel", "conv_gemm_pp_kernel", "conv3x3_halo_kernel")
+CONV = ("conv_gemm_kernel", "conv_gemm_dma_kernel", "conv_gemm_pp_kernel", "conv3x3_halo_kernel", "conv_gemm_small_kernel")
 
 
 def parse(path):
