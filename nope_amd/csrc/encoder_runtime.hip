@@ -12,8 +12,10 @@
 // a fixed-order reduce that also applies bias / residual / ReLU).  Activations live in five ping-pong buffers of a
 // caller-provided workspace: no allocation, no host sync, one stream.
 #include <cstdio>
+#include <cstdlib>
 #include <initializer_list>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -42,6 +44,7 @@ struct nope_encoder {
     std::vector<void*> allocs;
     mutable std::vector<EGraph> graphs;      // hipGraph cache (the ~85 launches of a pass are 5-15 us each at 1-2 images)
     mutable bool graphs_ok = true;           // cleared when capture is unavailable: direct launches from then on
+    mutable std::mutex graph_mu;             // the cache is edited from a const entry point while ctypes callers have released the GIL
     float* stem_w = nullptr;      // [147][64] f32, bn1 scale folded
     float* stem_shift = nullptr;  // [64]
     std::vector<Bottleneck> blocks;
@@ -293,6 +296,9 @@ int nope_encoder_forward(const nope_encoder* enc, const float* image, int n_img,
         ar.base = base + sb; ar.cap = workspace_bytes - sb;
         return run_encoder(enc, src, n_img, H, W, dst, ar, s);
     };
+    const bool graphs_wanted = !(getenv("NOPE_ENC_GRAPH") && atoi(getenv("NOPE_ENC_GRAPH")) == 0);      // (read per call: the tests compare both paths)
+    if (!graphs_wanted) return direct(image, out);
+    std::lock_guard<std::mutex> lock(enc->graph_mu);
     if (!enc->graphs_ok) return direct(image, out);
 
     const size_t in_bytes = (size_t)n_img * 3 * H * W * 4;

@@ -270,6 +270,33 @@ def test_unet_graph_replay_matches_direct(gpu):
         assert torch.equal(u.forward_hypotheses(x, poses[:, :5].contiguous()), direct5) and h.graph_replays() == 4
 
 
+def test_encoder_graph_replay_matches_direct(gpu):
+    """The encoder's hipGraph replay (on by default: 54 launches of 5-15 us) against direct launches (NOPE_ENC_GRAPH=0), on the default and on a
+    side stream (the stream `generate_and_retrieve` encodes the query on): equal bits."""
+    from nope_amd.encoder import FeatureExtractor
+    from nope_amd.weights import synth_init_
+    e = FeatureExtractor(8, 0.2, False, compute_dtype="f16")
+    synth_init_(e, 2022, prefix="encoder.")
+    e = e.cuda()
+    img = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(4)).cuda() * 2 - 1
+    side = torch.cuda.Stream()
+    outs = {}
+    for tag, env in (("graph", None), ("direct", "0")):
+        if env is not None:
+            os.environ["NOPE_ENC_GRAPH"] = env
+        a = e.encode_image(img)
+        b = e.encode_image(img)              # second call: the replay proper
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            c = e.encode_image(img)
+        side.synchronize()
+        torch.cuda.synchronize()
+        os.environ.pop("NOPE_ENC_GRAPH", None)
+        assert torch.equal(a, b) and torch.equal(a, c), tag
+        outs[tag] = a
+    assert torch.equal(outs["graph"], outs["direct"])
+
+
 def test_two_stream_split_close_to_single_batch(gpu):
     """`two_stream_below` (off by default): the two half batches on two HIP streams agree with the single batch to rounding -- not bit
     for bit, the halves have other GEMM row counts and so other launch plans -- and the bank is complete when the call returns."""
