@@ -173,6 +173,28 @@ def test_bench_batch_vs_oracle(gpu, model_f32, cdt, tol):
     assert e < tol
 
 
+@pytest.mark.parametrize("cdt,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("f16", 8e-3)])
+@pytest.mark.parametrize("n", [26, 64, 91])
+def test_reference_sized_banks_vs_oracle(gpu, model_f32, cdt, tol, n):
+    """The reference's own bank sizes (26 / 91 templates = upper-hemisphere icosphere levels 0 / 1, shapeNet.py:248-263) and the 64-template
+    shard of a 512-template bank, one reference image at a 32 x 32 latent through the full-size U-Net: the launch regime of round 4 -- small-tile
+    kernel, split-K on the tap-resident kernel with the statistics-emitting reduce, statistics folded inside gn_apply -- hypothesis by
+    hypothesis against the CPU restatement on four of them; and the same bank twice (every launch has a fixed summation order)."""
+    m = model_f32 if cdt == "f32" else cached_model(cdt, "f32")
+    g = torch.Generator().manual_seed(100 + n)
+    feat = torch.randn(1, 8, 32, 32, generator=g)
+    poses = torch.randn(1, n, 6, generator=g)
+    bank = m.generate_templates_from_feat(feat.cuda(), poses.cuda())
+    again = m.generate_templates_from_feat(feat.cuda(), poses.cuda())
+    assert torch.equal(bank, again), "not reproducible"
+    sel = [0, n // 3, n - 2, n - 1]
+    sd = {k: v.detach().cpu() for k, v in m.u_net.own_state_dict().items()}
+    want = R.generate_templates(sd, feat, poses[:, sel])
+    e = rel(bank.float().cpu()[:, sel], want)
+    print(f"{n}-template bank {cdt}: rel err {e:.2e} on hypotheses {sel}")
+    assert e < tol
+
+
 @pytest.fixture(scope="module")
 def cfg2_oracle(model_f32):
     """BASELINE configs[1] through the CPU restatement (about half a minute of host time), shared by the per-mode tests below."""
