@@ -329,7 +329,39 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
     bool inrange[TL::NTL];              // f16 storage: this lane's values of column tile j are known to lie inside the format's range
 #pragma unroll
     for (int j = 0; j < TL::NTL; ++j) inrange[j] = false;
-    if (p.colstats) {
+    if (p.colstats && p.stat_rows == 16) {
+        // ... per 16-row block: maps of 16 pixels (the 4 x 4 level: a wave's 64 rows are four samples).  A lane's accumulator registers
+        // r < 8 / r >= 8 of a 32 x 32 tile are rows 0-15 / 16-31 of it (out_row), a 16 x 16 tile is one block: the sums split in the lane,
+        // only the fold over the lanes that share a column stays.  Same order and single-writer rule as the 64-row form below.
+        constexpr int HALVES = TL::TM == 32 ? 2 : 1, RH = TL::R / HALVES;
+#pragma unroll
+        for (int j = 0; j < TL::NTL; ++j) {
+            const int n = n0 + wn * 96 + j * TL::TM + TL::out_col(lane);
+            const float bv = bvj[j];
+            float qtot = 0.f;
+#pragma unroll
+            for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                for (int h = 0; h < HALVES; ++h) {
+                    f32x2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+                    for (int r = h * RH; r < (h + 1) * RH; r += 2) {
+                        const f32x2_t v = f32x2_t{acc[i][j][r], acc[i][j][r + 1]} + bv;
+                        s2 += v; q2 += v * v;
+                    }
+                    float s = s2.x + s2.y, q = q2.x + q2.y;
+                    qtot += q;
+#pragma unroll
+                    for (int o = TL::TM; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+                    const int mrow = m0 + wm * 64 + i * TL::TM + h * 16;
+                    if (lane < TL::TM && n < p.Cout && mrow < p.M) {
+                        float* cs = p.colstats + ((size_t)(mrow >> 4) * p.Cout + n) * 2;
+                        cs[0] = s; cs[1] = q;
+                    }
+                }
+            if (Elt<T>::SATURATES) inrange[j] = qtot <= kF16Max * kF16Max;
+        }
+    } else if (p.colstats) {
         // GroupNorm statistics of the conv output, fused: per column (sum, sum of squares) over this wave's 64
         // rows, straight from the accumulators (f32, before the rounding to T): a lane adds up the rows it
         // holds, the 64/TM lanes sharing a column are folded with cross-lane adds.  Fixed order and exactly one

@@ -558,6 +558,7 @@ struct ConvPlan { bool dma, pp, posmajor, halo; int small; int hsplit; };      /
 static int plan_small(int dt, const ConvArgs& a, bool dma) {
     const int mode_env = getenv("NOPE_CONV_SMALL") ? atoi(getenv("NOPE_CONV_SMALL")) : 1;
     if (!dma || mode_env == 0 || a.mode == NOPE_CONV_UP2 || a.ntaps == 16 || a.force_generic) return -1;
+    if (mode_env == 1 && getenv("NOPE_CONV_PP") && (atoi(getenv("NOPE_CONV_PP")) & 8)) return -1;      // bit 3 = "ping-pong kernels at ANY tile count" (their tests)
     const bool phased = a.mode == NOPE_CONV_UP2P;
     const long long M = (long long)a.nhyp * (phased ? a.Hs * a.Ws : a.Ho * a.Wo);
     const long long tiles128 = (long long)cdiv((int)M, BM) * cdiv(a.Cout, BN) * (phased ? 4 : 1);
@@ -665,18 +666,21 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
 // Would launch_conv run this conv in position-major row order?
 bool conv_is_posmajor(int dt, const ConvArgs& a) { return plan_conv(dt, a).posmajor; }
 
-// Fused GroupNorm column statistics: every kernel emits them per 64-row block (64-row blocks must not straddle samples); the
-// small-tile kernel also per 16 / 32 rows, which covers the 4 x 4 level (16 pixels per sample) and removes its gn_stats pass.
+// Fused GroupNorm column statistics, rows per block (0: this conv cannot emit them): 64 wherever samples are whole 64-row blocks; 16 on
+// 16-pixel maps (the 4 x 4 level: per-sample blocks, every LDS-DMA kernel's wide epilogue, the small-tile kernel, the split-K reduce) -- which
+// removes that level's gn_stats passes; 32 on 32-pixel maps from the small-tile kernel and the split-K reduce.
 int conv_stat_rows(int dt, const ConvArgs& a) {
     const int vec = dt_vec(dt);
     if (a.mode == NOPE_CONV_UP2P || a.resid || a.out_nchw || a.Cout % vec || a.Cout > 2048) return 0;
     const long long HW = (long long)a.Ho * a.Wo, M = (long long)a.nhyp * HW;
+    if (HW % 64 == 0) return 64;
+    // 16-pixel maps (the 4 x 4 level): per-sample blocks of 16 rows -- every kernel with the wide epilogue, the small-tile kernel and the
+    // split-K reduce emit them; 32-pixel maps only the latter two
     ConvArgs b = a;
     b.colstats = nullptr;
-    if (halo_split_factor(dt, b) > 1)                 // split-K on the tap-resident kernel: the reduce kernel emits the statistics, per sample
-        return HW % 64 == 0 ? 64 : ((HW == 16 || HW == 32) && M % HW == 0 ? (int)HW : 0);      // or 64-row block
-    if (HW % 64 == 0) return 64;
-    if ((HW == 16 || HW == 32) && M % HW == 0 && plan_conv(dt, b).small >= 0) return (int)HW;
+    const bool small_or_split = halo_split_factor(dt, b) > 1 || plan_conv(dt, b).small >= 0;
+    if (HW == 16 && M % 16 == 0 && (small_or_split || plan_conv(dt, b).dma)) return 16;
+    if (HW == 32 && M % 32 == 0 && small_or_split) return 32;
     return 0;
 }
 
@@ -762,7 +766,8 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.w_phase_bytes = phased ? (unsigned)bw : 0u;
     const ConvPlan plan = plan_conv(dt, a);
     const bool dma = plan.dma;
-    if (a.colstats && a.stat_rows != 64 && plan.small < 0 && plan.hsplit <= 1) return NOPE_ERR_ARG;   // 16 / 32-row blocks: small-tile kernel or split-K reduce only
+    if (a.colstats && a.stat_rows == 32 && plan.small < 0 && plan.hsplit <= 1) return NOPE_ERR_ARG;   // 32-row blocks: small-tile kernel or split-K reduce only
+    if (a.colstats && a.stat_rows == 16 && plan.small < 0 && plan.hsplit <= 1 && (!dma || plan.posmajor)) return NOPE_ERR_ARG;
     p.bytes1 = (unsigned)(dma ? b1 : 0); p.bytes2 = (unsigned)(dma ? b2 : 0); p.bytesw = (unsigned)(dma ? bw : 0);
     // NOPE_CONV_VARIANT=4 selects the 256x192 / 8-wave tile (measured on par with the default 128x192 / 4-wave
     // tile in round 1; kept for tuning, see DESIGN.md section 4 for the other variants that were tried).
