@@ -679,7 +679,8 @@ int conv_stat_rows(int dt, const ConvArgs& a) {
     ConvArgs b = a;
     b.colstats = nullptr;
     const bool small_or_split = halo_split_factor(dt, b) > 1 || plan_conv(dt, b).small >= 0;
-    if (HW == 16 && M % 16 == 0 && (small_or_split || plan_conv(dt, b).dma)) return 16;
+    const bool wide16 = !(getenv("NOPE_STATS16") && atoi(getenv("NOPE_STATS16")) == 0);      // (A/B switch: 0 = the 128 x 192 / ping-pong kernels leave 16-pixel maps to gn_stats)
+    if (HW == 16 && M % 16 == 0 && (small_or_split || (wide16 && plan_conv(dt, b).dma))) return 16;
     if (HW == 32 && M % 32 == 0 && small_or_split) return 32;
     return 0;
 }

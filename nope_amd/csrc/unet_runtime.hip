@@ -269,10 +269,11 @@ struct Fwd {
         int nch = 1;
         GnApplyArgs ga;
         if (st.cs) {
-            // Small batches: every gn_apply workgroup folds its sample's column statistics itself (the fold is st.blocks * C * 8 bytes
-            // per workgroup out of L2; a separate launch costs ~8 us).  Large ones keep the fold launch: at 512 hypotheses the six
-            // workgroups of a level-0 sample would each repeat a 24 KiB fold (+0.25 ms per step, measured in round 2).
-            const long long fold_inline_max = getenv("NOPE_GN_FOLD_INLINE") ? atoll(getenv("NOPE_GN_FOLD_INLINE")) : 16ll << 20;
+            // Every gn_apply workgroup folds its sample's column statistics itself (st.blocks * C * 8 bytes out of L2 per workgroup; a
+            // separate fold launch costs ~7 us + a kernel boundary).  Round 2 measured the inline fold +0.25 ms per 512-hypothesis step
+            // (one thread per group then); with the wave-wide group sums of round 4 it is -0.02 .. -0.05 ms there and -0.2 ms at 64
+            // hypotheses (profiles/r04o_fold_inline_ab.txt): always on.  NOPE_GN_FOLD_INLINE = most re-read bytes per launch (0 = never).
+            const long long fold_inline_max = getenv("NOPE_GN_FOLD_INLINE") ? atoll(getenv("NOPE_GN_FOLD_INLINE")) : (1ll << 50);
             const long long refold = (long long)nhyp * gn_apply_blocks(HW, nm.C, net->sdt, nhyp) * st.blocks * nm.C * 8;
             if (refold <= fold_inline_max) { ga.colstats = st.cs; ga.stat_blocks = st.blocks; }
             else chk(launch_gn_fold(st.cs, gn_partial, nx, st.blocks, nm.C, G, s));
