@@ -1,7 +1,10 @@
 """GPU-only randomized sweeps of the operator entry points of the C ABI. Conv: against torch's own convolution (float64) on the
 same (dtype-rounded) operands: 120 seeded draws over tap geometry, channel counts on and off the LDS-DMA path, virtual
 concat with broadcast sources, bias / residual / ReLU / NCHW epilogues and the launch regimes that switch code paths
-(position-major rows on small maps with a multiple of 128 samples, persistent tile walk above 512 tiles)."""
+(position-major rows on small maps with a multiple of 128 samples, persistent tile walk above 512 tiles), each draw under three launch
+policies: the default (round 4: small-tile kernel for launches that cannot fill the chip), the round-3 kernels alone (NOPE_CONV_SMALL=0)
+and with the split-K scratch the runtimes hand the launcher (split-K on the tap-resident and the 128 x 192 kernel)."""
+import os
 import random
 
 import pytest
@@ -68,8 +71,14 @@ def test_conv_random_sweep(gpu, dt):
         relu = rng.random() < 0.3
         nchw = (not use_res) and mode != hip.CONV_UP2P and rng.random() < 0.2
         rs = rn(n, cout, ho, wo) if use_res else None
-        y = hip.op_conv(dt, hip.to_nhwc(x1, dt), wt, b, src2=None if x2 is None else hip.to_nhwc(x2, dt), mode=mode, rep1=rep1,
-                        resid=None if rs is None else hip.to_nhwc(rs, dt), n_hyp=n, out_nchw=nchw, out_dtype=hip.F32, act_relu=relu)
+        ys = []
+        for env, split_k in (({}, False), ({"NOPE_CONV_SMALL": "0"}, False), ({"NOPE_HALO_SPLIT_MIN_CHUNKS": "2"}, True)):
+            os.environ.update(env)
+            ys.append(hip.op_conv(dt, hip.to_nhwc(x1, dt), wt, b, src2=None if x2 is None else hip.to_nhwc(x2, dt), mode=mode, rep1=rep1,
+                                  resid=None if rs is None else hip.to_nhwc(rs, dt), n_hyp=n, out_nchw=nchw, out_dtype=hip.F32, act_relu=relu,
+                                  split_k=split_k))
+            for k in env:
+                os.environ.pop(k)
         xin = q(x1).repeat_interleave(rep1, 0)
         if x2 is not None:
             xin = torch.cat((xin, q(x2)), 1)
@@ -79,10 +88,11 @@ def test_conv_random_sweep(gpu, dt):
             want = want + q(rs).double()
         if relu:
             want = F.relu(want)
-        got = y if nchw else hip.to_nchw(y, dt)
-        e = rel(got.double(), want)
-        worst = max(worst, e)
-        assert e < tol, (it, mode, ks, c1, c2, cout, n, h, w_, rep1, use_res, relu, nchw, e)
+        for pol, y in enumerate(ys):
+            got = y if nchw else hip.to_nchw(y, dt)
+            e = rel(got.double(), want)
+            worst = max(worst, e)
+            assert e < tol, (it, pol, mode, ks, c1, c2, cout, n, h, w_, rep1, use_res, relu, nchw, e)
     print(f"conv sweep dtype {dt}: worst rel err {worst:.2e}")
 
 
