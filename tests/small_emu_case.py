@@ -39,9 +39,7 @@ def run(hip, dev, dts=(1, 0), tiles=(0, 1, 2, 3), light=False):
                 os.environ["NOPE_SMALL_TILE"] = str(tile)
                 y = fn()
                 os.environ.pop("NOPE_SMALL_TILE")
-                yy = hip.to_nchw(y, dt).cpu() if y.dim() == 4 and y.shape[-1] != ref.shape[-1] or (y.dtype != torch.float32) else y.cpu().float()
-                if yy.shape != ref.shape:
-                    yy = hip.to_nchw(y, dt).cpu()
+                yy = y.cpu().float() if tuple(y.shape) == tuple(ref.shape) else hip.to_nchw(y, dt).cpu()      # (NCHW f32 outputs come back as they are)
                 e = rel(yy, ref)
                 worst = max(worst, e / t)
                 assert e < t, (what, dt, tile, e)
