@@ -603,7 +603,10 @@ static int halo_split_factor(int dt, const ConvArgs& a) {
     const int nchunks = Cin / bk;
     const long long tiles = (long long)cdiv((int)M, 256) * cdiv(a.Cout, BN);
     const int min_chunks = getenv("NOPE_HALO_SPLIT_MIN_CHUNKS") ? atoi(getenv("NOPE_HALO_SPLIT_MIN_CHUNKS")) : 12;
-    if (tiles >= 128 || nchunks < min_chunks) return 1;
+    // 128 tiles split in two fill the 256 CUs in one round (256 hypotheses at the 4 x 4 level: 11.35 -> 10.76 ms per step, run t); above that a
+    // split needs a second round of workgroups and loses (176 tiles, 341 hypotheses: 14.8 -> 15.3 ms)
+    const int max_tiles = getenv("NOPE_HALO_SPLIT_MAX_TILES") ? atoi(getenv("NOPE_HALO_SPLIT_MAX_TILES")) : 128;
+    if (tiles > max_tiles || nchunks < min_chunks) return 1;
     // as many splits as fit ONE round of 256 workgroups (one per CU: 158 KiB of LDS each): 88 tiles x 3 = 264 would run a second
     // round for 8 of them
     int S = (int)(256 / tiles);
