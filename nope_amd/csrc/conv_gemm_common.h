@@ -48,7 +48,7 @@ struct ConvParams {
     int act;                           // 0 none, 1 ReLU (after bias and residual)
     int tiles_m, tiles_n, xcd_map, wide_out;
     int nchw_staged;                   // out_nchw through the per-wave LDS panels (epilogue_nchw): whole 64-row blocks inside one sample
-    int xcd_gn;                        // xcd_map == 2: XCD columns the weight panels are split over (tile_coords)
+    int xcd_gn;                        // (xcd_map: 0 none, 1 one panel per XCD, 2 below, 3 small-tile kernel, 4 any tiles_n) xcd_map == 2: XCD columns the weight panels are split over (tile_coords)
     int variant;                       // tuning switches (NOPE_CONV_VARIANT), 0 in production
     FastDiv d_hw, d_w, d_rep1, d_rep2; // / (Hm*Wm), / Wm, / rep1, / rep2
     unsigned char pos_order[64];       // posmajor: pixel positions by descending number of valid taps
@@ -172,6 +172,13 @@ __device__ __forceinline__ void tile_coords(const ConvParams& p, int& tile_m, in
         const int xm = x / p.xcd_gn, xn = x - xm * p.xcd_gn;
         tile_n = xn * span + (j & (span - 1));
         tile_m = xm * (p.tiles_m / (8 / p.xcd_gn)) + j / span;
+    } else if (p.xcd_map == 4) {   // any tiles_n (the LDM variant's 256 / 512 / 1024-channel linears: 3, 6, 11, 22 ... panels), tiles_m % 8 == 0
+        // XCD x owns a contiguous run of tiles_m / 8 M tiles and walks every weight panel of each before the next: an activation
+        // tile crosses the fabric once instead of once per XCD its tiles_n consumers would otherwise land on
+        const int x = g & 7, j = g >> 3;
+        const int q = j / p.tiles_n;
+        tile_n = j - q * p.tiles_n;
+        tile_m = x * (p.tiles_m >> 3) + q;
     } else if (p.xcd_map) {   // tiles_n in {1,2,4,8}, tiles_m % (8 / tiles_n) == 0
         // XCD x = g & 7 keeps one weight panel (tile_n) and a CONTIGUOUS run of M tiles, so the
         // 3x3 halo rows shared by neighbouring tiles hit the same XCD's L2.

@@ -837,6 +837,8 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         }
         if (p.xcd_gn != tn) p.xcd_map = 2;
     }
+    // Panel counts outside {1, 2, 4, 8} (no launch of the default U-Net; the LDM variant's linears): map 4 of tile_coords.  NOPE_XCD_ANY=0: off.
+    if (!p.xcd_map && plan.small < 0 && tn > 1 && p.tiles_m % 8 == 0 && !(getenv("NOPE_XCD_ANY") && atoi(getenv("NOPE_XCD_ANY")) == 0)) p.xcd_map = 4;
     // Persistent walk: 512 workgroups (2 per CU), each `iters` tiles 64 / span tile_m apart (same XCD, same weight panel; span =
     // panels an XCD interleaves under map 2).
     p.persist_iters = 1; p.persist_d1 = p.persist_d2 = 0; p.persist_dm = 0; p.timeline = nullptr;
@@ -845,7 +847,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         const long long hw = (long long)a.Hs * a.Ws;
         static const int persist_on = getenv("NOPE_CONV_PERSIST") ? atoi(getenv("NOPE_CONV_PERSIST")) : 1;
         const int span = p.xcd_map == 2 ? tn / p.xcd_gn : 1;
-        if (persist_on && dma && plan.small < 0 && bm == BM && dt != NOPE_F32 && a.mode == NOPE_CONV_PLAIN && !p.posmajor && p.splits == 1 && p.xcd_map &&
+        if (persist_on && dma && plan.small < 0 && bm == BM && dt != NOPE_F32 && a.mode == NOPE_CONV_PLAIN && !p.posmajor && p.splits == 1 && p.xcd_map && p.xcd_map != 4 &&
             p.wide_out && a.rep1 == 1 && a.rep2 == 1 && M % BM == 0 && nblocks > 512 && nblocks % 512 == 0 && 64 % span == 0 &&
             ((64ll / span) * BM) % hw == 0 && !(variant & 2)) {
             p.persist_iters = (int)(nblocks / 512);
@@ -858,7 +860,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     // The tap-resident kernel walks tiles too (bf16): one workgroup per CU, tiles gx / 8 apart inside the XCD's run of M tiles,
     // the next tile's prologue in flight under the epilogue.  NOPE_HALO_PERSIST = workgroups (default 256, 0 = one tile per
     // workgroup; read per launch: the tests use small grids).
-    if (plan.halo && dt != NOPE_F32 && p.xcd_map) {
+    if (plan.halo && dt != NOPE_F32 && p.xcd_map && p.xcd_map != 4) {
         const int want = getenv("NOPE_HALO_PERSIST") ? atoi(getenv("NOPE_HALO_PERSIST")) : 256;
         const long long hw = (long long)a.Hs * a.Ws;
         const int span = p.xcd_map == 2 ? tn / p.xcd_gn : 1;     // workgroups of one XCD that share an M tile

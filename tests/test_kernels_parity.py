@@ -554,6 +554,28 @@ def test_conv_persistent_walk(be):
         assert rel(hip.to_nchw(y, dt).cpu(), F.conv2d(q(x), q(w3), padding=1)) < BF16_TOL
 
 
+def test_conv_any_panel_count_xcd_map(be, monkeypatch):
+    """Panel counts outside {1, 2, 4, 8} (the LDM variant's 256 / 512 / 1024-channel linears: Cout 576 = 3 panels of 192, ragged 400 = 3) with
+    tiles_m % 8 == 0 take tile_coords' map 4 (every XCD a run of M tiles, all panels of each): each output tile still written exactly once,
+    bit-identical to the unmapped order."""
+    hip, dev, kind = be
+    g = torch.Generator().manual_seed(43)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    d = lambda x: x.to(dev)
+    monkeypatch.setenv("NOPE_CONV_SMALL", "0")          # (so few tiles would otherwise go to the small-tile kernel, which has its own map)
+    for dt, tol in ((hip.BF16, BF16_TOL), (hip.F32, 1e-5)):
+        q = lambda x: _q(x, dt, hip)
+        for cout, ks in ((576, 1), (400, 1), (1000, 3) if kind == "gpu" else (400, 1)):
+            x, w, b, rs = rn(16, 64, 8, 8), rn(cout, 64, ks, ks) / (8 * ks), rn(cout), rn(16, cout, 8, 8)      # M = 1024 rows = 8 tiles of 128
+            args = (dt, hip.to_nhwc(d(x), dt), d(w), d(b))
+            y = hip.op_conv(*args, resid=hip.to_nhwc(d(rs), dt))
+            assert rel(hip.to_nchw(y, dt).cpu(), F.conv2d(q(x), q(w), b, padding=ks // 2) + q(rs)) < tol
+            monkeypatch.setenv("NOPE_XCD_ANY", "0")
+            y0 = hip.op_conv(*args, resid=hip.to_nhwc(d(rs), dt))
+            monkeypatch.delenv("NOPE_XCD_ANY")
+            assert torch.equal(y.cpu(), y0.cpu())
+
+
 @pytest.mark.parametrize("n_hyp", [1, 3])
 def test_workspace_canary_odd_hypotheses(be, n_hyp):
     """with M % 128 == 64 (odd hypothesis count on an 8x8 map) the fused GroupNorm-statistics epilogue of the
