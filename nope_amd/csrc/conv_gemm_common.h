@@ -47,6 +47,7 @@ struct ConvParams {
     int out_nchw, out_dt;
     int act;                           // 0 none, 1 ReLU (after bias and residual)
     int tiles_m, tiles_n, xcd_map, wide_out;
+    int geglu;                         // host side only: selects the GEGLU-epilogue instantiation (ConvArgs::geglu)
     int nchw_staged;                   // out_nchw through the per-wave LDS panels (epilogue_nchw): whole 64-row blocks inside one sample
     int xcd_gn;                        // (xcd_map: 0 none, 1 one panel per XCD, 2 below, 3 small-tile kernel, 4 any tiles_n) xcd_map == 2: XCD columns the weight panels are split over (tile_coords)
     int variant;                       // tuning switches (NOPE_CONV_VARIANT), 0 in production
@@ -315,7 +316,8 @@ template <class T> struct Ep {
 // DRAIN: wait for the vector-memory queue (a prefetch issued before the call) after the first panel is filled, before the
 // first store.
 struct NoStamp { __device__ __forceinline__ void operator()() const {} };
-template <class T, bool PN, bool DRAIN = false, class Stamp = NoStamp>
+// GG: GEGLU on column pairs (ConvArgs::geglu; packed 16-bit path only -- the launcher guarantees it is the one taken).
+template <class T, bool PN, bool DRAIN = false, class Stamp = NoStamp, bool GG = false>
 __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL],
                                               int m0, int n0, int wm, int wn, int lane, unsigned char* lds_wave, Stamp stamp = Stamp()) {
     typedef Tile<T> TL;
@@ -477,7 +479,20 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                         lo[k] = (e & 0xffffu) | (o << 16);
                         hi[k] = (e >> 16) | (o & 0xffff0000u);
                     }
-                    if (n < p.Cout) {
+                    if constexpr (GG) {
+                        // the lane's 8 columns are four (x, gate) pairs, already rounded to T exactly as a stored projection would be: x * gelu(gate),
+                        // four values = 8 bytes per row into the [M][Cout / 2] output
+                        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                        float vl[8], vh[8];
+                        Elt<T>::unpack(lo, vl);
+                        Elt<T>::unpack(hi, vh);
+                        const u32x2_t yl = {Elt<T>::cvt_pk(geglu_f(vl[0], vl[1]), geglu_f(vl[2], vl[3])), Elt<T>::cvt_pk(geglu_f(vl[4], vl[5]), geglu_f(vl[6], vl[7]))};
+                        const u32x2_t yh = {Elt<T>::cvt_pk(geglu_f(vh[0], vh[1]), geglu_f(vh[2], vh[3])), Elt<T>::cvt_pk(geglu_f(vh[4], vh[5]), geglu_f(vh[6], vh[7]))};
+                        if (n < p.Cout) {
+                            if (ok[t][0]) *reinterpret_cast<u32x2_t*>(out + (ro[t][0] >> 1) + (n >> 1)) = yl;
+                            if (ok[t][1]) *reinterpret_cast<u32x2_t*>(out + (ro[t][1] >> 1) + (n >> 1)) = yh;
+                        }
+                    } else if (n < p.Cout) {
                         if (ok[t][0]) st16(out + ro[t][0] + n, lo);
                         if (ok[t][1]) st16(out + ro[t][1] + n, hi);
                     }

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(ConvParams p) {
 // step k+1 fly under the MFMAs of step k, and nothing passes through VGPRs or ds_write.
 
 // RB = bytes of K per row per stage (128), NS = LDS stages (2), BMT = tile rows (128: 4 waves, 256: 8 waves).
-template <class T, int MODE, int RB, int NS, int BMT, bool PN>
+template <class T, int MODE, int RB, int NS, int BMT, bool PN, bool GG = false>
 __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p) {
     constexpr int VEC = Elt<T>::VEC;
     constexpr unsigned ES = (unsigned)sizeof(T);
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
                     ld_tap = 0; ld_kc = 0;
                     if (nk > 0) issue(0);          // stage 0 of the next tile; the panels below sit in stage 1
                 }
-                epilogue_wide<T, PN>(p, acc, m0e, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
+                epilogue_wide<T, PN, false, NoStamp, GG>(p, acc, m0e, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
 #pragma unroll
                 for (int i = 0; i < Tile<T>::MT; ++i)
 #pragma unroll
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
         } else epilogue_split<T>(p, acc, m0, n0, wm, wn, lane);
     } else if (p.wide_out) {
         __syncthreads();                       // every wave is done reading the last stage
-        epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
+        epilogue_wide<T, PN, false, NoStamp, GG>(p, acc, m0, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
     } else if (!PN && p.nchw_staged) {
         __syncthreads();
         epilogue_nchw<T>(p, acc, m0, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
@@ -525,6 +525,9 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
 
 template <class T, int RB, int NS, int BMT>
 void launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
+    if constexpr (sizeof(T) == 2 && BMT == 128 && RB == 128) {
+        if (p.geglu) { hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT, false, true>), grid, dim3(BMT * 2), 0, s, p); return; }
+    }
     if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT, true>), grid, dim3(BMT * 2), 0, s, p);   // 1x1 only
     else if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT, false>), grid, dim3(BMT * 2), 0, s, p);
     else if (p.mode == NOPE_CONV_UP2) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_UP2, RB, NS, BMT, false>), grid, dim3(BMT * 2), 0, s, p);
@@ -631,7 +634,7 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     // LDS-DMA kernels: a K step (128 B of channels) never straddles sources and 32-bit offsets suffice
     // (the 4x4 stride-2 conv of the non-default soft downsampling runs on the generic kernel: its tap geometry is not a 3x3 mask)
     pl.dma = !a.force_generic && a.ntaps != 16 && Cin % bk == 0 && (a.C2 == 0 || (a.C1 % bk == 0 && a.mode == NOPE_CONV_PLAIN)) && b1 < lim && b2 < lim && bw < lim;
-    if (!pl.dma) return pl;
+    if (!pl.dma || a.geglu) return pl;          // (GEGLU epilogue: an instantiation of the 128 x 192 kernel only)
     if (a.splitk_ws) {
         const int hs = halo_split_factor(dt, a);
         const long long Mr = (long long)a.nhyp * a.Ho * a.Wo;
@@ -664,6 +667,22 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     pl.halo = pl.pp && !pl.posmajor && a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.Ws <= conv_halo_max_width() && a.rep1 == 1 &&
               !(pp_mode & 16);
     return pl;
+}
+
+// ConvArgs::geglu: 16-bit storage, a plain 1x1 conv on the 128 x 192 LDS-DMA kernel's packed wide epilogue (no residual / statistics / PreNorm /
+// activation / split), column pairs whole inside a lane's 8-column chunk and 8-byte output rows
+static bool geglu_shape_ok(int dt, const ConvArgs& a, const ConvPlan& pl) {
+    static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
+    return dt_es(dt) == 2 && a.mode == NOPE_CONV_PLAIN && a.ntaps == 1 && !a.resid && !a.colstats && !a.pn_ms && !a.out_nchw && !a.act && !a.splitk_ws &&
+           a.Cout % 16 == 0 && pl.dma && !pl.pp && pl.small < 0 && !pl.posmajor && variant == 0;
+}
+bool conv_geglu_fusable(int dt, const ConvArgs& a0) {
+    const int mode = getenv("NOPE_GEGLU_FUSED") ? atoi(getenv("NOPE_GEGLU_FUSED")) : 1;      // (A/B switch, read per call; 2: only launches the 128 x 192 kernel would get anyway)
+    if (mode == 0) return false;
+    if (mode == 2) { const ConvPlan q = plan_conv(dt, a0); if (q.pp || q.small >= 0) return false; }
+    ConvArgs a = a0;
+    a.geglu = 1;
+    return geglu_shape_ok(dt, a, plan_conv(dt, a));
 }
 
 // Would launch_conv run this conv in position-major row order?
@@ -770,6 +789,8 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.w_phase_bytes = phased ? (unsigned)bw : 0u;
     const ConvPlan plan = plan_conv(dt, a);
     const bool dma = plan.dma;
+    if (a.geglu && !geglu_shape_ok(dt, a, plan)) return NOPE_ERR_UNSUPPORTED;
+    p.geglu = a.geglu;
     if (a.colstats && a.stat_rows == 32 && plan.small < 0 && plan.hsplit <= 1) return NOPE_ERR_ARG;   // 32-row blocks: small-tile kernel or split-K reduce only
     if (a.colstats && a.stat_rows == 16 && plan.small < 0 && plan.hsplit <= 1 && (!dma || plan.posmajor)) return NOPE_ERR_ARG;
     p.bytes1 = (unsigned)(dma ? b1 : 0); p.bytes2 = (unsigned)(dma ? b2 : 0); p.bytesw = (unsigned)(dma ? bw : 0);
@@ -870,12 +891,12 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         }
     }
     const dim3 grid(gx, phased ? 4u : 1u, (unsigned)p.splits), block(NT);
-    static const bool trace = getenv("NOPE_CONV_TRACE") != nullptr;     // tuning aid: one line per launch
+    const bool trace = getenv("NOPE_CONV_TRACE") != nullptr;     // tuning aid: one line per launch (read per launch: a test switches it on)
     if (trace && plan.small >= 0) fprintf(stderr, "conv small%d mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u xcd %d/%d\n", plan.small, a.mode, a.ntaps, Cin, a.Cout, M,
                                         p.tiles_m, p.tiles_n, grid.x, grid.y, grid.z, p.xcd_map, p.xcd_gn);
-    else if (trace) fprintf(stderr, "conv %s mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u posmajor %d persist %d xcd %d/%d\n",
+    else if (trace) fprintf(stderr, "conv %s mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u posmajor %d persist %d xcd %d/%d%s\n",
                        plan.halo ? "halo256" : plan.pp ? "pp256" : dma ? "dma128" : "generic", a.mode, a.ntaps, Cin, a.Cout, M, p.tiles_m, p.tiles_n, grid.x, grid.y, grid.z,
-                       p.posmajor, p.persist_iters, p.xcd_map, p.xcd_gn);
+                       p.posmajor, p.persist_iters, p.xcd_map, p.xcd_gn, a.geglu ? " geglu" : "");
     if (plan.small >= 0) {
         launch_conv_small(dt, &p, plan.small, grid, s);
     } else if (plan.pp) {

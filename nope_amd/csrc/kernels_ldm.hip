@@ -44,7 +44,8 @@ __global__ __launch_bounds__(NT) void layernorm_kernel(const T* __restrict__ x, 
 }
 
 // ---- GEGLU (attention.py:37-44): in (M, 2*D) = [x | gate] -> out (M, D) = x * gelu(gate), exact (erf) GELU ---------------
-template <class T>
+// (IL: the columns of `in` are (x_j, gate_j) pairs -- the layout the runtime packs the projection's rows in for the fused epilogue)
+template <class T, bool IL>
 __global__ __launch_bounds__(NT) void geglu_kernel(const T* __restrict__ in, T* __restrict__ out, long long M, int D) {
     constexpr int VEC = Elt<T>::VEC;
     const int nv = D / VEC;
@@ -53,10 +54,18 @@ __global__ __launch_bounds__(NT) void geglu_kernel(const T* __restrict__ in, T* 
         const long long m = i / nv;
         const int v = (int)(i - m * nv);
         float a[VEC], g[VEC];
-        Elt<T>::unpack(ld16(in + m * 2 * D + v * VEC), a);
-        Elt<T>::unpack(ld16(in + m * 2 * D + D + v * VEC), g);
+        if (IL) {
+            float lo[VEC], hi[VEC];
+            Elt<T>::unpack(ld16(in + m * 2 * D + 2 * v * VEC), lo);
+            Elt<T>::unpack(ld16(in + m * 2 * D + 2 * v * VEC + VEC), hi);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) a[e] = a[e] * (0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752f)));
+            for (int e = 0; e < VEC / 2; ++e) { a[e] = lo[2 * e]; g[e] = lo[2 * e + 1]; a[VEC / 2 + e] = hi[2 * e]; g[VEC / 2 + e] = hi[2 * e + 1]; }
+        } else {
+            Elt<T>::unpack(ld16(in + m * 2 * D + v * VEC), a);
+            Elt<T>::unpack(ld16(in + m * 2 * D + D + v * VEC), g);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = geglu_f(a[e], g[e]);
         st16(out + m * D + v * VEC, Elt<T>::pack(a));
     }
 }
@@ -306,11 +315,12 @@ int launch_layernorm(int dt, const void* x, void* y, const float* gamma, const f
     return NOPE_OK;
 }
 
-int launch_geglu(int dt, const void* in, void* out, long long M, int D, hipStream_t s) {
+int launch_geglu(int dt, const void* in, void* out, long long M, int D, hipStream_t s, int interleaved) {
     const int vec = dt_vec(dt);
     if (!in || !out || M <= 0 || D <= 0 || D % vec) return NOPE_ERR_ARG;
     const dim3 grid(grid_for_ll(M * (D / vec)));
-    NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((geglu_kernel<T>), grid, dim3(NT), 0, s, (const T*)in, (T*)out, M, D));
+    if (interleaved) { NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((geglu_kernel<T, true>), grid, dim3(NT), 0, s, (const T*)in, (T*)out, M, D)); }
+    else { NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((geglu_kernel<T, false>), grid, dim3(NT), 0, s, (const T*)in, (T*)out, M, D)); }
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

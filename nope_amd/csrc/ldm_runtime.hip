@@ -81,6 +81,37 @@ struct Loader {
         net->allocs.push_back(p);
         return p;
     }
+    std::vector<void*> temps;                  // staging buffers of create time, freed after its final synchronize
+    void* tmalloc(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { if (err == NOPE_OK) err = NOPE_ERR_ALLOC; return nullptr; }
+        temps.push_back(p);
+        return p;
+    }
+    void free_temps() { for (void* p : temps) hipFree(p); temps.clear(); }
+    // GEGLU's projection (attention.py:37-44: `x, gate = proj(x).chunk(2, dim=-1)`): rows (x_j, gate_j) interleaved, so that a lane of the conv
+    // epilogue holds whole pairs (ConvArgs::geglu); the unfused path reads the same layout (launch_geglu(..., interleaved))
+    LConv conv_geglu(const std::string& pfx, int Cin, int D) {
+        LConv c;
+        c.Cin = Cin; c.Cout = 2 * D; c.mode = NOPE_CONV_PLAIN; c.ntaps = 1;
+        const nope_tensor_desc* d = get(pfx + "weight", {2 * D, Cin});
+        const nope_tensor_desc* bd = get(pfx + "bias", {2 * D});
+        if (!d || !bd) return c;
+        float* wi = (float*)tmalloc((size_t)2 * D * Cin * 4);
+        c.w = dmalloc((size_t)2 * D * Cin * (size_t)dt_es(net->dt));
+        c.bias = (float*)dmalloc((size_t)2 * D * 4);
+        if (!wi || !c.w || !c.bias) return c;
+        const size_t rb = (size_t)Cin * 4;
+        const float* w0 = (const float*)d->data;
+        const float* b0 = (const float*)bd->data;
+        bool ok = hipMemcpy2DAsync(wi, 2 * rb, w0, rb, rb, D, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                  hipMemcpy2DAsync(wi + Cin, 2 * rb, w0 + (size_t)D * Cin, rb, rb, D, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                  hipMemcpy2DAsync(c.bias, 8, b0, 4, 4, D, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                  hipMemcpy2DAsync(c.bias + 1, 8, b0 + D, 4, 4, D, hipMemcpyDeviceToDevice, s) == hipSuccess;
+        if (!ok) { chk(NOPE_ERR_LAUNCH); return c; }
+        chk(launch_pack_conv_w(net->dt, wi, c.w, 2 * D, Cin, 1, NOPE_CONV_PLAIN, s));
+        return c;
+    }
     float* copy_f32(const std::string& name, std::initializer_list<int64_t> shape) {
         const nope_tensor_desc* d = get(name, shape);
         if (!d) return nullptr;
@@ -150,7 +181,7 @@ struct Loader {
         const nope_tensor_desc* wv = get(b + "attn1.to_v.weight", {C, C});
         t.qkv.Cin = C; t.qkv.Cout = 3 * C; t.qkv.ntaps = 1;
         if (wq && wk && wv) {
-            float* cat = (float*)dmalloc((size_t)3 * C * C * 4);
+            float* cat = (float*)tmalloc((size_t)3 * C * C * 4);
             const size_t es = (size_t)dt_es(net->dt);
             t.qkv.w = dmalloc((size_t)3 * C * C * es);
             if (cat && t.qkv.w) {
@@ -175,7 +206,7 @@ struct Loader {
             u_parts.push_back(UPart{comb, o2_b, C, u_total});
             u_total += C;
         }
-        t.ff1 = conv(b + "ff.net.0.proj.", C, 8 * C, 1, NOPE_CONV_PLAIN, true, true);
+        t.ff1 = conv_geglu(b + "ff.net.0.proj.", C, 4 * C);
         t.ff2 = conv(b + "ff.net.2.", 4 * C, C, 1, NOPE_CONV_PLAIN, true, true);
         T.blocks.push_back(t);
         }
@@ -303,8 +334,20 @@ struct Fwd {
             // feed-forward (GEGLU) + residual
             void* f = o;                                     // reuse: LN3(tok1)
             if (live()) chk(launch_layernorm(net->sdt, tok1, f, B.ln3.gamma, B.ln3.beta, M, C, 1e-5f, s));
-            conv(B.ff1, Act{f, C, x.H, x.W}, g, x.H, x.W);
-            if (live()) chk(launch_geglu(net->sdt, g, gg, M, 4 * C, s));
+            // (x_j, gate_j) column pairs: x * gelu(gate) in the projection's epilogue where the launch qualifies (16-bit modes on the
+            //  128 x 192 kernel), else the projection as stored + geglu_kernel on the same layout -- bit-identical results
+            if (live()) {
+                ConvArgs ca;
+                ca.src1 = f; ca.C1 = C; ca.Hs = ca.Ho = x.H; ca.Ws = ca.Wo = x.W; ca.ntaps = 1; ca.w = B.ff1.w; ca.bias = B.ff1.bias;
+                ca.Cout = 8 * C; ca.nhyp = nhyp; ca.out = gg;
+                if (conv_geglu_fusable(net->dt, ca)) {
+                    ca.geglu = 1;
+                    chk(launch_conv(net->dt, ca, s));
+                } else {
+                    conv(B.ff1, Act{f, C, x.H, x.W}, g, x.H, x.W);
+                    chk(launch_geglu(net->sdt, g, gg, M, 4 * C, s, 1));
+                }
+            }
             conv(B.ff2, Act{gg, 4 * C, x.H, x.W}, tok, x.H, x.W, tok1);      // (tok is dead after the attn1 residual: the block's output)
         }
         conv(T.proj_out, Act{tok, C, x.H, x.W}, out, x.H, x.W, x.p);
@@ -523,7 +566,8 @@ int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors,
                 hipMemcpyAsync(net->u_b + up.off, up.bias, (size_t)up.C * 4, hipMemcpyDeviceToDevice, s);
             }
     }
-    if (ld.err == NOPE_OK && hipStreamSynchronize(s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess && ld.err == NOPE_OK) ld.err = NOPE_ERR_LAUNCH;
+    ld.free_temps();
     if (ld.err != NOPE_OK) {
         if (!ld.missing.empty()) fprintf(stderr, "nope_ldm_create: missing or mis-shaped tensor '%s'\n", ld.missing.c_str());
         nope_ldm_destroy(net);

@@ -166,6 +166,9 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// x * gelu(gate), exact (erf) GELU: one definition for geglu_kernel and the fused conv epilogue
+__device__ __forceinline__ float geglu_f(float x, float g) { return x * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f))); }
+
 template <bool FAST> __device__ __forceinline__ float silu_f(float x) {
     if (FAST) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));   // v_exp_f32 + v_rcp_f32 (1 ulp each)
     return x / (1.0f + expf(-x));
@@ -243,8 +246,13 @@ struct ConvArgs {
     const float* pn_ms = nullptr;   // [nhyp][2] (mean, rstd)
     const float* pn_c0 = nullptr;   // [Cout]  sum_c W[n,c] * beta[c]
     const float* pn_c1 = nullptr;   // [Cout]  sum_c W[n,c] * gamma[c]
+    // GEGLU in the epilogue (the LDM variant's feed-forward projection, ldm/attention.py:37-44): output columns are (x_j, gate_j) pairs --
+    // the caller interleaved the weight rows -- and out is [M][Cout / 2] = x_j * gelu(gate_j).  16-bit types, 1x1, 128 x 192 kernel only
+    // (conv_geglu_fusable); same operands (rounded to the storage type) and same formula as geglu_kernel: bit-identical to conv + geglu.
+    int geglu = 0;
 };
 int launch_conv(int dt, const ConvArgs& a, hipStream_t s);
+bool conv_geglu_fusable(int dt, const ConvArgs& a);   // would launch_conv take this conv with geglu = 1?
 int conv_splitk_factor(int dt, const ConvArgs& a);
 bool conv_is_posmajor(int dt, const ConvArgs& a);
 int conv_kernel_kind(int dt, const ConvArgs& a);      // NOPE_CONV_KERNEL_* launch_conv would pick
@@ -300,7 +308,7 @@ int launch_cast(int dt, const float* in, void* out, size_t n, hipStream_t s);
 
 // LDM variant (kernels_ldm.hip)
 int launch_layernorm(int dt, const void* x, void* y, const float* gamma, const float* beta, long long M, int C, float eps, hipStream_t s);
-int launch_geglu(int dt, const void* in, void* out, long long M, int D, hipStream_t s);
+int launch_geglu(int dt, const void* in, void* out, long long M, int D, hipStream_t s, int interleaved = 0);   // interleaved: in = (x_j, gate_j) pairs
 int launch_add_rowvec(int dt, const void* x, void* y, const float* u, long long M, int tokens, int C, hipStream_t s, int u_stride = 0);   // (u_stride 0 = C)
 int launch_token_attention(int dt, const void* qkv, void* out, int nsmp, int N, int C, int dim_head, hipStream_t s);
 int launch_copy_cols(int dt, const void* x, void* y, long long M, int C, int C2, int off, hipStream_t s);

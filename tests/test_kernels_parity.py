@@ -654,6 +654,30 @@ def test_ldm_unet_vs_reference_golden(be, golden, tag):
             assert rel(yh, want) < tol
 
 
+def test_ldm_geglu_in_the_projection_epilogue(be, golden, monkeypatch, capfd):
+    """16-bit modes: the feed-forward's x * gelu(gate) runs in the epilogue of its projection (weight rows interleaved at create time) when the launch
+    is on the 128 x 192 kernel; the fallback (projection stored, then geglu_kernel on the same interleaved layout) must give the same bits."""
+    hip, dev, name = be
+    from tests.test_oracle_golden import build_ldm
+    g = golden("ldm_tiny.npz")
+    x, pose, ref = g["m32/x"], g["m32/pose"], g["m32/out"]
+    monkeypatch.setenv("NOPE_CONV_SMALL", "0")            # (the tiny fixture's launches would otherwise all go to the small-tile kernel)
+    monkeypatch.setenv("NOPE_CONV_TRACE", "1")
+    for cdt, tol in (("bf16", 8e-2), ("f16", 1e-2)):
+        if name == "emu" and cdt == "f16":
+            continue
+        m = build_ldm("m32", cdt).to(dev)
+        capfd.readouterr()
+        y = m(x.to(dev), pose.to(dev)).cpu()
+        assert " geglu" in capfd.readouterr().err
+        assert rel(y, ref) < tol
+        monkeypatch.setenv("NOPE_GEGLU_FUSED", "0")
+        y0 = m(x.to(dev), pose.to(dev)).cpu()
+        monkeypatch.delenv("NOPE_GEGLU_FUSED")
+        assert " geglu" not in capfd.readouterr().err
+        assert torch.equal(y, y0)
+
+
 def test_ldm_shipped_latent_channels(be):
     """configs/model/vae_cin_ldm.yaml ships in_channels = out_channels = 4: the input conv's K axis is padded to one 16-byte vector
     at pack time (zero weights against zero-padded input channels), so every compute mode accepts it; checked against the oracle
