@@ -187,11 +187,17 @@ def conv_roofline(model, step, dtype: str, dev, templates: int, size: int):
     family, and one line per launch shape."""
     h = model.u_net._get_handle(dev)
     torch.cuda.synchronize()
-    h.profile(True)
-    step()
-    torch.cuda.synchronize()
-    launches = h.profile_launches()
+    reps = []
+    for _ in range(3):          # three profiled steps, per-launch median: one step's events carry the odd stall of the event pair itself
+        h.profile(True)
+        step()
+        torch.cuda.synchronize()
+        reps.append(h.profile_launches())
     h.profile(False)
+    launches = reps[0]
+    if all(len(r) == len(launches) for r in reps):
+        for j, r in enumerate(launches):
+            r["ms"] = sorted(x[j]["ms"] for x in reps)[len(reps) // 2]
     peak = PEAK_MFMA_TFLOPS[dtype]
 
     def agg(rows):
@@ -235,7 +241,7 @@ def conv_roofline(model, step, dtype: str, dev, templates: int, size: int):
             "classes": table,
             "note": "flops = multiply-adds x2 the launches execute (nearest-x2 convs run as four 2x2 phase convs = 4/9 of the reference "
                     "MACs; position-major launches skip padding taps)" + (f" x {passes} MFMA passes per product (bf16x3)" if passes > 1 else "") +
-                    "; time = HIP events around each launch on the launch stream; achieved / frac are the dominant kernel's own"}
+                    "; time = HIP events around each launch on the launch stream, per-launch median of three profiled steps; achieved / frac are the dominant kernel's own"}
 
 
 def parity_record(a, dev, batch, bench_model, bench_sim, bench_idx, bench_ms, spot_out):
