@@ -1,4 +1,4 @@
-"""What a read-one-tensor / write-one-tensor streaming kernel can reach on this GPU: torch's device copy of a 201 MB f16 tensor (the size of
+"""What the RUNTIME's device copy reaches (not the streaming ceiling: hand-written copy kernels are 10-20 % faster, tools/probes/copy_probe.hip): torch's device copy of a 201 MB f16 tensor (the size of
 a level-0 activation at 512 hypotheses) and of a 403 MB one, bytes read + bytes written per second.  gn_apply is this access pattern plus
 arithmetic; the 8 TB/s HBM peak is not reachable by a kernel that writes half its bytes.   python tools/copy_ceiling.py"""
 import torch
