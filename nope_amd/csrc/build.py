@@ -15,7 +15,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["kernels_gemm.hip", "kernels_gemm_pp.hip", "kernels_gemm_small.hip", "kernels_norm.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_retrieval.hip", "kernels_metric.hip",
+SOURCES = ["kernels_gemm_dma_bf16_variants.hip", "kernels_gemm_dma_f32.hip", "kernels_gemm_dma_bf16.hip", "kernels_gemm_dma_f16.hip", "kernels_gemm_dma_bf16x3.hip",      # (longest first)
+           "kernels_gemm.hip", "kernels_gemm_pp.hip", "kernels_gemm_small.hip", "kernels_norm.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_retrieval.hip", "kernels_metric.hip",
            "kernels_encoder.hip", "kernels_ldm.hip", "unet_runtime.hip", "encoder_runtime.hip", "ldm_runtime.hip", "capi.hip"]
 LIB = os.path.join(HERE, "libnope_hip.so")
 ARCH = "gfx950"
@@ -61,7 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(ROOT, "build", "hip")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(HERE, "nope_common.h"), os.path.join(HERE, "conv_gemm_common.h"), os.path.join(ROOT, "include", "nope_hip.h")]
+    headers = [os.path.join(HERE, "nope_common.h"), os.path.join(HERE, "conv_gemm_common.h"), os.path.join(HERE, "conv_gemm_dma.h"), os.path.join(ROOT, "include", "nope_hip.h")]
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
     def compile_one(src: str) -> str:

@@ -24,7 +24,7 @@ def build(force: bool = False) -> str:
     from nope_amd.csrc.build import SOURCES
     objdir = os.path.join(ROOT, "build", "emu")
     os.makedirs(objdir, exist_ok=True)
-    deps = [os.path.join(CSRC, "nope_common.h"), os.path.join(CSRC, "conv_gemm_common.h"), os.path.join(ROOT, "include", "nope_hip.h"),
+    deps = [os.path.join(CSRC, "nope_common.h"), os.path.join(CSRC, "conv_gemm_common.h"), os.path.join(CSRC, "conv_gemm_dma.h"), os.path.join(ROOT, "include", "nope_hip.h"),
             os.path.join(HERE, "include", "hip", "hip_runtime.h")]
     flags = ["-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-I", os.path.join(HERE, "include"),
              "-Wno-unused-value", "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-Wno-unknown-pragmas",
