@@ -9,12 +9,15 @@ One "step" = one pass of the hot path over one batch, inputs resident in HBM:
     retrieval(query, bank)                         encoder(query) + scoring + top-5
 issued as ONE call, PoseConditional.generate_and_retrieve (same values; the query's encoder pass runs on a second HIP
 stream underneath the reference encoder and the first U-Net kernels); --two-calls times the literal two-call sequence.
-Workload: BASELINE.json configs[1] -- one 256x256 query against 512 viewpoint templates, 16-bit.  configs[1] names bf16; the TIMED mode is
-f16 (16-bit storage + f16 MFMA at the same rate and bytes, f32 accumulation / statistics, f16 bank) because on this very step bf16's score
-error (4.6e-3 of the score scale) is LARGER than the gap between the best and the second-best template (`top1_margin` 0.65: the best
-template survives by luck), while f16's (8e-4) leaves a margin of 3.6; bf16 runs 5 % faster and is timed next to it.  All four compute
-modes (bf16x3 and f32 are the two INSIDE north_star's 1e-4 score tolerance) are timed on the same step in the `parity` record, and the
-line says at top level whether the timed mode meets the tolerance (`tolerance_met`), what the fastest mode that does delivers
+Workload: BASELINE.json configs[1] -- one 256x256 query against 512 viewpoint templates.  north_star asks for scores "within 1e-4 ... and
+bit-exact on the argmax pose index" of the reference's fp32 path, so the TIMED mode is the fastest one that delivers that: `f16x2` (f32
+storage; the tap-resident 3x3 convolutions = 9/10 of the work as one f16 MFMA pass + one MX-scaled fp8 MFMA pass for both cross terms of a
+hi / lo operand split, every other launch as bf16x3; ~1e-5 on the scores, top-5 bit-exact).  configs[1] names bf16: that mode, literally,
+is timed next to it and reported at top level (`configs1_as_literally_stated`: ~2x faster, but its score error, 4.6e-3 of the score
+scale, is LARGER than this step's gap between the best and the second-best template -- `top1_margin` 0.65: the best template survives
+by luck); so is f16 (`value_f16_argmax_exact`: 16-bit storage + f16 MFMA, 8e-4, margin 3.6 -- the arg-max-exact throughput mode).  All
+five compute modes are timed on the same step in the `parity` record (f16x2, bf16x3 and f32 are the three INSIDE the tolerance), and
+the line says at top level whether the timed mode meets the tolerance (`tolerance_met`), what the fastest mode that does delivers
 (`value_within_tolerance`), and how far the timed mode's error is from flipping the best template (`top1_margin`).
 For N>1 the template axis of that SAME 512-template bank is sharded over the GPUs (`scaling: "strong"`, 512 / N templates per
 GPU -- north_star's "512-template bank at 1/2/4/8 GPUs, >= 3.5x at 8"), the per-rank scores are all-gathered over RCCL before the top-5;
@@ -32,7 +35,7 @@ Extra legs on rank 0 at N=1 (outside the timed region):
                 launches, `classes` = one line per launch shape;
   parity        the same step in every compute mode against the f32 parity mode of this library (pinned to the reference at
                 1e-4 / bit-exact top-5 by tests/, spot-checked against the CPU oracle here): score error, top-5 / top-1
-                equality and throughput of bf16, f16 and bf16x3 (the split-precision mode that holds the 1e-4 tolerance);
+                equality and throughput of bf16, f16, f16x2 and bf16x3 (the split-precision modes that hold the 1e-4 tolerance);
   scoring       the similarity kernel on a 1.07 GB resident bank, vs 8 TB/s HBM;
   cpu_baseline  the oracle (CPU restatement, kind "port") on the host cores, bounded sample: `value` on the hoisted-encoder schedule (the
                 faster CPU schedule), `value_reference_schedule` on the reference's literal one (encoder re-run per template, model.py:115 via :219).
@@ -179,7 +182,9 @@ def scoring_roofline(dtype: torch.dtype, N: int = 0):
             "hyp_per_s": B * N / med * 1e3}
 
 
-PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f32": 157.3}   # dense MFMA peak of the instruction each mode issues
+# dense MFMA peak of the instruction each mode issues.  f16x2: its tap-resident launches count 2 pass equivalents per product against the
+# f16 peak (one f16 pass + one fp8 pass of twice the K at twice the rate = the same time as a second f16 pass); its other launches are bf16x3's.
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f16x2": 2500.0, "f32": 157.3}
 
 
 def conv_roofline(model, step, dtype: str, dev, templates: int, size: int):
@@ -240,7 +245,7 @@ def conv_roofline(model, step, dtype: str, dev, templates: int, size: int):
                        "algorithmic_bytes_per_launch": fam["algorithmic_bytes"] / fam["launches"]},
             "classes": table,
             "note": "flops = multiply-adds x2 the launches execute (nearest-x2 convs run as four 2x2 phase convs = 4/9 of the reference "
-                    "MACs; position-major launches skip padding taps)" + (f" x {passes} MFMA passes per product (bf16x3)" if passes > 1 else "") +
+                    "MACs; position-major launches skip padding taps)" + (f" x {passes} MFMA pass equivalents per product ({dtype})" if passes > 1 else "") +
                     "; time = HIP events around each launch on the launch stream, per-launch median of three profiled steps; achieved / frac are the dominant kernel's own"}
 
 
@@ -270,7 +275,7 @@ def parity_record(a, dev, batch, bench_model, bench_sim, bench_idx, bench_ms, sp
     spot_out["q_feat"] = m32.u_net.encoder.encode_image(query[:1], mode="mode")
     spot_out["bank32"], spot_out["sim32"] = bank32, sim32
     kernel_frac = {}
-    for mode in ("bf16", "f16", "bf16x3", "f32"):
+    for mode in ("bf16", "f16", "f16x2", "bf16x3", "f32"):
         if mode == "f32":
             sim, idx, ms = sim32, idx32, ms32
         elif mode == a.dtype:
@@ -305,11 +310,12 @@ def main():
                     help="nccl = RCCL, one rank per GPU (production); gloo = ranks may share a GPU (the 8-rank tests on a 1-GPU box)")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "bf16x3", "f32"],
-                    help="compute mode.  f16 (default) and bf16 (what BASELINE configs[1] names): 16-bit storage + 16-bit MFMA at the same rate and "
-                         "bytes; f16 carries 3 more significand bits: its score error stays below the top-1 / top-2 gap of the benchmarked step "
-                         "(top1_margin 3.6), bf16's does not (0.65).  bf16x3: f32 storage, split-precision MFMA -- the fast mode inside the 1e-4 score "
-                         "tolerance.  f32: exact-f32 MFMA, the parity mode.  All four are timed in the `parity` record.")
+    ap.add_argument("--dtype", default="f16x2", choices=["f16x2", "f16", "bf16", "bf16x3", "f32"],
+                    help="compute mode.  f16x2 (default): f32 storage, the tap-resident 3x3 convs as one f16 + one MX-fp8 MFMA pass, the rest as bf16x3 -- "
+                         "the fastest mode inside north_star's 1e-4 score tolerance.  f16 and bf16 (what BASELINE configs[1] names): 16-bit storage + "
+                         "16-bit MFMA, ~2x faster, outside the tolerance (8e-4 / 4.6e-3); f16's error stays below the top-1 / top-2 gap of the "
+                         "benchmarked step (top1_margin 3.6), bf16's does not (0.65).  bf16x3: f32 storage, three bf16 MFMA passes.  f32: exact-f32 "
+                         "MFMA, the parity mode.  All five are timed in the `parity` record.")
     ap.add_argument("--bank-dtype", default=None, choices=["bf16", "f32", "f16"], help="template-bank storage (default: --dtype; f16 for --scoring-only)")
     ap.add_argument("--scoring-only", action="store_true", help="time scoring + top-5 on a resident bank (SURVEY 8(d) metric (i))")
     ap.add_argument("--skip-extras", action="store_true", help="skip roofline / cpu_baseline legs")
@@ -398,7 +404,10 @@ def main():
         "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"{a.batch} query {a.size}x{a.size} x {n_total} viewpoint templates, {a.dtype} (BASELINE configs[1]" +
                                ("; configs[1] names bf16: f16 replaces it -- same MFMA rate and bytes, 8x smaller score error, the only 16-bit mode whose "
-                                "error stays below this step's top-1 / top-2 score gap, see top1_margin and parity.modes.bf16" if a.dtype == "f16" else "") + ")" +
+                                "error stays below this step's top-1 / top-2 score gap, see top1_margin and parity.modes.bf16" if a.dtype == "f16" else "") +
+                               ("; configs[1] names bf16, whose score error (4.6e-3) is 46x north_star's 1e-4 tolerance: the timed mode is f16x2, the fastest "
+                                "one INSIDE the tolerance (f32 storage, split-precision f16 + MX-fp8 MFMA); bf16 as literally stated and f16 are timed next "
+                                "to it: configs1_as_literally_stated, value_f16_argmax_exact" if a.dtype == "f16x2" else "") + ")" +
                                (f", bank sharded over {world} GPUs = {per_gpu} templates per GPU" if world > 1 else "") +
                                f"; U-Net u_net_dim=192 (305.8M params, random init) at {a.size // 8}x{a.size // 8} latent + ResNet-50 "
                                f"template encoder + l2 scoring + top-5",
@@ -441,6 +450,15 @@ def main():
         res["value_within_tolerance"] = ok_modes[best]["hyp_per_s"] if best else None
         res["value_within_tolerance_mode"] = best
         res["top1_margin"] = timed["top1_margin"]
+        m16 = res["parity"]["modes"]
+        res["configs1_as_literally_stated"] = {"dtype": "bf16", "value": m16["bf16"]["hyp_per_s"], "ms_per_step": m16["bf16"]["ms_per_step"],
+                                               "score_rel_err": m16["bf16"]["score_rel_err"], "top5_equal": m16["bf16"]["top5_equal"],
+                                               "top1_margin": m16["bf16"]["top1_margin"], "tolerance_met": m16["bf16"]["meets_1e-4"],
+                                               "note": "BASELINE configs[1] names bf16: 16-bit storage + bf16 MFMA, measured on this very step"}
+        res["value_f16_argmax_exact"] = {"dtype": "f16", "value": m16["f16"]["hyp_per_s"], "ms_per_step": m16["f16"]["ms_per_step"],
+                                         "score_rel_err": m16["f16"]["score_rel_err"], "top5_equal": m16["f16"]["top5_equal"],
+                                         "top1_margin": m16["f16"]["top1_margin"], "tolerance_met": m16["f16"]["meets_1e-4"],
+                                         "note": "the fastest mode whose score error stays below this step's top-1 / top-2 gap (same top-5 as f32), outside the 1e-4 tolerance"}
         res["scoring_roofline"] = [scoring_roofline(torch.bfloat16), scoring_roofline(torch.float32),
                                    scoring_roofline(torch.float16, N=1024),     # BASELINE configs[4]: fp16 bank, 8192 / 8 templates per GPU
                                    scoring_roofline(torch.bfloat16, N=512)]     # BASELINE configs[3]: 32 x 4096 bf16 sharded 8-way -> 512 per GPU

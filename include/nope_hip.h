@@ -30,9 +30,17 @@ enum { NOPE_F32 = 0, NOPE_BF16 = 1,
        NOPE_F16 = 2,   /* IEEE half: storage type of the template bank (nope_similarity's bank_dtype, nope_unet_forward's out_dtype,
                           BASELINE configs[4]) and a compute mode of the networks: f16 storage + f16 MFMA, f32 accumulate / statistics
                           -- the MFMA rate of NOPE_BF16 with 3 more mantissa bits; stores saturate at +-65504 (no inf; a NaN is stored as -65504) */
-       NOPE_BF16X3 = 3 /* compute mode only: f32 storage, every conv / linear as three bf16 MFMA passes over (hi, lo) bf16 splits of
+       NOPE_BF16X3 = 3,/* compute mode only: f32 storage, every conv / linear as three bf16 MFMA passes over (hi, lo) bf16 splits of
                           both operands (hi*hi + hi*lo + lo*hi, f32 accumulate): ~2^-17 relative per product instead of bf16's 2^-9
-                          at 3/16 of the exact-f32 MFMA cost -- the fast mode that meets the 1e-4 score tolerance */ };
+                          at 3/16 of the exact-f32 MFMA cost -- meets the 1e-4 score tolerance */
+       NOPE_F16X2 = 4  /* compute mode only: NOPE_BF16X3 (f32 storage, same kernels) except that the 3x3 convolutions the tap-resident kernel
+                          runs -- 9/10 of the U-Net's work -- cost TWO pass equivalents instead of three: a_hi w_hi on the f16 MFMA
+                          (hi = f16 part) plus ONE MX-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, twice the f16 rate) for both
+                          cross terms, K-concatenated: [e4m3(a_lo) | e4m3(a)] x [e4m3(w) ; e4m3(w_lo)], power-of-two pre-scales undone by
+                          the instruction's block scale.  The cross terms carry <= 2^-11 of the result, so 4-bit operands leave ~2^-15
+                          per product -- the fast mode that meets the 1e-4 score tolerance.  As an element type of nope_op_conv /
+                          nope_op_pack_conv_weight it names that kernel and its weight layout (3x3, stride 1, Cin % 32 == 0 only);
+                          |activation| <= 65504 (the f16 part saturates) */ };
 /* Tap geometries of nope_op_conv.  UP2P is UP2 (nearest-x2 upsample + 3x3, pad 1) rewritten as four
  * 2x2 convolutions over the un-upsampled input, one per output-pixel parity, with the 3x3 weights that
  * fall on the same source pixel pre-summed at pack time: same function, 4/9 of the multiply-adds. */
@@ -52,9 +60,10 @@ typedef void* nope_stream_t;
 
 /* Bumped whenever a struct of this header changes layout or an enum gains a meaning (2: nope_unet_config.soft_up_down;
  * 3: NOPE_F16 / NOPE_BF16X3 compute modes, 4x4 STRIDE2, nope_ldm_config.transformer_depth;
- * 4: nope_op_geodesic, nope_unet_graph_limit -- hipGraph replay became opt-in).  Callers compare nope_abi_version() against the header they were
+ * 4: nope_op_geodesic, nope_unet_graph_limit -- hipGraph replay became opt-in;
+ * 5: NOPE_F16X2, nope_tuning_reload).  Callers compare nope_abi_version() against the header they were
  * built with before passing any struct (nope_amd/hip.py does at load time). */
-#define NOPE_ABI_VERSION 4
+#define NOPE_ABI_VERSION 5
 const char* nope_strerror(int code);
 int nope_abi_version(void);
 
@@ -117,7 +126,7 @@ typedef struct {
     int pose_mlp_layers;   /* 1 = "single_layer", 2 = "two_layers" (u_net.py:63-72) */
     int compute_dtype;     /* NOPE_F32: f32 storage + f32-input MFMA (bit-faithful fp32 sums);
                               NOPE_BF16 / NOPE_F16: 16-bit storage + 16-bit MFMA, f32 accumulate / statistics;
-                              NOPE_BF16X3: f32 storage, split-precision bf16 MFMA (see the enum) */
+                              NOPE_BF16X3 / NOPE_F16X2: f32 storage, split-precision MFMA (see the enum) */
     int soft_up_down;      /* 0: use_hard_up_down = True, the shipped configuration (HardDownsample / HardUpsample, u_net.py:54-56);
                               1: use_hard_up_down = False -- Downsample = Conv2d(4, stride 2, pad 1) at "downs.l.3.weight",
                               Upsample = ConvTranspose2d(4, stride 2, pad 1) at "ups.l.3.weight" (model_utils.py:119-136) */
@@ -193,7 +202,7 @@ typedef struct {
     int pose_dim;           /* rot_representation_dim, 6 */
     int pose_mlp_layers;    /* 1 = "single_layer", 2 = "two_layers" */
     int injecting_condition_twice;   /* 0: timestep embedding is zeros; 1: emb = pose_mlp_timesteps(pose) */
-    int compute_dtype;      /* NOPE_F32 | NOPE_BF16 | NOPE_F16 | NOPE_BF16X3, as nope_unet_config */
+    int compute_dtype;      /* NOPE_F32 | NOPE_BF16 | NOPE_F16 | NOPE_BF16X3 | NOPE_F16X2 (= NOPE_BF16X3 here: no tap-resident launches), as nope_unet_config */
     int use_scale_shift_norm;        /* 1: ResBlocks apply out_norm(h) * (1 + scale) + shift with (scale, shift) = emb_layers(emb) */
     int transformer_depth;           /* BasicTransformerBlocks per SpatialTransformer (attention.py:232-262); 1 in vae_cin_ldm.yaml; 0 reads as 1 */
 } nope_ldm_config;
@@ -214,7 +223,7 @@ int nope_ldm_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, 
 typedef struct nope_encoder nope_encoder;
 typedef struct {
     int descriptor_size;   /* 8 (configs/model/template_base.yaml:10) */
-    int compute_dtype;     /* NOPE_F32 | NOPE_BF16 | NOPE_F16 | NOPE_BF16X3, as nope_unet_config */
+    int compute_dtype;     /* NOPE_F32 | NOPE_BF16 | NOPE_F16 | NOPE_BF16X3 | NOPE_F16X2 (= NOPE_BF16X3 here: no tap-resident launches), as nope_unet_config */
     float bn_eps;          /* BatchNorm2d eps; <= 0 selects the torch default 1e-5 */
 } nope_encoder_config;
 

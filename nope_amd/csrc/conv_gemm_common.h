@@ -68,9 +68,11 @@ struct ConvParams {
     int stat_rows;                     // 64 (every kernel), 16 / 32 (small-tile kernel only)
     const float* pn_ms; const float* pn_c0; const float* pn_c1;   // optional fused PreNorm (see ConvArgs)
     unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
+    const int* x2_scale;               // NOPE_F16X2 (tap-resident kernel only): the tail of the packed weights, [0] = E8M0 scale of the A operand
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 // MFMA tile of a wave's 64 x 96 output block, per element type.
 //   f32 : v_mfma_f32_16x16x4_f32  -- 4 x 6 tiles, a lane's 16-byte fragment = 4 channels = 4 chained steps
@@ -83,7 +85,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // feeds; out_row / out_col: the C/D map.  prep_step turns the raw A reads into MFMA operands (a no-op except for f32s).
 template <class T> struct Tile;
 template <> struct Tile<float> {
-    static constexpr int TM = 16, MT = 4, NTL = 6, R = 4, STEP_SLOTS = 4, RAW = 1;
+    static constexpr int TM = 16, MT = 4, NTL = 6, R = 4, STEP_SLOTS = 4, RAW = 1, RAW_STRIDE = 1;
     typedef f32x4 acc_t;
     static __device__ __forceinline__ int frag_row(int lane) { return lane & 15; }
     static __device__ __forceinline__ int frag_slot(int lane) { return lane >> 4; }
@@ -91,7 +93,7 @@ template <> struct Tile<float> {
     static __device__ __forceinline__ int out_col(int lane) { return lane & 15; }
     static __device__ __forceinline__ void prep_step(u32x4 (&)[RAW][MT]) {}
     static constexpr int TERMS = 1;
-    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c) {
+    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c, int = 0) {
         const f32x4 fa = __builtin_bit_cast(f32x4, a[0][i]), fb = __builtin_bit_cast(f32x4, b[0][j]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q], fb[q], c, 0, 0, 0);
@@ -106,20 +108,20 @@ struct Tile32 {
     static __device__ __forceinline__ int out_col(int lane) { return lane & 31; }
 };
 template <> struct Tile<bf16_t> : Tile32 {
-    static constexpr int STEP_SLOTS = 2, RAW = 1;
+    static constexpr int STEP_SLOTS = 2, RAW = 1, RAW_STRIDE = 1;
     static __device__ __forceinline__ int frag_slot(int lane) { return lane >> 5; }
     static __device__ __forceinline__ void prep_step(u32x4 (&)[RAW][MT]) {}
     static constexpr int TERMS = 1;
-    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c) {
+    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c, int = 0) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0][i]), __builtin_bit_cast(bf16x8, b[0][j]), c, 0, 0, 0);
     }
 };
 template <> struct Tile<f16_t> : Tile32 {
-    static constexpr int STEP_SLOTS = 2, RAW = 1;
+    static constexpr int STEP_SLOTS = 2, RAW = 1, RAW_STRIDE = 1;
     static __device__ __forceinline__ int frag_slot(int lane) { return lane >> 5; }
     static __device__ __forceinline__ void prep_step(u32x4 (&)[RAW][MT]) {}
     static constexpr int TERMS = 1;
-    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c) {
+    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c, int = 0) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0][i]), __builtin_bit_cast(f16x8, b[0][j]), c, 0, 0, 0);
     }
 };
@@ -131,7 +133,7 @@ template <> struct Tile<f16_t> : Tile32 {
 // kernels, under the other group's MFMAs) and the step issues  acc += a_lo w_hi;  acc += a_hi w_lo;  acc += a_hi w_hi  --
 // the three products whose error is O(2^-17) per operand; a_lo w_lo (2^-18 relative) is dropped.
 template <> struct Tile<f32s_t> : Tile32 {
-    static constexpr int STEP_SLOTS = 4, RAW = 2;
+    static constexpr int STEP_SLOTS = 4, RAW = 2, RAW_STRIDE = 1;
     static __device__ __forceinline__ int frag_slot(int lane) { return (lane >> 5) * 2; }
     static __device__ __forceinline__ void prep_step(u32x4 (&a)[RAW][MT]) {
 #pragma unroll
@@ -154,12 +156,41 @@ template <> struct Tile<f32s_t> : Tile32 {
         }
     }
     static constexpr int TERMS = 3;           // (lo, hi), (hi, lo), (hi, hi): term outer in the callers' loops, so MFMAs on one accumulator sit 6 apart
-    static __device__ __forceinline__ void mma(int t, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c) {
+    static __device__ __forceinline__ void mma(int t, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c, int = 0) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t == 0 ? 1 : 0][i]), __builtin_bit_cast(bf16x8, b[t == 1 ? 1 : 0][j]), c, 0, 0, 0);
     }
 };
+// NOPE_F16X2 (tap-resident 3x3 kernel only).  Both operands hold 32 channels per 128-byte row, as NOPE_BF16X3, in EIGHT 16-byte slots:
+//     slot 2 ks + h        (ks, h in {0, 1})   f16 hi parts of channels 16 ks + 8 h .. + 7        -- the operands of two 32x32x16 f16 MFMAs
+//     slot 4 + 2 p + h     (p, h in {0, 1})    e4m3 bytes of channels 16 p .. 16 p + 15:  h = 0: A: a_lo * 2^9,  B: w * 2^sw
+//                                                                                         h = 1: A: a * 2^-2,    B: w_lo * 2^(sw + 11)
+// (hi = f16(x), lo = x - hi; the weights arrive like this from pack_conv_w_x2_kernel, the activations are rewritten in LDS by the wave
+// that staged them: convert_piece in conv3x3_halo_kernel).  A lane of half h = lane >> 5 reads slot h + 2 r for r = 0..3 (RAW_STRIDE 2:
+// the XOR of raw_slot into a fragment address stays disjoint from frag_slot's bit): reads 0, 1 feed the two f16 MFMAs, reads 2 + 3 are
+// the 32 bytes of its half of ONE v_mfma_scale_f32_32x32x64_f8f6f4 whose K axis is the concatenation [a_lo | a] x [w ; w_lo] over the
+// step's 32 channels -- both cross terms at once, at twice the f16 rate, into the same accumulator: the instruction's E8M0 block scale
+// (one value for every lane, `sc` = 127 - 9 - sw; B's is 1.0) undoes the pre-scales.  What the instruction really does with operands and
+// scales is pinned by tools/probes/mx_probe.hip (byte e of lane half h pairs with byte e of lane half h; its 64-term sum is truncated at
+// ~2^-12 of the largest term: irrelevant for terms that are 2^-11 of the result).  Three "terms" per step = 2 pass equivalents of an f16
+// MFMA step against NOPE_BF16X3's 3.
+template <> struct Tile<f16x2_t> : Tile32 {
+    static constexpr int STEP_SLOTS = 8, RAW = 4, RAW_STRIDE = 2;
+    static __device__ __forceinline__ int frag_slot(int lane) { return lane >> 5; }
+    static __device__ __forceinline__ void prep_step(u32x4 (&)[RAW][MT]) {}
+    static constexpr int TERMS = 3;
+    static __device__ __forceinline__ void mma(int t, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c, int sc) {
+        if (t < 2) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[t][i]), __builtin_bit_cast(f16x8, b[t][j]), c, 0, 0, 0);
+        } else {
+            const u32x4 a0 = a[2][i], a1 = a[3][i], b0 = b[2][j], b1 = b[3][j];
+            const i32x8 va = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+            const i32x8 vb = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+            c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, c, 0, 0, 0, sc, 0, 127);      // (cbsz = blgp = 0: e4m3 x e4m3)
+        }
+    }
+};
 // slot offset of raw read q (= step * RAW + r) of a staged row, to be XORed into a fragment address (<< 4)
-template <class T> __device__ __forceinline__ constexpr int raw_slot(int q) { return (q / Tile<T>::RAW) * Tile<T>::STEP_SLOTS + (q % Tile<T>::RAW); }
+template <class T> __device__ __forceinline__ constexpr int raw_slot(int q) { return (q / Tile<T>::RAW) * Tile<T>::STEP_SLOTS + (q % Tile<T>::RAW) * Tile<T>::RAW_STRIDE; }
 
 __device__ __forceinline__ void tile_coords(const ConvParams& p, int& tile_m, int& tile_n) {
     const int g = blockIdx.x;

@@ -216,7 +216,7 @@ int nope_encoder_create(const nope_encoder_config* cfg, const nope_tensor_desc* 
     nope_encoder* enc = new nope_encoder();
     enc->cfg = *cfg;
     if (enc->cfg.bn_eps <= 0.f) enc->cfg.bn_eps = 1e-5f;      // nn.BatchNorm2d default
-    enc->dt = cfg->compute_dtype;
+    enc->dt = dt_base(cfg->compute_dtype);      // (NOPE_F16X2 = NOPE_BF16X3 here: the encoder has no tap-resident launches worth a second weight pack)
     ELoader L{enc, (hipStream_t)stream};
     for (int i = 0; i < n_tensors; ++i) if (tensors[i].name) L.tab[tensors[i].name] = &tensors[i];
 

@@ -268,6 +268,7 @@ struct ConvPlan { bool dma, pp, posmajor, halo; int small; int hsplit; };      /
 // NOPE_SMALL_MAX_TILES (default 320) tiles of 128 x 192.  NOPE_CONV_SMALL: 0 = never, 1 = that policy (default), 2 = whenever the
 // kernel applies (tests); NOPE_SMALL_TILE forces the tile.
 static int plan_small(int dt, const ConvArgs& a, bool dma) {
+    dt = dt_base(dt);      // (NOPE_F16X2 plans as NOPE_BF16X3: same storage, same tiles)
     const int mode_env = getenv("NOPE_CONV_SMALL") ? atoi(getenv("NOPE_CONV_SMALL")) : 1;
     if (!dma || mode_env == 0 || a.mode == NOPE_CONV_UP2 || a.ntaps == 16 || a.force_generic) return -1;
     if (mode_env == 1 && getenv("NOPE_CONV_PP") && (atoi(getenv("NOPE_CONV_PP")) & 8)) return -1;      // bit 3 = "ping-pong kernels at ANY tile count" (their tests)
@@ -305,6 +306,7 @@ static int plan_small(int dt, const ConvArgs& a, bool dma) {
 // launches (profiles/r04b: 51 us for 1536 -> 1536 at 4 x 4 x 64 on the 128 x 192 kernel split 8 ways = 1.9 us per K step, 111 us on 64 x 64
 // tiles).  Returns the number of splits (1: does not apply).  NOPE_HALO_SPLIT=0 turns it off.
 static int halo_split_factor(int dt, const ConvArgs& a) {
+    dt = dt_base(dt);      // (NOPE_F16X2 plans as NOPE_BF16X3: same storage, same tiles)
     if (getenv("NOPE_HALO_SPLIT") && atoi(getenv("NOPE_HALO_SPLIT")) == 0) return 1;
     const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : (dt != NOPE_F32 ? 3 : 0);
     if (!(pp_mode & 1) || (pp_mode & 16)) return 1;
@@ -328,6 +330,7 @@ static int halo_split_factor(int dt, const ConvArgs& a) {
 }
 
 static ConvPlan plan_conv(int dt, const ConvArgs& a) {
+    dt = dt_base(dt);      // (NOPE_F16X2 plans as NOPE_BF16X3: same storage, same tiles)
     // (read per launch: the tests toggle it.  f32 -- the parity mode -- stays on the 128 x 192 kernel unless asked: its MFMA phase is
     //  16x longer per K step, loads were never its bound, and two workgroups per CU beat one: 126 vs 135 ms per 512-template step)
     const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : (dt != NOPE_F32 ? 3 : 0);
@@ -401,6 +404,7 @@ bool conv_is_posmajor(int dt, const ConvArgs& a) { return plan_conv(dt, a).posma
 // 16-pixel maps (the 4 x 4 level: per-sample blocks, every LDS-DMA kernel's wide epilogue, the small-tile kernel, the split-K reduce) -- which
 // removes that level's gn_stats passes; 32 on 32-pixel maps from the small-tile kernel and the split-K reduce.
 int conv_stat_rows(int dt, const ConvArgs& a) {
+    dt = dt_base(dt);      // (NOPE_F16X2 plans as NOPE_BF16X3: same storage, same tiles)
     const int vec = dt_vec(dt);
     if (a.mode == NOPE_CONV_UP2P || a.resid || a.out_nchw || a.Cout % vec || a.Cout > 2048) return 0;
     const long long HW = (long long)a.Ho * a.Wo, M = (long long)a.nhyp * HW;
@@ -424,12 +428,14 @@ int conv_kernel_kind(int dt, const ConvArgs& a) {
 // Multiply-adds x2 the launch actually executes (position-major launches skip the taps that lie in the padding:
 // (3H-2)(3W-2) of the 9 H W tap instances remain).
 double conv_executed_flops(int dt, const ConvArgs& a) {
+    dt = dt_base(dt);      // (NOPE_F16X2 plans as NOPE_BF16X3: same storage, same tiles)
     double taps = (double)a.ntaps;
     if (conv_is_posmajor(dt, a)) taps = (double)(3 * a.Hs - 2) * (3 * a.Ws - 2) / ((double)a.Hs * a.Ws);
     return 2.0 * (double)a.nhyp * a.Ho * a.Wo * a.Cout * taps * (a.C1 + a.C2);
 }
 
 int conv_splitk_factor(int dt, const ConvArgs& a) {
+    dt = dt_base(dt);      // (NOPE_F16X2 plans as NOPE_BF16X3: same storage, same tiles)
     {
         const int hs = halo_split_factor(dt, a);      // long 3x3 convs with few tiles: split-K on the tap-resident kernel (its reduce kernel
         if (hs > 1) return hs;                        // also serves a colstats request)
@@ -450,7 +456,14 @@ int conv_splitk_factor(int dt, const ConvArgs& a) {
 }
 
 int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
-    if (!a.src1 || !a.w || !a.out || a.C1 <= 0 || a.Cout <= 0 || a.nhyp <= 0) return NOPE_ERR_ARG;
+    if (dt == NOPE_F16X2) {      // as an element type (nope_op_conv): `w` is in the NOPE_F16X2 layout, which only the tap-resident kernel reads
+        if (a.w_x2) return NOPE_ERR_ARG;
+        ConvArgs b = a;
+        b.w_x2 = a.w; b.w = nullptr;
+        return launch_conv(NOPE_BF16X3, b, s);
+    }
+    if (a.w_x2 && dt != NOPE_BF16X3) return NOPE_ERR_ARG;
+    if (!a.src1 || (!a.w && !a.w_x2) || !a.out || a.C1 <= 0 || a.Cout <= 0 || a.nhyp <= 0) return NOPE_ERR_ARG;
     if (a.C2 > 0 && !a.src2) return NOPE_ERR_ARG;
     const int vec = dt_vec(dt);
     if (!dt_is_compute(dt)) return NOPE_ERR_UNSUPPORTED;
@@ -498,6 +511,10 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.w_phase_bytes = phased ? (unsigned)bw : 0u;
     const ConvPlan plan = plan_conv(dt, a);
     const bool dma = plan.dma;
+    const bool x2 = a.w_x2 && plan.halo && plan.small < 0;      // the f16 + MX-fp8 tile: tap-resident launches of a layer that carries the second pack
+    if (!x2 && !a.w) return NOPE_ERR_UNSUPPORTED;               // (NOPE_F16X2 as an element type on a shape the tap-resident kernel does not take)
+    p.x2_scale = nullptr;
+    if (x2) { p.w = (const unsigned char*)a.w_x2; p.x2_scale = reinterpret_cast<const int*>(p.w + bw); }
     if (a.geglu && !geglu_shape_ok(dt, a, plan)) return NOPE_ERR_UNSUPPORTED;
     p.geglu = a.geglu;
     if (a.colstats && a.stat_rows == 32 && plan.small < 0 && plan.hsplit <= 1) return NOPE_ERR_ARG;   // 32-row blocks: small-tile kernel or split-K reduce only
@@ -605,12 +622,12 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
                                         p.tiles_m, p.tiles_n, grid.x, grid.y, grid.z, p.xcd_map, p.xcd_gn);
     else if (trace) fprintf(stderr, "conv %s mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u posmajor %d persist %d xcd %d/%d%s\n",
                        plan.halo ? "halo256" : plan.pp ? "pp256" : dma ? "dma128" : "generic", a.mode, a.ntaps, Cin, a.Cout, M, p.tiles_m, p.tiles_n, grid.x, grid.y, grid.z,
-                       p.posmajor, p.persist_iters, p.xcd_map, p.xcd_gn, a.geglu ? " geglu" : "");
+                       p.posmajor, p.persist_iters, p.xcd_map, p.xcd_gn, a.geglu ? " geglu" : x2 ? " x2" : "");
     if (plan.small >= 0) {
         launch_conv_small(dt, &p, plan.small, grid, s);
     } else if (plan.pp) {
         if (const char* v = getenv("NOPE_PP_VARIANT")) p.variant = atoi(v);      // tuning ablations of the ping-pong kernel
-        if (plan.halo) launch_conv_halo(dt, &p, grid, s);
+        if (plan.halo) launch_conv_halo(x2 ? NOPE_F16X2 : dt, &p, grid, s);
         else launch_conv_pp(dt, &p, grid, s);
     } else if (dt == NOPE_F32) {
         if (dma) launch_conv_dma_f32(&p, bm, grid, s);

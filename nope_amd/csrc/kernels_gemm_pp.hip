@@ -472,9 +472,39 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     // for all lanes before either write is issued (same wave, in-order LDS queue + data dependence), other waves read the piece
     // only behind the barrier that ends this LOAD phase.  Zero rows and out-of-range rows are zeros either way.
     constexpr bool A_SPLIT_LDS = TL::RAW > 1;
+    constexpr bool X2 = Elt<T>::DT == NOPE_F16X2;
     const int cv_half = (lslot ^ swz_of<RB>(r0)) & 1;                         // which half of its 8-channel group this lane's slot holds
+    // ---- NOPE_F16X2: same in-place rewrite, into the layout of Tile<f16x2_t>.  A lane's 16-byte slot holds channels 4 ls .. 4 ls + 3 of the
+    // chunk (ls = its LOGICAL slot); it writes their four f16 hi parts into half of logical slot ls / 2 (8 bytes), the four e4m3 bytes of
+    // a_lo * 2^9 into slot 4 + 2 (ls / 4) and the four of a * 2^-2 into slot 5 + 2 (ls / 4), each at byte 4 (ls % 4) (two ds_write_b32).
+    // The f16 part saturates at +-65504, the fp8 parts at +-448 (v_med3_f32: a NaN becomes the lower bound, as in the f16 mode).
+    const int x2_sc = X2 ? p.x2_scale[0] : 0;                                 // E8M0 block scale of the cross-term MFMA (uniform; waited for with the prologue's DMA)
     auto convert_piece = [&](int i, int stage) __attribute__((always_inline)) {
-        if constexpr (A_SPLIT_LDS) {
+        if constexpr (X2) {
+            unsigned char* row = a_dst + stage * A_STAGE + i * 8192 + rsub * RB;
+            const u32x4 v = ld16(row + lslot * 16);
+            const int sw = swz_of<RB>(r0), ls = lslot ^ sw;
+            unsigned hi[2], lo8, a8;
+            float x[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const unsigned u = v[e]; x[e] = __builtin_bit_cast(float, u); }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const unsigned h = cvt_pk_f16(x[2 * e], x[2 * e + 1]);
+                hi[e] = h;
+                union { unsigned u; f16_t f[2]; } hh; hh.u = h;
+                l[2 * e] = x[2 * e] - (float)hh.f[0];
+                l[2 * e + 1] = x[2 * e + 1] - (float)hh.f[1];
+            }
+            constexpr float SLO = (float)(1 << kX2ALoShift), SA = 1.0f / (float)(1 << -kX2AShift);
+            lo8 = cvt_pk_e4m3(l[0] * SLO, l[1] * SLO) | (cvt_pk_e4m3(l[2] * SLO, l[3] * SLO) << 16);
+            a8 = cvt_pk_e4m3(x[0] * SA, x[1] * SA) | (cvt_pk_e4m3(x[2] * SA, x[3] * SA) << 16);
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            __builtin_amdgcn_wave_barrier();       // every lane's read precedes every lane's write (see below)
+            *reinterpret_cast<u32x2*>(row + (((ls >> 1) ^ sw) << 4) + 8 * (ls & 1)) = u32x2{hi[0], hi[1]};
+            *reinterpret_cast<unsigned*>(row + (((4 + 2 * (ls >> 2)) ^ sw) << 4) + 4 * (ls & 3)) = lo8;
+            *reinterpret_cast<unsigned*>(row + (((5 + 2 * (ls >> 2)) ^ sw) << 4) + 4 * (ls & 3)) = a8;
+        } else if constexpr (A_SPLIT_LDS) {
             unsigned char* row = a_dst + stage * A_STAGE + i * 8192 + rsub * RB;
             const u32x4 v = ld16(row + lslot * 16);
             unsigned hi[2], lo[2];
@@ -664,7 +694,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
 #pragma unroll
                         for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
-                            for (int j = 0; j < TL::NTL; ++j) TL::mma(t, af[ks], bfr[ks], i, j, acc[i][j]);
+                            for (int j = 0; j < TL::NTL; ++j) TL::mma(t, af[ks], bfr[ks], i, j, acc[i][j], x2_sc);
             } else {
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) {
@@ -795,12 +825,14 @@ void launch_conv_halo(int dt, const void* params, dim3 grid, hipStream_t s) {
         if (dt == NOPE_F32) hipLaunchKernelGGL((conv3x3_halo_kernel<float, false, true>), grid, block, 0, s, p);
         else if (dt == NOPE_BF16X3) hipLaunchKernelGGL((conv3x3_halo_kernel<f32s_t, false, true>), grid, block, 0, s, p);
         else if (dt == NOPE_F16) hipLaunchKernelGGL((conv3x3_halo_kernel<f16_t, false, true>), grid, block, 0, s, p);
+        else if (dt == NOPE_F16X2) hipLaunchKernelGGL((conv3x3_halo_kernel<f16x2_t, false, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((conv3x3_halo_kernel<bf16_t, false, true>), grid, block, 0, s, p);
         return;
     }
     if (dt == NOPE_F32) hipLaunchKernelGGL((conv3x3_halo_kernel<float>), grid, block, 0, s, p);
     else if (dt == NOPE_BF16X3) hipLaunchKernelGGL((conv3x3_halo_kernel<f32s_t>), grid, block, 0, s, p);
     else if (dt == NOPE_F16) hipLaunchKernelGGL((conv3x3_halo_kernel<f16_t>), grid, block, 0, s, p);
+    else if (dt == NOPE_F16X2) hipLaunchKernelGGL((conv3x3_halo_kernel<f16x2_t>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((conv3x3_halo_kernel<bf16_t>), grid, block, 0, s, p);
 }
 

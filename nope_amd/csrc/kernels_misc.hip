@@ -68,6 +68,48 @@ __global__ __launch_bounds__(NT) void pack_conv_w_kernel(const float* __restrict
     }
 }
 
+// ---- NOPE_F16X2 weight layout (Tile<f16x2_t>, conv_gemm_common.h): [Cout][tap][Cin / 32] chunks of 128 bytes = eight 16-byte slots:
+// slots 0..3 the f16 hi parts of the chunk's 32 channels (8 per slot), slot 4 + 2 p + h (p = channel / 16 inside the chunk) 16 e4m3 bytes:
+// h = 0: w * 2^sw, h = 1: (w - hi) * 2^(sw + 11).  sw is the layer's power-of-two pre-scale, the largest that keeps max |w| * 2^sw below 256
+// (the format reaches 448); |w - hi| <= 2^-11 max |w|, so the second operand cannot overflow either.  Two launches: max |w| into the tail of
+// the packed buffer (bits of a non-negative float order like unsigned integers), then the rows; the first thread also writes the E8M0
+// scale byte the conv kernel hands to the MFMA: 127 - 9 - sw (nope_common.h).
+__global__ __launch_bounds__(NT) void absmax_bits_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        const float v = fabsf(w[i]);
+        const unsigned b = __builtin_bit_cast(unsigned, v);
+        if (v == v && b > m) m = b;                    // (a NaN weight does not decide the scale)
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+__device__ __forceinline__ int x2_weight_shift(unsigned maxbits) {
+    const int e = (int)(maxbits >> 23) - 127;          // floor(log2 max |w|) (normal numbers; zero / subnormal maxima give e = -127)
+    const int sw = 7 - e;                              // max |w| * 2^sw in [128, 256)
+    return sw < -64 ? -64 : (sw > 100 ? 100 : sw);
+}
+__global__ __launch_bounds__(NT) void pack_conv_w_x2_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Cin, size_t total, int* __restrict__ tail) {
+    const int sw = x2_weight_shift((unsigned)tail[2]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { tail[0] = 127 - kX2ALoShift - sw; tail[1] = sw; tail[3] = 0; }
+    const float s8 = ldexpf(1.0f, sw), sl8 = ldexpf(1.0f, sw + kX2WLoExtra);
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % Cin);
+        const size_t t = i / Cin;
+        const int tap = (int)(t % 9);
+        const size_t co = t / 9;
+        const float v = w[(co * Cin + c) * 9 + tap];       // torch [Cout][Cin][3][3]
+        const f16_t hi = f32_to_f16_sat(v);
+        const float lo = v - (float)hi;
+        unsigned char* chunk = out + (t * (size_t)Cin + (size_t)(c & ~31)) * 4;      // 4 bytes per channel and row: 128-byte chunks
+        const int cc = c & 31;
+        reinterpret_cast<f16_t*>(chunk)[cc] = hi;                                    // slots 0..3
+        chunk[(4 + 2 * (cc >> 4)) * 16 + (cc & 15)] = (unsigned char)(cvt_pk_e4m3(v * s8, 0.f) & 0xffu);
+        chunk[(5 + 2 * (cc >> 4)) * 16 + (cc & 15)] = (unsigned char)(cvt_pk_e4m3(lo * sl8, 0.f) & 0xffu);
+    }
+}
+
 // out[r] = sum_k packed[r][k] (f32 sum of the values as the GEMM will see them)
 template <class T>
 __global__ __launch_bounds__(NT) void rowsum_kernel(const T* __restrict__ a, float* __restrict__ out, int rows, int K) {
@@ -182,6 +224,10 @@ int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int
     if (!w || !out || Cout <= 0 || Cin <= 0 || ntaps <= 0 || Cin_src < 0 || Cin_src > Cin) return NOPE_ERR_ARG;
     if (Cin_src && Cin_src != Cin && (mode == NOPE_CONV_UP2P || cin_scale)) return NOPE_ERR_ARG;
     const int csrc = Cin_src ? Cin_src : Cin;
+    if (dt == NOPE_F16X2) {                                             // the tap-resident kernel's layout: 3x3 stride 1 only
+        if (mode != NOPE_CONV_PLAIN || ntaps != 9 || cin_scale || cout_scale || csrc != Cin) return NOPE_ERR_UNSUPPORTED;
+        return launch_pack_conv_w_x2(w, out, Cout, Cin, s);
+    }
     if (mode == NOPE_CONV_DOWN2 && ntaps != 4) return NOPE_ERR_ARG;
     if (dt == NOPE_BF16X3 && Cin % 8) return NOPE_ERR_UNSUPPORTED;      // (hi, lo) groups of 8 channels
     if (mode == NOPE_CONV_UP2P && ntaps == 16) {     // source is a ConvTranspose2d(4, 2, 1) weight
@@ -200,6 +246,21 @@ int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int
     }
     const size_t total = (size_t)Cout * ntaps * Cin;
     NOPE_DISPATCH_W(dt, T, hipLaunchKernelGGL((pack_conv_w_kernel<T>), dim3(grid_for(total)), dim3(NT), 0, s, w, (T*)out, Cin, ntaps, mode, total, cin_scale, cout_scale, csrc));
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+size_t conv_w_x2_bytes(int Cout, int Cin) { return (size_t)Cout * 9 * Cin * 4 + kX2TailBytes; }
+
+int launch_pack_conv_w_x2(const float* w, void* out, int Cout, int Cin, hipStream_t s) {
+    if (!w || !out || Cout <= 0 || Cin <= 0) return NOPE_ERR_ARG;
+    if (Cin % 32) return NOPE_ERR_UNSUPPORTED;                          // whole 32-channel chunks
+    const size_t total = (size_t)Cout * 9 * Cin;
+    int* tail = reinterpret_cast<int*>((unsigned char*)out + total * 4);
+    if (hipMemsetAsync(tail, 0, kX2TailBytes, s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid_for(total)), dim3(NT), 0, s, w, total, reinterpret_cast<unsigned*>(tail) + 2);
+    NOPE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pack_conv_w_x2_kernel, dim3(grid_for(total)), dim3(NT), 0, s, w, (unsigned char*)out, Cin, total, tail);
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

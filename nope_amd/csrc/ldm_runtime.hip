@@ -479,7 +479,7 @@ int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors,
     hipStream_t s = (hipStream_t)stream;
     nope_ldm* net = new nope_ldm();
     net->cfg = *cfg;
-    net->dt = cfg->compute_dtype;
+    net->dt = dt_base(cfg->compute_dtype);      // (NOPE_F16X2 = NOPE_BF16X3 in this variant)
     net->sdt = dt_storage(net->dt);
     net->emb_dim = cfg->model_channels * 4;
     const int mc = cfg->model_channels;

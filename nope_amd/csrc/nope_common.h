@@ -146,11 +146,39 @@ template <> struct Elt<f32s_t> {
     static __device__ __forceinline__ u32x4 pack(const float* o) { return Elt<float>::pack(o); }
 };
 
+// NOPE_F16X2: f32 activations as NOPE_BF16X3; the tag selects the tap-resident 3x3 kernel's f16 + MX-fp8 tile (Tile<f16x2_t>,
+// conv_gemm_common.h) and its weight layout (pack_conv_w_x2_kernel, kernels_misc.hip).  No other kernel is instantiated for it.
+struct f16x2_t { float f; };
+template <> struct Elt<f16x2_t> {
+    static constexpr int VEC = 4;
+    static constexpr int DT = NOPE_F16X2;
+    static constexpr bool SATURATES = false;
+    static __device__ __forceinline__ float ld(const f16x2_t* p) { return p->f; }
+    static __device__ __forceinline__ void st(f16x2_t* p, float v) { p->f = v; }
+    static __device__ __forceinline__ void unpack(const u32x4& v, float* o) { Elt<float>::unpack(v, o); }
+    static __device__ __forceinline__ u32x4 pack(const float* o) { return Elt<float>::pack(o); }
+};
+// Two f32 -> two OCP e4m3 bytes (bits 0..15 of the result; v_cvt_pk_fp8_f32: round to nearest even, subnormals kept, 480 and beyond
+// become NaN -- tools/probes/mx_probe.hip -- hence the clamp to the format's largest value first, as HIP's own fp8 header does)
+constexpr float kE4M3Max = 448.0f;
+__device__ __forceinline__ unsigned cvt_pk_e4m3(float lo, float hi) {
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(lo, -kE4M3Max, kE4M3Max), __builtin_amdgcn_fmed3f(hi, -kE4M3Max, kE4M3Max), 0, false) & 0xffffu;
+}
+// Power-of-two pre-scales of the f16x2 cross-term operands (exact multiplications), undone by the MFMA's E8M0 block scale:
+//   e4m3(a_lo * 2^9), e4m3(a * 2^-2)  [activations, fixed]      e4m3(w * 2^sw), e4m3(w_lo * 2^(sw + 11))  [weights, sw per layer]
+// chosen so that BOTH products of the K-concatenated instruction, a_lo w and a w_lo, carry the same total 2^(9 + sw): one scale for all
+// lanes (the instruction's scale blocks follow byte positions, not lane halves: tools/probes/mx_probe.hip fact 3h).  |a| up to 1792
+// and |a_lo| of |a| up to 2048 stay below the clamp; beyond, the element degrades towards plain f16 accuracy.
+constexpr int kX2ALoShift = 9, kX2AShift = -2, kX2WLoExtra = 11;
+constexpr int kX2TailBytes = 16;      // behind the packed weights: int A-scale byte (127 - 9 - sw), int sw, float max |w|, 0
+
 // dtype code -> bytes per stored element / elements per 16-byte vector / the dtype the non-conv kernels see
-static inline int dt_es(int dt) { return (dt == NOPE_F32 || dt == NOPE_BF16X3) ? 4 : 2; }
+static inline int dt_es(int dt) { return (dt == NOPE_F32 || dt == NOPE_BF16X3 || dt == NOPE_F16X2) ? 4 : 2; }
 static inline int dt_vec(int dt) { return 16 / dt_es(dt); }
-static inline int dt_storage(int dt) { return dt == NOPE_BF16X3 ? NOPE_F32 : dt; }
-static inline bool dt_is_compute(int dt) { return dt == NOPE_F32 || dt == NOPE_BF16 || dt == NOPE_F16 || dt == NOPE_BF16X3; }
+static inline int dt_storage(int dt) { return (dt == NOPE_BF16X3 || dt == NOPE_F16X2) ? NOPE_F32 : dt; }
+static inline bool dt_is_compute(int dt) { return dt == NOPE_F32 || dt == NOPE_BF16 || dt == NOPE_F16 || dt == NOPE_BF16X3 || dt == NOPE_F16X2; }
+// the element type every launch EXCEPT the tap-resident 3x3 kernel sees under a compute mode (NOPE_F16X2 is NOPE_BF16X3 there)
+static inline int dt_base(int dt) { return dt == NOPE_F16X2 ? NOPE_BF16X3 : dt; }
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
@@ -228,6 +256,8 @@ struct ConvArgs {
     int mode = NOPE_CONV_PLAIN;  // NOPE_CONV_PLAIN | UP2 | DOWN2 | UP2P | STRIDE2
     int ntaps = 1;               // 1 or 9 (PLAIN, STRIDE2), 9 (UP2), 4 (DOWN2, UP2P)
     const void* w = nullptr;     // packed [Cout][ntaps][Cin]
+    const void* w_x2 = nullptr;  // NOPE_BF16X3 launches only: the same weights in the NOPE_F16X2 layout (launch_pack_conv_w_x2) -- taken, with
+                                 // the f16 + MX-fp8 tile, when the launch goes to the tap-resident kernel; `w` (may be null then) otherwise
     const float* bias = nullptr; // [Cout] or null
     const void* resid = nullptr; // optional NHWC [M][Cout] added in the epilogue
     void* out = nullptr;
@@ -291,6 +321,10 @@ int launch_nchw_to_nhwc(int dt, const float* x, void* y, int n, int C, int HW, h
 int launch_nhwc_to_nchw_f32(int dt, const void* x, float* y, int n, int C, int HW, hipStream_t s);
 int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s,
                        const float* cin_scale = nullptr, const float* cout_scale = nullptr, int Cin_src = 0);   // Cin_src < Cin: zero weights for the padding
+// NOPE_F16X2 layout of a 3x3 stride-1 weight [Cout][Cin][3][3], Cin % 32 == 0: conv_w_x2_bytes() bytes (the rows + a 16-byte tail with the
+// layer's block scale, derived on the device from max |w|: no host round trip)
+size_t conv_w_x2_bytes(int Cout, int Cin);
+int launch_pack_conv_w_x2(const float* w, void* out, int Cout, int Cin, hipStream_t s);
 // template encoder (kernels_encoder.hip)
 int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale, float* shift,
                    int C, hipStream_t s);

@@ -30,7 +30,7 @@ using namespace nope;
 
 namespace {
 
-struct Conv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; };
+struct Conv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; void* w_x2 = nullptr; };   // w_x2: NOPE_F16X2 only, 3x3 stride-1 layers: the tap-resident kernel's layout
 struct Norm { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct Res { Conv c1, c2, res; Norm n1, n2; bool has_res = false; int emb_off = -1; };
 // PreNorm's GroupNorm(1) is folded into the qkv conv: gamma into the packed weights, c0 = W beta, c1 = W gamma
@@ -51,6 +51,7 @@ struct nope_unet {
     nope_unet_config cfg;
     int dt = NOPE_F32;      // compute dtype: what the conv kernels and the weight packing see
     int sdt = NOPE_F32;     // storage dtype of the activations: what every other kernel sees (NOPE_BF16X3 keeps f32 activations)
+    bool x2 = false;        // NOPE_F16X2: dt = NOPE_BF16X3 everywhere, plus a second weight pack per 3x3 layer for the tap-resident kernel's f16 + MX-fp8 tile
     std::vector<void*> allocs;
     int dims[9];
     int classes = 0;
@@ -129,6 +130,10 @@ struct Loader {
             const size_t es = (size_t)dt_es(net->dt);
             c.w = dmalloc((size_t)Cout * c.ntaps * Cin * es * (mode == NOPE_CONV_UP2P ? 4 : 1));
             if (c.w) { int e = launch_pack_conv_w(net->dt, d->data, c.w, Cout, Cin, convT ? 16 : c.ntaps, mode, s, cin_scale, nullptr, Csrc); if (e && err == NOPE_OK) err = e; }
+            if (net->x2 && mode == NOPE_CONV_PLAIN && ksz == 3 && !cin_scale && Csrc == Cin && Cin % 32 == 0) {
+                c.w_x2 = dmalloc(conv_w_x2_bytes(Cout, Cin));
+                if (c.w_x2) { int e = launch_pack_conv_w_x2((const float*)d->data, c.w_x2, Cout, Cin, s); if (e && err == NOPE_OK) err = e; }
+            }
         }
         if (has_bias) c.bias = copy_f32(pfx + "bias", {Cout});
         return c;
@@ -216,7 +221,7 @@ struct Fwd {
         ca.src1 = a.p; ca.C1 = a.C; ca.rep1 = rep1;
         if (b) { ca.src2 = b->p; ca.C2 = b->C; ca.rep2 = rep2; }
         ca.Hs = a.H; ca.Ws = a.W; ca.Ho = Ho; ca.Wo = Wo;
-        ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.bias = c.bias; ca.resid = resid;
+        ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.w_x2 = c.w_x2; ca.bias = c.bias; ca.resid = resid;
         ca.out = out; ca.Cout = c.Cout; ca.nhyp = n; ca.out_nchw = out_nchw; ca.out_dt = out_dt;
         if (a.C + (b ? b->C : 0) != c.Cin) { chk(NOPE_ERR_ARG); return; }
         float* colstats = nullptr;
@@ -251,7 +256,8 @@ struct Fwd {
             ev.bytes = ((double)(n / rep1) * a.H * a.W * a.C + (b ? (double)(n / rep2) * a.H * a.W * b->C : 0.0) +
                         (double)c.Cout * c.ntaps * c.Cin * (c.mode == NOPE_CONV_UP2P ? 4 : 1) + (double)n * Ho * Wo * c.Cout) * (double)es;
             ev.info = nope_conv_launch_info{0.0, ev.flops, ev.bytes, conv_kernel_kind(net->dt, ca), c.mode, c.ntaps, c.Cin, c.Cout, a.H, a.W, n,
-                                            net->dt == NOPE_BF16X3 ? 3 : 1, conv_is_posmajor(net->dt, ca) ? 1 : 0};
+                                            net->dt != NOPE_BF16X3 ? 1 : (ca.w_x2 && conv_kernel_kind(net->dt, ca) == NOPE_CONV_KERNEL_HALO256) ? 2 : 3,
+                                            conv_is_posmajor(net->dt, ca) ? 1 : 0};
             hipEventRecord(ev.a, s);
             chk(launch_conv(net->dt, ca, s));
             hipEventRecord(ev.b, s);
@@ -516,7 +522,8 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
     hipStream_t s = (hipStream_t)stream;
     nope_unet* net = new nope_unet();
     net->cfg = *cfg;
-    net->dt = cfg->compute_dtype;
+    net->x2 = cfg->compute_dtype == NOPE_F16X2;
+    net->dt = dt_base(cfg->compute_dtype);
     net->sdt = dt_storage(net->dt);
     const int L = cfg->n_levels;
     net->dims[0] = cfg->u_net_dim;

@@ -141,7 +141,7 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--templates", type=int, default=64)
     ap.add_argument("--size", type=int, default=128)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16x3", "f16", "bf16"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16x2", "bf16x3", "f16", "bf16"])
     ap.add_argument("--bank-dtype", default="f32", choices=["f32", "bf16", "f16"])
     ap.add_argument("--seed", type=int, default=2022)
     ap.add_argument("--category", default="synthetic")

@@ -13,7 +13,8 @@ from typing import Dict, Optional, Tuple
 import torch
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3      # BF16X3: compute mode only (f32 storage, three bf16 MFMA passes per product)
-ABI_VERSION = 4                          # NOPE_ABI_VERSION of include/nope_hip.h these ctypes structs mirror
+F16X2 = 4                                # compute mode only: BF16X3, but the tap-resident 3x3 launches run one f16 + one MX-fp8 MFMA pass (include/nope_hip.h)
+ABI_VERSION = 5                          # NOPE_ABI_VERSION of include/nope_hip.h these ctypes structs mirror
 CONV_PLAIN, CONV_UP2, CONV_DOWN2, CONV_UP2P, CONV_STRIDE2 = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -194,12 +195,12 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def torch_dtype(dt: int) -> torch.dtype:
     """torch dtype of tensors STORED under dtype code dt (BF16X3 keeps f32 activations)."""
-    return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16, BF16X3: torch.float32}[dt]
+    return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16, BF16X3: torch.float32, F16X2: torch.float32}[dt]
 
 
 def storage_code(dt: int) -> int:
     """dtype code the non-conv operators see for tensors of compute mode dt."""
-    return F32 if dt == BF16X3 else dt
+    return F32 if dt in (BF16X3, F16X2) else dt
 
 
 def dtype_code(dt) -> int:
@@ -211,6 +212,8 @@ def dtype_code(dt) -> int:
         return F16
     if dt in (BF16X3, "bf16x3"):
         return BF16X3
+    if dt in (F16X2, "f16x2"):
+        return F16X2
     raise NopeError(f"unsupported dtype {dt!r}")
 
 
@@ -602,7 +605,10 @@ def pack_conv_weight(w: torch.Tensor, dt: int, mode: int = CONV_PLAIN) -> Tuple[
         cin, ntaps = w.shape[1], 4
     else:
         cin, ntaps = w.shape[1], w.shape[2] * w.shape[3]
-    out = torch.empty((4 if mode == CONV_UP2P else 1, cout, ntaps, cin), dtype=torch_dtype(dt), device=w.device)
+    if dt == F16X2:      # the tap-resident kernel's layout (3x3 stride 1 only): 4 bytes per weight + a 16-byte tail with the layer's block scale
+        out = torch.empty(cout * ntaps * cin + 4, dtype=torch.float32, device=w.device)
+    else:
+        out = torch.empty((4 if mode == CONV_UP2P else 1, cout, ntaps, cin), dtype=torch_dtype(dt), device=w.device)
     l = lib()
     l.check(l.dll.nope_op_pack_conv_weight(dt, _ptr(w), _ptr(out), cout, cin, ntaps, mode, _stream(w)), "pack_conv_weight")
     return out, cin, ntaps

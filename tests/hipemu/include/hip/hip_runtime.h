@@ -391,6 +391,64 @@ inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x8 b
     }
     return c;
 }
+// ---- OCP e4m3 (fn) and the MX-scaled fp8 MFMA, as measured on gfx950 by tools/probes/mx_probe.hip
+inline float hipemu_e4m3_to_f32(unsigned char v) {
+    const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+    float r;
+    if (e == 15 && m == 7) r = NAN;
+    else if (e == 0) r = ldexpf((float)m, -9);
+    else r = ldexpf(1.0f + m / 8.0f, e - 7);
+    return s ? -r : r;
+}
+inline unsigned char hipemu_f32_to_e4m3(float x) {       // round to nearest even; beyond the largest value (448 + half a step): NaN
+    const unsigned char sign = std::signbit(x) ? 0x80 : 0;
+    const float ax = fabsf(x);
+    if (!(ax == ax) || ax >= 480.0f) return (unsigned char)(sign | 0x7f);
+    unsigned char best = 0; float bd = INFINITY;
+    for (int v = 0; v < 127; ++v) {
+        const float dd = fabsf(hipemu_e4m3_to_f32((unsigned char)v) - ax);
+        if (dd < bd || (dd == bd && !(v & 1) && (best & 1))) { bd = dd; best = (unsigned char)v; }
+    }
+    return (unsigned char)(best | sign);
+}
+// v_cvt_pk_fp8_f32 dst, a, b: byte 0 (or 2 with word_sel) = e4m3(a), byte 1 (3) = e4m3(b); the other half of `old` is kept
+inline int hipemu_cvt_pk_fp8_f32(float a, float b, int old, bool word_sel) {
+    const unsigned pk = (unsigned)hipemu_f32_to_e4m3(a) | ((unsigned)hipemu_f32_to_e4m3(b) << 8);
+    return word_sel ? (int)(((unsigned)old & 0x0000ffffu) | (pk << 16)) : (int)(((unsigned)old & 0xffff0000u) | pk);
+}
+#define __builtin_amdgcn_cvt_pk_fp8_f32 hipemu_cvt_pk_fp8_f32
+// v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 x e4m3 (cbsz = blgp = 0), op_sel 0: byte e of lane (i, half h) of A pairs with byte e of lane
+// (j, half h) of B; an element's scale block is its byte-position half: bytes 0..15 take byte 0 of the scale register of lane i (j),
+// bytes 16..31 that of lane i + 32 (j + 32); value x 2^(scale - 127).  The 64-term sum is exact here (the hardware truncates it at ~2^-12
+// of the largest term).
+typedef __attribute__((ext_vector_type(8))) int hipemu_i32x8;
+inline hipemu_f32x16 hipemu_mfma_scale_f32_32x32x64_f8f6f4(hipemu_i32x8 a, hipemu_i32x8 b, hipemu_f32x16 c, int cbsz, int blgp, int opsel_a, int scale_a,
+                                                          int opsel_b, int scale_b) {
+    if (cbsz || blgp || opsel_a || opsel_b) { fprintf(stderr, "hipemu: only the e4m3 x e4m3, op_sel 0 form of the MX MFMA is emulated\n"); abort(); }
+    struct P { unsigned char a[32], b[32]; int sa, sb; } p;
+    memcpy(p.a, &a, 32); memcpy(p.b, &b, 32); p.sa = scale_a & 0xff; p.sb = scale_b & 0xff;
+    // (the wave_exchange slot is 64 bytes: send the two operands in two rounds)
+    struct Q { unsigned char v[32]; int s; };
+    Q qa, qb;
+    memcpy(qa.v, p.a, 32); qa.s = p.sa; memcpy(qb.v, p.b, 32); qb.s = p.sb;
+    Q A[64], B[64];
+    { auto s = hipemu::wave_exchange(&qa, sizeof(Q)); for (int l = 0; l < 64; ++l) memcpy(&A[l], s[l], sizeof(Q)); }
+    { auto s = hipemu::wave_exchange(&qb, sizeof(Q)); for (int l = 0; l < 64; ++l) memcpy(&B[l], s[l], sizeof(Q)); }
+    int lane = hipemu::lane_id();
+    int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        double acc = 0.0;
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 32; ++e) {
+                const double sa = ldexp(1.0, A[row + 32 * (e >> 4)].s - 127), sb = ldexp(1.0, B[col + 32 * (e >> 4)].s - 127);
+                acc += (double)hipemu_e4m3_to_f32(A[row + 32 * h].v[e]) * sa * (double)hipemu_e4m3_to_f32(B[col + 32 * h].v[e]) * sb;
+            }
+        c[r] = (float)((double)c[r] + acc);
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4 hipemu_mfma_scale_f32_32x32x64_f8f6f4
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu_mfma_f32_32x32x16_f16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_f32_16x16x32_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
@@ -459,6 +517,11 @@ inline float atomicAdd(float* p, float v) {
 }
 
 inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicMax(unsigned* p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 
 // ---- runtime API shims --------------------------------------------------------------------
 inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorOutOfMemory; }

@@ -1,0 +1,141 @@
+"""The tap-resident 3x3 kernel's NOPE_F16X2 instantiation (f16 hi x hi + one MX-scaled fp8 MFMA for both cross terms, kernels_gemm_pp.hip /
+Tile<f16x2_t>) on small shapes under tests/hipemu: against the f32 convolution (tolerance of the mode) AND against a torch restatement of
+the exact arithmetic the kernel performs (operands rounded as convert_piece / pack_conv_w_x2_kernel round them: tight tolerance -- a wrong
+slot, byte position, pre-scale or block scale shows here, not in the loose check).  Run by tests/test_conv_pingpong.py with the
+interpreter's adversarial settings; `run(hip, "cuda")` is the GPU form of the same cases."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+import torch
+import torch.nn.functional as F
+
+from tests.util import rel
+
+X2 = 4                      # hip.F16X2
+A_LO_SHIFT, A_SHIFT, W_LO_EXTRA = 9, -2, 11      # nope_common.h: kX2ALoShift, kX2AShift, kX2WLoExtra
+
+
+def q8(x, log2_scale):
+    s = 2.0 ** log2_scale
+    return (x * s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() / s
+
+
+def x2_reference(x, w, b):
+    """out = f16(a) f16(w) + e4m3(a_lo 2^9) e4m3(w 2^sw) 2^-(9+sw) + e4m3(a 2^-2) e4m3(w_lo 2^(sw+11)) 2^-(9+sw), f64 accumulation"""
+    m = float(w.abs().max())
+    e = torch.frexp(torch.tensor(m))[1].item() - 1          # floor(log2 m)
+    sw = 7 - e
+    ah, wh = x.clamp(-65504, 65504).half().float(), w.half().float()
+    al, wl = x - ah, w - wh
+    d = torch.float64
+    out = F.conv2d(ah.to(d), wh.to(d), None, padding=1)
+    out = out + F.conv2d(q8(al, A_LO_SHIFT).to(d), q8(w, sw).to(d), None, padding=1)
+    out = out + F.conv2d(q8(x, A_SHIFT).to(d), q8(wl, sw + W_LO_EXTRA).to(d), None, padding=1)
+    if b is not None:
+        out = out + b.to(d)[None, :, None, None]
+    return out.float()
+
+
+def run(hip, dev, light=False):
+    os.environ["NOPE_CONV_PP"] = "13"          # ping-pong kernels at any tile count
+    g = torch.Generator().manual_seed(91)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    d = lambda t: t.to(dev)
+    C = 32
+    worst = 0.0
+
+    def chk(y, x, w, b, what, extra=None):
+        nonlocal worst
+        y = hip.to_nchw(y, 0).cpu()
+        want32 = F.conv2d(x, w, b, padding=1)
+        want = x2_reference(x, w, b)
+        if extra is not None:
+            want32, want = want32 + extra, want + extra
+        e_exact, e32 = rel(y, want), rel(y, want32)
+        worst = max(worst, e_exact / 2e-6, e32 / 3e-5)
+        assert e_exact < 2e-6, (what, "vs the restated arithmetic", e_exact)
+        assert e32 < 3e-5, (what, "vs the f32 convolution", e32)
+    try:
+        # concat of two sources, ragged M (270 rows = 2 tiles), two N tiles, bias: chunks from both sources
+        x1, x2 = rn(3, C, 10, 9), rn(3, C, 10, 9)
+        w, b = rn(200, 2 * C, 3, 3) / 30, rn(200)
+        y = hip.op_conv(X2, hip.to_nhwc(d(x1), 0), d(w), d(b), src2=hip.to_nhwc(d(x2), 0))
+        chk(y, torch.cat((x1, x2), 1), w, b, "halo 3x3 concat")
+        # broadcast second source
+        xb = rn(1, C, 10, 9)
+        y = hip.op_conv(X2, hip.to_nhwc(d(x2), 0), d(w), d(b), src2=hip.to_nhwc(d(xb), 0), rep1=1, rep2=3, n_hyp=3)
+        chk(y, torch.cat((x2, xb.expand(3, -1, -1, -1)), 1), w, b, "halo 3x3 concat, broadcast second source")
+        # 4x4 maps, many samples per tile; activations with a wide dynamic range (large values saturate the fp8 parts, tiny ones flush):
+        # the restated arithmetic saturates / flushes the same way
+        xs = rn(40, C, 4, 4) * torch.exp(2.5 * rn(40, C, 4, 4))
+        xs[0, 0, 0, 0], xs[1, 3, 2, 1] = 3000.0, -70000.0
+        ws_, bs = rn(24, C, 3, 3) / (3 * C ** 0.5), rn(24)
+        y = hip.op_conv(X2, hip.to_nhwc(d(xs), 0), d(ws_), d(bs))
+        yy = hip.to_nchw(y, 0).cpu()
+        want = x2_reference(xs, ws_, bs)
+        assert rel(yy, want) < 2e-6, ("halo 4x4 x 40 samples, wide range", rel(yy, want))
+        # residual in the epilogue; widest supported map
+        if not light:
+            xw, ww = rn(1, 2 * C, 9, 32), rn(16, 2 * C, 3, 3) / (3 * (2 * C) ** 0.5)
+            rs = rn(1, 16, 9, 32)
+            y = hip.op_conv(X2, hip.to_nhwc(d(xw), 0), d(ww), None, resid=hip.to_nhwc(d(rs), 0))
+            chk(y, xw, ww, None, "halo W=32 + residual", extra=rs)
+            # a workgroup walking several tiles, and split-K over the channel chunks: same bits as the plain launch
+            xq, wq, bq = rn(64, 4 * C, 8, 8), rn(200, 4 * C, 3, 3) / (3 * (4 * C) ** 0.5), rn(200)
+            y0 = hip.op_conv(X2, hip.to_nhwc(d(xq), 0), d(wq), d(bq))
+            chk(y0, xq, wq, bq, "halo 64 x 8x8, 4 chunks")
+            os.environ["NOPE_CONV_PP"] = "11"
+            os.environ["NOPE_HALO_PERSIST"] = "16"
+            y1 = hip.op_conv(X2, hip.to_nhwc(d(xq), 0), d(wq), d(bq))
+            os.environ.pop("NOPE_HALO_PERSIST")
+            os.environ["NOPE_CONV_PP"] = "13"
+            assert torch.equal(y0, y1), "walking workgroups differ from one tile per workgroup"
+            os.environ["NOPE_HALO_SPLIT_MIN_CHUNKS"] = "2"
+            y2 = hip.op_conv(X2, hip.to_nhwc(d(xq[:8]), 0), d(wq), d(bq), split_k=True)
+            os.environ.pop("NOPE_HALO_SPLIT_MIN_CHUNKS")
+            chk(y2, xq[:8], wq, bq, "halo split-K")
+        # a shape the tap-resident kernel does not take (1x1): the element type refuses it
+        try:
+            hip.op_conv(X2, hip.to_nhwc(d(x2), 0), d(rn(24, C, 1, 1)), None)
+            raise AssertionError("NOPE_F16X2 accepted a 1x1 convolution")
+        except hip.NopeError:
+            pass
+    finally:
+        os.environ.pop("NOPE_CONV_PP", None)
+    return worst
+
+
+def run_unet(hip, dev, dim=64, n_hyp=5, hw=16):
+    """Whole U-Net in the f16x2 compute mode against the oracle (tolerance of the mode) with the tap-resident kernel wherever it applies."""
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    from oracle import nope_ref as R
+    from tests.util import StubEncoder
+    os.environ["NOPE_CONV_PP"] = "11"
+    try:
+        u = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype="f16x2")
+        synth_init_(u, 2022)
+        sd = {k: v.clone() for k, v in u.own_state_dict().items()}
+        u = u.to(dev)
+        g = torch.Generator().manual_seed(23)
+        x, pose = torch.randn(1, 8, hw, hw, generator=g), torch.randn(1, n_hyp, 6, generator=g)
+        y = u.forward_hypotheses(x.to(dev), pose.to(dev)).cpu()[0]
+        want = R.unet_forward(sd, x.expand(n_hyp, -1, -1, -1), pose[0])
+        return rel(y, want)
+    finally:
+        os.environ.pop("NOPE_CONV_PP")
+
+
+if __name__ == "__main__":
+    import build_emu
+    from nope_amd import hip
+    hip._set_library_for_testing(hip.NopeLib(build_emu.build()))
+    if "--unet" in sys.argv:
+        e = run_unet(hip, "cpu", 32, n_hyp=2, hw=8)
+        assert e < 1e-4, e
+        print("x2 unet ok", e)
+    else:
+        print("x2 ok", run(hip, "cpu", light="--light" in sys.argv))
