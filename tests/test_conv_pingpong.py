@@ -29,9 +29,48 @@ def test_pingpong_kernel_under_adversarial_interpreter(emu):
     envs.append({"HIPEMU_SHUFFLE": "1"})
     procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pp_emu_case.py"), "--unet16"], env=dict(os.environ, HIPEMU_THREADS="4", **envs[-1]),
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    # fourth: the tap-resident kernel's NOPE_F16X2 tile (in-LDS operand rewrite + MX-scaled fp8 MFMA) with late DMA + shuffled waves; fifth: a
+    # whole U-Net in the f16x2 compute mode (second weight pack per 3x3 layer, block scale read from the packed tail, the other launches as
+    # bf16x3) with the tap-resident kernel forced onto every eligible launch, against the oracle.  (The remaining op-level cases -- tile walk,
+    # split-K, residual epilogue, widest map -- run on the GPU, test_f16x2_tile_gpu, and by hand: python tests/x2_emu_case.py.)
+    for e, extra in (({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--light"]), ({"HIPEMU_SHUFFLE": "2"}, ["--unet"])):
+        envs.append(e)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "x2_emu_case.py")] + extra, env=dict(os.environ, HIPEMU_THREADS="2", **e),
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     for e, pr in zip(envs, procs):
         out, _ = pr.communicate(timeout=1500)
-        assert pr.returncode == 0 and "pp_emu_case OK" in out, (e, out[-2000:])
+        assert pr.returncode == 0 and ("pp_emu_case OK" in out or "x2 ok" in out or "x2 unet ok" in out), (e, out[-2000:])
+
+
+@pytest.mark.gpu
+def test_f16x2_tile_gpu(gpu):
+    """The same cases on the device: against the restated arithmetic (2e-6: operand rounding, pre-scales, block scale, slot layout) and the f32
+    convolution (3e-5); then the shapes of the 512-hypothesis step -- reproducible, tile walk == one tile per workgroup, split-K == fixed-order sum
+    within rounding -- against the bf16x3 launch of the same operands."""
+    from tests import x2_emu_case
+    hip = gpu
+    assert x2_emu_case.run(hip, "cuda") < 1.0
+    e = x2_emu_case.run_unet(hip, "cuda")
+    print(f"U-Net (u_net_dim 64, 5 hypotheses, 16 x 16) in the f16x2 mode, tap-resident kernel forced: {e:.2e} vs the oracle")
+    assert e < 1e-4
+    g = torch.Generator(device="cuda").manual_seed(6)
+    for c1, c2, cout, h, n in ((192, 0, 192, 32, 512), (192, 192, 192, 32, 256), (384, 192, 384, 16, 512), (768, 0, 768, 8, 512), (1536, 0, 1536, 4, 512)):
+        cin = c1 + c2
+        w = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (cin * 9) ** 0.5
+        s1 = torch.randn(n, h, h, c1, device="cuda", generator=g)
+        s2 = torch.randn(n, h, h, c2, device="cuda", generator=g) if c2 else None
+        b = torch.randn(cout, device="cuda", generator=g)
+        ys = [hip.op_conv(hip.F16X2, s1, w, b, src2=s2) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert all(torch.equal(ys[0], y) for y in ys[1:]), ("not reproducible", c1, c2, cout, h)
+        y3 = hip.op_conv(hip.BF16X3, s1, w, b, src2=s2)
+        e = float((ys[0] - y3).abs().max() / y3.abs().max())
+        print(f"f16x2 vs bf16x3, {cin} -> {cout} @ {h}x{h} x {n}: {e:.2e}")
+        assert e < 3e-5
+        os.environ["NOPE_HALO_PERSIST"] = "0"
+        y1 = hip.op_conv(hip.F16X2, s1, w, b, src2=s2)
+        os.environ.pop("NOPE_HALO_PERSIST")
+        assert torch.equal(ys[0], y1), ("tile walk differs", c1, c2, cout, h)
 
 
 @pytest.mark.gpu

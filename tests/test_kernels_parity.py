@@ -17,7 +17,12 @@ from oracle import nope_ref as R
 from tests.util import StubEncoder, rel
 
 BACKENDS = [pytest.param("emu"), pytest.param("gpu", marks=pytest.mark.gpu)]
-F32_TOL = 1e-4
+# Regression bounds of whole-network / block outputs per mode (tests/util.py MODE_BOUNDS has the rationale): ~3x what is observed; north_star's
+# 1e-4 is the stated bar, these are the guards.  Tiny networks amplify less than the full-size one, so the same bounds hold here.
+F32_TOL = 1e-5
+X3_TOL = 5e-5       # bf16x3, f16x2 (tiny networks never reach the tap-resident kernel by themselves: f16x2 runs as bf16x3 unless forced)
+F16_TOL = 3e-3
+BF16_TOL = 4e-2
 BF16_TOL = 4e-2
 # per compute mode (hip.F32, BF16, F16, BF16X3): operator-level tolerance against the reference evaluated on inputs rounded to
 # the mode's storage type.  F16 = f16 storage + f16 MFMA; BF16X3 = f32 storage, three bf16 MFMA passes per product.
@@ -295,7 +300,7 @@ def test_tiny_unet_vs_reference_golden(be, golden, tag, dim, mlp):
     g = golden("unet_tiny.npz")
     x, pose, ref = g[f"{tag}/x"], g[f"{tag}/pose"], g[f"{tag}/out"]
     # bf16x3 (f32 storage, split-precision MFMA) has to hold the f32 tolerance; f16 = 16-bit storage with 11 significand bits
-    for cdt, tol in (("f32", F32_TOL), ("bf16x3", F32_TOL), ("bf16", 6e-2), ("f16", 8e-3)):
+    for cdt, tol in (("f32", F32_TOL), ("bf16x3", X3_TOL), ("bf16", BF16_TOL), ("f16", F16_TOL)):
         if name == "emu" and ((cdt == "bf16" and tag != "d8") or (cdt == "bf16x3" and tag != "d8") or cdt == "f16"):
             continue      # keep the CPU suite short (f16 differs from bf16 in one MFMA builtin: operator tests + pp_emu_case cover it)
         m = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name=mlp, compute_dtype=cdt,
@@ -320,7 +325,7 @@ def test_unet_latent_channels_padded(be):
     g = torch.Generator().manual_seed(19)
     x, pose = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 3, 6, generator=g)
     sd = None
-    for cdt, tol in (("f32", F32_TOL), ("bf16x3", F32_TOL), ("f16", 8e-3), ("bf16", 6e-2)):
+    for cdt, tol in (("f32", F32_TOL), ("bf16x3", X3_TOL), ("f16x2", X3_TOL), ("f16", F16_TOL), ("bf16", BF16_TOL)):
         if name == "emu" and cdt != "f32":
             continue      # keep the CPU suite short (the padding is the same code in every mode)
         u = UNet(u_net_dim=8, rot_representation_dim=6, encoder=StubEncoder(4), pose_mlp_name="single_layer", compute_dtype=cdt)
@@ -451,7 +456,7 @@ def test_encoder_tiny_image_emu(emu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cdt,tol", [("f32", F32_TOL), ("bf16", 6e-2)])
+@pytest.mark.parametrize("cdt,tol", [("f32", F32_TOL), ("bf16", BF16_TOL)])
 def test_encoder_golden_gpu(gpu, golden, cdt, tol):
     """encode_image on the device against the feature map recorded from the reference FeatureExtractor
     (tests/golden/encoder.npz: 2 x 3 x 64 x 64 -> 2 x 8 x 8 x 8)."""
@@ -690,7 +695,7 @@ def test_ldm_shipped_latent_channels(be):
     g = torch.Generator().manual_seed(17)
     x, pose = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 3, 6, generator=g)
     sd = None
-    for cdt, tol in (("f32", F32_TOL), ("bf16x3", F32_TOL), ("f16", 1e-2), ("bf16", 8e-2)):
+    for cdt, tol in (("f32", F32_TOL), ("bf16x3", X3_TOL), ("f16", 1e-2), ("bf16", 8e-2)):
         if name == "emu" and cdt != "f32":
             continue      # keep the CPU suite short (the padding is identical in every mode; the other modes run on the GPU)
         m = UNetModelPose(encoder=StubEncoder(4), rot_representation_dim=6, image_size=8, in_channels=4, out_channels=4, num_head_channels=32,

@@ -9,6 +9,14 @@ def rel(a, b):
     return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
 
 
+# Regression bounds per compute mode, (embedding maps, similarity scores), relative to the tensor's largest magnitude: ~3x what an MI355X
+# shows on the full-size network (f32 2.0-2.7e-6 / 5e-7; bf16x3 1.3-1.5e-5 / 6e-6; f16x2 1.6-2.9e-5 / 1.6e-5; f16 1.0-1.3e-3 / 8.7e-4;
+# bf16 1.6e-2 / 4.3-5e-3).  north_star's bar -- 1e-4 on the scores AND a bit-exact top-5 -- is a different thing and is asserted
+# separately for the modes that claim it (TOLERANCE_MODES).  A 30x regression of the f32 mode passed the old 1e-4 guard; it does not pass these.
+MODE_BOUNDS = {"f32": (1e-5, 1e-5), "bf16x3": (5e-5, 5e-5), "f16x2": (1e-4, 5e-5), "f16": (3e-3, 2.5e-3), "bf16": (4e-2, 1.5e-2)}
+TOLERANCE_MODES = ("f32", "bf16x3", "f16x2")
+NORTH_STAR_SCORE_TOL = 1e-4
+
 _MODELS = {}
 
 

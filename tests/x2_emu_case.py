@@ -114,7 +114,7 @@ def run_unet(hip, dev, dim=64, n_hyp=5, hw=16):
     from nope_amd.weights import synth_init_
     from oracle import nope_ref as R
     from tests.util import StubEncoder
-    os.environ["NOPE_CONV_PP"] = "11"
+    os.environ["NOPE_CONV_PP"] = "9"       # ping-pong kernels (tap-resident for the 3x3 convs) at any tile count
     try:
         u = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype="f16x2")
         synth_init_(u, 2022)
@@ -134,7 +134,7 @@ if __name__ == "__main__":
     from nope_amd import hip
     hip._set_library_for_testing(hip.NopeLib(build_emu.build()))
     if "--unet" in sys.argv:
-        e = run_unet(hip, "cpu", 32, n_hyp=2, hw=8)
+        e = run_unet(hip, "cpu", 32, n_hyp=1, hw=8)
         assert e < 1e-4, e
         print("x2 unet ok", e)
     else:
