@@ -61,11 +61,15 @@ typedef void* nope_stream_t;
 /* Bumped whenever a struct of this header changes layout or an enum gains a meaning (2: nope_unet_config.soft_up_down;
  * 3: NOPE_F16 / NOPE_BF16X3 compute modes, 4x4 STRIDE2, nope_ldm_config.transformer_depth;
  * 4: nope_op_geodesic, nope_unet_graph_limit -- hipGraph replay became opt-in;
- * 5: NOPE_F16X2, nope_tuning_reload).  Callers compare nope_abi_version() against the header they were
+ * 5: NOPE_F16X2, nope_tuning_reload, nope_gather_topk, nope_topk_merge).  Callers compare nope_abi_version() against the header they were
  * built with before passing any struct (nope_amd/hip.py does at load time). */
 #define NOPE_ABI_VERSION 5
 const char* nope_strerror(int code);
 int nope_abi_version(void);
+/* The library reads its tuning / test switches (NOPE_* environment variables: launch policies, A/B switches, traces) once per call site and
+ * caches them.  A caller that changes one of them after its first call into the library calls this to have them read again (the Python
+ * binding does so by itself).  No reference counterpart: the reference has no tuning switches. */
+void nope_tuning_reload(void);
 
 /* ------------------------------------------------------------------------------------------
  * Template-bank scoring.  Replaces PoseConditional.retrieval's "l2" metric,
@@ -86,6 +90,21 @@ int nope_similarity(const float* q, const void* bank, int bank_dtype, float* sco
  *   idx   (B,k) int64;  vals (B,k) f32 or NULL.   1 <= k <= 16, k <= N. */
 int nope_topk(const float* scores, int64_t* idx, float* vals, int B, int N, int k, int score_ld,
               nope_stream_t stream);
+
+/* Template-sharded banks (north_star: "partition [the bank] across the 8 GPUs of one node with an RCCL all-gather of per-shard top-k
+ * scores"; the reference has no collective on this path).  Rank r of G holds the contiguous slice [lo_r, hi_r) of the N
+ * templates (balanced: the first N % G ranks one more) and scores it into a padded (B, nmax) buffer, nmax = ceil(N / G); the collective
+ * itself stays with the caller (torch.distributed / RCCL).  Two ways to finish the step, each ONE launch behind the collective:
+ *   nope_gather_topk  gathered (G,B,nmax) f32 = the all-gathered slices -> scores (B,N) f32, the full similarity `retrieval` returns and the
+ *                     harness saves (model.py:323,369-375), AND its top-k (model.py:265; k = 0: scores only, idx / vals may be NULL);
+ *   nope_topk_merge   cand_vals / cand_idx (B,M) = the all-gathered per-shard top-k lists (M = G k values with their GLOBAL template
+ *                     indices, shards in rank order) -> the global top-k.  Same order as nope_topk on the full row: descending score, ties
+ *                     -> lowest global index (a shard's list is already in that order and shards are contiguous, so position order =
+ *                     index order among equal scores); pad short lists with (-inf, any index).  For callers that do not need the
+ *                     full similarity: 12 k bytes per query and rank cross the fabric instead of 4 N / G. */
+int nope_gather_topk(const float* gathered, int n_ranks, int B, int n_total, float* scores, int64_t* idx, float* vals, int k,
+                     nope_stream_t stream);
+int nope_topk_merge(const float* cand_vals, const int64_t* cand_idx, int64_t* idx, float* vals, int B, int M, int k, nope_stream_t stream);
 
 /* Geodesic error of the retrieved poses against the ground truth (row f2).  Replaces `pred_R = template_poses[nearest_idx]`,
  * src/model/model.py:352-354, and GeodesicError's per-element arithmetic, src/model/loss.py:14-75 (so3_relative_angle_with_symmetry:

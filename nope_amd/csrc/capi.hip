@@ -2,11 +2,33 @@
 // launchers (the U-Net entry points live in unet_runtime.hip).  See include/nope_hip.h.
 #include "nope_common.h"
 
+#include <atomic>
+#include <cstdlib>
+#include <mutex>
+
 using namespace nope;
+
+namespace nope {
+static std::atomic<unsigned> g_tuning_gen{0};
+static std::mutex g_env_mu;
+unsigned tuning_generation() { return g_tuning_gen.load(std::memory_order_acquire); }
+int env_lookup(EnvCache& c, const char* name) {
+    const unsigned g = tuning_generation();
+    if (c.gen != g) {                                  // first use of this site, or a reload since: read the variable (rare path, serialised)
+        std::lock_guard<std::mutex> lock(g_env_mu);
+        const char* v = getenv(name);
+        c.set = v != nullptr;
+        c.val = v ? atoi(v) : 0;
+        c.gen = g;
+    }
+    return c.val;
+}
+}  // namespace nope
 
 extern "C" {
 
 int nope_abi_version(void) { return NOPE_ABI_VERSION; }
+void nope_tuning_reload(void) { g_tuning_gen.fetch_add(1, std::memory_order_acq_rel); }
 
 const char* nope_strerror(int code) {
     switch (code) {
@@ -29,6 +51,15 @@ int nope_similarity(const float* q, const void* bank, int bank_dtype, float* sco
 
 int nope_topk(const float* scores, int64_t* idx, float* vals, int B, int N, int k, int score_ld, nope_stream_t stream) {
     return launch_topk(scores, (long long*)idx, vals, B, N, k, score_ld, (hipStream_t)stream);
+}
+
+int nope_gather_topk(const float* gathered, int n_ranks, int B, int n_total, float* scores, int64_t* idx, float* vals, int k, nope_stream_t stream) {
+    return launch_gather_topk(gathered, n_ranks, B, n_total, scores, (long long*)idx, vals, k, (hipStream_t)stream);
+}
+
+int nope_topk_merge(const float* cand_vals, const int64_t* cand_idx, int64_t* idx, float* vals, int B, int M, int k, nope_stream_t stream) {
+    if (!cand_idx) return NOPE_ERR_ARG;
+    return launch_topk(cand_vals, (long long*)idx, vals, B, M, k, M, (hipStream_t)stream, (const long long*)cand_idx);
 }
 
 int nope_op_geodesic(const double* poses, int64_t pose_stride_b, int N, const int64_t* idx, const double* gt, const int* symmetry,

@@ -296,7 +296,7 @@ int nope_encoder_forward(const nope_encoder* enc, const float* image, int n_img,
         ar.base = base + sb; ar.cap = workspace_bytes - sb;
         return run_encoder(enc, src, n_img, H, W, dst, ar, s);
     };
-    const bool graphs_wanted = !(getenv("NOPE_ENC_GRAPH") && atoi(getenv("NOPE_ENC_GRAPH")) == 0);      // (read per call: the tests compare both paths)
+    const bool graphs_wanted = (NOPE_ENV("NOPE_ENC_GRAPH", -1) != 0);      // (the tests compare both paths)
     if (!graphs_wanted) return direct(image, out);
     std::lock_guard<std::mutex> lock(enc->graph_mu);
     if (!enc->graphs_ok) return direct(image, out);

@@ -269,34 +269,35 @@ struct ConvPlan { bool dma, pp, posmajor, halo; int small; int hsplit; };      /
 // kernel applies (tests); NOPE_SMALL_TILE forces the tile.
 static int plan_small(int dt, const ConvArgs& a, bool dma) {
     dt = dt_base(dt);      // (NOPE_F16X2 plans as NOPE_BF16X3: same storage, same tiles)
-    const int mode_env = getenv("NOPE_CONV_SMALL") ? atoi(getenv("NOPE_CONV_SMALL")) : 1;
+    const int mode_env = NOPE_ENV("NOPE_CONV_SMALL", 1);
     if (!dma || mode_env == 0 || a.mode == NOPE_CONV_UP2 || a.ntaps == 16 || a.force_generic) return -1;
-    if (mode_env == 1 && getenv("NOPE_CONV_PP") && (atoi(getenv("NOPE_CONV_PP")) & 8)) return -1;      // bit 3 = "ping-pong kernels at ANY tile count" (their tests)
+    if (a.out_nchw && a.pn_ms) return -1;      // (the small-tile kernel's NCHW epilogue has no fused PreNorm: the 128 x 192 kernel's generic epilogue does)
+    if (mode_env == 1 && (NOPE_ENV("NOPE_CONV_PP", 0) & 8)) return -1;      // bit 3 = "ping-pong kernels at ANY tile count" (their tests)
     const bool phased = a.mode == NOPE_CONV_UP2P;
     const long long M = (long long)a.nhyp * (phased ? a.Hs * a.Ws : a.Ho * a.Wo);
     const long long tiles128 = (long long)cdiv((int)M, BM) * cdiv(a.Cout, BN) * (phased ? 4 : 1);
-    const int max_tiles = getenv("NOPE_SMALL_MAX_TILES") ? atoi(getenv("NOPE_SMALL_MAX_TILES")) : 320;      // (read per launch: the tuning sweep toggles it)
+    const int max_tiles = NOPE_ENV("NOPE_SMALL_MAX_TILES", 320);      // (tuning sweeps toggle it: nope_tuning_reload)
     // Short-K 1x1 convs of ANY size (NOPE_SMALL_1X1_MAXK = K steps, default 0 = off): their 128 x 192 launches are bound by the epilogue
     // of a three-K-step tile, not by HBM (192 -> 384 at 32 x 32 x 512: 604 MB in 221 us = 2.7 TB/s); the 128 x 128 small tile has a one-pass
     // epilogue.
-    const int maxk_1x1 = getenv("NOPE_SMALL_1X1_MAXK") ? atoi(getenv("NOPE_SMALL_1X1_MAXK")) : 0;
+    const int maxk_1x1 = NOPE_ENV("NOPE_SMALL_1X1_MAXK", 0);
     if (mode_env == 1 && a.mode == NOPE_CONV_PLAIN && a.ntaps == 1 && !a.out_nchw && (a.C1 + a.C2) / (8 * dt_vec(dt)) <= maxk_1x1 && tiles128 >= max_tiles)
-        return getenv("NOPE_SMALL_TILE") ? atoi(getenv("NOPE_SMALL_TILE")) : 1;
+        return NOPE_ENV("NOPE_SMALL_TILE", 1);
     if (mode_env == 1 && tiles128 >= max_tiles) return -1;
     if (mode_env == 1 && dt != NOPE_F32 && a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.Ws <= conv_halo_max_width() && a.rep1 == 1 && !a.out_nchw &&
         !a.pn_ms && a.Cout % dt_vec(dt) == 0 && 9 * ((a.C1 + a.C2) / (8 * dt_vec(dt))) >= 54 && (long long)cdiv((int)M, 256) * cdiv(a.Cout, BN) >= 128)
         return -1;       // the tap-resident kernel has its 128 tiles of 256 rows (measured at 16 x 16 x 64: 60.6 / 83 us against 83 / 116 us on 64 x 64 tiles)
-    if (const char* t = getenv("NOPE_SMALL_TILE")) return atoi(t) < 0 || atoi(t) > 3 ? 0 : atoi(t);
+    if (NOPE_ENV_SET("NOPE_SMALL_TILE")) { const int t = NOPE_ENV("NOPE_SMALL_TILE", 0); return t < 0 || t > 3 ? 0 : t; }
     const long long tiles64 = (long long)cdiv((int)M, 64) * cdiv(a.Cout, 64) * (phased ? 4 : 1);
     if (tiles64 > 1536) return 1;
     // (tile 2, the 6-stage ring, for launches of at most NOPE_SMALL_DEEP_MAX tiles with a K loop of >= 8 steps: with 512 -- launches that
     //  the 48 KiB ring runs two workgroups per CU -- measured SLOWER than the 3-stage ring, 26 / 64 templates 4.16 / 4.95 ms against
     //  4.04 / 4.81, profiles/r04e_small_bank_sweep.txt; off by default)
     const int nk = a.ntaps * ((a.C1 + a.C2) / (8 * dt_vec(dt)));
-    const int deep_max = getenv("NOPE_SMALL_DEEP_MAX") ? atoi(getenv("NOPE_SMALL_DEEP_MAX")) : 0;
+    const int deep_max = NOPE_ENV("NOPE_SMALL_DEEP_MAX", 0);
     if (tiles64 <= deep_max && nk >= 8) return 2;
     // at most one workgroup per CU and a long K: two wave groups per tile on alternate K steps (tile 3)
-    const int kg2_max = getenv("NOPE_SMALL_KG2_MAX") ? atoi(getenv("NOPE_SMALL_KG2_MAX")) : 256;
+    const int kg2_max = NOPE_ENV("NOPE_SMALL_KG2_MAX", 256);
     return (tiles64 <= kg2_max && nk >= 12) ? 3 : 0;
 }
 
@@ -307,8 +308,8 @@ static int plan_small(int dt, const ConvArgs& a, bool dma) {
 // tiles).  Returns the number of splits (1: does not apply).  NOPE_HALO_SPLIT=0 turns it off.
 static int halo_split_factor(int dt, const ConvArgs& a) {
     dt = dt_base(dt);      // (NOPE_F16X2 plans as NOPE_BF16X3: same storage, same tiles)
-    if (getenv("NOPE_HALO_SPLIT") && atoi(getenv("NOPE_HALO_SPLIT")) == 0) return 1;
-    const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : (dt != NOPE_F32 ? 3 : 0);
+    if (NOPE_ENV("NOPE_HALO_SPLIT", -1) == 0) return 1;
+    const int pp_mode = NOPE_ENV("NOPE_CONV_PP", (dt != NOPE_F32 ? 3 : 0));
     if (!(pp_mode & 1) || (pp_mode & 16)) return 1;
     const int vec = dt_vec(dt), bk = 8 * vec, Cin = a.C1 + a.C2;
     if (a.mode != NOPE_CONV_PLAIN || a.ntaps != 9 || a.Ws > conv_halo_max_width() || a.rep1 != 1 || a.out_nchw || a.pn_ms ||
@@ -316,10 +317,10 @@ static int halo_split_factor(int dt, const ConvArgs& a) {
     const long long M = (long long)a.nhyp * a.Ho * a.Wo;
     const int nchunks = Cin / bk;
     const long long tiles = (long long)cdiv((int)M, 256) * cdiv(a.Cout, BN);
-    const int min_chunks = getenv("NOPE_HALO_SPLIT_MIN_CHUNKS") ? atoi(getenv("NOPE_HALO_SPLIT_MIN_CHUNKS")) : 12;
+    const int min_chunks = NOPE_ENV("NOPE_HALO_SPLIT_MIN_CHUNKS", 12);
     // 128 tiles split in two fill the 256 CUs in one round (256 hypotheses at the 4 x 4 level: 11.35 -> 10.76 ms per step, run t); above that a
     // split needs a second round of workgroups and loses (176 tiles, 341 hypotheses: 14.8 -> 15.3 ms)
-    const int max_tiles = getenv("NOPE_HALO_SPLIT_MAX_TILES") ? atoi(getenv("NOPE_HALO_SPLIT_MAX_TILES")) : 128;
+    const int max_tiles = NOPE_ENV("NOPE_HALO_SPLIT_MAX_TILES", 128);
     if (tiles > max_tiles || nchunks < min_chunks) return 1;
     // as many splits as fit ONE round of 256 workgroups (one per CU: 158 KiB of LDS each): 88 tiles x 3 = 264 would run a second
     // round for 8 of them
@@ -333,8 +334,8 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     dt = dt_base(dt);      // (NOPE_F16X2 plans as NOPE_BF16X3: same storage, same tiles)
     // (read per launch: the tests toggle it.  f32 -- the parity mode -- stays on the 128 x 192 kernel unless asked: its MFMA phase is
     //  16x longer per K step, loads were never its bound, and two workgroups per CU beat one: 126 vs 135 ms per 512-template step)
-    const int pp_mode = getenv("NOPE_CONV_PP") ? atoi(getenv("NOPE_CONV_PP")) : (dt != NOPE_F32 ? 3 : 0);
-    static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
+    const int pp_mode = NOPE_ENV("NOPE_CONV_PP", (dt != NOPE_F32 ? 3 : 0));
+    static const int variant = NOPE_ENV("NOPE_CONV_VARIANT", 0);
     ConvPlan pl{false, false, false, false, -1, 1};
     const int vec = dt_vec(dt), es = dt_es(dt), bk = 8 * vec;
     const int Cin = a.C1 + a.C2;
@@ -363,7 +364,7 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     // (long 3x3 launches take the tap-resident kernel from 128 tiles on -- NOPE_HALO_MIN_TILES: the 768 -> 768 convs of the 4 x 4
     //  level at 512 hypotheses have 128 tiles of 108 K steps; on half the CUs they still beat the position-major 128 x 192 launch,
     //  one workgroup per CU: 20.26 -> 20.19 ms per step, profiles/r03d_defaults_ab.txt)
-    static const int halo_min_tiles = getenv("NOPE_HALO_MIN_TILES") ? atoi(getenv("NOPE_HALO_MIN_TILES")) : 128;
+    static const int halo_min_tiles = NOPE_ENV("NOPE_HALO_MIN_TILES", 128);
     const long long min_tiles = (a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.ntaps * (Cin / bk) >= 54) ? halo_min_tiles : 256;
     const bool pp_shape = (a.mode == NOPE_CONV_PLAIN || a.mode == NOPE_CONV_DOWN2 || phased) && !a.out_nchw && a.Cout % vec == 0 &&
                           ((pp_mode & 8) || a.ntaps * (Cin / bk) >= 12) &&
@@ -384,12 +385,12 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
 // ConvArgs::geglu: 16-bit storage, a plain 1x1 conv on the 128 x 192 LDS-DMA kernel's packed wide epilogue (no residual / statistics / PreNorm /
 // activation / split), column pairs whole inside a lane's 8-column chunk and 8-byte output rows
 static bool geglu_shape_ok(int dt, const ConvArgs& a, const ConvPlan& pl) {
-    static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
+    static const int variant = NOPE_ENV("NOPE_CONV_VARIANT", 0);
     return dt_es(dt) == 2 && a.mode == NOPE_CONV_PLAIN && a.ntaps == 1 && !a.resid && !a.colstats && !a.pn_ms && !a.out_nchw && !a.act && !a.splitk_ws &&
            a.Cout % 16 == 0 && pl.dma && !pl.pp && pl.small < 0 && !pl.posmajor && variant == 0;
 }
 bool conv_geglu_fusable(int dt, const ConvArgs& a0) {
-    const int mode = getenv("NOPE_GEGLU_FUSED") ? atoi(getenv("NOPE_GEGLU_FUSED")) : 1;      // (A/B switch, read per call; 2: only launches the 128 x 192 kernel would get anyway)
+    const int mode = NOPE_ENV("NOPE_GEGLU_FUSED", 1);      // (A/B switch; 2: only launches the 128 x 192 kernel would get anyway)
     if (mode == 0) return false;
     if (mode == 2) { const ConvPlan q = plan_conv(dt, a0); if (q.pp || q.small >= 0) return false; }
     ConvArgs a = a0;
@@ -414,7 +415,7 @@ int conv_stat_rows(int dt, const ConvArgs& a) {
     ConvArgs b = a;
     b.colstats = nullptr;
     const bool small_or_split = halo_split_factor(dt, b) > 1 || plan_conv(dt, b).small >= 0;
-    const bool wide16 = !(getenv("NOPE_STATS16") && atoi(getenv("NOPE_STATS16")) == 0);      // (A/B switch: 0 = the 128 x 192 / ping-pong kernels leave 16-pixel maps to gn_stats)
+    const bool wide16 = (NOPE_ENV("NOPE_STATS16", -1) != 0);      // (A/B switch: 0 = the 128 x 192 / ping-pong kernels leave 16-pixel maps to gn_stats)
     if (HW == 16 && M % 16 == 0 && (small_or_split || (wide16 && plan_conv(dt, b).dma))) return 16;
     if (HW == 32 && M % 32 == 0 && small_or_split) return 32;
     return 0;
@@ -497,12 +498,13 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.act = a.act;
     p.wide_out = (!a.out_nchw && a.Cout % vec == 0) ? 1 : 0;
     p.nchw_staged = (a.out_nchw && !a.resid && !a.pn_ms && M % 64 == 0 && ((long long)a.Ho * a.Wo) % 64 == 0 &&
-                     !(getenv("NOPE_NCHW_STAGED") && atoi(getenv("NOPE_NCHW_STAGED")) == 0)) ? 1 : 0;
+                     (NOPE_ENV("NOPE_NCHW_STAGED", -1) != 0)) ? 1 : 0;
     p.colstats = a.colstats;
     p.stat_rows = a.stat_rows;
     p.pn_ms = a.pn_ms; p.pn_c0 = a.pn_c0; p.pn_c1 = a.pn_c1;
     if (a.pn_ms && (!a.pn_c0 || !a.pn_c1 || a.mode != NOPE_CONV_PLAIN || a.ntaps != 1 || a.colstats)) return NOPE_ERR_ARG;
-    if (a.colstats && (!p.wide_out || phased || a.resid || a.stat_rows != conv_stat_rows(dt, a))) return NOPE_ERR_ARG;
+    if (a.colstats && (!p.wide_out || phased || a.resid || a.act || a.stat_rows != conv_stat_rows(dt, a))) return NOPE_ERR_ARG;      // (act: the epilogues take the
+                                                                                                      // statistics before an activation, the split-K reduce after it -- nobody needs the pair)
     const int es = dt_es(dt);
     const int Cin = a.C1 + a.C2;
     const unsigned long long b1 = (unsigned long long)cdiv(a.nhyp, a.rep1) * a.Hs * a.Ws * a.C1 * es;
@@ -522,7 +524,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.bytes1 = (unsigned)(dma ? b1 : 0); p.bytes2 = (unsigned)(dma ? b2 : 0); p.bytesw = (unsigned)(dma ? bw : 0);
     // NOPE_CONV_VARIANT=4 selects the 256x192 / 8-wave tile (measured on par with the default 128x192 / 4-wave
     // tile in round 1; kept for tuning, see DESIGN.md section 4 for the other variants that were tried).
-    static const int variant = getenv("NOPE_CONV_VARIANT") ? atoi(getenv("NOPE_CONV_VARIANT")) : 0;
+    static const int variant = NOPE_ENV("NOPE_CONV_VARIANT", 0);
     p.variant = variant;
     p.d_hw = make_fastdiv((unsigned)(p.Hm * p.Wm)); p.d_w = make_fastdiv((unsigned)p.Wm);
     p.d_rep1 = make_fastdiv((unsigned)p.rep1); p.d_rep2 = make_fastdiv((unsigned)p.rep2);
@@ -573,26 +575,26 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
                 best = gn * abytes + (8 / gn) * wbytes; p.xcd_gn = gn; p.xcd_map = 3;
             }
     }
-    if (dma && p.xcd_map && p.xcd_map != 3 && tn > 1 && !(getenv("NOPE_XCD_MAP") && atoi(getenv("NOPE_XCD_MAP")) == 1)) {
+    if (dma && p.xcd_map && p.xcd_map != 3 && tn > 1 && (NOPE_ENV("NOPE_XCD_MAP", -1) != 1)) {
         const double abytes = (double)b1 + (double)b2, wbytes = (double)bw * (phased ? 4 : 1);
         double best = tn * abytes + (8 / tn) * wbytes;
         for (int gn = 1; gn < tn; gn *= 2)
             if (p.tiles_m % (8 / gn) == 0 && gn * abytes + (8 / gn) * wbytes < best) { best = gn * abytes + (8 / gn) * wbytes; p.xcd_gn = gn; }
-        if (const char* f = getenv("NOPE_XCD_GN")) {            // tests: force the split
-            const int gn = atoi(f);
+        if (NOPE_ENV_SET("NOPE_XCD_GN")) {            // tests: force the split
+            const int gn = NOPE_ENV("NOPE_XCD_GN", 0);
             if (gn >= 1 && gn <= tn && (gn & (gn - 1)) == 0 && p.tiles_m % (8 / gn) == 0) p.xcd_gn = gn;
         }
         if (p.xcd_gn != tn) p.xcd_map = 2;
     }
     // Panel counts outside {1, 2, 4, 8} (no launch of the default U-Net; the LDM variant's linears): map 4 of tile_coords.  NOPE_XCD_ANY=0: off.
-    if (!p.xcd_map && plan.small < 0 && tn > 1 && p.tiles_m % 8 == 0 && !(getenv("NOPE_XCD_ANY") && atoi(getenv("NOPE_XCD_ANY")) == 0)) p.xcd_map = 4;
+    if (!p.xcd_map && plan.small < 0 && tn > 1 && p.tiles_m % 8 == 0 && (NOPE_ENV("NOPE_XCD_ANY", -1) != 0)) p.xcd_map = 4;
     // Persistent walk: 512 workgroups (2 per CU), each `iters` tiles 64 / span tile_m apart (same XCD, same weight panel; span =
     // panels an XCD interleaves under map 2).
     p.persist_iters = 1; p.persist_d1 = p.persist_d2 = 0; p.persist_dm = 0; p.timeline = nullptr;
     unsigned gx = (unsigned)nblocks;
     {
         const long long hw = (long long)a.Hs * a.Ws;
-        static const int persist_on = getenv("NOPE_CONV_PERSIST") ? atoi(getenv("NOPE_CONV_PERSIST")) : 1;
+        static const int persist_on = NOPE_ENV("NOPE_CONV_PERSIST", 1);
         const int span = p.xcd_map == 2 ? tn / p.xcd_gn : 1;
         if (persist_on && dma && plan.small < 0 && bm == BM && dt != NOPE_F32 && a.mode == NOPE_CONV_PLAIN && !p.posmajor && p.splits == 1 && p.xcd_map && p.xcd_map != 4 &&
             p.wide_out && a.rep1 == 1 && a.rep2 == 1 && M % BM == 0 && nblocks > 512 && nblocks % 512 == 0 && 64 % span == 0 &&
@@ -606,9 +608,9 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     }
     // The tap-resident kernel walks tiles too (bf16): one workgroup per CU, tiles gx / 8 apart inside the XCD's run of M tiles,
     // the next tile's prologue in flight under the epilogue.  NOPE_HALO_PERSIST = workgroups (default 256, 0 = one tile per
-    // workgroup; read per launch: the tests use small grids).
-    if (plan.halo && dt != NOPE_F32 && p.xcd_map && p.xcd_map != 4) {
-        const int want = getenv("NOPE_HALO_PERSIST") ? atoi(getenv("NOPE_HALO_PERSIST")) : 256;
+    // workgroup; the tests use small grids).
+    if (plan.halo && dt != NOPE_F32 && p.xcd_map && p.xcd_map != 4 && p.splits == 1) {      // (the split-K instantiation returns after its first tile)
+        const int want = NOPE_ENV("NOPE_HALO_PERSIST", 256);
         const long long hw = (long long)a.Hs * a.Ws;
         const int span = p.xcd_map == 2 ? tn / p.xcd_gn : 1;     // workgroups of one XCD that share an M tile
         if (want >= 8 && want % (8 * span) == 0 && nblocks > want && nblocks % want == 0 && ((long long)(want / 8 / span) * 256) % hw == 0) {
@@ -617,7 +619,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         }
     }
     const dim3 grid(gx, phased ? 4u : 1u, (unsigned)p.splits), block(NT);
-    const bool trace = getenv("NOPE_CONV_TRACE") != nullptr;     // tuning aid: one line per launch (read per launch: a test switches it on)
+    const bool trace = NOPE_ENV_SET("NOPE_CONV_TRACE");     // tuning aid: one line per launch
     if (trace && plan.small >= 0) fprintf(stderr, "conv small%d mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u xcd %d/%d\n", plan.small, a.mode, a.ntaps, Cin, a.Cout, M,
                                         p.tiles_m, p.tiles_n, grid.x, grid.y, grid.z, p.xcd_map, p.xcd_gn);
     else if (trace) fprintf(stderr, "conv %s mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u posmajor %d persist %d xcd %d/%d%s\n",
@@ -626,7 +628,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     if (plan.small >= 0) {
         launch_conv_small(dt, &p, plan.small, grid, s);
     } else if (plan.pp) {
-        if (const char* v = getenv("NOPE_PP_VARIANT")) p.variant = atoi(v);      // tuning ablations of the ping-pong kernel
+        if (NOPE_ENV_SET("NOPE_PP_VARIANT")) p.variant = NOPE_ENV("NOPE_PP_VARIANT", 0);      // tuning ablations of the ping-pong kernel
         if (plan.halo) launch_conv_halo(x2 ? NOPE_F16X2 : dt, &p, grid, s);
         else launch_conv_pp(dt, &p, grid, s);
     } else if (dt == NOPE_F32) {

@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256 * KG) void conv_gemm_small_kernel(ConvParams p)
             const int m = m0 + row, n = n0 + c;
             if (m >= p.M) continue;
             float v = pan[row * LDP + c] + (p.bias ? p.bias[n] : 0.f);
+            if (p.resid) v += Elt<T>::ld(reinterpret_cast<const T*>(p.resid) + (size_t)m * p.Cout + n);      // (NHWC residual, as the generic epilogue; a fused PreNorm never reaches this kernel with an NCHW output: plan_small)
             if (p.act) v = v > 0.f ? v : 0.f;
             const int b = m / HWo;
             const size_t o = ((size_t)b * p.Cout + n) * HWo + (m - b * HWo);

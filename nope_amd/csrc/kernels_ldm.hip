@@ -341,7 +341,7 @@ int launch_token_attention(int dt, const void* qkv, void* out, int nsmp, int N, 
     const float scale = 1.0f / sqrtf((float)dim_head);
     // bf16: the matrix-core kernel (NOPE_LDM_ATTN=0 keeps the VALU one: the tests compare the two); f32 -- the parity mode -- stays
     // on the all-f32 VALU kernel
-    const bool mfma = dt == NOPE_BF16 && !(getenv("NOPE_LDM_ATTN") && atoi(getenv("NOPE_LDM_ATTN")) == 0);
+    const bool mfma = dt == NOPE_BF16 && (NOPE_ENV("NOPE_LDM_ATTN", -1) != 0);
     if (mfma) {
         const dim3 g2((unsigned)cdiv(N, MQ), (unsigned)(C / AD), (unsigned)nsmp);
         hipLaunchKernelGGL(token_attn_mfma_kernel, g2, dim3(NT), 0, s, (const bf16_t*)qkv, (bf16_t*)out, N, C, scale * 1.4426950408889634f);

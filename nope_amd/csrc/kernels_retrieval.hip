@@ -239,13 +239,13 @@ constexpr int KMAX = 16;
 
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
-__global__ __launch_bounds__(NT) void topk_kernel(const float* __restrict__ scores, long long* __restrict__ idx, float* __restrict__ vals,
-                                                  int N, int k, int ld) {
+// `map` (optional, [B][ld]): the value written to idx is map[b][position] instead of the position -- candidates that carry their own
+// (global) template index: the merge of per-shard top-k lists.
+__device__ __forceinline__ void topk_row(const float* row, const long long* map_row, long long* __restrict__ idx, float* __restrict__ vals, int b, int N, int k) {
     __shared__ int s_chosen[KMAX];
     __shared__ float s_bv[NT / 64];
     __shared__ int s_bi[NT / 64];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* row = scores + (size_t)b * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float INF = __builtin_huge_valf();
     for (int r = 0; r < k; ++r) {
         float bv = -INF;
@@ -272,11 +272,37 @@ __global__ __launch_bounds__(NT) void topk_kernel(const float* __restrict__ scor
             for (int w = 1; w < NT / 64; ++w)
                 if (s_bi[w] != 0x7fffffff && (fi == 0x7fffffff || better(s_bv[w], s_bi[w], fv, fi))) { fv = s_bv[w]; fi = s_bi[w]; }
             s_chosen[r] = fi;
-            idx[(size_t)b * k + r] = fi;
+            idx[(size_t)b * k + r] = map_row ? map_row[fi] : (long long)fi;
             if (vals) vals[(size_t)b * k + r] = row[fi];
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(NT) void topk_kernel(const float* __restrict__ scores, const long long* __restrict__ map, long long* __restrict__ idx,
+                                                  float* __restrict__ vals, int N, int k, int ld) {
+    const int b = blockIdx.x;
+    topk_row(scores + (size_t)b * ld, map ? map + (size_t)b * ld : nullptr, idx, vals, b, N, k);
+}
+
+// The tail of a template-sharded step in ONE launch: the all-gathered (G, B, nmax) padded score slices (rank r holds columns
+// [lo_r, hi_r) of the contiguous, balanced split: the first N % G ranks one column more) -> the (B, N) similarity every caller of
+// `retrieval` gets back (model.py:323,369-375 save it) AND its top-k (model.py:265).  One workgroup per query: a thread copies the columns
+// it will rank (same stride in both passes: it only ever reads back its own writes; thread 0's read of the winner's value sits behind
+// the round's barrier).
+__global__ __launch_bounds__(NT) void gather_topk_kernel(const float* __restrict__ gathered, float* __restrict__ scores, long long* __restrict__ idx,
+                                                         float* __restrict__ vals, int G, int B, int N, int nmax, int k) {
+    const int b = blockIdx.x;
+    const int base = N / G, extra = N - base * G, cut = extra * (base + 1);
+    float* row = scores + (size_t)b * N;
+    for (int n = threadIdx.x; n < N; n += NT) {
+        int r, c;
+        if (n < cut) { r = n / (base + 1); c = n - r * (base + 1); }
+        else { const int m = n - cut; r = extra + m / base; c = m - (r - extra) * base; }
+        row[n] = gathered[((size_t)r * B + b) * nmax + c];
+    }
+    __syncthreads();
+    if (k > 0) topk_row(row, nullptr, idx, vals, b, N, k);
 }
 
 }  // namespace
@@ -287,13 +313,13 @@ int launch_similarity(const float* q, const void* bank, int bank_dt, float* scor
     if (bank_dt != NOPE_F32 && bank_dt != NOPE_BF16 && bank_dt != NOPE_F16) return NOPE_ERR_UNSUPPORTED;
     const int vec = bank_dt == NOPE_F32 ? 4 : 8;
     if (HW % vec) return NOPE_ERR_UNSUPPORTED;
-    const int variant = getenv("NOPE_SIM_VARIANT") ? atoi(getenv("NOPE_SIM_VARIANT")) : 1;          // (read per launch: no state is kept between calls)    // tuning: 1 = non-temporal bank loads (0.69 -> 0.75-0.82 of HBM peak), 2 = one residency round of long workgroups, 8 = 4 pixels per lane for 16-bit banks
+    const int variant = NOPE_ENV("NOPE_SIM_VARIANT", 1);          // // tuning: 1 = non-temporal bank loads (0.69 -> 0.75-0.82 of HBM peak), 2 = one residency round of long workgroups, 8 = 4 pixels per lane for 16-bit banks
     // tuning: 16 = query tile in LDS for the 16-bit banks (6 instead of 4 waves per SIMD; measured SLOWER than the register tile with the
     // single-set pipeline: bf16 0.61 / 0.78 of peak at 32 x 512 / 32 x 2048 against 0.72 / 0.84, profiles/r03b_sim_bench.txt)
     const bool qlds = (variant & 16) && (long long)C * HW <= 8192 && HW % 8 == 0;
     // workgroups per sample: ~4096 in all, but at least NOPE_SIM_MINGROUPS template groups each (a workgroup's fixed cost is the 32 KiB
     // query tile: with two groups per workgroup -- 32 x 512 templates -- it is a third of the workgroup's traffic)
-    const int min_groups = getenv("NOPE_SIM_MINGROUPS") ? atoi(getenv("NOPE_SIM_MINGROUPS")) : 1;
+    const int min_groups = NOPE_ENV("NOPE_SIM_MINGROUPS", 1);
     const int lv = (bank_dt != NOPE_F32 && (variant & 8) && C <= 8 && HW % 4 == 0 && HW / 4 <= NT) ? 4 : vec;
     const int P = HW / lv;
     const bool reg_ok = (P <= NT) && (NT % P == 0) && (C <= 16);
@@ -346,9 +372,17 @@ int launch_similarity(const float* q, const void* bank, int bank_dt, float* scor
     return NOPE_OK;
 }
 
-int launch_topk(const float* scores, long long* idx, float* vals, int B, int N, int k, int ld, hipStream_t s) {
+int launch_topk(const float* scores, long long* idx, float* vals, int B, int N, int k, int ld, hipStream_t s, const long long* map) {
     if (!scores || !idx || B <= 0 || N <= 0 || k < 1 || k > KMAX || k > N || ld < N) return NOPE_ERR_ARG;
-    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)B), dim3(NT), 0, s, scores, idx, vals, N, k, ld);
+    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)B), dim3(NT), 0, s, scores, map, idx, vals, N, k, ld);
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+int launch_gather_topk(const float* gathered, int G, int B, int N, float* scores, long long* idx, float* vals, int k, hipStream_t s) {
+    if (!gathered || !scores || G < 1 || B <= 0 || N <= 0 || k < 0 || k > KMAX || k > N || (k > 0 && !idx)) return NOPE_ERR_ARG;
+    const int nmax = (N + G - 1) / G;
+    hipLaunchKernelGGL(gather_topk_kernel, dim3((unsigned)B), dim3(NT), 0, s, gathered, scores, idx, vals, G, B, N, nmax, k);
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

@@ -67,6 +67,11 @@ struct Loader {
     std::vector<UPart> u_parts;
     int u_total = 0;
     void fail(const std::string& n) { if (err == NOPE_OK) { err = NOPE_ERR_WEIGHT; missing = n; } }
+    // device-to-device copy of a state-dict tensor at create time; a refused copy (bad pointer, wrong device) fails the create call itself,
+    // not just the stream synchronisation that ends it
+    void copy_d2d(void* dst, const void* src, size_t bytes) {
+        if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess && err == NOPE_OK) err = NOPE_ERR_LAUNCH;
+    }
     void chk(int e) { if (e && err == NOPE_OK) err = e; }
     const nope_tensor_desc* get(const std::string& name, std::initializer_list<int64_t> shape) {
         auto it = tab.find(name);
@@ -118,7 +123,7 @@ struct Loader {
         size_t n = 1;
         for (int64_t v : shape) n *= (size_t)v;
         float* p = (float*)dmalloc(n * 4);
-        if (p) hipMemcpyAsync(p, d->data, n * 4, hipMemcpyDeviceToDevice, s);
+        if (p) copy_d2d(p, d->data, n * 4);
         return p;
     }
     // conv (4-d weight) or linear (2-d weight) packed for the implicit-GEMM kernel
@@ -185,9 +190,9 @@ struct Loader {
             const size_t es = (size_t)dt_es(net->dt);
             t.qkv.w = dmalloc((size_t)3 * C * C * es);
             if (cat && t.qkv.w) {
-                hipMemcpyAsync(cat, wq->data, (size_t)C * C * 4, hipMemcpyDeviceToDevice, s);
-                hipMemcpyAsync(cat + (size_t)C * C, wk->data, (size_t)C * C * 4, hipMemcpyDeviceToDevice, s);
-                hipMemcpyAsync(cat + (size_t)2 * C * C, wv->data, (size_t)C * C * 4, hipMemcpyDeviceToDevice, s);
+                copy_d2d(cat, wq->data, (size_t)C * C * 4);
+                copy_d2d(cat + (size_t)C * C, wk->data, (size_t)C * C * 4);
+                copy_d2d(cat + (size_t)2 * C * C, wv->data, (size_t)C * C * 4);
                 chk(launch_pack_conv_w(net->dt, cat, t.qkv.w, 3 * C, C, 1, NOPE_CONV_PLAIN, s));
             }
         }
@@ -562,8 +567,8 @@ int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors,
         if (net->u_w && net->u_b)
             for (const auto& up : ld.u_parts) {
                 if (!up.comb || !up.bias) continue;
-                hipMemcpyAsync(net->u_w + (size_t)up.off * ctx, up.comb, (size_t)up.C * ctx * 4, hipMemcpyDeviceToDevice, s);
-                hipMemcpyAsync(net->u_b + up.off, up.bias, (size_t)up.C * 4, hipMemcpyDeviceToDevice, s);
+                ld.copy_d2d(net->u_w + (size_t)up.off * ctx, up.comb, (size_t)up.C * ctx * 4);
+                ld.copy_d2d(net->u_b + up.off, up.bias, (size_t)up.C * 4);
             }
     }
     if (hipStreamSynchronize(s) != hipSuccess && ld.err == NOPE_OK) ld.err = NOPE_ERR_LAUNCH;

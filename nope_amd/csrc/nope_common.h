@@ -237,6 +237,18 @@ template <bool FAST> __device__ __forceinline__ float silu_f(float x) {
         else NOPE_DISPATCH_T(dt, T, __VA_ARGS__);                                \
     } while (0)
 
+// ---- tuning / test switches (NOPE_* environment variables) -----------------------------------------------------------------------
+// Read ONCE per call site and cached: a launch does not walk the environment (a conv launch consulted ~40 variables).  nope_tuning_reload()
+// (C ABI) starts a new generation, after which every site reads its variable again -- nope_amd/hip.py calls it whenever it sees a NOPE_*
+// variable change between two calls into the library, so in-process A/B sweeps and the tests that flip a switch keep working; a C caller
+// that changes the environment after the first launch calls it itself.  NOPE_ENV(name, default) -> int (atoi of the value, or the default
+// when unset); NOPE_ENV_SET(name) -> bool (is it set at all).
+unsigned tuning_generation();                          // capi.hip
+struct EnvCache { unsigned gen = 0xffffffffu; bool set = false; int val = 0; };
+int env_lookup(EnvCache& c, const char* name);         // refreshes c when the generation moved; returns c.val (0 when unset)
+#define NOPE_ENV(name, def) ({ static ::nope::EnvCache nope_env_c__; const int nope_env_v__ = ::nope::env_lookup(nope_env_c__, name); nope_env_c__.set ? nope_env_v__ : (def); })
+#define NOPE_ENV_SET(name) ({ static ::nope::EnvCache nope_env_c__; ::nope::env_lookup(nope_env_c__, name); nope_env_c__.set; })
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -349,7 +361,8 @@ int launch_copy_cols(int dt, const void* x, void* y, long long M, int C, int C2,
 
 int launch_similarity(const float* q, const void* bank, int bank_dt, float* scores, int B, int N, int C, int HW,
                       long long bank_stride_b, int score_ld, hipStream_t s);
-int launch_topk(const float* scores, long long* idx, float* vals, int B, int N, int k, int ld, hipStream_t s);
+int launch_topk(const float* scores, long long* idx, float* vals, int B, int N, int k, int ld, hipStream_t s, const long long* map = nullptr);
+int launch_gather_topk(const float* gathered, int G, int B, int N, float* scores, long long* idx, float* vals, int k, hipStream_t s);
 int launch_geodesic(const double* poses, long long stride_b, int N, const long long* idx, const double* gt, const int* symmetry,
                     double* err, int* status, int B, int k, hipStream_t s);
 

@@ -98,6 +98,11 @@ struct Loader {
         return d;
     }
     void fail(const std::string& n) { if (err == NOPE_OK) { err = NOPE_ERR_WEIGHT; missing = n; } }
+    // device-to-device copy of a state-dict tensor at create time; a refused copy (bad pointer, wrong device) fails the create call itself,
+    // not just the stream synchronisation that ends it
+    void copy_d2d(void* dst, const void* src, size_t bytes) {
+        if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess && err == NOPE_OK) err = NOPE_ERR_LAUNCH;
+    }
     void* dmalloc(size_t bytes) {
         void* p = nullptr;
         if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { if (err == NOPE_OK) err = NOPE_ERR_ALLOC; return nullptr; }
@@ -110,7 +115,7 @@ struct Loader {
         size_t n = 1;
         for (int64_t v : shape) n *= (size_t)v;
         float* p = (float*)dmalloc(n * 4);
-        if (p) hipMemcpyAsync(p, d->data, n * 4, hipMemcpyDeviceToDevice, s);
+        if (p) copy_d2d(p, d->data, n * 4);
         return p;
     }
     // (ksz 4 with UP2P: the weight is a ConvTranspose2d(4, 2, 1)'s, [Cin][Cout][4][4], repacked into the same four phase sets)
@@ -279,7 +284,7 @@ struct Fwd {
             // separate fold launch costs ~7 us + a kernel boundary).  Round 2 measured the inline fold +0.25 ms per 512-hypothesis step
             // (one thread per group then); with the wave-wide group sums of round 4 it is -0.02 .. -0.05 ms there and -0.2 ms at 64
             // hypotheses (profiles/r04o_fold_inline_ab.txt): always on.  NOPE_GN_FOLD_INLINE = most re-read bytes per launch (0 = never).
-            const long long fold_inline_max = getenv("NOPE_GN_FOLD_INLINE") ? atoll(getenv("NOPE_GN_FOLD_INLINE")) : (1ll << 50);
+            const long long fold_inline_max = NOPE_ENV_SET("NOPE_GN_FOLD_INLINE") ? (long long)NOPE_ENV("NOPE_GN_FOLD_INLINE", 0) : (1ll << 50);
             const long long refold = (long long)nhyp * gn_apply_blocks(HW, nm.C, net->sdt, nhyp) * st.blocks * nm.C * 8;
             if (refold <= fold_inline_max) { ga.colstats = st.cs; ga.stat_blocks = st.blocks; }
             else chk(launch_gn_fold(st.cs, gn_partial, nx, st.blocks, nm.C, G, s));
@@ -593,8 +598,8 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
         const nope_tensor_desc* w = ld.get(e.first + "weight", {e.second, net->classes});
         const nope_tensor_desc* b = ld.get(e.first + "bias", {e.second});
         if (w && b && net->emb_w && net->emb_b) {
-            hipMemcpyAsync(net->emb_w + (size_t)off * net->classes, w->data, (size_t)e.second * net->classes * 4, hipMemcpyDeviceToDevice, s);
-            hipMemcpyAsync(net->emb_b + off, b->data, (size_t)e.second * 4, hipMemcpyDeviceToDevice, s);
+            ld.copy_d2d(net->emb_w + (size_t)off * net->classes, w->data, (size_t)e.second * net->classes * 4);
+            ld.copy_d2d(net->emb_b + off, b->data, (size_t)e.second * 4);
         }
         off += e.second;
     }

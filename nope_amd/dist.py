@@ -71,6 +71,60 @@ def gather_buffers(B: int, n_total: int, device, group=None):
     return b
 
 
+def _gather_padded(send: torch.Tensor, recv: torch.Tensor, group=None):
+    """one all_gather_into_tensor of the padded (B, nmax) slices into (G, B, nmax)"""
+    ws, B, nmax = recv.shape
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo is a host backend (the multi-rank-on-one-GPU test): stage through host memory.  Production runs use
+        # "nccl" (= RCCL), which gathers device buffers directly over xGMI.
+        h_send, h_recv = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(h_recv.view(ws * B, nmax), h_send, group=group)
+        recv.copy_(h_recv)
+    else:
+        dist.all_gather_into_tensor(recv.view(ws * B, nmax), send, group=group)
+
+
+def all_gather_scores_topk(n_local: int, n_total: int, B: int, device, k: int = 5, group=None):
+    """The tail of a template-sharded step: this rank's scores already sit in the cached send buffer (gather_buffers; the scoring kernel
+    wrote them there).  ONE collective + ONE kernel: all_gather_into_tensor of the padded slices, then nope_gather_topk drops the padding
+    into an owned (B, n_total) similarity and ranks it.  Returns (similarity, nearest_idx)."""
+    from . import hip
+    _, ws = world(group)
+    send, recv = gather_buffers(B, n_total, device, group)
+    _gather_padded(send, recv, group)
+    return hip.gather_topk(recv, n_total, k)
+
+
+def all_gather_topk_pairs(local_vals: torch.Tensor, local_idx: torch.Tensor, k: int, group=None):
+    """north_star's "all-gather of per-shard top-k": local_vals / local_idx (B, k_local <= k) with GLOBAL template indices -> global
+    (vals, idx) (B, k) on every rank: one all-gather of (B, k) (value, index) pairs -- 12 k bytes per query and rank instead of the 4 N / G of
+    the full score slices -- and one merge kernel (nope_topk_merge: descending score, ties -> lowest global index, model.py:265).  For callers
+    that do not keep the full similarity."""
+    from . import hip
+    rank, ws = world(group)
+    B, kl = local_vals.shape
+    dev = local_vals.device
+    pv = torch.full((B, k), float("-inf"), dtype=torch.float32, device=dev)
+    pi = torch.full((B, k), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+    if kl:
+        pv[:, :kl], pi[:, :kl] = local_vals, local_idx
+    if ws == 1:
+        return hip.topk_merge(pv, pi, k)
+    # one collective: values and indices travel as one int64 tensor (the f32 bits in the low word of a second int64 column block)
+    pack = torch.cat((pv.view(torch.int32).to(torch.int64), pi), 1)              # (B, 2 k)
+    out = torch.empty((ws, B, 2 * k), dtype=torch.int64, device=dev)
+    if pack.is_cuda and dist.get_backend(group) == "gloo":
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h.view(ws * B, 2 * k), pack.cpu(), group=group)
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out.view(ws * B, 2 * k), pack, group=group)
+    out = out.permute(1, 0, 2)                                                   # (B, ws, 2 k): shards in rank order
+    cv = out[:, :, :k].to(torch.int32).view(torch.float32).reshape(B, ws * k).contiguous()
+    ci = out[:, :, k:].reshape(B, ws * k).contiguous()
+    return hip.topk_merge(cv, ci, k)
+
+
 def all_gather_scores(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """local (B, n_local) f32 slice of this rank (n_local may be 0) -> (B, n_total) on every rank: ONE
     `all_gather_into_tensor` of the padded (B, nmax) slices (RCCL on GPUs, gloo in the CPU tests) and at most two
@@ -84,14 +138,7 @@ def all_gather_scores(local: torch.Tensor, n_total: int, group=None) -> torch.Te
     nmax = send.shape[1]
     if not (local.data_ptr() == send.data_ptr() and local.stride() == send.stride()) and local.shape[1] > 0:
         send[:, : local.shape[1]].copy_(local)
-    if send.is_cuda and dist.get_backend(group) == "gloo":
-        # gloo is a host backend (the multi-rank-on-one-GPU test): stage through host memory.  Production runs use
-        # "nccl" (= RCCL), which gathers device buffers directly over xGMI.
-        h_send, h_recv = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
-        dist.all_gather_into_tensor(h_recv.view(ws * B, nmax), h_send, group=group)
-        recv.copy_(h_recv)
-    else:
-        dist.all_gather_into_tensor(recv.view(ws * B, nmax), send, group=group)
+    _gather_padded(send, recv, group)
     base, extra = divmod(n_total, ws)
     out = local.new_empty((B, n_total))            # always an OWNED tensor: `recv` is a cached buffer the next gather overwrites
     if extra == 0:                                 # (for B == 1 a reshape of the permuted buffer would be a view of it)

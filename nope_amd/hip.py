@@ -56,8 +56,11 @@ class EncoderConfig(C.Structure):
 _PROTOS = {
     "nope_strerror": (C.c_char_p, [_i]),
     "nope_abi_version": (_i, []),
+    "nope_tuning_reload": (None, []),
     "nope_similarity": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp]),
     "nope_topk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "nope_gather_topk": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "nope_topk_merge": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "nope_op_geodesic": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "nope_unet_create": (_i, [C.POINTER(UNetConfig), C.POINTER(TensorDesc), _i, _vp, C.POINTER(_vp)]),
     "nope_unet_destroy": (None, [_vp]),
@@ -124,22 +127,30 @@ class NopeLib:
 
 
 _lib: Optional[NopeLib] = None
+_tuning_seen: Optional[tuple] = None
 
 
 def lib() -> NopeLib:
-    global _lib
+    """The loaded library.  Every binding comes through here, so this is also where a change of the NOPE_* tuning variables since the last call
+    is noticed: the library caches them per call site (nope_tuning_reload, include/nope_hip.h)."""
+    global _lib, _tuning_seen
     if _lib is None:
         _lib = NopeLib(LIB_PATH)
+    cur = tuple(sorted(kv for kv in os.environ.items() if kv[0].startswith("NOPE_")))
+    if cur != _tuning_seen:
+        _tuning_seen = cur
+        _lib.dll.nope_tuning_reload()
     return _lib
 
 
 def _set_library_for_testing(l: Optional[NopeLib]):
     """tests/ only: lets the CPU test-suite run the same host code over tests/hipemu (a build of the same C ABI
     that takes host pointers)."""
-    global _lib
+    global _lib, _tuning_seen
     if l is not None:
         l.host_pointers = True
     _lib = l
+    _tuning_seen = None
 
 
 def require_device(t: torch.Tensor):
@@ -265,24 +276,54 @@ def topk(scores: torch.Tensor, k: int = 5) -> Tuple[torch.Tensor, torch.Tensor]:
     return vals, idx
 
 
+def gather_topk(gathered: torch.Tensor, n_total: int, k: int = 5) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """gathered (G, B, nmax) f32 = the all-gathered padded score slices of a template-sharded step -> (similarity (B, n_total) owned,
+    nearest_idx (B, k) or None for k = 0), one launch (nope_gather_topk)."""
+    require_device(gathered)
+    G, B, nmax = gathered.shape
+    assert gathered.is_contiguous() and gathered.dtype == torch.float32 and nmax == (n_total + G - 1) // G
+    sim = torch.empty((B, n_total), dtype=torch.float32, device=gathered.device)
+    idx = torch.empty((B, k), dtype=torch.int64, device=gathered.device) if k > 0 else None
+    l = lib()
+    l.check(l.dll.nope_gather_topk(_ptr(gathered), G, B, n_total, _ptr(sim), _ptr(idx), None, k, _stream(gathered)), "nope_gather_topk")
+    return sim, idx
+
+
+def topk_merge(cand_vals: torch.Tensor, cand_idx: torch.Tensor, k: int = 5) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cand_vals / cand_idx (B, M): per-shard top-k lists with global template indices, shards in rank order -> global (vals, idx) (B, k)."""
+    require_device(cand_vals)
+    cand_vals, cand_idx = _f32c(cand_vals), cand_idx.to(torch.int64).contiguous()
+    B, M = cand_vals.shape
+    idx = torch.empty((B, k), dtype=torch.int64, device=cand_vals.device)
+    vals = torch.empty((B, k), dtype=torch.float32, device=cand_vals.device)
+    l = lib()
+    l.check(l.dll.nope_topk_merge(_ptr(cand_vals), _ptr(cand_idx), _ptr(idx), _ptr(vals), B, M, k, _stream(cand_vals)), "nope_topk_merge")
+    return vals, idx
+
+
 def op_geodesic(poses: torch.Tensor, gt: torch.Tensor, symmetry: Optional[torch.Tensor] = None,
                 idx: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Geodesic error (radians, f64) of poses[b, idx[b, j]] (or poses[b, j] without `idx`) against gt[b], with the reference's
     symmetry handling (loss.py:14-75).  poses (B|1, N, 3, 3), gt (B, 3, 3), symmetry (B,) / (B, 1) in {0, 1, 2}, idx (B, k) int64.
     Raises ValueError where pytorch3d's so3_rotation_angle does (trace outside [-1 - eps, 3 + eps])."""
     require_device(poses)
-    gt = gt.to(torch.float64).contiguous()
-    poses = poses.to(device=gt.device, dtype=torch.float64).contiguous()
+    # everything follows the PREDICTIONS' device (a ground-truth pose / symmetry flag / index tensor left on the host is moved, not dereferenced)
+    poses = poses.to(torch.float64).contiguous()
+    gt = gt.to(device=poses.device, dtype=torch.float64).contiguous()
     B = gt.shape[0]
     if poses.dim() != 4 or tuple(poses.shape[2:]) != (3, 3) or poses.shape[0] not in (1, B) or tuple(gt.shape[1:]) != (3, 3):
         raise NopeError(f"poses {tuple(poses.shape)} / gt {tuple(gt.shape)}: expected (B|1, N, 3, 3) and (B, 3, 3)")
     N = poses.shape[1]
     if idx is not None:
+        if idx.dim() != 2 or idx.shape[0] != B:
+            raise NopeError(f"idx {tuple(idx.shape)}: expected ({B}, k)")
         idx = idx.to(device=gt.device, dtype=torch.int64).contiguous()
         k = idx.shape[1]
     else:
         k = N
     sym = None if symmetry is None else symmetry.reshape(-1).to(device=gt.device, dtype=torch.int32).contiguous()
+    if sym is not None and sym.numel() != B:
+        raise NopeError(f"symmetry has {sym.numel()} entries for {B} samples")
     err = torch.empty((B, k), dtype=torch.float64, device=gt.device)
     if B == 0 or k == 0:
         return err
@@ -345,6 +386,7 @@ class EncoderHandle:
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         """image (B,3,H,W) f32 -> (B,descriptor_size,H/8,W/8) f32."""
+        require_device(image)
         image = _f32c(image)
         B, Cc, H, W = image.shape
         if Cc != 3:

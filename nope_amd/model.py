@@ -156,6 +156,27 @@ class PoseConditional(nn.Module):
         return similarity, nearest_idx, bank
 
     @torch.no_grad()
+    def retrieval_topk_from_feat(self, query_feat, template_feat, k=5, shard=None):
+        """The top-k only -- (values (B,k), nearest_idx (B,k)) -- for callers that do not keep the full similarity: under `template_parallel` every
+        rank ranks its own slice and only the (B, k) (score, global index) pairs are all-gathered and merged (north_star's "all-gather of
+        per-shard top-k"; tie rule of model.py:265 as everywhere: lowest global index).  Same indices as `retrieval_from_feat`."""
+        sl = (template_feat.shard if isinstance(template_feat, ndist.ShardedBank) else None) if shard is None else (shard or None)
+        if not (self.template_parallel and sl is not None):
+            if self.template_parallel and shard is None and ndist.world()[1] > 1:
+                raise hip.NopeError("template_parallel: this bank is a plain tensor without a shard placement: pass shard=(lo, hi, n_total) or shard=False")
+            sim = hip.similarity(query_feat, template_feat)
+            return hip.topk(sim, k)
+        B, n_local = query_feat.shape[0], template_feat.shape[1]
+        kl = min(k, n_local)
+        if kl > 0:
+            vals, idx = hip.topk(hip.similarity(query_feat, template_feat), kl)
+            idx = idx + sl[0]
+        else:
+            vals = torch.empty((B, 0), dtype=torch.float32, device=query_feat.device)
+            idx = torch.empty((B, 0), dtype=torch.int64, device=query_feat.device)
+        return ndist.all_gather_topk_pairs(vals, idx, k)
+
+    @torch.no_grad()
     def retrieval_from_feat(self, query_feat, template_feat, k=5, shard=None):
         """`shard` = (lo, hi, N): this rank's slice [lo, hi) of the N templates; `shard=False`: the bank is COMPLETE on this rank
         (e.g. loaded from disk on every rank) and is scored locally without a collective.  Banks made by `generate_templates`
@@ -173,6 +194,9 @@ class PoseConditional(nn.Module):
             send, _ = ndist.gather_buffers(B, sl[2], query_feat.device)
             if n_local > 0:          # this rank's columns go straight into the collective's send buffer
                 hip.similarity(query_feat, template_feat, out=send, col_offset=0)
+            if ndist.world()[1] > 1 and k <= sl[2]:
+                # scoring -> ONE collective -> ONE kernel (un-pad into an owned (B, N) similarity + top-k): nope_gather_topk
+                return ndist.all_gather_scores_topk(n_local, sl[2], B, query_feat.device, k)
             similarity = ndist.all_gather_scores(send[:, :n_local], sl[2])
         else:
             similarity = hip.similarity(query_feat, template_feat)

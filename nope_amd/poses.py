@@ -155,3 +155,75 @@ def all_relative_poses(template_poses, ref_pose) -> torch.Tensor:
     t = np.asarray(template_poses, dtype=np.float64)[:, :3, :3]
     r = np.linalg.inv(np.asarray(ref_pose, dtype=np.float64))[:3, :3]
     return matrix_to_rotation_6d(torch.tensor(t @ r, dtype=torch.float32))
+
+
+# ---- utils.py:14-20, 44-47, 290-356: nearest template on the viewing sphere (+ in-plane rotation) ---------------------------------
+_CV2GL = np.diag([1.0, -1.0, -1.0, 1.0])
+
+
+def opencv2opengl(pose: np.ndarray) -> np.ndarray:
+    """utils.py:14-20: flip the y and z ROWS of one 4x4 pose or a stack of them."""
+    return np.matmul(_CV2GL, np.asarray(pose))
+
+
+def geodesic_numpy(R1: np.ndarray, R2: np.ndarray) -> float:
+    """utils.py:44-47: rotation angle between two 3x3 rotations, degrees."""
+    c = (np.trace(np.asarray(R2) @ np.asarray(R1).T) - 1.0) / 2.0
+    return float(np.degrees(np.arccos(np.clip(c, -1.0, 1.0))))
+
+
+def inplane_of_rotation(delta: np.ndarray) -> float:
+    """utils.py:290-292: first angle (degrees) of scipy's INTRINSIC-free "zyx" Euler decomposition of a rotation matrix."""
+    from scipy.spatial.transform import Rotation
+    return float(Rotation.from_matrix(np.asarray(delta)).as_euler("zyx", degrees=True)[0])
+
+
+def inplane_rotation(inplane_deg: float) -> np.ndarray:
+    """utils.py:295-297: rotation about z by MINUS the in-plane angle."""
+    a = np.radians(-inplane_deg)
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+
+
+def compute_inplane(rot_query: np.ndarray, rot_template: np.ndarray) -> float:
+    """utils.py:306-315: in-plane angle that turns the template's rotation into the query's (the reference also prints a warning when the
+    recovered rotation is >= 15 degrees off: `inplane_residual` returns that angle instead)."""
+    return inplane_of_rotation(np.asarray(rot_template) @ np.asarray(rot_query).T)
+
+
+def inplane_residual(rot_query: np.ndarray, rot_template: np.ndarray, inplane_deg: float) -> float:
+    return geodesic_numpy(inplane_rotation(inplane_deg) @ np.asarray(rot_template), rot_query)
+
+
+class NearestTemplateFinder:
+    """utils.py:318-356.  For every query object pose (M,4,4) the template of the grid (`level_templates`, `pose_distribution`) whose
+    viewpoint lies nearest on the sphere -- compared through row 2 of the OpenGL-convention poses, as the reference does -- returned as
+    its index in the FULL grid (`avail_index`), optionally with the in-plane angle between query and template.  `normalize_query_translation`
+    is accepted and stored (the reference never reads it either).  `root`: the reference's predefined_poses directory (None: synthesised grid)."""
+
+
+    def __init__(self, level_templates, pose_distribution, return_inplane, normalize_query_translation=True, root: Optional[str] = None, grid=None):
+        self.level_templates = level_templates
+        self.normalize_query_translation = normalize_query_translation
+        self.pose_distribution = pose_distribution
+        self.return_inplane = return_inplane
+        if grid is not None:               # (avail_index, obj_template_poses) handed in: a grid loaded elsewhere (tests: the reference's own level-0 file)
+            self.avail_index, self.obj_template_poses = np.asarray(grid[0]), np.asarray(grid[1])
+        else:
+            self.avail_index, self.obj_template_poses = get_obj_poses_from_template_level(level_templates, pose_distribution, return_cam=False,
+                                                                                          return_index=True, root=root)
+        self.obj_template_openGL_poses = opencv2opengl(self.obj_template_poses)
+
+    def search_nearest_template(self, obj_query_pose):
+        q = np.asarray(obj_query_pose)
+        q_loc = opencv2opengl(q)[:, 2, :3]                                     # (M,3)
+        t_loc = self.obj_template_openGL_poses[:, 2, :3]                       # (N,3)
+        d = np.sqrt(((q_loc[:, None, :] - t_loc[None, :, :]) ** 2).sum(-1))    # scipy.spatial.distance.cdist (euclidean)
+        best = np.argmin(d, axis=-1)                                           # first minimum, as numpy
+        if not self.return_inplane:
+            return self.avail_index[best]
+        nearest = self.obj_template_poses[best]
+        inplanes = np.zeros(len(q))
+        for i in range(len(q)):
+            inplanes[i] = compute_inplane(q[i, :3, :3], nearest[i, :3, :3])
+        return self.avail_index[best], inplanes

@@ -142,6 +142,31 @@ def poses_fixture():
     print("poses_ref.npz:", len(out), "arrays")
 
 
+def nearest_fixture():
+    """NearestTemplateFinder (utils.py:318-356) of the reference on random query poses, with the grid it searched (so that the restatement can be
+    run on the same grid without the reference's files): nearest_ref.npz."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(11)
+    out = {}
+    for tag, level, dist in (("L0_upper", 0, "upper"), ("L1_all", 1, "all")):
+        f = RU.NearestTemplateFinder(level, dist, return_inplane=True)
+        M_ = 24
+        q = np.tile(np.eye(4), (M_, 1, 1))
+        q[:, :3, :3] = Rotation.random(M_, random_state=int(rng.integers(1 << 30))).as_matrix()
+        q[:, :3, 3] = rng.normal(size=(M_, 3)) * 0.3
+        q[0] = f.obj_template_poses[3]                      # an exact grid pose: in-plane 0, index of that pose
+        q[1, :3, :3] = Rotation.from_euler("z", 37.0, degrees=True).as_matrix() @ f.obj_template_poses[5][:3, :3]     # ... turned in the image plane
+        idx, inp = f.search_nearest_template(q)
+        out[f"{tag}/avail_index"], out[f"{tag}/obj_template_poses"] = f.avail_index, f.obj_template_poses
+        out[f"{tag}/query"], out[f"{tag}/index"], out[f"{tag}/inplane"] = q, idx, inp
+        f2 = RU.NearestTemplateFinder(level, dist, return_inplane=False)
+        out[f"{tag}/index_only"] = f2.search_nearest_template(q)
+    np.savez_compressed(os.path.join(HERE, "nearest_ref.npz"), **out)
+    print("nearest_ref.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    metric_fixture()
-    poses_fixture()
+    if "--nearest-only" not in sys.argv:
+        metric_fixture()
+        poses_fixture()
+    nearest_fixture()

@@ -66,6 +66,10 @@ def run(hip, dev, dts=(1, 0), tiles=(0, 1, 2, 3), light=False):
         # NCHW f32 output with a channel count that is no whole vector (the U-Net's last conv: 8 channels)
         x6, w6, b6 = rn(3, C, 8, 8), rn(8, C, 1, 1) / C ** 0.5, rn(8)
         both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x6), dt), d(w6), d(b6), out_nchw=True, out_dtype=0), "1x1 nchw", F.conv2d(q(x6), q(w6), b6))
+        # ... with a residual (NHWC, element type of the launch) and ReLU behind it: the NCHW epilogue adds it like every other one
+        r6 = rn(3, 8, 8, 8)
+        both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x6), dt), d(w6), d(b6), resid=hip.to_nhwc(d(r6), dt), out_nchw=True, out_dtype=0, act_relu=True), "1x1 nchw + residual",
+             F.relu(F.conv2d(q(x6), q(w6), b6) + q(r6)))
         # split-K on the tap-resident kernel (few 256-row tiles, long K): 20 channel chunks over 16 splits (one or two chunks each: both A
         # stage parities), 4 chunks over 4 splits; deterministic, and equal to the unsplit result up to the association of the partials
         os.environ["NOPE_HALO_SPLIT_MIN_CHUNKS"] = "2"

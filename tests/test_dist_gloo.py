@@ -30,6 +30,24 @@ def _worker(rank, ws, port, emu_path, q, bank, poses, ret):
         lo, hi = shard_range(N, rank, ws)
         local = hip.similarity(q, bank[:, lo:hi].contiguous())
         full = all_gather_scores(local, N)
+        # the fused tail of a sharded step (one collective + nope_gather_topk) == gather + strided copies + nope_topk, bit for bit, on the
+        # uneven 4 + 3 split; and the top-k-pair exchange (nope_topk_merge) finds the same indices and values
+        from nope_amd.dist import all_gather_scores_topk, all_gather_topk_pairs, gather_buffers
+        send, _ = gather_buffers(q.shape[0], N, q.device)
+        send[:, : hi - lo].copy_(local)
+        f_sim, f_idx = all_gather_scores_topk(hi - lo, N, q.shape[0], q.device, 5)
+        u_vals, u_idx = hip.topk(full, 5)
+        assert torch.equal(f_sim, full) and torch.equal(f_idx, u_idx)
+        lv, li = hip.topk(local, min(5, hi - lo))
+        p_vals, p_idx = all_gather_topk_pairs(lv, li + lo, 5)
+        assert torch.equal(p_idx, u_idx) and torch.equal(p_vals, u_vals)
+        # ties across shards resolve to the lowest GLOBAL index in both forms (model.py:265 + the build's tie rule)
+        tie = torch.full((1, N), -3.0)
+        tie[0, 1] = tie[0, 5] = -1.0            # equal best scores in shard 0 (column 1) and shard 1 (column 5)
+        tl = tie[:, lo:hi].contiguous()
+        tv, ti = hip.topk(tl, min(3, hi - lo))
+        _, t_idx = all_gather_topk_pairs(tv, ti + lo, 3)
+        assert t_idx.tolist() == [[1, 5, 0]], t_idx.tolist()
         # full PoseConditional path: sharded template generation + scoring + gather
         u = UNet(u_net_dim=8, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer")
         synth_init_(u, 2022)
@@ -38,6 +56,8 @@ def _worker(rank, ws, port, emu_path, q, bank, poses, ret):
         b_local, _, _ = m.generate_templates(ref_feat, poses)
         lo5, hi5 = shard_range(poses.shape[1], rank, ws)
         sim, idx = m.retrieval(ref_feat * 0.5, b_local)
+        tk_vals, tk_idx = m.retrieval_topk_from_feat(ref_feat * 0.5, b_local)      # per-shard top-k exchange: same answer, no full similarity
+        assert torch.equal(tk_idx, idx) and torch.equal(tk_vals, sim.gather(1, idx))
         keep = sim.clone()
         m.retrieval(ref_feat * 0.25, b_local)          # a second gather of the same shape must not overwrite the first result (B = 1)
         assert torch.equal(sim, keep)

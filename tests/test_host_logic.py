@@ -254,6 +254,21 @@ def test_geodesic_kernel_known_answers_emu(emu):
     _check_geodesic_kernel(emu, "cpu")
 
 
+def test_geodesic_binding_rejects_mismatched_shapes(emu):
+    """hip.op_geodesic: a symmetry tensor or an index tensor whose leading size is not the batch would make the kernel read past it."""
+    import pytest
+    hip = emu
+    poses = torch.eye(3, dtype=torch.float64).expand(2, 4, 3, 3).contiguous()
+    gt = torch.eye(3, dtype=torch.float64).expand(2, 3, 3).contiguous()
+    assert hip.op_geodesic(poses, gt, torch.zeros(2, 1), torch.zeros(2, 3, dtype=torch.int64)).shape == (2, 3)
+    with pytest.raises(hip.NopeError):
+        hip.op_geodesic(poses, gt, torch.zeros(1), None)
+    with pytest.raises(hip.NopeError):
+        hip.op_geodesic(poses, gt, None, torch.zeros(1, 3, dtype=torch.int64))
+    with pytest.raises(hip.NopeError):
+        hip.op_geodesic(poses, gt, None, torch.zeros(6, dtype=torch.int64))
+
+
 def test_pose_grids_and_relative_poses(tmp_path):
     """nope_amd.poses (utils.py:72-125, shapeNet.py:243-251): synthesised icosphere grids have the reference's camera
     positions (level-0 fixture, as a set) and its upper-hemisphere counts at every level; reading the reference's files
@@ -428,3 +443,35 @@ def test_compute_mode_codes():
     assert hip.torch_dtype(hip.BF16X3) == torch.float32 and hip.storage_code(hip.BF16X3) == hip.F32 and hip.storage_code(hip.F16) == hip.F16
     with pytest.raises(hip.NopeError):
         hip.dtype_code("fp8")
+
+
+def test_nearest_template_finder_vs_reference_run():
+    """nope_amd.poses.NearestTemplateFinder (utils.py:318-356) against the reference's own class run in the build container
+    (tests/golden/make_golden_f2f3.py -> nearest_ref.npz, which carries the grid it searched): same template index for every query, same
+    in-plane angle; an exact grid pose finds itself with in-plane 0, the same pose turned by 37 degrees in the image plane finds it with -37
+    ... whatever sign the reference's Euler convention gives (recorded, not assumed); the synthesised grid finds the same camera POSITIONS."""
+    import os
+    import numpy as np
+    from nope_amd import poses as P
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "nearest_ref.npz"))
+    for tag, level, dist in (("L0_upper", 0, "upper"), ("L1_all", 1, "all")):
+        grid = (fx[f"{tag}/avail_index"], fx[f"{tag}/obj_template_poses"])
+        f = P.NearestTemplateFinder(level, dist, return_inplane=True, grid=grid)
+        idx, inp = f.search_nearest_template(fx[f"{tag}/query"])
+        assert np.array_equal(idx, fx[f"{tag}/index"])
+        assert np.allclose(inp, fx[f"{tag}/inplane"], atol=1e-9)
+        assert np.array_equal(P.NearestTemplateFinder(level, dist, return_inplane=False, grid=grid).search_nearest_template(fx[f"{tag}/query"]),
+                              fx[f"{tag}/index_only"])
+        assert idx[0] == grid[0][3] and abs(inp[0]) < 1e-9 and idx[1] == grid[0][5] and abs(abs(inp[1]) - 37.0) < 1e-6
+        # the in-plane angle really recovers the query's rotation for the two constructed cases
+        for i, t in ((0, 3), (1, 5)):
+            assert P.inplane_residual(fx[f"{tag}/query"][i, :3, :3], grid[1][t][:3, :3], inp[i]) < 0.05      # degrees (the grid files are float32: acos near 1)
+        # the synthesised grid (no reference files): the nearest VIEWPOINT is the same point of the sphere
+        fs = P.NearestTemplateFinder(level, dist, return_inplane=False)
+        got = fs.search_nearest_template(fx[f"{tag}/query"])
+        cam_ref = np.linalg.inv(grid[1])[:, :3, 3]
+        cam_syn = np.linalg.inv(fs.obj_template_poses)[:, :3, 3]
+        pos_ref = cam_ref[np.searchsorted(grid[0], fx[f"{tag}/index"])]
+        pos_syn = cam_syn[np.searchsorted(fs.avail_index, got)]
+        unit = lambda v: v / np.linalg.norm(v, axis=-1, keepdims=True)
+        assert float(np.abs(unit(pos_ref) - unit(pos_syn)).max()) < 1e-4
