@@ -479,10 +479,17 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     // a_lo * 2^9 into slot 4 + 2 (ls / 4) and the four of a * 2^-2 into slot 5 + 2 (ls / 4), each at byte 4 (ls % 4) (two ds_write_b32).
     // The f16 part saturates at +-65504, the fp8 parts at +-448 (v_med3_f32: a NaN becomes the lower bound, as in the f16 mode).
     const int x2_sc = X2 ? p.x2_scale[0] : 0;                                 // E8M0 block scale of the cross-term MFMA (uniform; waited for with the prologue's DMA)
-    auto convert_piece = [&](int i, int stage) __attribute__((always_inline)) {
+    // (two halves.  bf16x3: the READ of a piece opens the LOAD phase, the DMA pieces of the phase are issued and the tap's fragment addresses
+    //  formed underneath it, then the arithmetic + writes: -1.6 % on the kernel against read + rewrite back to back.  f16x2: back to back, the
+    //  same order measured +1.3 % there -- same-box A/B, profiles/r05h_rewrite_order_ab.txt.  Carrying the value across the barrier from the
+    //  previous COMPUTE phase spills: 256 VGPRs)
+    constexpr bool CV_UNDER_ISSUE = A_SPLIT_LDS && !X2;
+    auto convert_load = [&](int i, int stage) __attribute__((always_inline)) -> u32x4 {
+        return ld16(a_dst + stage * A_STAGE + i * 8192 + rsub * RB + lslot * 16);
+    };
+    auto convert_store = [&](const u32x4& v, int i, int stage) __attribute__((always_inline)) {
         if constexpr (X2) {
             unsigned char* row = a_dst + stage * A_STAGE + i * 8192 + rsub * RB;
-            const u32x4 v = ld16(row + lslot * 16);
             const int sw = swz_of<RB>(r0), ls = lslot ^ sw;
             unsigned hi[2], lo8, a8;
             float x[4], l[4];
@@ -496,9 +503,8 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                 l[2 * e] = x[2 * e] - (float)hh.f[0];
                 l[2 * e + 1] = x[2 * e + 1] - (float)hh.f[1];
             }
-            constexpr float SLO = (float)(1 << kX2ALoShift), SA = 1.0f / (float)(1 << -kX2AShift);
-            lo8 = cvt_pk_e4m3(l[0] * SLO, l[1] * SLO) | (cvt_pk_e4m3(l[2] * SLO, l[3] * SLO) << 16);
-            a8 = cvt_pk_e4m3(x[0] * SA, x[1] * SA) | (cvt_pk_e4m3(x[2] * SA, x[3] * SA) << 16);
+            lo8 = cvt4_e4m3_scaled<kX2ALoShift>(l[0], l[1], l[2], l[3]);
+            a8 = cvt4_e4m3_scaled<kX2AShift>(x[0], x[1], x[2], x[3]);
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
             __builtin_amdgcn_wave_barrier();       // every lane's read precedes every lane's write (see below)
             *reinterpret_cast<u32x2*>(row + (((ls >> 1) ^ sw) << 4) + 8 * (ls & 1)) = u32x2{hi[0], hi[1]};
@@ -506,7 +512,6 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             *reinterpret_cast<unsigned*>(row + (((5 + 2 * (ls >> 2)) ^ sw) << 4) + 4 * (ls & 3)) = a8;
         } else if constexpr (A_SPLIT_LDS) {
             unsigned char* row = a_dst + stage * A_STAGE + i * 8192 + rsub * RB;
-            const u32x4 v = ld16(row + lslot * 16);
             unsigned hi[2], lo[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -524,6 +529,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             *reinterpret_cast<u32x2*>(row + ((lslot ^ cv_half ^ 1) << 4) + 8 * cv_half) = u32x2{lo[0], lo[1]};
         }
     };
+    auto convert_piece = [&](int i, int stage) __attribute__((always_inline)) { convert_store(convert_load(i, stage), i, stage); };
     // ---- B pieces: 24 rows per wave (group 1: panel rows 0..95, group 0: rows 96..191), as in conv_gemm_pp_kernel
     const int brow0 = 96 * (1 - grp) + 24 * wl;
     unsigned b_off[3];
@@ -649,8 +655,11 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             // (bf16x3: the piece this wave issued in the previous step has landed -- its vmcnt(0) closed that step -- split it in place,
             //  first thing in the phase, while no fragment register is live; the stage is first read three or more steps from
             //  now, behind this step's barrier.  The LOAD phase has the slack: it is the shorter one with 36 MFMAs per step.)
-            if (A_SPLIT_LDS && dma_on && tap >= 1 && tap <= 6 && !last && (tap - 1 < 4 || (tap - 1 == 4 ? a_has4 : a_has5))) {
-                convert_piece(tap - 1, par ^ 1);
+            const bool cv_now = A_SPLIT_LDS && dma_on && tap >= 1 && tap <= 6 && !last && (tap - 1 < 4 || (tap - 1 == 4 ? a_has4 : a_has5));
+            u32x4 cv = {0u, 0u, 0u, 0u};
+            if (cv_now) {
+                if constexpr (CV_UNDER_ISSUE) cv = convert_load(tap - 1, par ^ 1);
+                else convert_piece(tap - 1, par ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // ---- LOAD: DMA pieces first (they fly for the rest of this phase and the whole next one), then the fragments
@@ -671,6 +680,11 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                 const int rr = frow + i * TL::TM + toff;
                 const int off = A_BASE + (rr << 7) + (((fslot ^ (rr >> 1)) & 7) << 4);
                 fa[i] = ((f_mask[i] >> tap) & 1u) ? off : A_BASE + ZROW;   // (absolute, stage 0)
+            }
+            if (CV_UNDER_ISSUE && cv_now) {
+                __builtin_amdgcn_sched_barrier(0);
+                convert_store(cv, tap - 1, par ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {

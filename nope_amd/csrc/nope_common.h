@@ -164,6 +164,18 @@ constexpr float kE4M3Max = 448.0f;
 __device__ __forceinline__ unsigned cvt_pk_e4m3(float lo, float hi) {
     return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(lo, -kE4M3Max, kE4M3Max), __builtin_amdgcn_fmed3f(hi, -kE4M3Max, kE4M3Max), 0, false) & 0xffffu;
 }
+// Four f32 -> four e4m3 bytes of (x * 2^shift), one dword: v_cvt_scalef32_pk_fp8_f32 divides by the power of two in its scale operand (only
+// the exponent counts) and writes the half of the destination word_sel names, so pre-scale, conversion and packing are two instructions
+// + the clamps (the instruction does not saturate either: probe fact 6).  shift is a compile-time constant.
+typedef short s16x2_hw_t __attribute__((ext_vector_type(2)));
+template <int SHIFT> __device__ __forceinline__ unsigned cvt4_e4m3_scaled(float x0, float x1, float x2, float x3) {
+    constexpr float LIM = kE4M3Max / (SHIFT >= 0 ? (float)(1 << (SHIFT >= 0 ? SHIFT : 0)) : 1.0f / (float)(1 << (SHIFT < 0 ? -SHIFT : 0)));      // 448 * 2^-SHIFT
+    constexpr float INV = SHIFT >= 0 ? 1.0f / (float)(1 << (SHIFT >= 0 ? SHIFT : 0)) : (float)(1 << (SHIFT < 0 ? -SHIFT : 0));                     // 2^-SHIFT: the divisor
+    s16x2_hw_t r = {0, 0};
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, __builtin_amdgcn_fmed3f(x0, -LIM, LIM), __builtin_amdgcn_fmed3f(x1, -LIM, LIM), INV, false);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, __builtin_amdgcn_fmed3f(x2, -LIM, LIM), __builtin_amdgcn_fmed3f(x3, -LIM, LIM), INV, true);
+    return __builtin_bit_cast(unsigned, r);
+}
 // Power-of-two pre-scales of the f16x2 cross-term operands (exact multiplications), undone by the MFMA's E8M0 block scale:
 //   e4m3(a_lo * 2^9), e4m3(a * 2^-2)  [activations, fixed]      e4m3(w * 2^sw), e4m3(w_lo * 2^(sw + 11))  [weights, sw per layer]
 // chosen so that BOTH products of the K-concatenated instruction, a_lo w and a w_lo, carry the same total 2^(9 + sw): one scale for all

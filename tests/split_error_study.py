@@ -149,6 +149,11 @@ SCHEMES = {
     # the candidates
     "f16+e4m3": lambda: F16Cross8("f16+e4m3"),
     "f16+e4m3(alo:2^9,a:2^-2)": lambda: F16Cross8("f16+e4m3(alo:2^9,a:2^-2)", sa_lo=9, sa=-2),
+    # one clamp for all three conversions (|a| <= 2^14 / 2^15 / 2^16 first): a * 2^-6 / 2^-7 / 2^-8 and a_lo * 2^5 / 2^4 / 2^3 cannot overflow e4m3 then
+    "f16+e4m3(alo:2^5,a:2^-6)": lambda: F16Cross8("f16+e4m3(alo:2^5,a:2^-6)", sa_lo=5, sa=-6),
+    "f16+e4m3(alo:2^4,a:2^-7)": lambda: F16Cross8("f16+e4m3(alo:2^4,a:2^-7)", sa_lo=4, sa=-7),
+    "f16+e4m3(alo:2^3,a:2^-8)": lambda: F16Cross8("f16+e4m3(alo:2^3,a:2^-8)", sa_lo=3, sa=-8),
+    "f16+e4m3(alo:2^7,a:2^-4)": lambda: F16Cross8("f16+e4m3(alo:2^7,a:2^-4)", sa_lo=7, sa=-4),
     "f16+e4m3(alo:2^11)": lambda: F16Cross8("f16+e4m3(alo:2^11)", sa_lo=11),
     "f16+e4m3(alo:2^5)": lambda: F16Cross8("f16+e4m3(alo:2^5)", sa_lo=5),
     "f16+e5m2(a),e4m3": lambda: F16Cross8("f16+e5m2(a),e4m3", fa=E5M2),
@@ -231,6 +236,10 @@ CONFIGS = {
     "f16+e4m3": ("f16+e4m3", None, None, None, None),
     "f16+e4m3(alo:2^9,a:2^-2)": ("f16+e4m3(alo:2^9,a:2^-2)", None, None, None, None),
     "f16+e4m3(alo:2^9,a:2^-2), f16 bank": ("f16+e4m3(alo:2^9,a:2^-2)", None, None, None, H),
+    "f16+e4m3(alo:2^7,a:2^-4)": ("f16+e4m3(alo:2^7,a:2^-4)", None, None, None, None),
+    "f16+e4m3(alo:2^5,a:2^-6)": ("f16+e4m3(alo:2^5,a:2^-6)", None, None, None, None),
+    "f16+e4m3(alo:2^4,a:2^-7)": ("f16+e4m3(alo:2^4,a:2^-7)", None, None, None, None),
+    "f16+e4m3(alo:2^3,a:2^-8)": ("f16+e4m3(alo:2^3,a:2^-8)", None, None, None, None),
     "f16+e4m3(alo:2^11)": ("f16+e4m3(alo:2^11)", None, None, None, None),
     "f16+e4m3(alo:2^5)": ("f16+e4m3(alo:2^5)", None, None, None, None),
     "f16+e5m2(a),e4m3": ("f16+e5m2(a),e4m3", None, None, None, None),

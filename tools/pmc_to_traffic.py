@@ -33,7 +33,8 @@ def base_name(n):
 
 # element type of a kernel instantiation as the profiler prints it: demangled ("<unsigned short", ...) or, for _Float16 (which the
 # profiler's demangler does not know), the Itanium mangling ("IDF16_")
-TAGS = {"bf16": ("<unsigned short", "kernelIt"), "f16": ("<_Float16", "kernelIDF16_"), "f32": ("<float", "kernelIf"), "bf16x3": ("f32s_t",)}
+TAGS = {"bf16": ("<unsigned short", "kernelIt"), "f16": ("<_Float16", "kernelIDF16_"), "f32": ("<float", "kernelIf"), "bf16x3": ("f32s_t",),
+        "f16x2": ("f16x2_t", "f32s_t")}      # (f16x2: the tap-resident launches on their own tile, everything else the bf16x3 instantiations)
 
 
 def main(argv):

@@ -10,6 +10,8 @@
 //      scale offered by lanes 0..31, bytes 16..31 the one offered by lanes 32..63 (measured; all-ones operands cannot tell the two apart).
 //      The f16x2 kernel offers ONE scale in every lane (3d), so only the pairing rule of fact 2 matters to it.
 //   4. the C/D map is the 32x32 one: col = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5); fp8 subnormals are kept (4a)
+//   6. v_cvt_scalef32_pk_fp8_f32 = e4m3(value / 2^floor(log2 scale)), round to nearest even, word_sel picks the half written -- the pre-scale
+//      multiply folded into the conversion; like the plain conversion it does NOT saturate
 //   5. accumulation: products are exact, but the 64-term sum is NOT f32-exact: measured error up to 2^-11.7 of the LARGEST term (the terms are
 //      aligned to the largest and truncated) -- harmless for cross terms that are 2^-11 of the result, fatal for a main term
 #include <hip/hip_runtime.h>
@@ -38,6 +40,17 @@ __global__ void mx_kernel(const unsigned char* a, const unsigned char* b, const 
 __global__ void cvt_kernel(const float* x, unsigned* out, int n) {
     const int i = threadIdx.x;
     if (2 * i + 1 < n + 1) out[i] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(x[2 * i], x[2 * i + 1], 0, false) & 0xffffu;
+}
+
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+__global__ void cvt_scale_kernel(const float* x, unsigned* out, int n, float scale) {
+    const int i = threadIdx.x;
+    if (2 * i + 1 < n + 1) {
+        s16x2 old = {0, 0};
+        s16x2 r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(old, x[2 * i], x[2 * i + 1], scale, false);
+        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, x[2 * i + 1], x[2 * i], scale, true);      // word_sel: the upper half, swapped pair
+        out[i] = __builtin_bit_cast(unsigned, r);
+    }
 }
 
 static float e4m3_to_f32(unsigned char v) {
@@ -112,6 +125,34 @@ int main() {
             if (in_range && got != want) ok = false;
         }
         report("1. v_cvt_pk_fp8_f32 = OCP e4m3fn, round to nearest even, inside +-448", ok);
+    }
+    // ---- 6. v_cvt_scalef32_pk_fp8_f32 (the conversion with the pre-scale folded in): value / scale?  value * scale?  saturation?
+    {
+        const float xs[] = {1.0f, 2.0f, 0.3f, -3.3f, 448.0f, 500.0f, 1e6f, -1e6f, 0.001953125f, 0.0009765625f, 100.0f, 200.0f, 7.0f, -0.0f, 17.0f, 19.0f};
+        const int n = 16;
+        float* dx; unsigned* dout;
+        hipMalloc(&dx, n * 4); hipMalloc(&dout, n * 4);
+        hipMemcpy(dx, xs, n * 4, hipMemcpyHostToDevice);
+        for (float scale : {1.0f, 4.0f, 0.25f, 3.0f}) {
+            hipLaunchKernelGGL(cvt_scale_kernel, dim3(1), dim3(n / 2), 0, 0, dx, dout, n, scale);
+            unsigned out[8];
+            hipMemcpy(out, dout, 32, hipMemcpyDeviceToHost);
+            printf("     cvt_scalef32_pk_fp8_f32, scale %g:", scale);
+            bool div_ok = true, hi_ok = true;
+            for (int i = 0; i < n; ++i) {
+                const unsigned char got = (out[i / 2] >> (8 * (i & 1))) & 0xff, hi = (out[i / 2] >> (16 + 8 * ((i & 1) ^ 1))) & 0xff;
+                printf(" %g->%g", xs[i], e4m3_to_f32(got));
+                const float pw = ldexpf(1.0f, ilogbf(scale));                 // only the exponent of `scale` counts (an E8M0 scale in f32 clothing)
+                const float want = xs[i] / pw;
+                if (fabsf(want) <= 448.0f ? got != f32_to_e4m3(want) : (fabsf(want) >= 480.0f && (got & 0x7f) != 0x7f)) div_ok = false;
+                if (hi != got) hi_ok = false;
+            }
+            printf("\n");
+            char name[128];
+            snprintf(name, sizeof(name), "6. scale %g: result = RNE e4m3(value / 2^floor(log2 scale)); NO saturation (NaN from 480 on): clamp first", scale);
+            report(name, div_ok);
+            if (!hi_ok) report("6. word_sel = true writes the same bytes into the upper half (old lower half kept)", false);
+        }
     }
     const unsigned char ONE = f32_to_e4m3(1.0f);
     std::vector<int> S0(64, 127);

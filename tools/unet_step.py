@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--templates", type=int, default=512)
 ap.add_argument("--dtype", default="bf16")
 a = ap.parse_args()
-m = build_model(compute_dtype=a.dtype, bank_dtype=a.dtype, device="cuda")
+m = build_model(compute_dtype=a.dtype, bank_dtype=a.dtype if a.dtype in ("bf16", "f16") else "f32", device="cuda")
 g = torch.Generator().manual_seed(0)
 feat = torch.randn(1, 8, 32, 32, generator=g).cuda()
 poses = torch.randn(1, a.templates, 6, generator=g).cuda()
