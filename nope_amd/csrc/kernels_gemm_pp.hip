@@ -477,7 +477,10 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     // ---- NOPE_F16X2: same in-place rewrite, into the layout of Tile<f16x2_t>.  A lane's 16-byte slot holds channels 4 ls .. 4 ls + 3 of the
     // chunk (ls = its LOGICAL slot); it writes their four f16 hi parts into half of logical slot ls / 2 (8 bytes), the four e4m3 bytes of
     // a_lo * 2^9 into slot 4 + 2 (ls / 4) and the four of a * 2^-2 into slot 5 + 2 (ls / 4), each at byte 4 (ls % 4) (two ds_write_b32).
-    // The f16 part saturates at +-65504, the fp8 parts at +-448 (v_med3_f32: a NaN becomes the lower bound, as in the f16 mode).
+    // The f16 part saturates at +-65504, the fp8 parts at +-448: the wave sets MODE.FP16_OVFL, under which the three conversions saturate by
+    // themselves (probe fact 7; a NaN stays a NaN, as in the f32 / bf16x3 modes) -- 16 VALU per piece and lane instead of 46 with explicit
+    // pre-scale multiplies, clamps and byte packing.
+    if constexpr (X2) fp16_ovfl_on();
     const int x2_sc = X2 ? p.x2_scale[0] : 0;                                 // E8M0 block scale of the cross-term MFMA (uniform; waited for with the prologue's DMA)
     // (two halves.  bf16x3: the READ of a piece opens the LOAD phase, the DMA pieces of the phase are issued and the tap's fragment addresses
     //  formed underneath it, then the arithmetic + writes: -1.6 % on the kernel against read + rewrite back to back.  f16x2: back to back, the
@@ -497,14 +500,14 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             for (int e = 0; e < 4; ++e) { const unsigned u = v[e]; x[e] = __builtin_bit_cast(float, u); }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const unsigned h = cvt_pk_f16(x[2 * e], x[2 * e + 1]);
+                const unsigned h = NOPE_CVT_PK_F16_OVFL(x[2 * e], x[2 * e + 1]);      // (saturating: the wave runs with MODE.FP16_OVFL = 1)
                 hi[e] = h;
                 union { unsigned u; f16_t f[2]; } hh; hh.u = h;
                 l[2 * e] = x[2 * e] - (float)hh.f[0];
                 l[2 * e + 1] = x[2 * e + 1] - (float)hh.f[1];
             }
-            lo8 = cvt4_e4m3_scaled<kX2ALoShift>(l[0], l[1], l[2], l[3]);
-            a8 = cvt4_e4m3_scaled<kX2AShift>(x[0], x[1], x[2], x[3]);
+            lo8 = cvt4_e4m3_scaled<kX2ALoShift, true>(l[0], l[1], l[2], l[3]);
+            a8 = cvt4_e4m3_scaled<kX2AShift, true>(x[0], x[1], x[2], x[3]);
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
             __builtin_amdgcn_wave_barrier();       // every lane's read precedes every lane's write (see below)
             *reinterpret_cast<u32x2*>(row + (((ls >> 1) ^ sw) << 4) + 8 * (ls & 1)) = u32x2{hi[0], hi[1]};

@@ -168,14 +168,28 @@ __device__ __forceinline__ unsigned cvt_pk_e4m3(float lo, float hi) {
 // the exponent counts) and writes the half of the destination word_sel names, so pre-scale, conversion and packing are two instructions
 // + the clamps (the instruction does not saturate either: probe fact 6).  shift is a compile-time constant.
 typedef short s16x2_hw_t __attribute__((ext_vector_type(2)));
-template <int SHIFT> __device__ __forceinline__ unsigned cvt4_e4m3_scaled(float x0, float x1, float x2, float x3) {
+// OVFL_MODE: the caller runs with MODE.FP16_OVFL = 1 (fp16_ovfl_on below), under which the conversion saturates by itself (probe fact 7): no clamps.
+template <int SHIFT, bool OVFL_MODE = false> __device__ __forceinline__ unsigned cvt4_e4m3_scaled(float x0, float x1, float x2, float x3) {
     constexpr float LIM = kE4M3Max / (SHIFT >= 0 ? (float)(1 << (SHIFT >= 0 ? SHIFT : 0)) : 1.0f / (float)(1 << (SHIFT < 0 ? -SHIFT : 0)));      // 448 * 2^-SHIFT
     constexpr float INV = SHIFT >= 0 ? 1.0f / (float)(1 << (SHIFT >= 0 ? SHIFT : 0)) : (float)(1 << (SHIFT < 0 ? -SHIFT : 0));                     // 2^-SHIFT: the divisor
     s16x2_hw_t r = {0, 0};
-    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, __builtin_amdgcn_fmed3f(x0, -LIM, LIM), __builtin_amdgcn_fmed3f(x1, -LIM, LIM), INV, false);
-    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, __builtin_amdgcn_fmed3f(x2, -LIM, LIM), __builtin_amdgcn_fmed3f(x3, -LIM, LIM), INV, true);
+    if constexpr (OVFL_MODE) {
+        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, x0, x1, INV, false);
+        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, x2, x3, INV, true);
+    } else {
+        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, __builtin_amdgcn_fmed3f(x0, -LIM, LIM), __builtin_amdgcn_fmed3f(x1, -LIM, LIM), INV, false);
+        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, __builtin_amdgcn_fmed3f(x2, -LIM, LIM), __builtin_amdgcn_fmed3f(x3, -LIM, LIM), INV, true);
+    }
     return __builtin_bit_cast(unsigned, r);
 }
+// MODE.FP16_OVFL (hwreg 1 = MODE, bit 23) for the rest of the wave's life: f32 -> f16 and f32 -> fp8 conversions SATURATE (+-65504 / +-448)
+// instead of producing inf / NaN; a NaN stays a NaN (tools/probes/mx_probe.hip fact 7).  The f16x2 operand rewrite runs under it: 12 clamps
+// per piece and lane gone.  NOPE_CVT_PK_F16_OVFL: the f16 pair conversion under that mode -- the plain one on the device; tests/hipemu
+// supplies its own, which consults the interpreter's copy of the mode bit (a host compiler's conversion knows nothing of it).
+__device__ __forceinline__ void fp16_ovfl_on() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
+#ifndef NOPE_CVT_PK_F16_OVFL
+#define NOPE_CVT_PK_F16_OVFL(lo, hi) cvt_pk_f16_raw(lo, hi)
+#endif
 // Power-of-two pre-scales of the f16x2 cross-term operands (exact multiplications), undone by the MFMA's E8M0 block scale:
 //   e4m3(a_lo * 2^9), e4m3(a * 2^-2)  [activations, fixed]      e4m3(w * 2^sw), e4m3(w_lo * 2^(sw + 11))  [weights, sw per layer]
 // chosen so that BOTH products of the K-concatenated instruction, a_lo w and a w_lo, carry the same total 2^(9 + sw): one scale for all

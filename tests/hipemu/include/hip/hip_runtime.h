@@ -90,6 +90,7 @@ struct BlockCtx {
 };
 
 inline thread_local BlockCtx* g_blk = nullptr;
+inline thread_local bool g_fp16_ovfl = false;     // the interpreter's copy of MODE.FP16_OVFL (see hipemu_s_setreg)
 inline thread_local hipemu_uint3 g_tid, g_bid, g_bdim, g_gdim;
 
 inline void yield_to_sched() {
@@ -127,6 +128,7 @@ inline void dma_wait(size_t keep) {
 
 inline void run_block(BlockCtx& b) {
     g_blk = &b;
+    g_fp16_ovfl = false;
     g_bid = b.bid; g_bdim = b.bdim; g_gdim = b.gdim;
     int n = b.nthreads;
     for (int i = 0; i < n; ++i) {
@@ -391,6 +393,14 @@ inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x8 b
     }
     return c;
 }
+// ---- MODE.FP16_OVFL (s_setreg hwreg(MODE, 23, 1)): saturating f16 / fp8 conversions for the rest of the wave's life.  One flag per OS thread
+// = per workgroup being interpreted, cleared when a block starts (hipemu::run_block).
+inline void hipemu_s_setreg(int hwreg, int value) {
+    if (hwreg == (1 | (23 << 6))) hipemu::g_fp16_ovfl = value != 0;
+    else { fprintf(stderr, "hipemu: s_setreg of hwreg encoding %d is not emulated\n", hwreg); abort(); }
+}
+#define __builtin_amdgcn_s_setreg hipemu_s_setreg
+#define NOPE_CVT_PK_F16_OVFL(lo, hi) (hipemu::g_fp16_ovfl ? cvt_pk_f16(lo, hi) : cvt_pk_f16_raw(lo, hi))
 // ---- OCP e4m3 (fn) and the MX-scaled fp8 MFMA, as measured on gfx950 by tools/probes/mx_probe.hip
 inline float hipemu_e4m3_to_f32(unsigned char v) {
     const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
@@ -403,7 +413,8 @@ inline float hipemu_e4m3_to_f32(unsigned char v) {
 inline unsigned char hipemu_f32_to_e4m3(float x) {       // round to nearest even; beyond the largest value (448 + half a step): NaN
     const unsigned char sign = std::signbit(x) ? 0x80 : 0;
     const float ax = fabsf(x);
-    if (!(ax == ax) || ax >= 480.0f) return (unsigned char)(sign | 0x7f);
+    if (!(ax == ax)) return (unsigned char)(sign | 0x7f);
+    if (ax >= 480.0f) return (unsigned char)(sign | (hipemu::g_fp16_ovfl ? 0x7e : 0x7f));      // FP16_OVFL: saturate at 448 (infinities too, close enough)
     unsigned char best = 0; float bd = INFINITY;
     for (int v = 0; v < 127; ++v) {
         const float dd = fabsf(hipemu_e4m3_to_f32((unsigned char)v) - ax);

@@ -236,6 +236,9 @@ CONFIGS = {
     "f16+e4m3": ("f16+e4m3", None, None, None, None),
     "f16+e4m3(alo:2^9,a:2^-2)": ("f16+e4m3(alo:2^9,a:2^-2)", None, None, None, None),
     "f16+e4m3(alo:2^9,a:2^-2), f16 bank": ("f16+e4m3(alo:2^9,a:2^-2)", None, None, None, H),
+    # ... and the remaining convs (1x1, up / down-sampling: bf16x3 today) with f16-rounded activation operands against exact weights: would a
+    # two-pass a16 x (w_hi + w_lo) tile do for them?
+    "f16+e4m3, other convs a16 x exact w": ("f16+e4m3(alo:2^9,a:2^-2)", None, "a16", None, None),
     "f16+e4m3(alo:2^7,a:2^-4)": ("f16+e4m3(alo:2^7,a:2^-4)", None, None, None, None),
     "f16+e4m3(alo:2^5,a:2^-6)": ("f16+e4m3(alo:2^5,a:2^-6)", None, None, None, None),
     "f16+e4m3(alo:2^4,a:2^-7)": ("f16+e4m3(alo:2^4,a:2^-7)", None, None, None, None),

@@ -12,6 +12,8 @@
 //   4. the C/D map is the 32x32 one: col = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5); fp8 subnormals are kept (4a)
 //   6. v_cvt_scalef32_pk_fp8_f32 = e4m3(value / 2^floor(log2 scale)), round to nearest even, word_sel picks the half written -- the pre-scale
 //      multiply folded into the conversion; like the plain conversion it does NOT saturate
+//   7. under MODE.FP16_OVFL = 1 (s_setreg hwreg(MODE, 23, 1)) v_cvt_pk_f16_f32, v_cvt_pk_fp8_f32 and v_cvt_scalef32_pk_fp8_f32 SATURATE (+-65504 /
+//      +-448) instead of producing inf / NaN; NaN inputs stay NaN -- the f16x2 operand rewrite runs under it and needs no clamps
 //   5. accumulation: products are exact, but the 64-term sum is NOT f32-exact: measured error up to 2^-11.7 of the LARGEST term (the terms are
 //      aligned to the largest and truncated) -- harmless for cross terms that are 2^-11 of the result, fatal for a main term
 #include <hip/hip_runtime.h>
@@ -50,6 +52,24 @@ __global__ void cvt_scale_kernel(const float* x, unsigned* out, int n, float sca
         s16x2 r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(old, x[2 * i], x[2 * i + 1], scale, false);
         r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, x[2 * i + 1], x[2 * i], scale, true);      // word_sel: the upper half, swapped pair
         out[i] = __builtin_bit_cast(unsigned, r);
+    }
+}
+
+// MODE.FP16_OVFL (hwreg 1, bit 23): do the fp8 / f16 conversions saturate under it?
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__global__ void ovfl_kernel(const float* x, unsigned* out, int n) {
+    __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
+    const int i = threadIdx.x;
+    if (2 * i + 1 < n + 1) {
+        s16x2 z = {0, 0};
+        const s16x2 a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(z, x[2 * i], x[2 * i + 1], 1.0f, false);
+        const unsigned b = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(x[2 * i], x[2 * i + 1], 0, false) & 0xffffu;
+        const f32x2_t v = {x[2 * i], x[2 * i + 1]};
+        const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+        out[3 * i] = __builtin_bit_cast(unsigned, a) & 0xffffu;
+        out[3 * i + 1] = b;
+        out[3 * i + 2] = __builtin_bit_cast(unsigned, h);
     }
 }
 
@@ -153,6 +173,31 @@ int main() {
             report(name, div_ok);
             if (!hi_ok) report("6. word_sel = true writes the same bytes into the upper half (old lower half kept)", false);
         }
+    }
+    // ---- 7. MODE.FP16_OVFL = 1: saturating conversions?
+    {
+        const float xs[] = {1.0f, 447.0f, 460.0f, 500.0f, 1e6f, -1e6f, 70000.0f, -70000.0f, INFINITY, NAN};
+        const int n = 10;
+        float* dx; unsigned* dout;
+        hipMalloc(&dx, n * 4); hipMalloc(&dout, n * 6);
+        hipMemcpy(dx, xs, n * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(ovfl_kernel, dim3(1), dim3(n / 2), 0, 0, dx, dout, n);
+        unsigned out[15];
+        hipMemcpy(out, dout, 60, hipMemcpyDeviceToHost);
+        bool sat8 = true, sat8p = true, sat16 = true;
+        printf("     under MODE.FP16_OVFL = 1:\n");
+        for (int i = 0; i < n; ++i) {
+            const unsigned char a = (out[3 * (i / 2)] >> (8 * (i & 1))) & 0xff, b = (out[3 * (i / 2) + 1] >> (8 * (i & 1))) & 0xff;
+            const unsigned short h = (out[3 * (i / 2) + 2] >> (16 * (i & 1))) & 0xffff;
+            _Float16 hf; memcpy(&hf, &h, 2);
+            printf("       %g -> cvt_scalef32_pk_fp8 %g, cvt_pk_fp8 %g, f16 %g\n", xs[i], e4m3_to_f32(a), e4m3_to_f32(b), (float)hf);
+            if (xs[i] == xs[i] && fabsf(xs[i]) > 448.0f && fabsf(xs[i]) < INFINITY) {
+                if (fabsf(e4m3_to_f32(a)) != 448.0f) sat8 = false;
+                if (fabsf(e4m3_to_f32(b)) != 448.0f) sat8p = false;
+                if (fabsf(xs[i]) > 65504.0f && fabsf((float)hf) != 65504.0f) sat16 = false;
+            }
+        }
+        printf("     -> v_cvt_scalef32_pk_fp8_f32 saturates: %s, v_cvt_pk_fp8_f32 saturates: %s, v_cvt_pk_f16_f32 saturates: %s (informational)\n", sat8 ? "yes" : "no", sat8p ? "yes" : "no", sat16 ? "yes" : "no");
     }
     const unsigned char ONE = f32_to_e4m3(1.0f);
     std::vector<int> S0(64, 127);

@@ -1,10 +1,10 @@
 #!/bin/bash
-# round 5, run h (template): SAME-BOX A/B of two builds of the tap-resident kernel (A = build/ab/libnope_hip_a.so through NOPE_HIP_LIB, B = the in-tree library), alternating, two rounds
+# round 5, run j: SAME-BOX A/B of the f16x2 operand rewrite under MODE.FP16_OVFL (B, in-tree: no clamps, 16 VALU per piece) against explicit v_med3 clamps (A, build/ab/libnope_hip_a.so = the previous commit's kernel, 28 VALU)
 
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-OUT=gpurun_out/r05h_rewrite_order_ab.txt
+OUT=gpurun_out/r05j_fp16_ovfl_ab.txt
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 : > $OUT
 for round in 1 2; do
