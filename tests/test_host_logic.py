@@ -475,3 +475,41 @@ def test_nearest_template_finder_vs_reference_run():
         pos_syn = cam_syn[np.searchsorted(fs.avail_index, got)]
         unit = lambda v: v / np.linalg.norm(v, axis=-1, keepdims=True)
         assert float(np.abs(unit(pos_ref) - unit(pos_syn)).max()) < 1e-4
+
+
+def test_tuning_switches_are_cached_and_reloaded(emu, capfd):
+    """The library reads a NOPE_* switch once per call site (nope_tuning_reload, include/nope_hip.h); the binding reloads when it sees the
+    environment change between two calls.  Seen through NOPE_CONV_TRACE's per-launch line: the same 3x3 conv goes to the tap-resident kernel
+    under NOPE_CONV_PP=13 and to the per-tap ping-pong kernel under 29, in one process; a change the binding is NOT told about (putenv behind
+    its back, no call through hip.lib()) is not seen until nope_tuning_reload()."""
+    import ctypes
+    import os
+    hip = emu
+    g = torch.Generator().manual_seed(2)
+    x, w = torch.randn(1, 32, 4, 4, generator=g), torch.randn(8, 32, 3, 3, generator=g) / 17
+    os.environ["NOPE_CONV_TRACE"] = "1"
+    try:
+        seen = []
+        for pp in ("13", "29", "13"):
+            os.environ["NOPE_CONV_PP"] = pp
+            capfd.readouterr()
+            hip.op_conv(0, hip.to_nhwc(x, 0), w, None)
+            seen.append("halo256" in capfd.readouterr().err)
+        assert seen == [True, False, True], seen
+        # behind the binding's back: the cached value stays until the reload entry point is called
+        libc = ctypes.CDLL(None)
+        libc.setenv(b"NOPE_CONV_PP", b"29", 1)
+        xs, pw = hip.to_nhwc(x, 0), hip.pack_conv_weight(w, 0)[0]
+        out = torch.empty(1, 4, 4, 8)
+        call = lambda: hip.lib().dll.nope_op_conv(0, xs.data_ptr(), 32, 1, None, 0, 1, 4, 4, 0, 9, pw.data_ptr(), None, None, out.data_ptr(), 8, 1, 0, 0, 0, None)
+        dll = hip.lib().dll              # (os.environ still says 13: the binding sees no change and does not reload)
+        capfd.readouterr()
+        assert dll.nope_op_conv(0, xs.data_ptr(), 32, 1, None, 0, 1, 4, 4, 0, 9, pw.data_ptr(), None, None, out.data_ptr(), 8, 1, 0, 0, 0, None) == 0
+        assert "halo256" in capfd.readouterr().err
+        dll.nope_tuning_reload()
+        assert dll.nope_op_conv(0, xs.data_ptr(), 32, 1, None, 0, 1, 4, 4, 0, 9, pw.data_ptr(), None, None, out.data_ptr(), 8, 1, 0, 0, 0, None) == 0
+        assert "halo256" not in capfd.readouterr().err
+    finally:
+        os.environ.pop("NOPE_CONV_TRACE", None)
+        os.environ.pop("NOPE_CONV_PP", None)
+        hip.lib().dll.nope_tuning_reload()
