@@ -155,7 +155,8 @@ def _set_library_for_testing(l: Optional[NopeLib]):
 
 def require_device(t: torch.Tensor):
     """The product library takes device pointers only: a host tensor is an error, never a detour through torch CPU ops."""
-    if not t.is_cuda and not getattr(lib(), "host_pointers", False):
+    l = lib()      # (always: every binding starts here, and lib() is where a changed NOPE_* tuning variable is noticed)
+    if not t.is_cuda and not getattr(l, "host_pointers", False):
         raise NopeError("nope_amd computes on the GPU only: pass CUDA (ROCm) tensors; there is no CPU path")
 
 
