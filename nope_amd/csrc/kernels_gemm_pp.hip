@@ -487,6 +487,17 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     //  same order measured +1.3 % there -- same-box A/B, profiles/r05h_rewrite_order_ab.txt.  Carrying the value across the barrier from the
     //  previous COMPUTE phase spills: 256 VGPRs)
     constexpr bool CV_UNDER_ISSUE = A_SPLIT_LDS && !X2;
+    // f16x2: the rewrite rides in the COMPUTE phase instead -- between the MFMAs of the wave that multiplies, whose VALU and LDS ports are
+    // idle while the matrix pipe works (a wave issues in order: the rewrite's instructions are dealt out two to four behind each MFMA of the
+    // second term, sched_group_barrier, so none of them waits behind an MFMA that waits for the pipe).  The piece is the same one, half a
+    // step later (its stage is first read three or more steps from now).  NOPE_X2_CV_COMPUTE (compile time) = 0 restores the LOAD-phase form.
+#ifndef NOPE_X2_CV_COMPUTE
+#define NOPE_X2_CV_COMPUTE 1
+#endif
+    constexpr bool CV_IN_COMPUTE = A_SPLIT_LDS && NOPE_X2_CV_COMPUTE;
+    // ... and so do the fragment addresses of the NEXT step (row + tap offset, swizzle, zero-row redirect: 12 VALU), carried across the barrier
+    // in two registers that are free at that point (the step's own 80 fragment registers are dead once its MFMAs are issued).
+    constexpr bool FA_AHEAD = CV_IN_COMPUTE;
     auto convert_load = [&](int i, int stage) __attribute__((always_inline)) -> u32x4 {
         return ld16(a_dst + stage * A_STAGE + i * 8192 + rsub * RB + lslot * 16);
     };
@@ -644,6 +655,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);                       // DMA landed
     const bool dma_on = !(p.variant & 16);                         // (tuning: 16 = no DMA stream)
 
+    int fa_next[TL::MT] = {};                                      // FA_AHEAD: fragment addresses of the step about to start (formed during the previous COMPUTE phase)
     // The nine K steps of channel chunk `chunk`, whose A stage is `par` (a literal at both call sites: after inlining and
     // unrolling every tap, stage and ring index below is an immediate).
     auto chunk_steps = [&](const int chunk, const int par) __attribute__((always_inline)) {
@@ -660,7 +672,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             //  now, behind this step's barrier.  The LOAD phase has the slack: it is the shorter one with 36 MFMAs per step.)
             const bool cv_now = A_SPLIT_LDS && dma_on && tap >= 1 && tap <= 6 && !last && (tap - 1 < 4 || (tap - 1 == 4 ? a_has4 : a_has5));
             u32x4 cv = {0u, 0u, 0u, 0u};
-            if (cv_now) {
+            if (cv_now && !(CV_IN_COMPUTE && tap <= 4)) {      // (f16x2: pieces 0..3 are rewritten inside the COMPUTE phase below; 4 and 5, which not every wave has, here)
                 if constexpr (CV_UNDER_ISSUE) cv = convert_load(tap - 1, par ^ 1);
                 else convert_piece(tap - 1, par ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -677,14 +689,20 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             }
             u32x4 af[KS][RAW][TL::MT], bfr[KS][RAW][TL::NTL];
             int fa[TL::MT];
-            const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);            // scalar: the tap's row offset along the flat pixel axis
+            auto tap_addresses = [&](int tp, int (&dst)[TL::MT]) __attribute__((always_inline)) {
+                const int toff = (tp / 3 - 1) * W + (tp % 3 - 1);          // scalar: the tap's row offset along the flat pixel axis
 #pragma unroll
-            for (int i = 0; i < TL::MT; ++i) {
-                const int rr = frow + i * TL::TM + toff;
-                const int off = A_BASE + (rr << 7) + (((fslot ^ (rr >> 1)) & 7) << 4);
-                fa[i] = ((f_mask[i] >> tap) & 1u) ? off : A_BASE + ZROW;   // (absolute, stage 0)
-            }
-            if (CV_UNDER_ISSUE && cv_now) {
+                for (int i = 0; i < TL::MT; ++i) {
+                    const int rr = frow + i * TL::TM + toff;
+                    const int off = A_BASE + (rr << 7) + (((fslot ^ (rr >> 1)) & 7) << 4);
+                    dst[i] = ((f_mask[i] >> tp) & 1u) ? off : A_BASE + ZROW;   // (absolute, stage 0)
+                }
+            };
+            if constexpr (FA_AHEAD) {
+#pragma unroll
+                for (int i = 0; i < TL::MT; ++i) fa[i] = fa_next[i];
+            } else tap_addresses(tap, fa);
+            if (CV_UNDER_ISSUE && cv_now && !(CV_IN_COMPUTE && tap <= 4)) {
                 __builtin_amdgcn_sched_barrier(0);
                 convert_store(cv, tap - 1, par ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -704,14 +722,49 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             // ---- COMPUTE: registers only
             __builtin_amdgcn_s_setprio(1);
             if (!(p.variant & 32)) {                       // (tuning: 32 = no MFMA)
+                // (taps 1..4 rewrite pieces 0..3, which every wave has: no run-time condition, so the phase stays ONE basic block -- the
+                //  scheduler deals instructions out inside a block only, and two copies of the phase behind a branch cost the register
+                //  allocator its accumulators: 500 bytes of scratch.  In the last chunk there is nothing new to rewrite; the rewrite then
+                //  re-converts whatever the other stage holds, which nothing reads before the next tile's prologue refills it.)
+                constexpr bool CV = CV_IN_COMPUTE;
+                const bool cv_c = CV && tap >= 1 && tap <= 4;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int t = 0; t < TL::TERMS; ++t)
+                    for (int t = 0; t < TL::TERMS; ++t) {
+                        if (cv_c && ks == 0 && t == 1) {
+                            // (the first term's six MFMAs are issued, their operand registers are free: read the piece now -- its LDS latency
+                            //  passes under the next three MFMAs -- and deal the rewrite out behind the remaining nine of the step)
+                            __builtin_amdgcn_sched_barrier(0);
+                            cv = convert_load(tap - 1, par ^ 1);
+                        }
+                        if (cv_c && ks == 0 && t == 2) convert_store(cv, tap - 1, par ^ 1);
+                        if (FA_AHEAD && ks == 0 && t == 1) {
+                            if (!cv_c) __builtin_amdgcn_sched_barrier(0);
+                            tap_addresses((tap + 1) % 9, fa_next);
+                        }
 #pragma unroll
                         for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
                             for (int j = 0; j < TL::NTL; ++j) TL::mma(t, af[ks], bfr[ks], i, j, acc[i][j], x2_sc);
+                        if (cv_c && ks == 0 && t == 2) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // the read
+                            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);         // three MFMAs cover its latency
+#pragma unroll
+                            for (int q = 0; q < 9; ++q) {                              // then one MFMA, up to four of the rewrite's / the address arithmetic's VALU / LDS instructions
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002 | 0x080, 4, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (FA_AHEAD && !cv_c && ks == 0 && t == 2) {
+#pragma unroll
+                            for (int q = 0; q < 12; ++q) {                             // the next step's address arithmetic alone: one instruction behind each MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
             } else {
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) {
@@ -732,6 +785,13 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             stamp();
         }
     };
+    if constexpr (FA_AHEAD) {                                      // tap 0 of the first step (the row geometry is the same for every tile of a walk)
+#pragma unroll
+        for (int i = 0; i < TL::MT; ++i) {
+            const int rr = f_row0 + i * TL::TM - W - 1;
+            fa_next[i] = (f_mask[i] & 1u) ? A_BASE + (rr << 7) + (((fslot ^ (rr >> 1)) & 7) << 4) : A_BASE + ZROW;
+        }
+    }
     for (int it = 0; it < iters; ++it) {
         if (A_SPLIT_LDS && dma_on) {                               // the prologue's A pieces have landed (vmcnt(0) above / in the epilogue's drain)
 #pragma unroll

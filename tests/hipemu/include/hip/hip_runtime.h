@@ -481,6 +481,7 @@ inline hipemu_f32x16 hipemu_mfma_scale_f32_32x32x64_f8f6f4(hipemu_i32x8 a, hipem
 inline void hipemu_s_waitcnt(unsigned imm) { hipemu::dma_wait((imm & 0xF) | (((imm >> 14) & 3) << 4)); }
 #define __builtin_amdgcn_s_waitcnt(x) hipemu_s_waitcnt(x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_amdgcn_s_barrier() hipemu::raw_barrier()
 inline void hipemu_wave_barrier() { int z = 0; hipemu::wave_exchange(&z, sizeof(z)); }
 #define __builtin_amdgcn_wave_barrier() hipemu_wave_barrier()
