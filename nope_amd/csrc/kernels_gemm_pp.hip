@@ -497,7 +497,12 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     constexpr bool CV_IN_COMPUTE = A_SPLIT_LDS && NOPE_X2_CV_COMPUTE;
     // ... and so do the fragment addresses of the NEXT step (row + tap offset, swizzle, zero-row redirect: 12 VALU), carried across the barrier
     // in two registers that are free at that point (the step's own 80 fragment registers are dead once its MFMAs are issued).
-    constexpr bool FA_AHEAD = CV_IN_COMPUTE;
+    // (the 16-bit instantiations would take the same address trick -- 12 VALU out of their LOAD phase -- but the f16 one sits at 256 VGPRs and
+    //  spills two registers with it: NOPE_FA_AHEAD_16, off)
+#ifndef NOPE_FA_AHEAD_16
+#define NOPE_FA_AHEAD_16 0
+#endif
+    constexpr bool FA_AHEAD = CV_IN_COMPUTE || (NOPE_FA_AHEAD_16 && TL::TM == 32 && sizeof(T) == 2);
     auto convert_load = [&](int i, int stage) __attribute__((always_inline)) -> u32x4 {
         return ld16(a_dst + stage * A_STAGE + i * 8192 + rsub * RB + lslot * 16);
     };
@@ -732,14 +737,15 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int t = 0; t < TL::TERMS; ++t) {
-                        if (cv_c && ks == 0 && t == 1) {
+                        const int g = ks * TL::TERMS + t;              // MFMA group of the step (6 MFMAs each): the extra work sits behind groups 1 and 2
+                        if (cv_c && g == 1) {
                             // (the first term's six MFMAs are issued, their operand registers are free: read the piece now -- its LDS latency
                             //  passes under the next three MFMAs -- and deal the rewrite out behind the remaining nine of the step)
                             __builtin_amdgcn_sched_barrier(0);
                             cv = convert_load(tap - 1, par ^ 1);
                         }
-                        if (cv_c && ks == 0 && t == 2) convert_store(cv, tap - 1, par ^ 1);
-                        if (FA_AHEAD && ks == 0 && t == 1) {
+                        if (cv_c && g == 2) convert_store(cv, tap - 1, par ^ 1);
+                        if (FA_AHEAD && g == 1) {
                             if (!cv_c) __builtin_amdgcn_sched_barrier(0);
                             tap_addresses((tap + 1) % 9, fa_next);
                         }
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                         for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
                             for (int j = 0; j < TL::NTL; ++j) TL::mma(t, af[ks], bfr[ks], i, j, acc[i][j], x2_sc);
-                        if (cv_c && ks == 0 && t == 2) {
+                        if (cv_c && g == 2) {
                             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // the read
                             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);         // three MFMAs cover its latency
 #pragma unroll
@@ -756,7 +762,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                                 __builtin_amdgcn_sched_group_barrier(0x002 | 0x080, 4, 0);
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                        } else if (FA_AHEAD && !cv_c && ks == 0 && t == 2) {
+                        } else if (FA_AHEAD && !cv_c && g == 2) {
 #pragma unroll
                             for (int q = 0; q < 12; ++q) {                             // the next step's address arithmetic alone: one instruction behind each MFMA
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
