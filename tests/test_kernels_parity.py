@@ -473,6 +473,30 @@ def test_encoder_golden_gpu(gpu, golden, cdt, tol):
     assert allf.shape == (3, 8, 8, 12) and torch.equal(allf, one)
 
 
+@pytest.mark.gpu
+def test_f16x2_is_bf16x3_outside_the_unet(gpu, golden):
+    """NOPE_F16X2 changes the tap-resident 3x3 launches of the default U-Net only: the template encoder and the LDM variant accept the mode and
+    compute exactly what they compute as bf16x3 (include/nope_hip.h); a default U-Net too small to reach the tap-resident kernel likewise."""
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    from tests.test_oracle_golden import build_ldm
+    g = golden("encoder.npz")
+    a = _encoder_pair(compute_dtype="f16x2").cuda().encode_image(g["img"].cuda())
+    b = _encoder_pair(compute_dtype="bf16x3").cuda().encode_image(g["img"].cuda())
+    assert torch.equal(a, b) and rel(a.cpu(), g["feat"]) < X3_TOL
+    gl = golden("ldm_tiny.npz")
+    x, pose = gl["m32/x"].cuda(), gl["m32/pose"].cuda()
+    ya, yb = build_ldm("m32", "f16x2").cuda()(x, pose), build_ldm("m32", "bf16x3").cuda()(x, pose)
+    assert torch.equal(ya, yb) and rel(ya.cpu(), gl["m32/out"]) < X3_TOL
+    outs = []
+    for cdt in ("f16x2", "bf16x3"):
+        u = UNet(u_net_dim=32, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype=cdt)
+        synth_init_(u, 2022)
+        gq = torch.Generator().manual_seed(5)
+        outs.append(u.cuda().forward_hypotheses(torch.randn(1, 8, 8, 8, generator=gq).cuda(), torch.randn(1, 3, 6, generator=gq).cuda()))
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("dt", [0, 1])
 def test_conv_position_major(be, dt):
     """3x3 convs on small maps with a multiple of 128 samples run with GEMM rows ordered (pixel position, sample), so

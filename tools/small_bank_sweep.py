@@ -1,5 +1,5 @@
 """One model, many launch policies: step time of `generate_and_retrieve` for reference-sized banks under a list of environment
-settings (the conv launcher reads its tuning variables per launch).   python tools/small_bank_sweep.py [--dtype f16] [--banks 26,64,341]"""
+settings (the binding reloads the cached tuning variables when it sees the environment change: nope_tuning_reload).   python tools/small_bank_sweep.py [--dtype f16] [--banks 26,64,341]"""
 import argparse
 import os
 import sys
