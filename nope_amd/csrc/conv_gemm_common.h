@@ -137,7 +137,11 @@ template <> struct Tile<f32s_t> : Tile32 {
     static __device__ __forceinline__ int frag_slot(int lane) { return (lane >> 5) * 2; }
     static __device__ __forceinline__ void prep_step(u32x4 (&a)[RAW][MT]) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < MT; ++i) prep_one(a, i);
+    }
+    // ... of ONE row tile (the per-tap ping-pong kernel splits them inside its COMPUTE phase, one row tile ahead of the MFMAs that use it)
+    static __device__ __forceinline__ void prep_one(u32x4 (&a)[RAW][MT], int i) {
+        {
             float x[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {      // (through a scalar: __builtin_bit_cast straight from a vector-element lvalue reads element 0)

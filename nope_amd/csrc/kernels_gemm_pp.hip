@@ -276,7 +276,11 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
         }
         if (k + 1 < nk) advance(ka);
         if (grp == 0 ? k + 1 < nk : k + 2 < nk) advance(kb);
-        if constexpr (RAW > 1) {                       // (bf16x3: split the f32 A values into hi / lo, still in the LOAD phase)
+#ifndef NOPE_PP_PREP_COMPUTE
+#define NOPE_PP_PREP_COMPUTE 1
+#endif
+        constexpr bool PREP_IN_COMPUTE = RAW > 1 && NOPE_PP_PREP_COMPUTE;
+        if constexpr (RAW > 1 && !PREP_IN_COMPUTE) {   // (bf16x3: split the f32 A values into hi / lo, still in the LOAD phase)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) TL::prep_step(af[ks]);
         }
@@ -287,6 +291,31 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
         // ---- COMPUTE k: registers only
         if (!(p.variant & 2)) __builtin_amdgcn_s_setprio(1);       // (tuning: 2 = no priority for the MFMA phase)
         if (!(p.variant & 32)) {                       // (tuning: 32 = no MFMA)
+            if constexpr (PREP_IN_COMPUTE) {
+                // bf16x3: the (hi, lo) split of the f32 A fragments (24 VALU per row tile) rides in THIS phase, one row tile ahead of the MFMAs
+                // that consume it and dealt out three behind each of the previous row tile's nine MFMAs -- the loading group's VALU takes issue
+                // slots from the other group's MFMAs, the multiplying wave's own does not (same finding as the tap-resident kernel's rewrite).
+                // Row tile outer, term inner: every accumulator still sees (lo, hi), (hi, lo), (hi, hi) per K step in the same order: same bits.
+                TL::prep_one(af[0], 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < KS * TL::MT; ++g) {
+                    const int ks = g / TL::MT, i = g % TL::MT;
+                    if (g + 1 < KS * TL::MT) TL::prep_one(af[(g + 1) / TL::MT], (g + 1) % TL::MT);
+#pragma unroll
+                    for (int t = 0; t < TL::TERMS; ++t)
+#pragma unroll
+                        for (int j = 0; j < TL::NTL; ++j) TL::mma(t, af[ks], bfr[ks], i, j, acc[i][j]);
+                    if (g + 1 < KS * TL::MT) {
+#pragma unroll
+                        for (int q = 0; q < TL::TERMS * TL::NTL; ++q) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -295,6 +324,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
                     for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
                         for (int j = 0; j < TL::NTL; ++j) TL::mma(t, af[ks], bfr[ks], i, j, acc[i][j]);
+            }
         } else {
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {          // keep the fragment reads alive
