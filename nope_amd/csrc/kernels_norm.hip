@@ -414,7 +414,9 @@ int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
         else     { if (res) NOPE_GN_APPLY_AR(T, FAST, OS, FILM, false, true); else NOPE_GN_APPLY_AR(T, FAST, OS, FILM, false, false); } \
     } while (0)
     if (a.film && a.out_stats) return NOPE_ERR_UNSUPPORTED;
-    if (dt == NOPE_F32) {
+    if (dt == NOPE_F32 && a.fast_silu && !a.film) {
+        if (a.out_stats) NOPE_GN_APPLY(float, true, true, false); else NOPE_GN_APPLY(float, true, false, false);
+    } else if (dt == NOPE_F32) {
         if (a.film) NOPE_GN_APPLY(float, false, false, true);
         else if (a.out_stats) NOPE_GN_APPLY(float, false, true, false); else NOPE_GN_APPLY(float, false, false, false);
     } else if (dt == NOPE_BF16) {

@@ -278,6 +278,7 @@ struct Fwd {
         ga.x = x; ga.y = y; ga.partial = gn_partial; ga.nchunk = nch; ga.gamma = nm.gamma; ga.beta = nm.beta;
         ga.nhyp = nhyp; ga.HW = HW; ga.C = nm.C; ga.G = 32; ga.act = act; ga.eps = eps;
         ga.film = film; ga.film_stride = film_stride;
+        ga.fast_silu = net->dt != NOPE_F32 ? 1 : 0;      // (f32 storage of the split-precision modes: hardware exp / rcp; the f32 mode keeps expf and the division)
         chk(launch_gn_apply(net->sdt, ga, s));
     }
     // ResBlock._forward, openaimodel.py:262-288 (no up/down)

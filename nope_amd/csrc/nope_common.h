@@ -344,6 +344,8 @@ struct GnApplyArgs {
     int resid_rep = 1;                 // resid shared by resid_rep consecutive hypotheses
     float* out_stats = nullptr;        // optional [nhyp][gn_apply_blocks()][2]: (sum, sum sq) of the values written
     float eps = 1e-5f;
+    int fast_silu = 0;                 // f32 storage only: SiLU on v_exp_f32 + v_rcp_f32 (1 ulp each, what the 16-bit types always use) instead of expf + an
+                                       // IEEE division -- set by the runtimes in the split-precision modes (bf16x3, f16x2), whose bar is 1e-4, not bit parity
 };
 int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s);
 int gn_apply_blocks(int HW, int C, int dt, int nhyp);      // workgroups per hypothesis of launch_gn_apply over nhyp samples (= chunks of out_stats)
