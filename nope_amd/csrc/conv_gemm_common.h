@@ -164,15 +164,18 @@ template <> struct Tile<f32s_t> : Tile32 {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t == 0 ? 1 : 0][i]), __builtin_bit_cast(bf16x8, b[t == 1 ? 1 : 0][j]), c, 0, 0, 0);
     }
 };
-// NOPE_F16X2 (tap-resident 3x3 kernel only).  Both operands hold 32 channels per 128-byte row, as NOPE_BF16X3, in EIGHT 16-byte slots:
-//     slot 2 ks + h        (ks, h in {0, 1})   f16 hi parts of channels 16 ks + 8 h .. + 7        -- the operands of two 32x32x16 f16 MFMAs
-//     slot 4 + 2 p + h     (p, h in {0, 1})    e4m3 bytes of channels 16 p .. 16 p + 15:  h = 0: A: a_lo * 2^9,  B: w * 2^sw
-//                                                                                         h = 1: A: a * 2^-2,    B: w_lo * 2^(sw + 11)
-// (hi = f16(x), lo = x - hi; the weights arrive like this from pack_conv_w_x2_kernel, the activations are rewritten in LDS by the wave
-// that staged them: convert_piece in conv3x3_halo_kernel).  A lane of half h = lane >> 5 reads slot h + 2 r for r = 0..3 (RAW_STRIDE 2:
-// the XOR of raw_slot into a fragment address stays disjoint from frag_slot's bit): reads 0, 1 feed the two f16 MFMAs, reads 2 + 3 are
-// the 32 bytes of its half of ONE v_mfma_scale_f32_32x32x64_f8f6f4 whose K axis is the concatenation [a_lo | a] x [w ; w_lo] over the
-// step's 32 channels -- both cross terms at once, at twice the f16 rate, into the same accumulator: the instruction's E8M0 block scale
+// NOPE_F16X2 (the ping-pong kernels).  Both operands hold 32 channels per 128-byte row, as NOPE_BF16X3, in EIGHT 16-byte slots:
+//     slot 2 ks + h   (ks, h in {0, 1})   f16 hi parts of channels 16 ks + 8 h .. + 7           -- the operands of two 32x32x16 f16 MFMAs
+//     slot 4 + h      e4m3 bytes over "channel set" h = channels 8 h .. 8 h + 7, 16 + 8 h .. 16 + 8 h + 7:   A: a_lo * 2^9,  B: w * 2^sw
+//     slot 6 + h      the same 16 channels:                                                               A: a * 2^-2,    B: w_lo * 2^(sw + 11)
+// (hi = f16(x), lo = x - hi; the weights arrive like this from launch_pack_conv_w_x2.  The activations: the tap-resident kernel rewrites
+// its staged rows in LDS -- convert_piece in conv3x3_halo_kernel, the rewrite amortised over nine taps -- and reads A exactly as B; the
+// per-tap kernel stages raw f32 rows and splits them in REGISTERS: a lane of half h reads the 16 f32 channels of its channel set -- raw
+// slots 2 h, 2 h + 1, 4 + 2 h, 5 + 2 h: frag_slot_raw / raw_slot_a -- and prep_hi / prep_lo turn them into the same four operands.)
+// A lane of half h = lane >> 5 reads slot h + 2 r for r = 0..3 (RAW_STRIDE 2: the XOR of raw_slot into a fragment address stays disjoint
+// from frag_slot's bit): reads 0, 1 feed the two f16 MFMAs, reads 2 + 3 are the 32 bytes of its half of ONE
+// v_mfma_scale_f32_32x32x64_f8f6f4 whose K axis is the concatenation [a_lo | a] x [w ; w_lo] over the channel sets of the step's 32
+// channels -- both cross terms at once, at twice the f16 rate, into the same accumulator: the instruction's E8M0 block scale
 // (one value for every lane, `sc` = 127 - 9 - sw; B's is 1.0) undoes the pre-scales.  What the instruction really does with operands and
 // scales is pinned by tools/probes/mx_probe.hip (byte e of lane half h pairs with byte e of lane half h; its 64-term sum is truncated at
 // ~2^-12 of the largest term: irrelevant for terms that are 2^-11 of the result).  Three "terms" per step = 2 pass equivalents of an f16
@@ -181,6 +184,33 @@ template <> struct Tile<f16x2_t> : Tile32 {
     static constexpr int STEP_SLOTS = 8, RAW = 4, RAW_STRIDE = 2;
     static __device__ __forceinline__ int frag_slot(int lane) { return lane >> 5; }
     static __device__ __forceinline__ void prep_step(u32x4 (&)[RAW][MT]) {}
+    // ---- A rows staged as raw f32 (per-tap kernel): which slots a lane reads, and the register split.  r = the lane's four raw reads of row
+    // tile i (channels 8 h .. + 3 | + 4 .. + 7 | 16 + 8 h .. + 3 | + 4 .. + 7), x = the four MFMA operands.  Same arithmetic as the LDS rewrite
+    // (saturating conversions: the wave runs with MODE.FP16_OVFL = 1).
+    static __device__ __forceinline__ int frag_slot_raw(int lane) { return (lane >> 5) * 2; }
+    static __device__ __forceinline__ constexpr int raw_slot_a(int q) { return (q & 1) | ((q >> 1) << 2); }
+    static __device__ __forceinline__ void prep_hi(const u32x4 (&r)[RAW][MT], u32x4 (&x)[RAW][MT], int i, int ks) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const unsigned u0 = r[2 * ks + q][i][2 * e], u1 = r[2 * ks + q][i][2 * e + 1];
+                x[ks][i][2 * q + e] = NOPE_CVT_PK_F16_OVFL(__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1));
+            }
+    }
+    static __device__ __forceinline__ void prep_lo(const u32x4 (&r)[RAW][MT], u32x4 (&x)[RAW][MT], int i, int q) {      // raw read q: 4 channels
+        float v[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const unsigned u = r[q][i][e]; v[e] = __builtin_bit_cast(float, u); }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            union { unsigned u; f16_t f[2]; } hh; hh.u = x[q >> 1][i][2 * (q & 1) + e];
+            l[2 * e] = v[2 * e] - (float)hh.f[0];
+            l[2 * e + 1] = v[2 * e + 1] - (float)hh.f[1];
+        }
+        x[2][i][q] = cvt4_e4m3_scaled<kX2ALoShift, true>(l[0], l[1], l[2], l[3]);
+        x[3][i][q] = cvt4_e4m3_scaled<kX2AShift, true>(v[0], v[1], v[2], v[3]);
+    }
     static constexpr int TERMS = 3;
     static __device__ __forceinline__ void mma(int t, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c, int sc) {
         if (t < 2) {

@@ -421,6 +421,12 @@ int conv_stat_rows(int dt, const ConvArgs& a) {
     return 0;
 }
 
+// the f16 + MX-fp8 tile: ping-pong launches (tap-resident or per-tap) of a layer that carries the second pack.  NOPE_X2_PP=0: tap-resident only
+static bool plan_takes_x2(const ConvArgs& a, const ConvPlan& plan) {
+    return a.w_x2 && plan.pp && plan.small < 0 && !a.pn_ms && !a.geglu && (a.C1 + a.C2) % 32 == 0 && (plan.halo || NOPE_ENV("NOPE_X2_PP", 1) != 0);
+}
+bool conv_takes_x2(int dt, const ConvArgs& a) { return dt_base(dt) == NOPE_BF16X3 && plan_takes_x2(a, plan_conv(dt, a)); }
+
 int conv_kernel_kind(int dt, const ConvArgs& a) {
     const ConvPlan pl = plan_conv(dt, a);
     return pl.small >= 0 ? NOPE_CONV_KERNEL_SMALL : pl.halo ? NOPE_CONV_KERNEL_HALO256 : pl.pp ? NOPE_CONV_KERNEL_PP256 : pl.dma ? NOPE_CONV_KERNEL_DMA128 : NOPE_CONV_KERNEL_GENERIC;
@@ -513,10 +519,10 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.w_phase_bytes = phased ? (unsigned)bw : 0u;
     const ConvPlan plan = plan_conv(dt, a);
     const bool dma = plan.dma;
-    const bool x2 = a.w_x2 && plan.halo && plan.small < 0;      // the f16 + MX-fp8 tile: tap-resident launches of a layer that carries the second pack
-    if (!x2 && !a.w) return NOPE_ERR_UNSUPPORTED;               // (NOPE_F16X2 as an element type on a shape the tap-resident kernel does not take)
+    const bool x2 = plan_takes_x2(a, plan);
+    if (!x2 && !a.w) return NOPE_ERR_UNSUPPORTED;               // (NOPE_F16X2 as an element type on a shape the ping-pong kernels do not take)
     p.x2_scale = nullptr;
-    if (x2) { p.w = (const unsigned char*)a.w_x2; p.x2_scale = reinterpret_cast<const int*>(p.w + bw); }
+    if (x2) { p.w = (const unsigned char*)a.w_x2; p.x2_scale = reinterpret_cast<const int*>(p.w + bw * (phased ? 4 : 1)); }
     if (a.geglu && !geglu_shape_ok(dt, a, plan)) return NOPE_ERR_UNSUPPORTED;
     p.geglu = a.geglu;
     if (a.colstats && a.stat_rows == 32 && plan.small < 0 && plan.hsplit <= 1) return NOPE_ERR_ARG;   // 32-row blocks: small-tile kernel or split-K reduce only
@@ -630,7 +636,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     } else if (plan.pp) {
         if (NOPE_ENV_SET("NOPE_PP_VARIANT")) p.variant = NOPE_ENV("NOPE_PP_VARIANT", 0);      // tuning ablations of the ping-pong kernel
         if (plan.halo) launch_conv_halo(x2 ? NOPE_F16X2 : dt, &p, grid, s);
-        else launch_conv_pp(dt, &p, grid, s);
+        else launch_conv_pp(x2 ? NOPE_F16X2 : dt, &p, grid, s);
     } else if (dt == NOPE_F32) {
         if (dma) launch_conv_dma_f32(&p, bm, grid, s);
         else if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_kernel<float, true>), grid, block, 0, s, p);

@@ -72,6 +72,12 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;       // 4 (M) x 2 (N) waves of 64 x 96
     const int grp = wave >> 2, wl = wave & 3;
+    // NOPE_F16X2: A rows are staged as raw f32 (every loader below is the bf16x3 one: 4 bytes per channel on both sides) and split into the
+    // tile's four operands in registers, inside the COMPUTE phase (Tile<f16x2_t>::prep_hi / prep_lo); saturating conversions as in the
+    // tap-resident kernel.  (The PreNorm instantiation is never launched for it: launch_conv.)
+    constexpr bool X2 = Elt<T>::DT == NOPE_F16X2;
+    if constexpr (X2) fp16_ovfl_on();
+    const int x2_sc = X2 ? p.x2_scale[0] : 0;
     int tile_m, tile_n;
     tile_coords(p, tile_m, tile_n);
     const int m0 = tile_m * PP_BM, n0 = tile_n * BN;
@@ -202,9 +208,16 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
     // fragment addresses of raw read 0 inside a stage; raw read q flips slot bits: off ^ (raw_slot(q) << 4)
     int fa[TL::MT], fb[TL::NTL];
 #pragma unroll
-    for (int i = 0; i < TL::MT; ++i) fa[i] = lds_off_rb<RB>(wm * 64 + i * TL::TM + TL::frag_row(lane), TL::frag_slot(lane));
+    for (int i = 0; i < TL::MT; ++i) {
+        if constexpr (X2) fa[i] = lds_off_rb<RB>(wm * 64 + i * TL::TM + TL::frag_row(lane), TL::frag_slot_raw(lane));
+        else fa[i] = lds_off_rb<RB>(wm * 64 + i * TL::TM + TL::frag_row(lane), TL::frag_slot(lane));
+    }
 #pragma unroll
     for (int j = 0; j < TL::NTL; ++j) fb[j] = lds_off_rb<RB>(wn * 96 + j * TL::TM + TL::frag_row(lane), TL::frag_slot(lane));
+    auto a_slot = [](int kk) constexpr -> int {      // slot bits of raw A read kk
+        if constexpr (X2) return TL::raw_slot_a(kk);
+        else return raw_slot<T>(kk);
+    };
 
     // ---- prologue: A_g(0), this group's half of B(0), and (group 1, which issues B one step ahead) its half of B(1)
     KPos ka{tap0, 0}, kb{tap0, 0};
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-                for (int i = 0; i < TL::MT; ++i) af[kk / RAW][kk % RAW][i] = ld16(la + (fa[i] ^ (raw_slot<T>(kk) << 4)));
+                for (int i = 0; i < TL::MT; ++i) af[kk / RAW][kk % RAW][i] = ld16(la + (fa[i] ^ (a_slot(kk) << 4)));
 #pragma unroll
                 for (int j = 0; j < TL::NTL; ++j) bfr[kk / RAW][kk % RAW][j] = ld16(lb + (fb[j] ^ (raw_slot<T>(kk) << 4)));
             }
@@ -261,7 +274,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
             constexpr int NFR = KK * (TL::MT + TL::NTL);
             auto frag = [&](int f) {      // f-th fragment read of the step, K sub-step major (static index after unrolling)
                 const int kk = f / (TL::MT + TL::NTL), r = f - kk * (TL::MT + TL::NTL);
-                if (r < TL::MT) af[kk / RAW][kk % RAW][r] = ld16(la + (fa[r] ^ (raw_slot<T>(kk) << 4)));
+                if (r < TL::MT) af[kk / RAW][kk % RAW][r] = ld16(la + (fa[r] ^ (a_slot(kk) << 4)));
                 else bfr[kk / RAW][kk % RAW][r - TL::MT] = ld16(lb + (fb[r - TL::MT] ^ (raw_slot<T>(kk) << 4)));
             };
 #pragma unroll
@@ -279,8 +292,8 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
 #ifndef NOPE_PP_PREP_COMPUTE
 #define NOPE_PP_PREP_COMPUTE 1
 #endif
-        constexpr bool PREP_IN_COMPUTE = RAW > 1 && NOPE_PP_PREP_COMPUTE;
-        if constexpr (RAW > 1 && !PREP_IN_COMPUTE) {   // (bf16x3: split the f32 A values into hi / lo, still in the LOAD phase)
+        constexpr bool PREP_IN_COMPUTE = RAW > 1 && NOPE_PP_PREP_COMPUTE && !X2;
+        if constexpr (RAW > 1 && !PREP_IN_COMPUTE && !X2) {   // (bf16x3: split the f32 A values into hi / lo, still in the LOAD phase)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) TL::prep_step(af[ks]);
         }
@@ -291,7 +304,41 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
         // ---- COMPUTE k: registers only
         if (!(p.variant & 2)) __builtin_amdgcn_s_setprio(1);       // (tuning: 2 = no priority for the MFMA phase)
         if (!(p.variant & 32)) {                       // (tuning: 32 = no MFMA)
-            if constexpr (PREP_IN_COMPUTE) {
+            if constexpr (X2) {
+                // f16x2 (KS = 1: a stage is one 32-channel step): the split of the two row tiles' raw f32 fragments -- 8 packed f16 conversions
+                // for the hi parts, then per row tile 16 unpack + 16 subtract + 16 packed e4m3 conversions -- rides behind the MFMAs that do
+                // not need it yet: term 0 (hi x hi, channels 0..15 of the step) waits for 4 conversions only, the cross-term MFMAs come last.
+                u32x4 ax[RAW][TL::MT];
+                TL::prep_hi(af[0], ax, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                TL::prep_hi(af[0], ax, 1, 0);
+                TL::prep_hi(af[0], ax, 0, 1);
+                TL::prep_hi(af[0], ax, 1, 1);
+#pragma unroll
+                for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                    for (int q = 0; q < RAW; ++q) TL::prep_lo(af[0], ax, i, q);
+#pragma unroll
+                for (int t = 0; t < TL::TERMS; ++t)
+#pragma unroll
+                    for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < TL::NTL; ++j) TL::mma(t, ax, bfr[0], i, j, acc[i][j], x2_sc);
+                // 12 f16 MFMAs (32 cycles each) carry the 12 remaining hi conversions and row tile 0's lo parts, the first cross-term MFMAs
+                // (64 cycles each) row tile 1's
+#pragma unroll
+                for (int g = 0; g < 12; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (PREP_IN_COMPUTE) {
                 // bf16x3: the (hi, lo) split of the f32 A fragments (24 VALU per row tile) rides in THIS phase, one row tile ahead of the MFMAs
                 // that consume it and dealt out three behind each of the previous row tile's nine MFMAs -- the loading group's VALU takes issue
                 // slots from the other group's MFMAs, the multiplying wave's own does not (same finding as the tap-resident kernel's rewrite).
@@ -506,7 +553,8 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     const int cv_half = (lslot ^ swz_of<RB>(r0)) & 1;                         // which half of its 8-channel group this lane's slot holds
     // ---- NOPE_F16X2: same in-place rewrite, into the layout of Tile<f16x2_t>.  A lane's 16-byte slot holds channels 4 ls .. 4 ls + 3 of the
     // chunk (ls = its LOGICAL slot); it writes their four f16 hi parts into half of logical slot ls / 2 (8 bytes), the four e4m3 bytes of
-    // a_lo * 2^9 into slot 4 + 2 (ls / 4) and the four of a * 2^-2 into slot 5 + 2 (ls / 4), each at byte 4 (ls % 4) (two ds_write_b32).
+    // a_lo * 2^9 into slot 4 + h and the four of a * 2^-2 into slot 6 + h, h = (ls / 2) % 2 its channel set, each at byte 8 (ls / 4) + 4 (ls % 2)
+    // (two ds_write_b32).
     // The f16 part saturates at +-65504, the fp8 parts at +-448: the wave sets MODE.FP16_OVFL, under which the three conversions saturate by
     // themselves (probe fact 7; a NaN stays a NaN, as in the f32 / bf16x3 modes) -- 16 VALU per piece and lane instead of 46 with explicit
     // pre-scale multiplies, clamps and byte packing.
@@ -557,8 +605,9 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
             __builtin_amdgcn_wave_barrier();       // every lane's read precedes every lane's write (see below)
             *reinterpret_cast<u32x2*>(row + (((ls >> 1) ^ sw) << 4) + 8 * (ls & 1)) = u32x2{hi[0], hi[1]};
-            *reinterpret_cast<unsigned*>(row + (((4 + 2 * (ls >> 2)) ^ sw) << 4) + 4 * (ls & 3)) = lo8;
-            *reinterpret_cast<unsigned*>(row + (((5 + 2 * (ls >> 2)) ^ sw) << 4) + 4 * (ls & 3)) = a8;
+            // (channels 4 ls .. 4 ls + 3 belong to channel set (ls >> 1) & 1, at bytes 8 (ls >> 2) + 4 (ls & 1) of its two e4m3 slots)
+            *reinterpret_cast<unsigned*>(row + (((4 + ((ls >> 1) & 1)) ^ sw) << 4) + 8 * (ls >> 2) + 4 * (ls & 1)) = lo8;
+            *reinterpret_cast<unsigned*>(row + (((6 + ((ls >> 1) & 1)) ^ sw) << 4) + 8 * (ls >> 2) + 4 * (ls & 1)) = a8;
         } else if constexpr (A_SPLIT_LDS) {
             unsigned char* row = a_dst + stage * A_STAGE + i * 8192 + rsub * RB;
             unsigned hi[2], lo[2];
@@ -906,6 +955,7 @@ void launch_conv_pp(int dt, const void* params, dim3 grid, hipStream_t s) {
     const ConvParams& p = *static_cast<const ConvParams*>(params);
     if (dt == NOPE_F32) launch_pp_t<float>(p, grid, s);
     else if (dt == NOPE_BF16X3) launch_pp_t<f32s_t>(p, grid, s);
+    else if (dt == NOPE_F16X2) launch_pp_t<f16x2_t>(p, grid, s);
     else if (dt == NOPE_F16) launch_pp_t<f16_t>(p, grid, s);
     else launch_pp_t<bf16_t>(p, grid, s);
 }

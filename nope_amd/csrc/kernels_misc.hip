@@ -68,12 +68,15 @@ __global__ __launch_bounds__(NT) void pack_conv_w_kernel(const float* __restrict
     }
 }
 
-// ---- NOPE_F16X2 weight layout (Tile<f16x2_t>, conv_gemm_common.h): [Cout][tap][Cin / 32] chunks of 128 bytes = eight 16-byte slots:
-// slots 0..3 the f16 hi parts of the chunk's 32 channels (8 per slot), slot 4 + 2 p + h (p = channel / 16 inside the chunk) 16 e4m3 bytes:
-// h = 0: w * 2^sw, h = 1: (w - hi) * 2^(sw + 11).  sw is the layer's power-of-two pre-scale, the largest that keeps max |w| * 2^sw below 256
-// (the format reaches 448); |w - hi| <= 2^-11 max |w|, so the second operand cannot overflow either.  Two launches: max |w| into the tail of
-// the packed buffer (bits of a non-negative float order like unsigned integers), then the rows; the first thread also writes the E8M0
-// scale byte the conv kernel hands to the MFMA: 127 - 9 - sw (nope_common.h).
+// ---- NOPE_F16X2 weight layout (Tile<f16x2_t>, conv_gemm_common.h): rows of Cin channels in chunks of 32 = 128 bytes = eight 16-byte slots:
+// slots 0..3 the f16 hi parts of the chunk's 32 channels (8 per slot); slot 4 + h the 16 e4m3 bytes of w * 2^sw over "channel set" h =
+// channels 8 h .. 8 h + 7 and 16 + 8 h .. 16 + 8 h + 7 (what the lanes of half h hold for the two f16 MFMAs), slot 6 + h those of
+// (w - hi) * 2^(sw + 11).  sw is the layer's power-of-two pre-scale, the largest that keeps max |w| * 2^sw below 256 (the format reaches
+// 448); |w - hi| <= 2^-11 max |w|, so the second operand cannot overflow either.  Three launches: the f32 rows in GEMM order into the
+// destination (pack_conv_w_kernel<float> and its phase-conv siblings: every conv mode, same row order as every other pack), max |w| of
+// those rows into the tail of the buffer (bits of a non-negative float order like unsigned integers), then the rows are encoded IN PLACE
+// -- a chunk is 128 bytes before and after, one thread owns it; the first thread also writes the E8M0 scale byte the conv kernel hands to
+// the MFMA: 127 - 9 - sw (nope_common.h).
 __global__ __launch_bounds__(NT) void absmax_bits_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ out) {
     unsigned m = 0;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
@@ -90,23 +93,31 @@ __device__ __forceinline__ int x2_weight_shift(unsigned maxbits) {
     const int sw = 7 - e;                              // max |w| * 2^sw in [128, 256)
     return sw < -64 ? -64 : (sw > 100 ? 100 : sw);
 }
-__global__ __launch_bounds__(NT) void pack_conv_w_x2_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, int Cin, size_t total, int* __restrict__ tail) {
+__global__ __launch_bounds__(NT) void encode_w_x2_kernel(unsigned char* __restrict__ buf, size_t chunks, int* __restrict__ tail) {
     const int sw = x2_weight_shift((unsigned)tail[2]);
     if (blockIdx.x == 0 && threadIdx.x == 0) { tail[0] = 127 - kX2ALoShift - sw; tail[1] = sw; tail[3] = 0; }
     const float s8 = ldexpf(1.0f, sw), sl8 = ldexpf(1.0f, sw + kX2WLoExtra);
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
-        const int c = (int)(i % Cin);
-        const size_t t = i / Cin;
-        const int tap = (int)(t % 9);
-        const size_t co = t / 9;
-        const float v = w[(co * Cin + c) * 9 + tap];       // torch [Cout][Cin][3][3]
-        const f16_t hi = f32_to_f16_sat(v);
-        const float lo = v - (float)hi;
-        unsigned char* chunk = out + (t * (size_t)Cin + (size_t)(c & ~31)) * 4;      // 4 bytes per channel and row: 128-byte chunks
-        const int cc = c & 31;
-        reinterpret_cast<f16_t*>(chunk)[cc] = hi;                                    // slots 0..3
-        chunk[(4 + 2 * (cc >> 4)) * 16 + (cc & 15)] = (unsigned char)(cvt_pk_e4m3(v * s8, 0.f) & 0xffu);
-        chunk[(5 + 2 * (cc >> 4)) * 16 + (cc & 15)] = (unsigned char)(cvt_pk_e4m3(lo * sl8, 0.f) & 0xffu);
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < chunks; i += (size_t)gridDim.x * NT) {
+        unsigned char* chunk = buf + i * 128;
+        float v[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const u32x4 t = reinterpret_cast<const u32x4*>(chunk)[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const unsigned u = t[e]; v[4 * q + e] = __builtin_bit_cast(float, u); }
+        }
+        union { unsigned char b[128]; u32x4 q[8]; } o;
+#pragma unroll
+        for (int cc = 0; cc < 32; ++cc) {
+            const f16_t hi = f32_to_f16_sat(v[cc]);
+            const float lo = v[cc] - (float)hi;
+            reinterpret_cast<f16_t*>(o.b)[cc] = hi;                                            // slots 0..3
+            const int h = (cc >> 3) & 1, pos = (cc >> 4) * 8 + (cc & 7);
+            o.b[(4 + h) * 16 + pos] = (unsigned char)(cvt_pk_e4m3(v[cc] * s8, 0.f) & 0xffu);
+            o.b[(6 + h) * 16 + pos] = (unsigned char)(cvt_pk_e4m3(lo * sl8, 0.f) & 0xffu);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) reinterpret_cast<u32x4*>(chunk)[q] = o.q[q];
     }
 }
 
@@ -224,9 +235,9 @@ int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int
     if (!w || !out || Cout <= 0 || Cin <= 0 || ntaps <= 0 || Cin_src < 0 || Cin_src > Cin) return NOPE_ERR_ARG;
     if (Cin_src && Cin_src != Cin && (mode == NOPE_CONV_UP2P || cin_scale)) return NOPE_ERR_ARG;
     const int csrc = Cin_src ? Cin_src : Cin;
-    if (dt == NOPE_F16X2) {                                             // the tap-resident kernel's layout: 3x3 stride 1 only
-        if (mode != NOPE_CONV_PLAIN || ntaps != 9 || cin_scale || cout_scale || csrc != Cin) return NOPE_ERR_UNSUPPORTED;
-        return launch_pack_conv_w_x2(w, out, Cout, Cin, s);
+    if (dt == NOPE_F16X2) {                                             // the f16 + MX-fp8 tile's layout (tap-resident and per-tap ping-pong kernels)
+        if (cin_scale || cout_scale || csrc != Cin) return NOPE_ERR_UNSUPPORTED;
+        return launch_pack_conv_w_x2(w, out, Cout, Cin, s, ntaps, mode);
     }
     if (mode == NOPE_CONV_DOWN2 && ntaps != 4) return NOPE_ERR_ARG;
     if (dt == NOPE_BF16X3 && Cin % 8) return NOPE_ERR_UNSUPPORTED;      // (hi, lo) groups of 8 channels
@@ -250,17 +261,20 @@ int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int
     return NOPE_OK;
 }
 
-size_t conv_w_x2_bytes(int Cout, int Cin) { return (size_t)Cout * 9 * Cin * 4 + kX2TailBytes; }
+static size_t x2_rows(int Cout, int ntaps, int mode) { return mode == NOPE_CONV_UP2P ? (size_t)16 * Cout : (size_t)Cout * ntaps; }      // (four phases x four taps)
+size_t conv_w_x2_bytes(int Cout, int Cin, int ntaps, int mode) { return x2_rows(Cout, ntaps, mode) * Cin * 4 + kX2TailBytes; }
 
-int launch_pack_conv_w_x2(const float* w, void* out, int Cout, int Cin, hipStream_t s) {
+int launch_pack_conv_w_x2(const float* w, void* out, int Cout, int Cin, hipStream_t s, int ntaps, int mode) {
     if (!w || !out || Cout <= 0 || Cin <= 0) return NOPE_ERR_ARG;
     if (Cin % 32) return NOPE_ERR_UNSUPPORTED;                          // whole 32-channel chunks
-    const size_t total = (size_t)Cout * 9 * Cin;
+    if (mode != NOPE_CONV_PLAIN && mode != NOPE_CONV_DOWN2 && mode != NOPE_CONV_UP2P) return NOPE_ERR_UNSUPPORTED;      // the modes of the ping-pong kernels
+    if (const int e = launch_pack_conv_w(NOPE_F32, w, out, Cout, Cin, ntaps, mode, s)) return e;
+    const size_t total = x2_rows(Cout, ntaps, mode) * Cin;
     int* tail = reinterpret_cast<int*>((unsigned char*)out + total * 4);
     if (hipMemsetAsync(tail, 0, kX2TailBytes, s) != hipSuccess) return NOPE_ERR_LAUNCH;
-    hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid_for(total)), dim3(NT), 0, s, w, total, reinterpret_cast<unsigned*>(tail) + 2);
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid_for(total)), dim3(NT), 0, s, (const float*)out, total, reinterpret_cast<unsigned*>(tail) + 2);
     NOPE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pack_conv_w_x2_kernel, dim3(grid_for(total)), dim3(NT), 0, s, w, (unsigned char*)out, Cin, total, tail);
+    hipLaunchKernelGGL(encode_w_x2_kernel, dim3(grid_for(total / 32)), dim3(NT), 0, s, (unsigned char*)out, total / 32, tail);
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

@@ -324,6 +324,7 @@ bool conv_geglu_fusable(int dt, const ConvArgs& a);   // would launch_conv take 
 int conv_splitk_factor(int dt, const ConvArgs& a);
 bool conv_is_posmajor(int dt, const ConvArgs& a);
 int conv_kernel_kind(int dt, const ConvArgs& a);      // NOPE_CONV_KERNEL_* launch_conv would pick
+bool conv_takes_x2(int dt, const ConvArgs& a);        // would launch_conv run this NOPE_BF16X3 launch on the f16 + MX-fp8 tile (a.w_x2 set)?
 int conv_stat_rows(int dt, const ConvArgs& a);        // rows per block of the fused column statistics this conv can emit (0: none)
 double conv_executed_flops(int dt, const ConvArgs& a);
 
@@ -361,10 +362,11 @@ int launch_nchw_to_nhwc(int dt, const float* x, void* y, int n, int C, int HW, h
 int launch_nhwc_to_nchw_f32(int dt, const void* x, float* y, int n, int C, int HW, hipStream_t s);
 int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int ntaps, int mode, hipStream_t s,
                        const float* cin_scale = nullptr, const float* cout_scale = nullptr, int Cin_src = 0);   // Cin_src < Cin: zero weights for the padding
-// NOPE_F16X2 layout of a 3x3 stride-1 weight [Cout][Cin][3][3], Cin % 32 == 0: conv_w_x2_bytes() bytes (the rows + a 16-byte tail with the
-// layer's block scale, derived on the device from max |w|: no host round trip)
-size_t conv_w_x2_bytes(int Cout, int Cin);
-int launch_pack_conv_w_x2(const float* w, void* out, int Cout, int Cin, hipStream_t s);
+// NOPE_F16X2 layout of a conv weight (any mode the ping-pong kernels run: PLAIN 1x1 / 3x3, DOWN2, UP2P incl. the ConvTranspose2d source with
+// ntaps = 16), Cin % 32 == 0: conv_w_x2_bytes() bytes (the rows, in launch_pack_conv_w's order, + a 16-byte tail with the layer's block scale,
+// derived on the device from max |w| of the rows the GEMM sees: no host round trip)
+size_t conv_w_x2_bytes(int Cout, int Cin, int ntaps = 9, int mode = NOPE_CONV_PLAIN);
+int launch_pack_conv_w_x2(const float* w, void* out, int Cout, int Cin, hipStream_t s, int ntaps = 9, int mode = NOPE_CONV_PLAIN);
 // template encoder (kernels_encoder.hip)
 int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale, float* shift,
                    int C, hipStream_t s);

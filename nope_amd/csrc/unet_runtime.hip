@@ -30,7 +30,7 @@ using namespace nope;
 
 namespace {
 
-struct Conv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; void* w_x2 = nullptr; };   // w_x2: NOPE_F16X2 only, 3x3 stride-1 layers: the tap-resident kernel's layout
+struct Conv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; void* w_x2 = nullptr; };   // w_x2: NOPE_F16X2 only: the same weights in the f16 + MX-fp8 tile's layout
 struct Norm { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct Res { Conv c1, c2, res; Norm n1, n2; bool has_res = false; int emb_off = -1; };
 // PreNorm's GroupNorm(1) is folded into the qkv conv: gamma into the packed weights, c0 = W beta, c1 = W gamma
@@ -135,9 +135,12 @@ struct Loader {
             const size_t es = (size_t)dt_es(net->dt);
             c.w = dmalloc((size_t)Cout * c.ntaps * Cin * es * (mode == NOPE_CONV_UP2P ? 4 : 1));
             if (c.w) { int e = launch_pack_conv_w(net->dt, d->data, c.w, Cout, Cin, convT ? 16 : c.ntaps, mode, s, cin_scale, nullptr, Csrc); if (e && err == NOPE_OK) err = e; }
-            if (net->x2 && mode == NOPE_CONV_PLAIN && ksz == 3 && !cin_scale && Csrc == Cin && Cin % 32 == 0) {
-                c.w_x2 = dmalloc(conv_w_x2_bytes(Cout, Cin));
-                if (c.w_x2) { int e = launch_pack_conv_w_x2((const float*)d->data, c.w_x2, Cout, Cin, s); if (e && err == NOPE_OK) err = e; }
+            // NOPE_F16X2: every layer a ping-pong kernel may run (3x3, 1x1, space-to-depth, phase convs) carries the second pack; launch_conv
+            // takes it when the launch's shape lands on one of them
+            if (net->x2 && (mode == NOPE_CONV_PLAIN || mode == NOPE_CONV_DOWN2 || mode == NOPE_CONV_UP2P) && (ksz == 3 || ksz == 1 || mode != NOPE_CONV_PLAIN) &&
+                !cin_scale && Csrc == Cin && Cin % 32 == 0) {
+                c.w_x2 = dmalloc(conv_w_x2_bytes(Cout, Cin, c.ntaps, mode));
+                if (c.w_x2) { int e = launch_pack_conv_w_x2((const float*)d->data, c.w_x2, Cout, Cin, s, convT ? 16 : c.ntaps, mode); if (e && err == NOPE_OK) err = e; }
             }
         }
         if (has_bias) c.bias = copy_f32(pfx + "bias", {Cout});
@@ -261,7 +264,7 @@ struct Fwd {
             ev.bytes = ((double)(n / rep1) * a.H * a.W * a.C + (b ? (double)(n / rep2) * a.H * a.W * b->C : 0.0) +
                         (double)c.Cout * c.ntaps * c.Cin * (c.mode == NOPE_CONV_UP2P ? 4 : 1) + (double)n * Ho * Wo * c.Cout) * (double)es;
             ev.info = nope_conv_launch_info{0.0, ev.flops, ev.bytes, conv_kernel_kind(net->dt, ca), c.mode, c.ntaps, c.Cin, c.Cout, a.H, a.W, n,
-                                            net->dt != NOPE_BF16X3 ? 1 : (ca.w_x2 && conv_kernel_kind(net->dt, ca) == NOPE_CONV_KERNEL_HALO256) ? 2 : 3,
+                                            net->dt != NOPE_BF16X3 ? 1 : conv_takes_x2(net->dt, ca) ? 2 : 3,
                                             conv_is_posmajor(net->dt, ca) ? 1 : 0};
             hipEventRecord(ev.a, s);
             chk(launch_conv(net->dt, ca, s));

@@ -648,8 +648,8 @@ def pack_conv_weight(w: torch.Tensor, dt: int, mode: int = CONV_PLAIN) -> Tuple[
         cin, ntaps = w.shape[1], 4
     else:
         cin, ntaps = w.shape[1], w.shape[2] * w.shape[3]
-    if dt == F16X2:      # the tap-resident kernel's layout (3x3 stride 1 only): 4 bytes per weight + a 16-byte tail with the layer's block scale
-        out = torch.empty(cout * ntaps * cin + 4, dtype=torch.float32, device=w.device)
+    if dt == F16X2:      # the f16 + MX-fp8 tile's layout (ping-pong kernels): 4 bytes per weight + a 16-byte tail with the layer's block scale
+        out = torch.empty((4 if mode == CONV_UP2P else 1) * cout * ntaps * cin + 4, dtype=torch.float32, device=w.device)
     else:
         out = torch.empty((4 if mode == CONV_UP2P else 1, cout, ntaps, cin), dtype=torch_dtype(dt), device=w.device)
     l = lib()

@@ -104,14 +104,14 @@ class F16Cross8(Scheme):
         lo = w - hi
         return hi, q8(w, self.fw, layer_log2_scale(w, self.fw)), q8(lo, self.fw_lo, layer_log2_scale(lo, self.fw_lo))
 
-    def conv3(self, a, w, b):
+    def conv3(self, a, w, b, stride=1, padding=1):
         wh, w8, wl8 = self.pack(w)
         ah = a.half().float()
-        out = TF.conv2d(ah, wh, b, padding=1)
+        out = TF.conv2d(ah, wh, b, stride, padding)
         if "alo" not in self.drop:
-            out = out + TF.conv2d(q8(a - ah, self.fa_lo, self.sa_lo), w8, None, padding=1)
+            out = out + TF.conv2d(q8(a - ah, self.fa_lo, self.sa_lo), w8, None, stride, padding)
         if "wlo" not in self.drop:
-            out = out + TF.conv2d(q8(a, self.fa, self.sa), wl8, None, padding=1)
+            out = out + TF.conv2d(q8(a, self.fa, self.sa), wl8, None, stride, padding)
         return out
 
 
@@ -194,6 +194,10 @@ class FShim:
         if w.shape[-1] == 3 and stride == 1 and padding == 1 and w.shape[1] % 32 == 0:
             self.n3 += 1
             return self.st(self.scheme.conv3(x, w, b))
+        if self.other == "x2":              # the same split-precision arithmetic on every other conv whose K the MX MFMA can tile
+            if w.shape[1] % 32 == 0:
+                return self.st(self.scheme.conv3(x, w, b, stride, padding))
+            return self.st(TF.conv2d(x, w, b, stride, padding, *a, **kw))
         if self.other is not None:
             x = x.to(H if self.other == "a16" else self.other).float()
         return self.st(TF.conv2d(x, self.wq(w), b, stride, padding, *a, **kw))
@@ -239,6 +243,8 @@ CONFIGS = {
     # ... and the remaining convs (1x1, up / down-sampling: bf16x3 today) with f16-rounded activation operands against exact weights: would a
     # two-pass a16 x (w_hi + w_lo) tile do for them?
     "f16+e4m3, other convs a16 x exact w": ("f16+e4m3(alo:2^9,a:2^-2)", None, "a16", None, None),
+    # ... or the full split-precision tile on them too (every conv with Cin % 32 == 0)
+    "f16+e4m3 on every conv": ("f16+e4m3(alo:2^9,a:2^-2)", None, "x2", None, None),
     "f16+e4m3(alo:2^7,a:2^-4)": ("f16+e4m3(alo:2^7,a:2^-4)", None, None, None, None),
     "f16+e4m3(alo:2^5,a:2^-6)": ("f16+e4m3(alo:2^5,a:2^-6)", None, None, None, None),
     "f16+e4m3(alo:2^4,a:2^-7)": ("f16+e4m3(alo:2^4,a:2^-7)", None, None, None, None),

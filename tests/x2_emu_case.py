@@ -1,7 +1,8 @@
-"""The tap-resident 3x3 kernel's NOPE_F16X2 instantiation (f16 hi x hi + one MX-scaled fp8 MFMA for both cross terms, kernels_gemm_pp.hip /
-Tile<f16x2_t>) on small shapes under tests/hipemu: against the f32 convolution (tolerance of the mode) AND against a torch restatement of
-the exact arithmetic the kernel performs (operands rounded as convert_piece / pack_conv_w_x2_kernel round them: tight tolerance -- a wrong
-slot, byte position, pre-scale or block scale shows here, not in the loose check).  Run by tests/test_conv_pingpong.py with the
+"""The ping-pong kernels' NOPE_F16X2 instantiations (f16 hi x hi + one MX-scaled fp8 MFMA for both cross terms, kernels_gemm_pp.hip /
+Tile<f16x2_t>: the tap-resident 3x3 kernel, which rewrites its staged rows in LDS, and the per-tap kernel -- 1x1, space-to-depth and
+phase convs --, which splits them in registers) on small shapes under tests/hipemu: against the f32 convolution (tolerance of the mode)
+AND against a torch restatement of the exact arithmetic the kernels perform (operands rounded as convert_piece / prep_hi + prep_lo /
+encode_w_x2_kernel round them: tight tolerance -- a wrong slot, byte position, pre-scale or block scale shows here, not in the loose check).  Run by tests/test_conv_pingpong.py with the
 interpreter's adversarial settings; `run(hip, "cuda")` is the GPU form of the same cases."""
 import os
 import sys
@@ -23,20 +24,45 @@ def q8(x, log2_scale):
     return (x * s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() / s
 
 
-def x2_reference(x, w, b):
-    """out = f16(a) f16(w) + e4m3(a_lo 2^9) e4m3(w 2^sw) 2^-(9+sw) + e4m3(a 2^-2) e4m3(w_lo 2^(sw+11)) 2^-(9+sw), f64 accumulation"""
+def x2_reference(x, w, b, conv=None):
+    """out = f16(a) f16(w) + e4m3(a_lo 2^9) e4m3(w 2^sw) 2^-(9+sw) + e4m3(a 2^-2) e4m3(w_lo 2^(sw+11)) 2^-(9+sw), f64 accumulation.
+    w: the weights AS THE GEMM SEES THEM (the phase-summed sets of an UP2P conv); conv(a, w): the bilinear map, default a 3x3 conv, padding 1"""
+    conv = conv or (lambda a, ww: F.conv2d(a, ww, None, padding=1))
     m = float(w.abs().max())
     e = torch.frexp(torch.tensor(m))[1].item() - 1          # floor(log2 m)
     sw = 7 - e
     ah, wh = x.clamp(-65504, 65504).half().float(), w.half().float()
     al, wl = x - ah, w - wh
     d = torch.float64
-    out = F.conv2d(ah.to(d), wh.to(d), None, padding=1)
-    out = out + F.conv2d(q8(al, A_LO_SHIFT).to(d), q8(w, sw).to(d), None, padding=1)
-    out = out + F.conv2d(q8(x, A_SHIFT).to(d), q8(wl, sw + W_LO_EXTRA).to(d), None, padding=1)
+    out = conv(ah.to(d), wh.to(d))
+    out = out + conv(q8(al, A_LO_SHIFT).to(d), q8(w, sw).to(d))
+    out = out + conv(q8(x, A_SHIFT).to(d), q8(wl, sw + W_LO_EXTRA).to(d))
     if b is not None:
         out = out + b.to(d)[None, :, None, None]
     return out.float()
+
+
+def up2p_phase_weights(w):
+    """nearest-x2 + 3x3 as four 2x2 phase convs over the SOURCE grid (model_utils.py:161-165; pack_up2p_w_kernel): (4, Cout, Cin, 2, 2), phase
+    (py, px), tap (ty, tx) = source pixel (y + ty + py - 1, x + tx + px - 1), carrying the sum of the 3x3 taps that land on it"""
+    rows = {(0, 0): [0], (0, 1): [1, 2], (1, 0): [0, 1], (1, 1): [2]}
+    out = torch.zeros(4, w.shape[0], w.shape[1], 2, 2, dtype=w.dtype)
+    for py in range(2):
+        for px in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    out[py * 2 + px, :, :, ty, tx] = w[:, :, rows[(py, ty)]][:, :, :, rows[(px, tx)]].sum((2, 3))
+    return out
+
+
+def up2p_conv(a, wp):
+    n, _, H, W = a.shape
+    ap = F.pad(a, (1, 1, 1, 1))
+    out = a.new_zeros(n, wp.shape[1], 2 * H, 2 * W)
+    for py in range(2):
+        for px in range(2):
+            out[:, :, py::2, px::2] = F.conv2d(ap[:, :, py:py + H + 1, px:px + W + 1], wp[py * 2 + px])
+    return out
 
 
 def run(hip, dev, light=False):
@@ -47,11 +73,11 @@ def run(hip, dev, light=False):
     C = 32
     worst = 0.0
 
-    def chk(y, x, w, b, what, extra=None):
+    def chk(y, x, w, b, what, extra=None, want32=None, conv=None, w_gemm=None):
         nonlocal worst
         y = hip.to_nchw(y, 0).cpu()
-        want32 = F.conv2d(x, w, b, padding=1)
-        want = x2_reference(x, w, b)
+        want32 = F.conv2d(x, w, b, padding=1) if want32 is None else want32
+        want = x2_reference(x, w if w_gemm is None else w_gemm, b, conv)
         if extra is not None:
             want32, want = want32 + extra, want + extra
         e_exact, e32 = rel(y, want), rel(y, want32)
@@ -97,10 +123,31 @@ def run(hip, dev, light=False):
             y2 = hip.op_conv(X2, hip.to_nhwc(d(xq[:8]), 0), d(wq), d(bq), split_k=True)
             os.environ.pop("NOPE_HALO_SPLIT_MIN_CHUNKS")
             chk(y2, xq[:8], wq, bq, "halo split-K")
-        # a shape the tap-resident kernel does not take (1x1): the element type refuses it
+        # ---- the per-tap kernel (operand split in registers): 1x1 over a concat of two sources (two K steps, one per source), ragged M and N
+        w1, b1 = rn(200, 2 * C, 1, 1) / 8, rn(200)
+        y = hip.op_conv(X2, hip.to_nhwc(d(x1), 0), d(w1), d(b1), src2=hip.to_nhwc(d(x2), 0))
+        xc = torch.cat((x1, x2), 1)
+        chk(y, xc, w1, b1, "per-tap 1x1 concat", want32=F.conv2d(xc, w1, b1), conv=lambda a, ww: F.conv2d(a, ww))
+        # space-to-depth (HardDownsample, model_utils.py:167-172): 1x1 over "b (c p1 p2) h w" = a 2x2 stride-2 conv
+        xd, wd, bd = rn(3, C, 8, 10), rn(48, 4 * C, 1, 1) / 11, rn(48)
+        y = hip.op_conv(X2, hip.to_nhwc(d(xd), 0), d(wd), d(bd), mode=hip.CONV_DOWN2)
+        wd2 = wd.view(48, C, 2, 2)
+        chk(y, xd, wd2, bd, "per-tap space-to-depth", want32=F.conv2d(xd, wd2, bd, stride=2), conv=lambda a, ww: F.conv2d(a, ww, None, stride=2))
+        # nearest-x2 + 3x3 as four phase convs (HardUpsample, model_utils.py:161-165): the block scale comes from the PHASE-SUMMED weights
+        xu, wu, bu = rn(3, 2 * C, 5, 6), rn(40, 2 * C, 3, 3) / 24, rn(40)
+        y = hip.op_conv(X2, hip.to_nhwc(d(xu), 0), d(wu), d(bu), mode=hip.CONV_UP2P)
+        chk(y, xu, wu, bu, "per-tap phase convs", want32=F.conv2d(F.interpolate(xu, scale_factor=2, mode="nearest"), wu, bu, padding=1),
+            conv=up2p_conv, w_gemm=up2p_phase_weights(wu))
+        if not light:
+            # 3x3 in position-major row order (the 4x4 level at hundreds of hypotheses): padding taps skipped per tile
+            xp, wp_, bp = rn(256, C, 4, 4), rn(24, C, 3, 3) / 17, rn(24)
+            y = hip.op_conv(X2, hip.to_nhwc(d(xp), 0), d(wp_), d(bp))
+            chk(y, xp, wp_, bp, "per-tap 3x3, position-major")
+        # a launch no ping-pong kernel takes (here: too few tiles under the default plan): the element type refuses it
+        os.environ.pop("NOPE_CONV_PP")
         try:
             hip.op_conv(X2, hip.to_nhwc(d(x2), 0), d(rn(24, C, 1, 1)), None)
-            raise AssertionError("NOPE_F16X2 accepted a 1x1 convolution")
+            raise AssertionError("NOPE_F16X2 accepted a launch that runs on the small-tile kernel")
         except hip.NopeError:
             pass
     finally:

@@ -67,6 +67,7 @@ def main():
         for rnd in range(a.rounds):
             for pp in pps:
                 os.environ["NOPE_CONV_PP"] = pp
+                hip.lib()                          # (notices the changed variable: nope_tuning_reload -- the library caches its switches)
                 for _ in range(2):
                     run()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,0 +1,299 @@
+// GPU probe: do LDS fragment reads of one wave overlap with the MFMAs of the other wave on the same SIMD (gfx950)?  The ping-pong kernels
+// (kernels_gemm_pp.hip) are built on "yes"; round 5's ablations (profiles/r05x_pp_stream_probe.txt) measured launch time = LOAD-only time +
+// MFMA-only time, i.e. "no".  This strips the schedule to its skeleton -- 8 waves, one workgroup per CU (136 KiB of LDS), per K step and wave
+// 20 ds_read_b128 (the 64 x 96 wave tile's fragments of a 128-byte-row stage, conflict-free) and 24 v_mfma_f32_32x32x16_f16 on six
+// accumulators fed by those registers -- and times it under three schedules:
+//     lockstep   every wave: LOAD, barrier, COMPUTE, barrier                       (nothing can overlap across waves: the baseline)
+//     pingpong   two groups of four waves half a step apart, one barrier per phase  (the kernels' schedule)
+//     free       every wave: LOAD (wait), COMPUTE, no barriers at all               (the hardware's own interleaving)
+// each with reads only, MFMAs only, and both; accumulators in ArchVGPRs or in AccVGPRs.
+//     hipcc --offload-arch=gfx950 -O2 tools/probes/overlap_probe.hip -o tools/probes/overlap_probe && tools/probes/overlap_probe
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LDS_BYTES = 139264;
+
+// what else a real LOAD phase issues, dealt out between the 20 reads: NV VALU and NS SALU instructions (address arithmetic), ND LDS-DMA pieces of
+// 1 KiB each (buffer_load_dwordx4 ... lds from an L2-resident buffer), waited for at the end of the following COMPUTE phase as the kernels do
+struct Extra { unsigned v[4]; unsigned s; __amdgpu_buffer_rsrc_t rsrc; unsigned voff; unsigned char* dst; };
+template <int NV, int NS, int ND>
+__device__ __forceinline__ void extras(Extra& x, int f) {      // after fragment read f of 20
+#pragma unroll
+    for (int q = f * NV / 20; q < (f + 1) * NV / 20; ++q) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x.v[q & 3]) : "v"(x.v[(q + 1) & 3]));
+#pragma unroll
+    for (int q = f * NS / 20; q < (f + 1) * NS / 20; ++q) asm volatile("s_add_u32 %0, %0, 3" : "+s"(x.s));
+#pragma unroll
+    for (int q = f * ND / 20; q < (f + 1) * ND / 20; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsrc, (__attribute__((address_space(3))) void*)(x.dst + q * 1024), 16, x.voff, q * 8192, 0, 0);
+}
+template <bool READ, int NV, int NS, int ND>
+__device__ __forceinline__ void load_phase(u32x4 (&af)[4][2], u32x4 (&bf)[4][3], unsigned a_addr, unsigned b_addr, Extra& x) {
+    if constexpr (READ) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                asm volatile("ds_read_b128 %0, %1" : "=v"(af[k][i]) : "v"(a_addr ^ (unsigned)(k << 4) ^ (unsigned)(i * 4096)));
+                extras<NV, NS, ND>(x, k * 5 + i);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bf[k][j]) : "v"(b_addr ^ (unsigned)(k << 4) ^ (unsigned)(j * 4096)));
+                extras<NV, NS, ND>(x, k * 5 + 2 + j);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <bool MMA, bool AGPR>
+__device__ __forceinline__ void compute_phase(const u32x4 (&af)[4][2], const u32x4 (&bf)[4][3], f32x16 (&acc)[2][3]) {
+    if constexpr (MMA) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[k][i]), "v"(bf[k][j]));
+                    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(af[k][i]), "v"(bf[k][j]));
+                }
+    }
+}
+
+// SCHED 0 lockstep, 1 pingpong, 2 free
+template <int SCHED, bool READ, bool MMA, bool AGPR, int NV = 0, int NS = 0, int ND = 0>
+__global__ __launch_bounds__(512, 2) void probe_kernel(float* out, int iters, const unsigned char* src = nullptr, int pattern = 0) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2;
+    // operand data: pattern 0 = every f16 is 1.0 (nothing toggles in the multipliers), 1 = random signs and mantissas, exponents 12..15
+    // (what real activations and weights look like to the datapath: the board's power management sees the difference)
+    for (int i = tid; i < LDS_BYTES / 4; i += 512) {
+        unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        reinterpret_cast<unsigned*>(lds)[i] = pattern ? ((h & 0x8fff8fffu) | 0x30003000u) : 0x3c003c00u;
+    }
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    // fragment addresses as the kernels form them: row = lane & 31 (128-byte rows), slot = (lane >> 5) ^ (row & 7): conflict-free b128 reads
+    const unsigned row = lane & 31;
+    const unsigned a_addr = (unsigned)((wave >> 1) * 8192 + row * 128 + ((((lane >> 5) * 2) ^ (row & 7)) << 4));
+    const unsigned b_addr = (unsigned)(65536 + (wave & 1) * 12288 + row * 128 + ((((lane >> 5) * 2) ^ (row & 7)) << 4));
+    u32x4 af[4][2], bf[4][3];
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[k][i] = u32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bf[k][j] = u32x4{0, 0, 0, 0};
+    }
+    Extra x;
+    x.v[0] = tid; x.v[1] = lane; x.v[2] = wave; x.v[3] = 7; x.s = (unsigned)iters;
+    x.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, (short)0, ND ? 1 << 20 : 0, 0x00020000);
+    x.voff = (unsigned)(wave * 1024 + lane * 16);
+    x.dst = lds + 106496 + wave * 4096;               // a region no fragment read touches
+    if (SCHED == 1 && grp == 1) __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < iters; ++it) {
+        load_phase<READ, NV, NS, ND>(af, bf, a_addr, b_addr, x);
+        if (SCHED != 2) __builtin_amdgcn_s_barrier();
+        if (SCHED == 1) __builtin_amdgcn_s_setprio(1);
+        compute_phase<MMA, AGPR>(af, bf, acc);
+        if (SCHED == 1) __builtin_amdgcn_s_setprio(0);
+        if (ND) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (SCHED != 2 && !(SCHED == 1 && grp == 1 && it == iters - 1)) __builtin_amdgcn_s_barrier();
+    }
+    if (x.v[0] + x.v[1] + x.v[2] + x.v[3] + x.s == 0x12345678u) out[1] = 1.f;
+    if (blockIdx.x == 0 && tid == 0) {      // shader clock actually delivered: s_memtime counts core cycles, s_memrealtime a constant 100 MHz
+        const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        out[2] = (float)(t1 - t0); out[3] = (float)(r1 - r0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s += acc[i][j][0] + acc[i][j][15];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += (float)(af[k][0][0] & 1u) + (float)(bf[k][2][3] & 1u);
+    if (s == 12345.678f) out[0] = s;
+}
+
+// MFMAs only, operands read ONCE from LDS (so they carry the pattern) and held in registers: which instruction costs the clock what?
+// KIND 0: v_mfma_f32_32x32x16_f16, 1: ..._bf16, 2: v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 x e4m3, unit scales): 24 / 24 / 12 per step = the same
+// 768 nominal cycles per wave
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <int KIND>
+__global__ __launch_bounds__(512, 2) void mfma_kind_kernel(float* out, int iters, int pattern) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < LDS_BYTES / 4; i += 512) {
+        unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const unsigned f16v = (h & 0x8fff8fffu) | 0x30003000u, bf16v = (h & 0x81ff81ffu) | 0x3e003e00u, f8v = (h & 0x8f8f8f8fu) | 0x30303030u;
+        reinterpret_cast<unsigned*>(lds)[i] = pattern ? (KIND == 0 ? f16v : KIND == 1 ? bf16v : f8v) : (KIND == 0 ? 0x3c003c00u : KIND == 1 ? 0x3f803f80u : 0x38383838u);
+    }
+    __syncthreads();
+    u32x4 af[4][2], bf[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[k][i] = *reinterpret_cast<const u32x4*>(lds + wave * 8192 + (k * 2 + i) * 1024 + lane * 16);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bf[k][j] = *reinterpret_cast<const u32x4*>(lds + 65536 + wave * 8192 + (k * 3 + j) * 1024 + lane * 16);
+    }
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < (KIND == 2 ? 2 : 4); ++k)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if constexpr (KIND == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[k][i]), __builtin_bit_cast(f16x8, bf[k][j]), acc[i][j], 0, 0, 0);
+                    else if constexpr (KIND == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[k][i]), __builtin_bit_cast(bf16x8, bf[k][j]), acc[i][j], 0, 0, 0);
+                    else {
+                        const u32x4 a0 = af[2 * k][i], a1 = af[2 * k + 1][i], b0 = bf[2 * k][j], b1 = bf[2 * k + 1][j];
+                        const i32x8 va = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+                        const i32x8 vb = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, acc[i][j], 0, 0, 0, 127, 0, 127);
+                    }
+                }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(acc[i][j]));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s += acc[i][j][0] + acc[i][j][15];
+    if (s == 12345.678f) out[0] = s;
+    if (blockIdx.x == 0 && tid == 0) {
+        const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        out[2] = (float)(t1 - t0); out[3] = (float)(r1 - r0);
+    }
+}
+static const unsigned char* g_src = nullptr;
+static int g_pattern = 0;
+static double g_mhz = 0.0;
+static double run_kind(int kind, float* out, int iters, int blocks, int pattern, double& mhz) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; ++rep) {
+        if (rep) hipEventRecord(e0, 0);
+        const int n = rep ? iters : 10;
+        if (kind == 0) hipLaunchKernelGGL((mfma_kind_kernel<0>), dim3(blocks), dim3(512), 0, 0, out, n, pattern);
+        else if (kind == 1) hipLaunchKernelGGL((mfma_kind_kernel<1>), dim3(blocks), dim3(512), 0, 0, out, n, pattern);
+        else hipLaunchKernelGGL((mfma_kind_kernel<2>), dim3(blocks), dim3(512), 0, 0, out, n, pattern);
+        hipDeviceSynchronize();
+    }
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    float clk[4] = {0, 0, 0, 0};
+    hipMemcpy(clk, out, sizeof(clk), hipMemcpyDeviceToHost);
+    mhz = clk[3] > 0 ? (double)clk[2] / (double)clk[3] * 100.0 : 0.0;
+    return (double)ms * 1e6 / iters;
+}
+template <int SCHED, bool READ, bool MMA, bool AGPR, int NV = 0, int NS = 0, int ND = 0>
+static double run(float* out, int iters, int blocks) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((probe_kernel<SCHED, READ, MMA, AGPR, NV, NS, ND>), dim3(blocks), dim3(512), 0, 0, out, 10, g_src, g_pattern);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((probe_kernel<SCHED, READ, MMA, AGPR, NV, NS, ND>), dim3(blocks), dim3(512), 0, 0, out, iters, g_src, g_pattern);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    float clk[4] = {0, 0, 0, 0};
+    hipMemcpy(clk, out, sizeof(clk), hipMemcpyDeviceToHost);
+    g_mhz = clk[3] > 0 ? (double)clk[2] / (double)clk[3] * 100.0 : 0.0;
+    return (double)ms * 1e6 / iters;      // ns per K step (one workgroup per CU, one round of workgroups)
+}
+
+int main() {
+    float* out = nullptr;
+    hipMalloc((void**)&out, 64);
+    int dev = 0, cus = 0, khz = 0;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev);
+    const int iters = 4000;
+    printf("%d CUs, %d MHz nominal; one workgroup of 8 waves per CU, %d K steps; ns per K step (and cycles at the nominal clock)\n", cus, khz / 1000, iters);
+    printf("ideal: 24 MFMAs x 32 cycles x 2 waves per SIMD = 1536 cycles of MFMA per step; 160 ds_read_b128 = 160 KiB = 1280 cycles of LDS at 128 B/clk\n");
+    const double c = khz * 1e-6;
+#define ROW(name, S, A)                                                                                                         \
+    {                                                                                                                           \
+        const double r = run<S, true, false, A>(out, iters, cus), m = run<S, false, true, A>(out, iters, cus),                  \
+                     b = run<S, true, true, A>(out, iters, cus);                                                                \
+        printf("%-9s acc in %s: reads only %7.1f ns (%5.0f cyc)   MFMAs only %7.1f ns (%5.0f cyc)   both %7.1f ns (%5.0f cyc)\n", name, \
+               A ? "AccVGPRs " : "ArchVGPRs", r, r * c, m, m * c, b, b * c);                                                    \
+    }
+    ROW("lockstep", 0, false)
+    ROW("pingpong", 1, false)
+    ROW("free", 2, false)
+    ROW("lockstep", 0, true)
+    ROW("pingpong", 1, true)
+    ROW("free", 2, true)
+    // ---- the ping-pong schedule with what a real LOAD phase carries besides its reads
+    unsigned char* src = nullptr;
+    hipMalloc((void**)&src, 1 << 20);
+    hipMemset(src, 0, 1 << 20);
+    g_src = src;
+#define EXTRA(NV, NS, ND)                                                                                                                    \
+    {                                                                                                                                        \
+        const double r = run<1, true, false, false, NV, NS, ND>(out, iters, cus), b = run<1, true, true, false, NV, NS, ND>(out, iters, cus); \
+        printf("pingpong + %3d VALU + %3d SALU + %d DMA pieces per LOAD phase: reads only %7.1f ns (%5.0f cyc)   both %7.1f ns (%5.0f cyc)\n", NV, NS, ND, r, r * c, b, b * c); \
+    }
+    EXTRA(20, 0, 0)
+    EXTRA(40, 0, 0)
+    EXTRA(80, 0, 0)
+    EXTRA(0, 20, 0)
+    EXTRA(0, 40, 0)
+    EXTRA(0, 0, 4)
+    EXTRA(0, 0, 8)
+    EXTRA(20, 20, 4)
+    EXTRA(40, 40, 4)
+    EXTRA(40, 40, 8)
+    // ---- the same skeleton on operands that toggle: how much of the nominal clock does the board deliver under a dense MFMA stream?
+    for (int pat = 0; pat < 2; ++pat) {
+        g_pattern = pat;
+        const int long_iters = 40000;      // ~30 ms: long enough for the power management to settle
+        const double m = run<1, false, true, false>(out, long_iters, cus); const double fm = g_mhz;
+        const double b = run<1, true, true, false, 20, 20, 4>(out, long_iters, cus); const double fb = g_mhz;
+        const double r = run<1, true, false, false, 20, 20, 4>(out, long_iters, cus); const double fr = g_mhz;
+        printf("operands %s: MFMAs only %7.1f ns per step at %4.0f MHz (s_memtime / s_memrealtime) | reads + 20 VALU + 20 SALU + 4 DMA + MFMAs %7.1f ns at %4.0f MHz | "
+               "no MFMAs %7.1f ns at %4.0f MHz\n", pat ? "random (sign, mantissa, 4 exponents)" : "all 1.0", m, fm, b, fb, r, fr);
+    }
+    // ---- MFMAs only, operands in registers: the price of each matrix instruction in clock
+    const char* kinds[3] = {"32x32x16 f16", "32x32x16 bf16", "32x32x64 MX e4m3"};
+    for (int kind = 0; kind < 3; ++kind)
+        for (int pat = 0; pat < 2; ++pat) {
+            double mhz = 0.0;
+            const double t = run_kind(kind, out, 40000, cus, pat, mhz);
+            const double tf = (double)cus * 8 * 24 * 32768.0 * 2 / 2 / (t * 1e-9) * 1e-12;      // 8 waves x 24 x (32 x 32 x 16 MACs) per step and CU
+            printf("MFMAs only, %-17s operands %-8s: %7.1f ns per step at %4.0f MHz = %6.0f TFLOP/s dense (nominal peak %s)\n", kinds[kind], pat ? "random" : "constant", t,
+                   mhz, tf * (kind == 2 ? 2.0 : 1.0), kind == 2 ? "5000" : "2500");
+        }
+    return 0;
+}
