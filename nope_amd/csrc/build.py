@@ -89,5 +89,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_probe(force: bool = False) -> str:
+    """tools/probes/overlap_probe: the standalone measurement of what the board delivers under a dense MFMA stream (bench.py's
+    `roofline.power_ceiling`).  Not part of the library: a plain HIP program, built next to its source."""
+    src = os.path.join(ROOT, "tools", "probes", "overlap_probe.hip")
+    out = src[:-4]
+    if force or not _newer(out, [src]):
+        subprocess.run([_hipcc(), "--offload-arch=" + ARCH, "-O2", "-w", src, "-o", out], check=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_probe(force="--force" in sys.argv))

@@ -36,6 +36,7 @@
 #include "conv_gemm_common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace nope {
 
@@ -50,7 +51,9 @@ constexpr int WAIT_LGKMCNT0 = 0xC07F;    // lgkmcnt(0): every ds_read of this wa
 
 struct KPos { int tap, kc; };
 
-template <class T, int MODE, bool PN>
+// TUNE: the instantiation that honours the NOPE_PP_VARIANT ablations (run-time tests inside the K loop); production launches (variant 0) take the
+// one without them.
+template <class T, int MODE, bool PN, bool TUNE = false>
 __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvParams p) {
     typedef Tile<T> TL;
     constexpr int VEC = Elt<T>::VEC;
@@ -67,7 +70,8 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];     // the ONLY LDS object (cdna_hip_programming.md, section 5 trap (a))
 
     const int tid = threadIdx.x;
-    if (p.variant & 128) { if (tid == 9999) lds[0] = 1; return; }   // tuning only (NOPE_PP_VARIANT): launch cost of the grid
+    const int variant = TUNE ? variant : 0;
+    if (variant & 128) { if (tid == 9999) lds[0] = 1; return; }   // tuning only (NOPE_PP_VARIANT): launch cost of the grid
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;       // 4 (M) x 2 (N) waves of 64 x 96
@@ -235,7 +239,10 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
     }
 
     int sa = 0, sb = 0;                                // A stage (k & 1) and B stage (k % 3) of the current K step
-    for (int k = 0; k < nk; ++k) {
+    // One K step.  FULL: a step of the steady state (k + 2 < nk) -- both DMA streams run, no barrier is skipped: the loop below runs these
+    // without a single run-time test on k; the last two steps take the general form.
+    auto k_step = [&](auto full_tag, int k) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
         // ---- LOAD k: fragments of step k into registers, then the DMA pieces of the steps after it
         const unsigned char* la = lds + sa * A_STAGE;
         const unsigned char* lb = lds + B_BASE + sb * B_STAGE;
@@ -245,12 +252,12 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
         const int sb2 = sb1 == 2 ? 0 : sb1 + 1;
         // (tuning: 16 = no DMA stream, 512 = A pieces only on the first tap of a channel chunk, 1024 = no B pieces: wrong results,
         //  they size what a tap-resident A stage / a cheaper B stream would buy)
-        const bool do_a = k + 1 < nk && !(p.variant & 16) && !((p.variant & 512) && ka.tap != tap0);
-        const bool do_b = (grp == 0 ? k + 1 < nk : k + 2 < nk) && !(p.variant & (16 | 1024));
-        if (p.variant & 4) __builtin_amdgcn_s_setprio(2);      // (tuning: 4 = the LOAD phase outranks the other group's MFMA issue)
+        const bool do_a = (FULL || k + 1 < nk) && !(variant & 16) && !((variant & 512) && ka.tap != tap0);
+        const bool do_b = (FULL || (grp == 0 ? k + 1 < nk : k + 2 < nk)) && !(variant & (16 | 1024));
+        if (variant & 4) __builtin_amdgcn_s_setprio(2);      // (tuning: 4 = the LOAD phase outranks the other group's MFMA issue)
         if (do_a) prep_a(ka, a_dst + sa1 * A_STAGE);
         if (do_b) prep_b(kb, b_dst + (grp == 0 ? sb1 : sb2) * B_STAGE);
-        if (p.variant & 1) {                           // (tuning: 1 = all fragment reads first, then all DMA pieces)
+        if (variant & 1) {                           // (tuning: 1 = all fragment reads first, then all DMA pieces)
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
@@ -287,8 +294,8 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (k + 1 < nk) advance(ka);
-        if (grp == 0 ? k + 1 < nk : k + 2 < nk) advance(kb);
+        if (FULL || k + 1 < nk) advance(ka);
+        if (FULL || (grp == 0 ? k + 1 < nk : k + 2 < nk)) advance(kb);
 #ifndef NOPE_PP_PREP_COMPUTE
 #define NOPE_PP_PREP_COMPUTE 1
 #endif
@@ -298,12 +305,12 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
             for (int ks = 0; ks < KS; ++ks) TL::prep_step(af[ks]);
         }
         __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);     // my reads of stage k are done: after the barrier the other group may overwrite it
-        if (p.variant & 4) __builtin_amdgcn_s_setprio(0);
+        if (variant & 4) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- COMPUTE k: registers only
-        if (!(p.variant & 2)) __builtin_amdgcn_s_setprio(1);       // (tuning: 2 = no priority for the MFMA phase)
-        if (!(p.variant & 32)) {                       // (tuning: 32 = no MFMA)
+        if (!(variant & 2)) __builtin_amdgcn_s_setprio(1);       // (tuning: 2 = no priority for the MFMA phase)
+        if (!(variant & 32)) {                       // (tuning: 32 = no MFMA)
             if constexpr (X2) {
                 // f16x2 (KS = 1: a stage is one 32-channel step): the split of the two row tiles' raw f32 fragments -- 8 packed f16 conversions
                 // for the hi parts, then per row tile 16 unpack + 16 subtract + 16 packed e4m3 conversions -- rides behind the MFMAs that do
@@ -382,17 +389,22 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        if (!(p.variant & 8))                          // (tuning: 8 = never wait for the DMA -- wrong results, shows the issue-bound time)
+        if (!(variant & 8))                          // (tuning: 8 = never wait for the DMA -- wrong results, shows the issue-bound time)
         __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);       // the pieces I issued in LOAD k have landed (they had this whole phase)
-        if (!(grp == 1 && k == nk - 1)) {              // (group 1 started one barrier late: it skips the last one)
+        if (FULL || !(grp == 1 && k == nk - 1)) {      // (group 1 started one barrier late: it skips the last one)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
         sa = sa1; sb = sb1;
+    };
+    {
+        int k = 0;
+        for (; k + 2 < nk; ++k) k_step(std::true_type{}, k);
+        for (; k < nk; ++k) k_step(std::false_type{}, k);
     }
     // Both groups have passed 2 nk + 1 barriers.  Group 0 arrives here while group 1 still multiplies (registers only);
     // every LDS stage read and every DMA is complete, so the per-wave epilogue panels may reuse the ring.
-    if (p.variant & 64) {                              // tuning only: no epilogue (keeps the accumulators live)
+    if (variant & 64) {                              // tuning only: no epilogue (keeps the accumulators live)
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;
         return;
     }
@@ -938,13 +950,18 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     }
 }
 
+template <class T, bool TUNE>
+void launch_pp_tt(const ConvParams& p, dim3 grid, hipStream_t s) {
+    const dim3 block(PP_WAVES * 64);
+    if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NOPE_CONV_PLAIN, true, TUNE>), grid, block, 0, s, p);
+    else if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NOPE_CONV_PLAIN, false, TUNE>), grid, block, 0, s, p);
+    else if (p.mode == NOPE_CONV_UP2P) hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NOPE_CONV_UP2P, false, TUNE>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NOPE_CONV_DOWN2, false, TUNE>), grid, block, 0, s, p);
+}
 template <class T>
 void launch_pp_t(const ConvParams& p, dim3 grid, hipStream_t s) {
-    const dim3 block(PP_WAVES * 64);
-    if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NOPE_CONV_PLAIN, true>), grid, block, 0, s, p);
-    else if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NOPE_CONV_PLAIN, false>), grid, block, 0, s, p);
-    else if (p.mode == NOPE_CONV_UP2P) hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NOPE_CONV_UP2P, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NOPE_CONV_DOWN2, false>), grid, block, 0, s, p);
+    if (p.variant) launch_pp_tt<T, true>(p, grid, s);      // (NOPE_PP_VARIANT ablations: tools/pp_stream_probe.py)
+    else launch_pp_tt<T, false>(p, grid, s);
 }
 
 }  // namespace

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstring>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -81,8 +82,9 @@ __global__ __launch_bounds__(512, 2) void probe_kernel(float* out, int iters, co
     const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     // fragment addresses as the kernels form them: row = lane & 31 (128-byte rows), slot = (lane >> 5) ^ (row & 7): conflict-free b128 reads
     const unsigned row = lane & 31;
-    const unsigned a_addr = (unsigned)((wave >> 1) * 8192 + row * 128 + ((((lane >> 5) * 2) ^ (row & 7)) << 4));
-    const unsigned b_addr = (unsigned)(65536 + (wave & 1) * 12288 + row * 128 + ((((lane >> 5) * 2) ^ (row & 7)) << 4));
+    const unsigned slot0 = (unsigned)((lane >> 5) * 2);
+    const unsigned a_addr = (unsigned)((wave >> 1) * 8192 + row * 128 + ((slot0 ^ (row & 7)) << 4));
+    const unsigned b_addr = (unsigned)(65536 + (wave & 1) * 12288 + row * 128 + ((slot0 ^ (row & 7)) << 4));
     u32x4 af[4][2], bf[4][3];
     f32x16 acc[2][3];
 #pragma unroll
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(512, 2) void probe_kernel(float* out, int iters, co
 }
 
 // MFMAs only, operands read ONCE from LDS (so they carry the pattern) and held in registers: which instruction costs the clock what?
-// KIND 0: v_mfma_f32_32x32x16_f16, 1: ..._bf16, 2: v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 x e4m3, unit scales): 24 / 24 / 12 per step = the same
-// 768 nominal cycles per wave
+// KIND 0: v_mfma_f32_32x32x16_f16, 1: ..._bf16, 2: v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 x e4m3, unit scales), 3: the NOPE_F16X2 tile's mix
+// (per 32 channels and accumulator two f16 MFMAs + one MX MFMA): 24 / 24 / 12 / 12 + 6 per step = the same 768 nominal cycles per wave
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 template <int KIND>
@@ -140,7 +142,10 @@ __global__ __launch_bounds__(512, 2) void mfma_kind_kernel(float* out, int iters
     for (int i = tid; i < LDS_BYTES / 4; i += 512) {
         unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
         const unsigned f16v = (h & 0x8fff8fffu) | 0x30003000u, bf16v = (h & 0x81ff81ffu) | 0x3e003e00u, f8v = (h & 0x8f8f8f8fu) | 0x30303030u;
-        reinterpret_cast<unsigned*>(lds)[i] = pattern ? (KIND == 0 ? f16v : KIND == 1 ? bf16v : f8v) : (KIND == 0 ? 0x3c003c00u : KIND == 1 ? 0x3f803f80u : 0x38383838u);
+        const int o = i * 4, chunk = o < 65536 ? (o % 8192) / 1024 : (o - 65536) / 1024;      // A: 8 chunks per wave (k = chunk / 2), B: 12 shared chunks (k = chunk / 3)
+        const int kk = o < 65536 ? chunk >> 1 : chunk / 3;
+        const int kind = KIND == 3 ? (kk < 2 ? 0 : 2) : KIND;
+        reinterpret_cast<unsigned*>(lds)[i] = pattern ? (kind == 0 ? f16v : kind == 1 ? bf16v : f8v) : (kind == 0 ? 0x3c003c00u : kind == 1 ? 0x3f803f80u : 0x38383838u);
     }
     __syncthreads();
     u32x4 af[4][2], bf[4][3];
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void mfma_kind_kernel(float* out, int iters
 #pragma unroll
         for (int i = 0; i < 2; ++i) af[k][i] = *reinterpret_cast<const u32x4*>(lds + wave * 8192 + (k * 2 + i) * 1024 + lane * 16);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) bf[k][j] = *reinterpret_cast<const u32x4*>(lds + 65536 + wave * 8192 + (k * 3 + j) * 1024 + lane * 16);
+        for (int j = 0; j < 3; ++j) bf[k][j] = *reinterpret_cast<const u32x4*>(lds + 65536 + (k * 3 + j) * 1024 + lane * 16);
     }
     f32x16 acc[2][3];
 #pragma unroll
@@ -161,12 +166,20 @@ __global__ __launch_bounds__(512, 2) void mfma_kind_kernel(float* out, int iters
     const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int k = 0; k < (KIND == 2 ? 2 : 4); ++k)
+        for (int k = 0; k < (KIND == 2 ? 2 : KIND == 3 ? 3 : 4); ++k)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    if constexpr (KIND == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[k][i]), __builtin_bit_cast(f16x8, bf[k][j]), acc[i][j], 0, 0, 0);
+                    if constexpr (KIND == 3) {
+                        if (k < 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[k][i]), __builtin_bit_cast(f16x8, bf[k][j]), acc[i][j], 0, 0, 0);
+                        else {
+                            const u32x4 a0 = af[2][i], a1 = af[3][i], b0 = bf[2][j], b1 = bf[3][j];
+                            const i32x8 va = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+                            const i32x8 vb = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+                            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, acc[i][j], 0, 0, 0, 118, 0, 127);
+                        }
+                    } else if constexpr (KIND == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[k][i]), __builtin_bit_cast(f16x8, bf[k][j]), acc[i][j], 0, 0, 0);
                     else if constexpr (KIND == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[k][i]), __builtin_bit_cast(bf16x8, bf[k][j]), acc[i][j], 0, 0, 0);
                     else {
                         const u32x4 a0 = af[2 * k][i], a1 = af[2 * k + 1][i], b0 = bf[2 * k][j], b1 = bf[2 * k + 1][j];
@@ -202,7 +215,8 @@ static double run_kind(int kind, float* out, int iters, int blocks, int pattern,
         const int n = rep ? iters : 10;
         if (kind == 0) hipLaunchKernelGGL((mfma_kind_kernel<0>), dim3(blocks), dim3(512), 0, 0, out, n, pattern);
         else if (kind == 1) hipLaunchKernelGGL((mfma_kind_kernel<1>), dim3(blocks), dim3(512), 0, 0, out, n, pattern);
-        else hipLaunchKernelGGL((mfma_kind_kernel<2>), dim3(blocks), dim3(512), 0, 0, out, n, pattern);
+        else if (kind == 2) hipLaunchKernelGGL((mfma_kind_kernel<2>), dim3(blocks), dim3(512), 0, 0, out, n, pattern);
+        else hipLaunchKernelGGL((mfma_kind_kernel<3>), dim3(blocks), dim3(512), 0, 0, out, n, pattern);
         hipDeviceSynchronize();
     }
     hipEventRecord(e1, 0);
@@ -232,12 +246,38 @@ static double run(float* out, int iters, int blocks) {
     return (double)ms * 1e6 / iters;      // ns per K step (one workgroup per CU, one round of workgroups)
 }
 
-int main() {
+// TFLOP/s of a step time: 8 waves x 24 MFMAs x 32 x 32 x 16 MACs per step and CU (KIND 3: the same count in f16 pass equivalents)
+static double tflops(double ns, int cus) { return (double)cus * 8 * 24 * 32768.0 / (ns * 1e-9) * 1e-12; }
+
+int main(int argc, char** argv) {
     float* out = nullptr;
     hipMalloc((void**)&out, 64);
     int dev = 0, cus = 0, khz = 0;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev);
+    if (argc > 1 && !strcmp(argv[1], "--json")) {
+        // bench.py's "power_ceiling" record: what this board delivers, now, on operands that toggle -- MFMAs from registers per instruction mix, and the
+        // ping-pong skeleton (fragment reads + 20 VALU + 20 SALU + 4 DMA pieces under the other group's MFMAs); ~30 ms per measurement
+        unsigned char* src = nullptr;
+        hipMalloc((void**)&src, 1 << 20);
+        hipMemset(src, 0, 1 << 20);
+        g_src = src;
+        g_pattern = 1;
+        const int n = 30000;
+        double mhz[4] = {0, 0, 0, 0}, t[4];
+        t[0] = run_kind(0, out, n, cus, 1, mhz[0]);
+        t[1] = run_kind(1, out, n, cus, 1, mhz[1]);
+        t[2] = run_kind(3, out, n, cus, 1, mhz[2]);
+        t[3] = run<1, true, true, false, 20, 20, 4>(out, n, cus); mhz[3] = g_mhz;
+        double mhz0 = 0.0;
+        const double t0 = run_kind(0, out, n, cus, 0, mhz0);
+        printf("{\"cus\": %d, \"nominal_mhz\": %d, \"operands\": \"random sign and mantissa, 4 exponents\", "
+               "\"mfma_from_registers\": {\"f16\": {\"tflops\": %.0f, \"sclk_mhz\": %.0f}, \"bf16\": {\"tflops\": %.0f, \"sclk_mhz\": %.0f}, "
+               "\"f16x2\": {\"tflops\": %.0f, \"sclk_mhz\": %.0f}, \"f16_constant_operands\": {\"tflops\": %.0f, \"sclk_mhz\": %.0f}}, "
+               "\"pingpong_skeleton_f16\": {\"tflops\": %.0f, \"sclk_mhz\": %.0f}}\n",
+               cus, khz / 1000, tflops(t[0], cus), mhz[0], tflops(t[1], cus), mhz[1], tflops(t[2], cus), mhz[2], tflops(t0, cus), mhz0, tflops(t[3], cus), mhz[3]);
+        return 0;
+    }
     const int iters = 4000;
     printf("%d CUs, %d MHz nominal; one workgroup of 8 waves per CU, %d K steps; ns per K step (and cycles at the nominal clock)\n", cus, khz / 1000, iters);
     printf("ideal: 24 MFMAs x 32 cycles x 2 waves per SIMD = 1536 cycles of MFMA per step; 160 ds_read_b128 = 160 KiB = 1280 cycles of LDS at 128 B/clk\n");
@@ -286,12 +326,12 @@ int main() {
                "no MFMAs %7.1f ns at %4.0f MHz\n", pat ? "random (sign, mantissa, 4 exponents)" : "all 1.0", m, fm, b, fb, r, fr);
     }
     // ---- MFMAs only, operands in registers: the price of each matrix instruction in clock
-    const char* kinds[3] = {"32x32x16 f16", "32x32x16 bf16", "32x32x64 MX e4m3"};
-    for (int kind = 0; kind < 3; ++kind)
+    const char* kinds[4] = {"32x32x16 f16", "32x32x16 bf16", "32x32x64 MX e4m3", "f16x2 mix 2 + 1"};
+    for (int kind = 0; kind < 4; ++kind)
         for (int pat = 0; pat < 2; ++pat) {
             double mhz = 0.0;
             const double t = run_kind(kind, out, 40000, cus, pat, mhz);
-            const double tf = (double)cus * 8 * 24 * 32768.0 * 2 / 2 / (t * 1e-9) * 1e-12;      // 8 waves x 24 x (32 x 32 x 16 MACs) per step and CU
+            const double tf = tflops(t, cus);
             printf("MFMAs only, %-17s operands %-8s: %7.1f ns per step at %4.0f MHz = %6.0f TFLOP/s dense (nominal peak %s)\n", kinds[kind], pat ? "random" : "constant", t,
                    mhz, tf * (kind == 2 ? 2.0 : 1.0), kind == 2 ? "5000" : "2500");
         }
