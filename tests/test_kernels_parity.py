@@ -9,6 +9,7 @@ Tolerances: f32 compute 1e-4 relative to max|ref| on scores and U-Net outputs (n
 relative), observed ~1e-6; bf16 compute/storage is a throughput configuration with
 no reference counterpart: bounded loosely and checked on arg-top indices.
 """
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -475,8 +476,10 @@ def test_encoder_golden_gpu(gpu, golden, cdt, tol):
 
 @pytest.mark.gpu
 def test_f16x2_is_bf16x3_outside_the_unet(gpu, golden):
-    """NOPE_F16X2 changes the tap-resident 3x3 launches of the default U-Net only: the template encoder and the LDM variant accept the mode and
-    compute exactly what they compute as bf16x3 (include/nope_hip.h); a default U-Net too small to reach the tap-resident kernel likewise."""
+    """NOPE_F16X2 changes the ping-pong launches (tap-resident 3x3, per-tap 1x1 / up / down) of the default U-Net only: the template encoder and
+    the LDM variant accept the mode and compute exactly what they compute as bf16x3 (include/nope_hip.h); so does a default U-Net none of
+    whose launches lands on a ping-pong kernel (a tiny one reaches the tap-resident kernel through its split-K form only: switched off here;
+    with it the two modes agree to the mode's tolerance, not bit for bit)."""
     from nope_amd.u_net import UNet
     from nope_amd.weights import synth_init_
     from tests.test_oracle_golden import build_ldm
@@ -488,13 +491,22 @@ def test_f16x2_is_bf16x3_outside_the_unet(gpu, golden):
     x, pose = gl["m32/x"].cuda(), gl["m32/pose"].cuda()
     ya, yb = build_ldm("m32", "f16x2").cuda()(x, pose), build_ldm("m32", "bf16x3").cuda()(x, pose)
     assert torch.equal(ya, yb) and rel(ya.cpu(), gl["m32/out"]) < X3_TOL
-    outs = []
-    for cdt in ("f16x2", "bf16x3"):
-        u = UNet(u_net_dim=32, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype=cdt)
-        synth_init_(u, 2022)
-        gq = torch.Generator().manual_seed(5)
-        outs.append(u.cuda().forward_hypotheses(torch.randn(1, 8, 8, 8, generator=gq).cuda(), torch.randn(1, 3, 6, generator=gq).cuda()))
-    assert torch.equal(outs[0], outs[1])
+    for split in ("0", None):
+        outs = []
+        if split is not None:
+            os.environ["NOPE_HALO_SPLIT"] = split
+        try:
+            for cdt in ("f16x2", "bf16x3"):
+                u = UNet(u_net_dim=32, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype=cdt)
+                synth_init_(u, 2022)
+                gq = torch.Generator().manual_seed(5)
+                outs.append(u.cuda().forward_hypotheses(torch.randn(1, 8, 8, 8, generator=gq).cuda(), torch.randn(1, 3, 6, generator=gq).cuda()))
+        finally:
+            os.environ.pop("NOPE_HALO_SPLIT", None)
+        if split == "0":
+            assert torch.equal(outs[0], outs[1])
+        else:
+            assert rel(outs[0].cpu(), outs[1].cpu()) < X3_TOL
 
 
 @pytest.mark.parametrize("dt", [0, 1])
