@@ -11,8 +11,8 @@ issued as ONE call, PoseConditional.generate_and_retrieve (same values; the quer
 stream underneath the reference encoder and the first U-Net kernels); --two-calls times the literal two-call sequence.
 Workload: BASELINE.json configs[1] -- one 256x256 query against 512 viewpoint templates.  north_star asks for scores "within 1e-4 ... and
 bit-exact on the argmax pose index" of the reference's fp32 path, so the TIMED mode is the fastest one that delivers that: `f16x2` (f32
-storage; the tap-resident 3x3 convolutions = 9/10 of the work as one f16 MFMA pass + one MX-scaled fp8 MFMA pass for both cross terms of a
-hi / lo operand split, every other launch as bf16x3; ~1e-5 on the scores, top-5 bit-exact).  configs[1] names bf16: that mode, literally,
+storage; the convolutions of the ping-pong kernels -- the tap-resident 3x3 ones = 9/10 of the work, the per-tap 1x1 / up / down ones -- as one f16
+MFMA pass + one MX-scaled fp8 MFMA pass for both cross terms of a hi / lo operand split, every other launch as bf16x3; ~1e-5 on the scores, top-5 bit-exact).  configs[1] names bf16: that mode, literally,
 is timed next to it and reported at top level (`configs1_as_literally_stated`: ~2x faster, but its score error, 4.6e-3 of the score
 scale, is LARGER than this step's gap between the best and the second-best template -- `top1_margin` 0.65: the best template survives
 by luck); so is f16 (`value_f16_argmax_exact`: 16-bit storage + f16 MFMA, 8e-4, margin 3.6 -- the arg-max-exact throughput mode).  All
@@ -184,7 +184,7 @@ def scoring_roofline(dtype: torch.dtype, N: int = 0):
             "hyp_per_s": B * N / med * 1e3}
 
 
-# dense MFMA peak of the instruction each mode issues.  f16x2: its tap-resident launches count 2 pass equivalents per product against the
+# dense MFMA peak of the instruction each mode issues.  f16x2: its ping-pong launches count 2 pass equivalents per product against the
 # f16 peak (one f16 pass + one fp8 pass of twice the K at twice the rate = the same time as a second f16 pass); its other launches are bf16x3's.
 PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f16x2": 2500.0, "f32": 157.3}
 
@@ -340,7 +340,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="f16x2", choices=["f16x2", "f16", "bf16", "bf16x3", "f32"],
-                    help="compute mode.  f16x2 (default): f32 storage, the tap-resident 3x3 convs as one f16 + one MX-fp8 MFMA pass, the rest as bf16x3 -- "
+                    help="compute mode.  f16x2 (default): f32 storage, the convs of the ping-pong kernels (tap-resident 3x3, per-tap 1x1 / up / down) as one f16 + one MX-fp8 MFMA pass, the rest as bf16x3 -- "
                          "the fastest mode inside north_star's 1e-4 score tolerance.  f16 and bf16 (what BASELINE configs[1] names): 16-bit storage + "
                          "16-bit MFMA, ~2x faster, outside the tolerance (8e-4 / 4.6e-3); f16's error stays below the top-1 / top-2 gap of the "
                          "benchmarked step (top1_margin 3.6), bf16's does not (0.65).  bf16x3: f32 storage, three bf16 MFMA passes.  f32: exact-f32 "

@@ -33,13 +33,15 @@ enum { NOPE_F32 = 0, NOPE_BF16 = 1,
        NOPE_BF16X3 = 3,/* compute mode only: f32 storage, every conv / linear as three bf16 MFMA passes over (hi, lo) bf16 splits of
                           both operands (hi*hi + hi*lo + lo*hi, f32 accumulate): ~2^-17 relative per product instead of bf16's 2^-9
                           at 3/16 of the exact-f32 MFMA cost -- meets the 1e-4 score tolerance */
-       NOPE_F16X2 = 4  /* compute mode only: NOPE_BF16X3 (f32 storage, same kernels) except that the 3x3 convolutions the tap-resident kernel
-                          runs -- 9/10 of the U-Net's work -- cost TWO pass equivalents instead of three: a_hi w_hi on the f16 MFMA
+       NOPE_F16X2 = 4  /* compute mode only: NOPE_BF16X3 (f32 storage, same kernels) except that the convolutions the ping-pong kernels run --
+                          the tap-resident 3x3 kernel, 9/10 of the U-Net's work, and the per-tap kernel's long 1x1 / space-to-depth / phase
+                          convs -- cost TWO pass equivalents instead of three: a_hi w_hi on the f16 MFMA
                           (hi = f16 part) plus ONE MX-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, twice the f16 rate) for both
                           cross terms, K-concatenated: [e4m3(a_lo) | e4m3(a)] x [e4m3(w) ; e4m3(w_lo)], power-of-two pre-scales undone by
                           the instruction's block scale.  The cross terms carry <= 2^-11 of the result, so 4-bit operands leave ~2^-15
                           per product -- the fast mode that meets the 1e-4 score tolerance.  As an element type of nope_op_conv /
-                          nope_op_pack_conv_weight it names that kernel and its weight layout (3x3, stride 1, Cin % 32 == 0 only);
+                          nope_op_pack_conv_weight it names those kernels and their weight layout (modes PLAIN 1x1 / 3x3, DOWN2, UP2P;
+                          Cin % 32 == 0; nope_op_conv refuses a launch whose shape no ping-pong kernel takes);
                           |activation| <= 65504 (the f16 part saturates) */ };
 /* Tap geometries of nope_op_conv.  UP2P is UP2 (nearest-x2 upsample + 3x3, pad 1) rewritten as four
  * 2x2 convolutions over the un-upsampled input, one per output-pixel parity, with the 3x3 weights that
@@ -221,7 +223,7 @@ typedef struct {
     int pose_dim;           /* rot_representation_dim, 6 */
     int pose_mlp_layers;    /* 1 = "single_layer", 2 = "two_layers" */
     int injecting_condition_twice;   /* 0: timestep embedding is zeros; 1: emb = pose_mlp_timesteps(pose) */
-    int compute_dtype;      /* NOPE_F32 | NOPE_BF16 | NOPE_F16 | NOPE_BF16X3 | NOPE_F16X2 (= NOPE_BF16X3 here: no tap-resident launches), as nope_unet_config */
+    int compute_dtype;      /* NOPE_F32 | NOPE_BF16 | NOPE_F16 | NOPE_BF16X3 | NOPE_F16X2 (= NOPE_BF16X3 here: its layers carry no second weight pack), as nope_unet_config */
     int use_scale_shift_norm;        /* 1: ResBlocks apply out_norm(h) * (1 + scale) + shift with (scale, shift) = emb_layers(emb) */
     int transformer_depth;           /* BasicTransformerBlocks per SpatialTransformer (attention.py:232-262); 1 in vae_cin_ldm.yaml; 0 reads as 1 */
 } nope_ldm_config;
@@ -242,7 +244,7 @@ int nope_ldm_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, 
 typedef struct nope_encoder nope_encoder;
 typedef struct {
     int descriptor_size;   /* 8 (configs/model/template_base.yaml:10) */
-    int compute_dtype;     /* NOPE_F32 | NOPE_BF16 | NOPE_F16 | NOPE_BF16X3 | NOPE_F16X2 (= NOPE_BF16X3 here: no tap-resident launches), as nope_unet_config */
+    int compute_dtype;     /* NOPE_F32 | NOPE_BF16 | NOPE_F16 | NOPE_BF16X3 | NOPE_F16X2 (= NOPE_BF16X3 here: its layers carry no second weight pack), as nope_unet_config */
     float bn_eps;          /* BatchNorm2d eps; <= 0 selects the torch default 1e-5 */
 } nope_encoder_config;
 

@@ -13,7 +13,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3      # BF16X3: compute mode only (f32 storage, three bf16 MFMA passes per product)
-F16X2 = 4                                # compute mode only: BF16X3, but the tap-resident 3x3 launches run one f16 + one MX-fp8 MFMA pass (include/nope_hip.h)
+F16X2 = 4                                # compute mode only: BF16X3, but the ping-pong launches (tap-resident 3x3, per-tap 1x1 / up / down) run one f16 + one MX-fp8 MFMA pass (include/nope_hip.h)
 ABI_VERSION = 5                          # NOPE_ABI_VERSION of include/nope_hip.h these ctypes structs mirror
 CONV_PLAIN, CONV_UP2, CONV_DOWN2, CONV_UP2P, CONV_STRIDE2 = 0, 1, 2, 3, 4
 
