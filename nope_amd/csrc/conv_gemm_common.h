@@ -68,7 +68,7 @@ struct ConvParams {
     int stat_rows;                     // 64 (every kernel), 16 / 32 (small-tile kernel only)
     const float* pn_ms; const float* pn_c0; const float* pn_c1;   // optional fused PreNorm (see ConvArgs)
     unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
-    const int* x2_scale;               // NOPE_F16X2 (tap-resident kernel only): the tail of the packed weights, [0] = E8M0 scale of the A operand
+    const int* x2_scale;               // NOPE_F16X2 (ping-pong kernels): the tail of the packed weights, [0] = E8M0 scale of the A operand
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;

@@ -463,7 +463,7 @@ int conv_splitk_factor(int dt, const ConvArgs& a) {
 }
 
 int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
-    if (dt == NOPE_F16X2) {      // as an element type (nope_op_conv): `w` is in the NOPE_F16X2 layout, which only the tap-resident kernel reads
+    if (dt == NOPE_F16X2) {      // as an element type (nope_op_conv): `w` is in the NOPE_F16X2 layout, which only the ping-pong kernels read
         if (a.w_x2) return NOPE_ERR_ARG;
         ConvArgs b = a;
         b.w_x2 = a.w; b.w = nullptr;

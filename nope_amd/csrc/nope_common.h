@@ -146,8 +146,8 @@ template <> struct Elt<f32s_t> {
     static __device__ __forceinline__ u32x4 pack(const float* o) { return Elt<float>::pack(o); }
 };
 
-// NOPE_F16X2: f32 activations as NOPE_BF16X3; the tag selects the tap-resident 3x3 kernel's f16 + MX-fp8 tile (Tile<f16x2_t>,
-// conv_gemm_common.h) and its weight layout (pack_conv_w_x2_kernel, kernels_misc.hip).  No other kernel is instantiated for it.
+// NOPE_F16X2: f32 activations as NOPE_BF16X3; the tag selects the ping-pong kernels' f16 + MX-fp8 tile (Tile<f16x2_t>, conv_gemm_common.h:
+// conv3x3_halo_kernel and conv_gemm_pp_kernel) and its weight layout (launch_pack_conv_w_x2, kernels_misc.hip).  No other kernel is instantiated for it.
 struct f16x2_t { float f; };
 template <> struct Elt<f16x2_t> {
     static constexpr int VEC = 4;
@@ -295,7 +295,7 @@ struct ConvArgs {
     int ntaps = 1;               // 1 or 9 (PLAIN, STRIDE2), 9 (UP2), 4 (DOWN2, UP2P)
     const void* w = nullptr;     // packed [Cout][ntaps][Cin]
     const void* w_x2 = nullptr;  // NOPE_BF16X3 launches only: the same weights in the NOPE_F16X2 layout (launch_pack_conv_w_x2) -- taken, with
-                                 // the f16 + MX-fp8 tile, when the launch goes to the tap-resident kernel; `w` (may be null then) otherwise
+                                 // the f16 + MX-fp8 tile, when the launch goes to a ping-pong kernel (conv_takes_x2); `w` (may be null then) otherwise
     const float* bias = nullptr; // [Cout] or null
     const void* resid = nullptr; // optional NHWC [M][Cout] added in the epilogue
     void* out = nullptr;
