@@ -513,3 +513,28 @@ def test_tuning_switches_are_cached_and_reloaded(emu, capfd):
         os.environ.pop("NOPE_CONV_TRACE", None)
         os.environ.pop("NOPE_CONV_PP", None)
         hip.lib().dll.nope_tuning_reload()
+
+
+def test_bench_power_ceiling_record(tmp_path, monkeypatch):
+    """bench.py's `roofline.power_ceiling`: the probe's JSON line + the kernel's fractions of it; None (not an exception) when the probe
+    is missing or cannot run (no GPU here)."""
+    import json
+    import stat
+    import bench
+    rf = {"achieved": 1000.0}
+    assert bench.power_ceiling(rf, "f16x2") is None or isinstance(bench.power_ceiling(rf, "f16x2"), dict)      # (the real probe: no device in this container)
+    fake_root = tmp_path / "repo"
+    (fake_root / "tools" / "probes").mkdir(parents=True)
+    monkeypatch.setattr(bench, "ROOT", str(fake_root))
+    assert bench.power_ceiling(rf, "f16x2") is None                                                            # no probe at all
+    rec = {"mfma_from_registers": {"f16": {"tflops": 1600, "sclk_mhz": 1600}, "bf16": {"tflops": 1800, "sclk_mhz": 1800},
+                                   "f16x2": {"tflops": 2000, "sclk_mhz": 1900}}, "pingpong_skeleton_f16": {"tflops": 1250, "sclk_mhz": 1500}}
+    exe = fake_root / "tools" / "probes" / "overlap_probe"
+    exe.write_text("#!/bin/sh\necho some banner\necho '" + json.dumps(rec) + "'\n")
+    exe.chmod(exe.stat().st_mode | stat.S_IEXEC)
+    out = bench.power_ceiling(rf, "f16x2")
+    assert out["instruction_mix"] == "f16x2" and abs(out["frac_of_registers_only"] - 0.5) < 1e-12 and abs(out["frac_of_skeleton_f16"] - 0.8) < 1e-12
+    assert bench.power_ceiling(rf, "bf16x3")["instruction_mix"] == "bf16"
+    assert "frac_of_registers_only" not in bench.power_ceiling(rf, "f32")                                      # exact-f32 MFMA: no such record
+    exe.write_text("#!/bin/sh\necho not json\n")
+    assert bench.power_ceiling(rf, "f16x2") is None
