@@ -30,11 +30,14 @@ templates); for N>1 every rank scores its slice, the (B, N/G) scores are all-gat
 
 Extra legs on rank 0 at N=1 (outside the timed region):
   roofline      the dominant kernel of the step, conv3x3_halo_kernel (the 3x3 convs: 45 of the U-Net's 83 implicit-GEMM launches,
-                ~half of the step): multiply-adds x2 its launches EXECUTE / their summed duration, measured with HIP events around
-                every launch on the launch stream, vs the 2.5 PFLOP/s dense bf16 / f16 peak; `family` = all implicit-GEMM
-                launches, `classes` = one line per launch shape; `power_ceiling` = what this board delivers under a dense MFMA
-                stream on toggling operands, measured by tools/probes/overlap_probe right after the timed region (the nominal
-                peak is reached on constant operands only: the shader clock drops from 2.4 to 1.5-1.8 GHz under real data);
+                ~two thirds of the step): `achieved` / `frac` (= `algorithmic_frac`) = multiply-adds x2 its launches EXECUTE, once per
+                product, / their summed duration (HIP events around every launch on the launch stream) vs the 2.5 PFLOP/s dense
+                f16 peak; `mfma_pipe_frac` = the same x the MFMA pass equivalents the mode spends per product (matrix-pipe occupancy);
+                `mfma_utilisation_reference_flops` = the reference graph's 35.05 GFLOP per hypothesis / whole step time / peak;
+                `family` = all implicit-GEMM launches, `classes` = one line per launch shape; `power_ceiling` = what this board
+                delivers under a dense MFMA stream on toggling operands, measured by tools/probes/overlap_probe right after the
+                timed region (the nominal peak is reached on constant operands only: the shader clock drops from 2.4 to
+                1.5-1.8 GHz under real data);
   parity        the same step in every compute mode against the f32 parity mode of this library (pinned to the reference at
                 1e-4 / bit-exact top-5 by tests/, spot-checked against the CPU oracle here): score error, top-5 / top-1
                 equality and throughput of bf16, f16, f16x2 and bf16x3 (the split-precision modes that hold the 1e-4 tolerance);
@@ -209,9 +212,9 @@ def power_ceiling(rf, dtype: str):
     if mix:
         reg = rec["mfma_from_registers"][mix]["tflops"]
         rec["instruction_mix"] = mix
-        rec["frac_of_registers_only"] = rf["achieved"] / reg if reg else None
+        rec["frac_of_registers_only"] = rf["achieved_pass_equivalents"] / reg if reg else None
         sk = rec["pingpong_skeleton_f16"]["tflops"]
-        rec["frac_of_skeleton_f16"] = rf["achieved"] / sk if sk else None
+        rec["frac_of_skeleton_f16"] = rf["achieved_pass_equivalents"] / sk if sk else None
     rec["source"] = "tools/probes/overlap_probe --json, run by bench.py after the timed region"
     return rec
 
@@ -238,7 +241,8 @@ def conv_roofline(model, step, dtype: str, dev, templates: int, size: int):
         ms = sum(r["ms"] for r in rows)
         fl = sum(r["flops"] * r["mfma_passes"] for r in rows)
         return {"launches": len(rows), "kernel_ms": ms, "mfma_flops": fl, "conv_flops": sum(r["flops"] for r in rows),
-                "algorithmic_bytes": sum(r["bytes"] for r in rows), "tflops": fl / ms / 1e9 if ms > 0 else 0.0}
+                "algorithmic_bytes": sum(r["bytes"] for r in rows), "tflops": fl / ms / 1e9 if ms > 0 else 0.0,
+                "alg_tflops": sum(r["flops"] for r in rows) / ms / 1e9 if ms > 0 else 0.0}
     by_kernel = {}
     for r in launches:
         by_kernel.setdefault(r["kernel"], []).append(r)
@@ -253,7 +257,7 @@ def conv_roofline(model, step, dtype: str, dev, templates: int, size: int):
         a = agg(rows)
         table.append({"kernel": key[0], "mode": key[1], "taps": key[2], "Cin": key[3], "Cout": key[4], "H": key[5], "W": key[6],
                       "n": key[7], "posmajor": key[8], "launches": a["launches"], "avg_ms": a["kernel_ms"] / a["launches"],
-                      "tflops": a["tflops"], "frac": a["tflops"] / peak})
+                      "tflops": a["alg_tflops"], "frac": a["alg_tflops"] / peak, "pipe_tflops": a["tflops"], "pipe_frac": a["tflops"] / peak})
     table.sort(key=lambda t: -t["avg_ms"] * t["launches"])
     # HBM traffic of the dominant kernel from rocprofv3 PMC passes over the same U-Net step (FETCH_SIZE / WRITE_SIZE in their own
     # runs, tools/gpu_pmc.sh); PMC cannot be read from inside the process, so the figure is loaded from the committed
@@ -266,16 +270,24 @@ def conv_roofline(model, step, dtype: str, dev, templates: int, size: int):
     except Exception:
         pass
     passes = by_kernel[dom][0]["mfma_passes"]
-    return {"bound": "mfma", "kernel": f"{dom}<{dtype}>", "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": d["tflops"] / peak,
+    return {"bound": "mfma", "kernel": f"{dom}<{dtype}>", "achieved": d["alg_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": d["alg_tflops"] / peak,
+            "algorithmic_frac": d["alg_tflops"] / peak,
+            "mfma_pipe_frac": d["tflops"] / peak, "achieved_pass_equivalents": d["tflops"], "mfma_passes_per_product": passes,
             "traffic": traffic, "algorithmic_bytes_per_launch": d["algorithmic_bytes"] / d["launches"], "launches_per_step": d["launches"],
-            "avg_launch_ms": d["kernel_ms"] / d["launches"], "kernel_ms_per_step": d["kernel_ms"], "flops_per_step": d["mfma_flops"],
+            "avg_launch_ms": d["kernel_ms"] / d["launches"], "kernel_ms_per_step": d["kernel_ms"], "flops_per_step": d["conv_flops"],
+            "flops_per_step_pass_equivalents": d["mfma_flops"],
             "family": {"kernels": sorted(by_kernel), "launches_per_step": fam["launches"], "kernel_ms_per_step": fam["kernel_ms"],
-                       "achieved": fam["tflops"], "frac": fam["tflops"] / peak, "flops_per_step": fam["mfma_flops"],
+                       "achieved": fam["alg_tflops"], "frac": fam["alg_tflops"] / peak, "mfma_pipe_frac": fam["tflops"] / peak,
+                       "flops_per_step": fam["conv_flops"], "flops_per_step_pass_equivalents": fam["mfma_flops"],
                        "algorithmic_bytes_per_launch": fam["algorithmic_bytes"] / fam["launches"]},
             "classes": table,
-            "note": "flops = multiply-adds x2 the launches execute (nearest-x2 convs run as four 2x2 phase convs = 4/9 of the reference "
-                    "MACs; position-major launches skip padding taps)" + (f" x {passes} MFMA pass equivalents per product ({dtype})" if passes > 1 else "") +
-                    "; time = HIP events around each launch on the launch stream, per-launch median of three profiled steps; achieved / frac are the dominant kernel's own"}
+            "note": "THREE fractions, all against the dense 16-bit MFMA peak: `frac` = `algorithmic_frac` = the multiply-adds x2 the dominant kernel's "
+                    "launches execute, counted ONCE per product, / their summed duration / peak (nearest-x2 convs run as four 2x2 phase convs = 4/9 of "
+                    "the reference MACs; position-major launches skip padding taps); `mfma_pipe_frac` = the same products x the MFMA pass "
+                    f"equivalents the mode issues per product ({passes} for {dtype}: the extra passes buy accuracy, not work) = how busy the matrix "
+                    "pipe is; `mfma_utilisation_reference_flops` (set by main) = SURVEY 8(d)'s definition for the WHOLE step: the reference graph's "
+                    "35.05 GFLOP per hypothesis x hypotheses / step time / peak.  Time = HIP events around each launch on the launch stream, "
+                    "per-launch median of three profiled steps"}
 
 
 def parity_record(a, dev, batch, bench_model, bench_sim, bench_idx, bench_ms, spot_out):
@@ -314,7 +326,7 @@ def parity_record(a, dev, batch, bench_model, bench_sim, bench_idx, bench_ms, sp
             sim, idx, _, ms = run(m, 3)
             # the dominant kernel's MFMA fraction in this mode too (same HIP-event measurement as `roofline`)
             rf = conv_roofline(m, lambda: m.generate_and_retrieve(query, reference, poses), mode, dev, a.templates, a.size)
-            kernel_frac[mode] = {"kernel": rf["kernel"], "frac": rf["frac"], "family_frac": rf["family"]["frac"]}
+            kernel_frac[mode] = {"kernel": rf["kernel"], "frac": rf["frac"], "mfma_pipe_frac": rf["mfma_pipe_frac"], "family_frac": rf["family"]["frac"]}
             del m
             torch.cuda.empty_cache()
         rec["modes"][mode] = {"score_rel_err": float((sim - sim32).abs().max()) / scale, "top5_equal": bool(torch.equal(idx, idx32)),
@@ -378,6 +390,12 @@ def main():
                 os.close(saved)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # RCCL builds its communicator (rings, xGMI peer mappings) lazily at the first collective: do that here, untimed, with the very
+            # collective a sharded step issues, so that a run with --warmup 0 does not time the initialisation
+            warm_send = torch.zeros((a.batch, 8), dtype=torch.float32, device=dev)
+            warm_recv = torch.empty((world * a.batch, 8), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(warm_recv, warm_send)
+            torch.cuda.synchronize()
 
     from nope_amd.harness import build_model, synthetic_batch
     if a.scoring_only:
@@ -461,10 +479,14 @@ def main():
         torch.cuda.empty_cache()
         res["scaling_lines"] = lines
     extras = set() if a.skip_extras else {e for e in a.extras.split(",") if e and e != "scaling"}
+    def ref_flops_frac(rf):
+        # the reference graph's multiply-adds x2 per hypothesis at a 32x32 latent (35.05 GFLOP) x hypotheses / step / peak
+        rf["mfma_utilisation_reference_flops"] = 35.05e9 * (a.size / 256.0) ** 2 * main_case["hyp"] / (main_case["ms_per_step"] * 1e-3) / (rf["peak"] * 1e12)
+        return rf
     if rank == 0 and world == 1 and extras == {"roofline"}:      # tuning runs: only the per-launch table
-        res["roofline"] = conv_roofline(model, step, a.dtype, dev, n_total, a.size)
+        res["roofline"] = ref_flops_frac(conv_roofline(model, step, a.dtype, dev, n_total, a.size))
     elif rank == 0 and world == 1 and extras:
-        res["roofline"] = conv_roofline(model, step, a.dtype, dev, n_total, a.size)
+        res["roofline"] = ref_flops_frac(conv_roofline(model, step, a.dtype, dev, n_total, a.size))
         res["roofline"]["power_ceiling"] = power_ceiling(res["roofline"], a.dtype)
         spot = {}
         a.templates = n_total

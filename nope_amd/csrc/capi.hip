@@ -12,16 +12,16 @@ namespace nope {
 static std::atomic<unsigned> g_tuning_gen{0};
 static std::mutex g_env_mu;
 unsigned tuning_generation() { return g_tuning_gen.load(std::memory_order_acquire); }
-int env_lookup(EnvCache& c, const char* name) {
+EnvVal env_lookup(EnvCache& c, const char* name) {
     const unsigned g = tuning_generation();
-    if (c.gen != g) {                                  // first use of this site, or a reload since: read the variable (rare path, serialised)
+    if (c.gen.load(std::memory_order_acquire) != g) {  // first use of this site, or a reload since: read the variable (rare path, serialised)
         std::lock_guard<std::mutex> lock(g_env_mu);
         const char* v = getenv(name);
-        c.set = v != nullptr;
-        c.val = v ? atoi(v) : 0;
-        c.gen = g;
+        c.set.store(v != nullptr, std::memory_order_relaxed);
+        c.val.store(v ? atoll(v) : 0, std::memory_order_relaxed);
+        c.gen.store(g, std::memory_order_release);
     }
-    return c.val;
+    return EnvVal{c.set.load(std::memory_order_relaxed), c.val.load(std::memory_order_relaxed)};
 }
 }  // namespace nope
 

@@ -335,7 +335,7 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     // (read per launch: the tests toggle it.  f32 -- the parity mode -- stays on the 128 x 192 kernel unless asked: its MFMA phase is
     //  16x longer per K step, loads were never its bound, and two workgroups per CU beat one: 126 vs 135 ms per 512-template step)
     const int pp_mode = NOPE_ENV("NOPE_CONV_PP", (dt != NOPE_F32 ? 3 : 0));
-    static const int variant = NOPE_ENV("NOPE_CONV_VARIANT", 0);
+    const int variant = NOPE_ENV("NOPE_CONV_VARIANT", 0);
     ConvPlan pl{false, false, false, false, -1, 1};
     const int vec = dt_vec(dt), es = dt_es(dt), bk = 8 * vec;
     const int Cin = a.C1 + a.C2;
@@ -364,7 +364,7 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     // (long 3x3 launches take the tap-resident kernel from 128 tiles on -- NOPE_HALO_MIN_TILES: the 768 -> 768 convs of the 4 x 4
     //  level at 512 hypotheses have 128 tiles of 108 K steps; on half the CUs they still beat the position-major 128 x 192 launch,
     //  one workgroup per CU: 20.26 -> 20.19 ms per step, profiles/r03d_defaults_ab.txt)
-    static const int halo_min_tiles = NOPE_ENV("NOPE_HALO_MIN_TILES", 128);
+    const int halo_min_tiles = NOPE_ENV("NOPE_HALO_MIN_TILES", 128);
     const long long min_tiles = (a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.ntaps * (Cin / bk) >= 54) ? halo_min_tiles : 256;
     const bool pp_shape = (a.mode == NOPE_CONV_PLAIN || a.mode == NOPE_CONV_DOWN2 || phased) && !a.out_nchw && a.Cout % vec == 0 &&
                           ((pp_mode & 8) || a.ntaps * (Cin / bk) >= 12) &&
@@ -385,7 +385,7 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
 // ConvArgs::geglu: 16-bit storage, a plain 1x1 conv on the 128 x 192 LDS-DMA kernel's packed wide epilogue (no residual / statistics / PreNorm /
 // activation / split), column pairs whole inside a lane's 8-column chunk and 8-byte output rows
 static bool geglu_shape_ok(int dt, const ConvArgs& a, const ConvPlan& pl) {
-    static const int variant = NOPE_ENV("NOPE_CONV_VARIANT", 0);
+    const int variant = NOPE_ENV("NOPE_CONV_VARIANT", 0);
     return dt_es(dt) == 2 && a.mode == NOPE_CONV_PLAIN && a.ntaps == 1 && !a.resid && !a.colstats && !a.pn_ms && !a.out_nchw && !a.act && !a.splitk_ws &&
            a.Cout % 16 == 0 && pl.dma && !pl.pp && pl.small < 0 && !pl.posmajor && variant == 0;
 }
@@ -530,7 +530,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     p.bytes1 = (unsigned)(dma ? b1 : 0); p.bytes2 = (unsigned)(dma ? b2 : 0); p.bytesw = (unsigned)(dma ? bw : 0);
     // NOPE_CONV_VARIANT=4 selects the 256x192 / 8-wave tile (measured on par with the default 128x192 / 4-wave
     // tile in round 1; kept for tuning, see DESIGN.md section 4 for the other variants that were tried).
-    static const int variant = NOPE_ENV("NOPE_CONV_VARIANT", 0);
+    const int variant = NOPE_ENV("NOPE_CONV_VARIANT", 0);
     p.variant = variant;
     p.d_hw = make_fastdiv((unsigned)(p.Hm * p.Wm)); p.d_w = make_fastdiv((unsigned)p.Wm);
     p.d_rep1 = make_fastdiv((unsigned)p.rep1); p.d_rep2 = make_fastdiv((unsigned)p.rep2);
@@ -600,7 +600,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     unsigned gx = (unsigned)nblocks;
     {
         const long long hw = (long long)a.Hs * a.Ws;
-        static const int persist_on = NOPE_ENV("NOPE_CONV_PERSIST", 1);
+        const int persist_on = NOPE_ENV("NOPE_CONV_PERSIST", 1);
         const int span = p.xcd_map == 2 ? tn / p.xcd_gn : 1;
         if (persist_on && dma && plan.small < 0 && bm == BM && dt != NOPE_F32 && a.mode == NOPE_CONV_PLAIN && !p.posmajor && p.splits == 1 && p.xcd_map && p.xcd_map != 4 &&
             p.wide_out && a.rep1 == 1 && a.rep2 == 1 && M % BM == 0 && nblocks > 512 && nblocks % 512 == 0 && 64 % span == 0 &&

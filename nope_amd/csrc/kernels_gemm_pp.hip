@@ -70,7 +70,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];     // the ONLY LDS object (cdna_hip_programming.md, section 5 trap (a))
 
     const int tid = threadIdx.x;
-    const int variant = TUNE ? variant : 0;
+    const int variant = TUNE ? p.variant : 0;
     if (variant & 128) { if (tid == 9999) lds[0] = 1; return; }   // tuning only (NOPE_PP_VARIANT): launch cost of the grid
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

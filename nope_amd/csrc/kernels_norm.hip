@@ -362,14 +362,14 @@ int gn_apply_blocks(int HW, int C, int dt, int nhyp) {
     // Streaming bytes per workgroup.  Every workgroup first rebuilds (mean, rstd) and its per-channel coefficients (a barrier and
     // ~25 dependent loads): at 32 KiB that set-up was a third of a workgroup's instructions; 16 / 32 / 64 / 128 KiB measured
     // 198 / 143 / 124 / 121 us per statistics + apply pass over 512 x 32 x 32 x 192 f16 (profiles/r03k_gn_apply_ab.txt).
-    static const int block_kb = NOPE_ENV("NOPE_GN_BLOCK_KB", 64);
+    const int block_kb = NOPE_ENV("NOPE_GN_BLOCK_KB", 64);
     const size_t bytes = (size_t)HW * C * dt_es(dt);
     int bph = (int)(bytes / ((size_t)(block_kb > 0 ? block_kb : 64) * 1024));
     if (bph < 1) bph = 1;
     // Small batches (the reference's 26 / 91-template banks, a 64-template shard): one 64 KiB workgroup per sample leaves 64 workgroups
     // on 256 CUs, each streaming its sample serially (11 us for a 3 MB tensor): spread a sample over more workgroups until the grid
     // has ~512 of them, at least 8 pixels each.  NOPE_GN_MIN_GRID=0 keeps the byte rule alone.
-    static const int min_grid = NOPE_ENV("NOPE_GN_MIN_GRID", 1024);
+    const int min_grid = NOPE_ENV("NOPE_GN_MIN_GRID", 1024);
     if (nhyp > 0 && (long long)nhyp * bph < min_grid) {
         // (a thread walks its pixels serially, two loads in flight: on a 16-pixel map with 1536 channels one workgroup per sample is eight
         //  dependent memory round trips -- 17 us for 3 MB, profiles/r04d -- so: down to one round trip per thread)

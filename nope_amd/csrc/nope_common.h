@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <atomic>
 #include <cstdint>
 
 #include "../../include/nope_hip.h"
@@ -267,13 +268,19 @@ template <bool FAST> __device__ __forceinline__ float silu_f(float x) {
 // Read ONCE per call site and cached: a launch does not walk the environment (a conv launch consulted ~40 variables).  nope_tuning_reload()
 // (C ABI) starts a new generation, after which every site reads its variable again -- nope_amd/hip.py calls it whenever it sees a NOPE_*
 // variable change between two calls into the library, so in-process A/B sweeps and the tests that flip a switch keep working; a C caller
-// that changes the environment after the first launch calls it itself.  NOPE_ENV(name, default) -> int (atoi of the value, or the default
-// when unset); NOPE_ENV_SET(name) -> bool (is it set at all).
+// that changes the environment after the first launch calls it itself.  NOPE_ENV(name, default) -> int (the value, or the default
+// when unset); NOPE_ENV_LL -> long long (byte thresholds); NOPE_ENV_SET(name) -> bool (is it set at all).  No site wraps a lookup in a
+// `static const`: every one of them follows a reload.
 unsigned tuning_generation();                          // capi.hip
-struct EnvCache { unsigned gen = 0xffffffffu; bool set = false; int val = 0; };
-int env_lookup(EnvCache& c, const char* name);         // refreshes c when the generation moved; returns c.val (0 when unset)
-#define NOPE_ENV(name, def) ({ static ::nope::EnvCache nope_env_c__; const int nope_env_v__ = ::nope::env_lookup(nope_env_c__, name); nope_env_c__.set ? nope_env_v__ : (def); })
-#define NOPE_ENV_SET(name) ({ static ::nope::EnvCache nope_env_c__; ::nope::env_lookup(nope_env_c__, name); nope_env_c__.set; })
+// One cache per call site.  Every field is an atomic: a site may be refreshed by one host thread (under capi.hip's mutex) while another
+// reads it; `gen` is published with release order AFTER val / set, and read with acquire order BEFORE them, so a reader that sees the
+// current generation sees that generation's (or a newer one's) value -- never a torn or stale one.
+struct EnvCache { std::atomic<unsigned> gen{0xffffffffu}; std::atomic<bool> set{false}; std::atomic<long long> val{0}; };
+struct EnvVal { bool set; long long val; };
+EnvVal env_lookup(EnvCache& c, const char* name);      // refreshes c when the generation moved; {is it set, atoll of its value (0 when unset)}
+#define NOPE_ENV(name, def) ({ static ::nope::EnvCache nope_env_c__; const ::nope::EnvVal nope_env_v__ = ::nope::env_lookup(nope_env_c__, name); nope_env_v__.set ? (int)nope_env_v__.val : (def); })
+#define NOPE_ENV_LL(name, def) ({ static ::nope::EnvCache nope_env_c__; const ::nope::EnvVal nope_env_v__ = ::nope::env_lookup(nope_env_c__, name); nope_env_v__.set ? nope_env_v__.val : (long long)(def); })
+#define NOPE_ENV_SET(name) ({ static ::nope::EnvCache nope_env_c__; ::nope::env_lookup(nope_env_c__, name).set; })
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

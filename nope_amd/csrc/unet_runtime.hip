@@ -287,7 +287,7 @@ struct Fwd {
             // separate fold launch costs ~7 us + a kernel boundary).  Round 2 measured the inline fold +0.25 ms per 512-hypothesis step
             // (one thread per group then); with the wave-wide group sums of round 4 it is -0.02 .. -0.05 ms there and -0.2 ms at 64
             // hypotheses (profiles/r04o_fold_inline_ab.txt): always on.  NOPE_GN_FOLD_INLINE = most re-read bytes per launch (0 = never).
-            const long long fold_inline_max = NOPE_ENV_SET("NOPE_GN_FOLD_INLINE") ? (long long)NOPE_ENV("NOPE_GN_FOLD_INLINE", 0) : (1ll << 50);
+            const long long fold_inline_max = NOPE_ENV_LL("NOPE_GN_FOLD_INLINE", 1ll << 50);
             const long long refold = (long long)nhyp * gn_apply_blocks(HW, nm.C, net->sdt, nhyp) * st.blocks * nm.C * 8;
             if (refold <= fold_inline_max) { ga.colstats = st.cs; ga.stat_blocks = st.blocks; }
             else chk(launch_gn_fold(st.cs, gn_partial, nx, st.blocks, nm.C, G, s));

@@ -203,7 +203,7 @@ def test_whole_configs_3_and_4_eight_ranks(gpu, n_total, cdt, bank_dtype):
     assert torch.equal(r0["sim"], r0["sim1"]) and torch.equal(r0["idx"], r0["idx1"])                       # (i)
     print(f"{n_total} templates x 32 queries over 8 ranks ({cdt} compute, {bank_dtype} bank): oracle spot check on {r0['oracle_pairs']}: "
           f"score rel err {r0['oracle_err']:.3e}")
-    assert r0["oracle_err"] < (5e-2 if cdt == "bf16" else 8e-3)                                            # (ii)
+    assert r0["oracle_err"] < 2 * MODE_BOUNDS[cdt][1]          # (ii) per-score relative error: 2 x the mode's bound (observed 4.6e-3 bf16 / 6.6e-4 f16)
     assert bool((r0["idx"][:, 0] == plant).all()) and bool((r0["sim"][:, plant] == 0).all())               # (iii)
     assert bool(torch.signbit(r0["sim"][:, plant]).all())                                                  # ... exactly -0.0
     assert bool(torch.isfinite(r0["sim"]).all())

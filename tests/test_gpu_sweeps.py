@@ -96,6 +96,62 @@ def test_conv_random_sweep(gpu, dt):
     print(f"conv sweep dtype {dt}: worst rel err {worst:.2e}")
 
 
+def test_conv_random_sweep_f16x2(gpu):
+    """dtype 4 (NOPE_F16X2: f32 storage, one f16 + one MX-fp8 MFMA pass) exists on the ping-pong kernels only, so its sweep draws
+    from the shapes they take -- 3x3 (tap-resident, whole and split along K), 1x1, space-to-depth and the four phase convs of an
+    up-sampling (per-tap), one or two sources, a broadcast second source, bias / residual / ReLU, ragged tile edges in M and Cout --
+    forced onto them at any tile count (NOPE_CONV_PP=11, what smoke() does), against torch's float64 convolution of the same f32
+    operands.  Bound: 3e-5 (the hi x hi f16 product is exact in f32, the cross terms carry 2^-11 x e4m3's 2^-4)."""
+    hip = gpu
+    rng = random.Random(4321)
+    g = torch.Generator(device="cuda").manual_seed(103)
+    rn = lambda *s: torch.randn(*s, generator=g, device="cuda")
+    dt = hip.F16X2
+    worst = 0.0
+    os.environ["NOPE_CONV_PP"] = "11"
+    try:
+        for it in range(60):
+            mode = rng.choice([hip.CONV_PLAIN] * 5 + [hip.CONV_UP2P, hip.CONV_DOWN2])
+            ks = 1 if (mode == hip.CONV_DOWN2 or (mode == hip.CONV_PLAIN and rng.random() < 0.3)) else 3
+            c1 = 32 * rng.choice([1, 2, 3, 6, 12])
+            c2 = 32 * rng.choice([1, 2, 6]) if (mode == hip.CONV_PLAIN and rng.random() < 0.35) else 0
+            cout = rng.choice([8, 24, 64, 192, 200, 384])
+            if rng.random() < 0.25:
+                n, h, w_ = rng.choice([64, 128, 200]), rng.choice([4, 8]), rng.choice([4, 8])      # many tiles: tile walk, XCD maps
+            else:
+                n, h, w_ = rng.choice([1, 2, 3, 5, 9]), 2 * rng.choice([1, 2, 4, 8]), 2 * rng.choice([1, 2, 3, 8])
+            rep2 = 2 if (c2 and n % 2 == 0 and rng.random() < 0.5) else 1
+            x1 = rn(n, c1, h, w_)
+            x2 = rn(n // rep2, c2, h, w_) if c2 else None
+            cin = c1 + c2
+            wshape = (cout, cin * 4, 1, 1) if mode == hip.CONV_DOWN2 else (cout, cin, ks, ks)
+            wt = rn(*wshape) / (wshape[1] * ks * ks) ** 0.5
+            b = rn(cout) if rng.random() < 0.6 else None
+            ho, wo = (2 * h, 2 * w_) if mode == hip.CONV_UP2P else ((h // 2, w_ // 2) if mode == hip.CONV_DOWN2 else (h, w_))
+            rs = rn(n, cout, ho, wo) if rng.random() < 0.4 else None
+            relu = rng.random() < 0.3
+            ys = []
+            for env, split_k in (({}, False), ({"NOPE_HALO_SPLIT_MIN_CHUNKS": "2"}, True)):
+                os.environ.update(env)
+                ys.append(hip.op_conv(dt, hip.to_nhwc(x1, dt), wt, b, src2=None if x2 is None else hip.to_nhwc(x2, dt), mode=mode, rep2=rep2,
+                                      resid=None if rs is None else hip.to_nhwc(rs, dt), n_hyp=n, out_dtype=hip.F32, act_relu=relu, split_k=split_k))
+                for k in env:
+                    os.environ.pop(k)
+            xin = x1 if x2 is None else torch.cat((x1, x2.repeat_interleave(rep2, 0)), 1)
+            want = _ref(mode, hip, xin.double(), wt.double(), None if b is None else b.double())
+            if rs is not None:
+                want = want + rs.double()
+            if relu:
+                want = F.relu(want)
+            for pol, y in enumerate(ys):
+                e = rel(hip.to_nchw(y, dt).double(), want)
+                worst = max(worst, e)
+                assert e < 3e-5, (it, pol, mode, ks, c1, c2, cout, n, h, w_, rep2, rs is not None, relu, e)
+    finally:
+        os.environ.pop("NOPE_CONV_PP", None)
+    print(f"conv sweep f16x2 (ping-pong kernels forced): worst rel err {worst:.2e}")
+
+
 def test_similarity_topk_random_sweep(gpu):
     """40 seeded draws of the scoring + top-k entry points against the CPU restatement: batch, template count (ragged
     against the per-workgroup split), channel count (register and LDS query paths), map size, bank dtype, k."""

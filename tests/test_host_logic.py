@@ -521,7 +521,7 @@ def test_bench_power_ceiling_record(tmp_path, monkeypatch):
     import json
     import stat
     import bench
-    rf = {"achieved": 1000.0}
+    rf = {"achieved": 500.0, "achieved_pass_equivalents": 1000.0}      # (algorithmic rate; x MFMA passes per product: what the probe ratios use)
     assert bench.power_ceiling(rf, "f16x2") is None or isinstance(bench.power_ceiling(rf, "f16x2"), dict)      # (the real probe: no device in this container)
     fake_root = tmp_path / "repo"
     (fake_root / "tools" / "probes").mkdir(parents=True)

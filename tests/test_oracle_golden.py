@@ -64,7 +64,10 @@ def test_encoder(golden, monkeypatch):
     sd = enc.state_dict()
     assert sha256_of(sd["backbone.conv1.weight"]) == str(g["sha_conv1"])
     assert rel(R.encode_image(sd, g["img"]), g["feat"]) < TOL
-    monkeypatch.setattr(hip, "_lib", object())                     # "a loaded product library" (no interpreter injected)
+    import types
+    stand_in = types.SimpleNamespace(dll=types.SimpleNamespace(nope_tuning_reload=lambda: None))
+    monkeypatch.setattr(hip, "_lib", stand_in)                     # "a loaded product library" (no interpreter injected; passes in isolation:
+    monkeypatch.setattr(hip, "_tuning_seen", None)                 #  hip.lib() calls nope_tuning_reload on whatever is loaded)
     with pytest.raises(hip.NopeError, match="no CPU path"):        # the product module never computes on host tensors
         enc.encode_image(g["img"])
 
