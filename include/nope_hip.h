@@ -41,8 +41,13 @@ enum { NOPE_F32 = 0, NOPE_BF16 = 1,
                           the instruction's block scale.  The cross terms carry <= 2^-11 of the result, so 4-bit operands leave ~2^-15
                           per product -- the fast mode that meets the 1e-4 score tolerance.  As an element type of nope_op_conv /
                           nope_op_pack_conv_weight it names those kernels and their weight layout (modes PLAIN 1x1 / 3x3, DOWN2, UP2P;
-                          Cin % 32 == 0; nope_op_conv refuses a launch whose shape no ping-pong kernel takes);
-                          |activation| <= 65504 (the f16 part saturates) */ };
+                          Cin % 32 == 0; nope_op_conv refuses a launch whose shape no ping-pong kernel takes).
+                          RANGE.  The activation operands are f16(a) (saturates at 65504), e4m3(a_lo * 2^(9 - t)), e4m3(a * 2^(-2 - t)): full
+                          accuracy for 2^(t - 4) <= |a| <= 1792 * 2^t, where t is a per-layer shift (0 at create time and for nope_op_conv:
+                          0.06 .. 1792).  A launch whose LARGEST |a| lies above 1792 * 2^t (saturated) or below 2^(t - 5) (all cross-term
+                          operands subnormal) has plain-f16 accuracy (~2^-11 per product) on those elements.  The kernels record max |a| per
+                          layer; nope_unet_x2_range_check reads it, re-centres t and says so -- nope_amd's U-Net calls it after every forward
+                          and re-runs (beyond 65504: as NOPE_BF16X3), so the mode is never silently outside its accuracy */ };
 /* Tap geometries of nope_op_conv.  UP2P is UP2 (nearest-x2 upsample + 3x3, pad 1) rewritten as four
  * 2x2 convolutions over the un-upsampled input, one per output-pixel parity, with the 3x3 weights that
  * fall on the same source pixel pre-summed at pack time: same function, 4/9 of the multiply-adds. */
@@ -55,7 +60,9 @@ enum {
     NOPE_ERR_WORKSPACE = -3,  /* workspace too small */
     NOPE_ERR_WEIGHT = -4,     /* missing / mis-shaped state-dict entry */
     NOPE_ERR_ALLOC = -5,
-    NOPE_ERR_UNSUPPORTED = -6
+    NOPE_ERR_UNSUPPORTED = -6,
+    NOPE_ERR_RANGE = -7,      /* nope_unet_x2_range_check: a NOPE_F16X2 launch saw activations outside its layer's window; the shifts were moved -- run the forward again */
+    NOPE_ERR_RANGE_F16 = -8   /* ... outside what f16 holds (|a| > 65504): run as NOPE_BF16X3 (nope_unet_x2_enable(net, 0)) */
 };
 
 typedef void* nope_stream_t;
@@ -63,9 +70,10 @@ typedef void* nope_stream_t;
 /* Bumped whenever a struct of this header changes layout or an enum gains a meaning (2: nope_unet_config.soft_up_down;
  * 3: NOPE_F16 / NOPE_BF16X3 compute modes, 4x4 STRIDE2, nope_ldm_config.transformer_depth;
  * 4: nope_op_geodesic, nope_unet_graph_limit -- hipGraph replay became opt-in;
- * 5: NOPE_F16X2, nope_tuning_reload, nope_gather_topk, nope_topk_merge).  Callers compare nope_abi_version() against the header they were
+ * 5: NOPE_F16X2, nope_tuning_reload, nope_gather_topk, nope_topk_merge;
+ * 6: nope_unet_x2_range_check / _x2_enable / _x2_shifts, NOPE_ERR_RANGE*).  Callers compare nope_abi_version() against the header they were
  * built with before passing any struct (nope_amd/hip.py does at load time). */
-#define NOPE_ABI_VERSION 5
+#define NOPE_ABI_VERSION 6
 const char* nope_strerror(int code);
 int nope_abi_version(void);
 /* The library reads its tuning / test switches (NOPE_* environment variables: launch policies, A/B switches, traces) once per call site and
@@ -179,6 +187,19 @@ int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep
  * (tests/test_gpu_configs.py::test_unet_graph_replay_matches_direct); a 64-hypothesis pass measured +-0 on MI355X, which is why it is
  * off.  nope_unet_graph_replays: forwards served by a replay since create. */
 int nope_unet_graph_limit(nope_unet* net, long long max_hyp_pixels);
+
+/* NOPE_F16X2 activation ranges (no reference counterpart: the reference computes in fp32, model_utils.py:240-252,271-279 see whatever
+ * magnitude the residual stream has).  nope_unet_x2_range_check SYNCHRONISES `stream`, reads the largest |activation| each f16x2 layer
+ * converted in the forwards issued on it since the previous check, and
+ *   returns NOPE_OK            every launch inside its layer's window (shifts within two binades of an end were re-centred for later calls);
+ *           NOPE_ERR_RANGE     some launch outside: its result has plain-f16 accuracy there; the shifts are fixed -- run the forward again;
+ *           NOPE_ERR_RANGE_F16 an activation beyond 65504: no shift helps; nope_unet_x2_enable(net, 0) makes every launch NOPE_BF16X3
+ *                              (same weights, the three-pass kernels), nope_unet_x2_enable(net, 1) returns to the two-pass tile.
+ * n_out_of_range / n_adjusted / max_abs (each may be null): layers outside their window, layers whose shift moved, largest |a| seen.
+ * A net created in another mode: NOPE_OK, nothing to check.  nope_unet_x2_shifts: the current per-layer shifts (creation order). */
+int nope_unet_x2_range_check(nope_unet* net, nope_stream_t stream, int* n_out_of_range, int* n_adjusted, float* max_abs);
+int nope_unet_x2_enable(nope_unet* net, int on);
+int nope_unet_x2_shifts(const nope_unet* net, int* shifts, int max, int* n);
 int nope_unet_graph_replays(const nope_unet* net);
 
 /* Measurement aid (bench.py roofline leg, no reference counterpart): while enabled, every

@@ -68,7 +68,8 @@ struct ConvParams {
     int stat_rows;                     // 64 (every kernel), 16 / 32 (small-tile kernel only)
     const float* pn_ms; const float* pn_c0; const float* pn_c1;   // optional fused PreNorm (see ConvArgs)
     unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
-    const int* x2_scale;               // NOPE_F16X2 (ping-pong kernels): the tail of the packed weights, [0] = E8M0 scale of the A operand
+    const int* x2_scale;               // NOPE_F16X2 (ping-pong kernels): the tail of the packed weights, [0] = E8M0 scale of the A operand, [3] = range shift t
+    unsigned* x2_amax;                 // NOPE_F16X2: optional device word, atomicMax of the bits of max |a| over every A element the launch converted
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -198,18 +199,19 @@ template <> struct Tile<f16x2_t> : Tile32 {
                 x[ks][i][2 * q + e] = NOPE_CVT_PK_F16_OVFL(__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1));
             }
     }
-    static __device__ __forceinline__ void prep_lo(const u32x4 (&r)[RAW][MT], u32x4 (&x)[RAW][MT], int i, int q) {      // raw read q: 4 channels
+    static __device__ __forceinline__ void prep_lo(const u32x4 (&r)[RAW][MT], u32x4 (&x)[RAW][MT], int i, int q, float div_lo, float div_a, float& amax) {      // raw read q: 4 channels
         float v[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const unsigned u = r[q][i][e]; v[e] = __builtin_bit_cast(float, u); }
+        amax = amax4(amax, v[0], v[1], v[2], v[3]);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             union { unsigned u; f16_t f[2]; } hh; hh.u = x[q >> 1][i][2 * (q & 1) + e];
             l[2 * e] = v[2 * e] - (float)hh.f[0];
             l[2 * e + 1] = v[2 * e + 1] - (float)hh.f[1];
         }
-        x[2][i][q] = cvt4_e4m3_scaled<kX2ALoShift, true>(l[0], l[1], l[2], l[3]);
-        x[3][i][q] = cvt4_e4m3_scaled<kX2AShift, true>(v[0], v[1], v[2], v[3]);
+        x[2][i][q] = cvt4_e4m3_div(l[0], l[1], l[2], l[3], div_lo);
+        x[3][i][q] = cvt4_e4m3_div(v[0], v[1], v[2], v[3], div_a);
     }
     static constexpr int TERMS = 3;
     static __device__ __forceinline__ void mma(int t, const u32x4 (&a)[RAW][MT], const u32x4 (&b)[RAW][NTL], int i, int j, acc_t& c, int sc) {

@@ -53,6 +53,15 @@ struct KPos { int tap, kc; };
 
 // TUNE: the instantiation that honours the NOPE_PP_VARIANT ablations (run-time tests inside the K loop); production launches (variant 0) take the
 // one without them.
+// NOPE_F16X2: a wave's max |a| over the A elements it converted -> the launch's range word (one atomic per wave and tile; the word is
+// read by the runtime that owns the layer, unet_runtime.hip: x2_range_check).  Non-negative floats order like their bit patterns.
+__device__ __forceinline__ void x2_publish_amax(const ConvParams& p, float m, int lane) {
+    if (!p.x2_amax) return;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) atomicMax(p.x2_amax, __builtin_bit_cast(unsigned, m));
+}
+
 template <class T, int MODE, bool PN, bool TUNE = false>
 __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvParams p) {
     typedef Tile<T> TL;
@@ -81,7 +90,10 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
     // tap-resident kernel.  (The PreNorm instantiation is never launched for it: launch_conv.)
     constexpr bool X2 = Elt<T>::DT == NOPE_F16X2;
     if constexpr (X2) fp16_ovfl_on();
-    const int x2_sc = X2 ? p.x2_scale[0] : 0;
+    const int x2_t = X2 ? p.x2_scale[3] : 0;                 // the layer's activation range shift (nope_common.h: kX2*)
+    const int x2_sc = X2 ? p.x2_scale[0] + x2_t : 0;
+    const float x2_dlo = x2_div_lo(x2_t), x2_da = x2_div_a(x2_t);
+    float x2_amax = 0.f;                                     // max |a| over the A elements this lane converts
     int tile_m, tile_n;
     tile_coords(p, tile_m, tile_n);
     const int m0 = tile_m * PP_BM, n0 = tile_n * BN;
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
 #pragma unroll
                 for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
-                    for (int q = 0; q < RAW; ++q) TL::prep_lo(af[0], ax, i, q);
+                    for (int q = 0; q < RAW; ++q) TL::prep_lo(af[0], ax, i, q, x2_dlo, x2_da, x2_amax);
 #pragma unroll
                 for (int t = 0; t < TL::TERMS; ++t)
 #pragma unroll
@@ -408,6 +420,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;
         return;
     }
+    if constexpr (X2) x2_publish_amax(p, x2_amax, lane);
     epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + wave * Ep<T>::WAVE_BYTES);
 }
 
@@ -571,7 +584,10 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     // themselves (probe fact 7; a NaN stays a NaN, as in the f32 / bf16x3 modes) -- 16 VALU per piece and lane instead of 46 with explicit
     // pre-scale multiplies, clamps and byte packing.
     if constexpr (X2) fp16_ovfl_on();
-    const int x2_sc = X2 ? p.x2_scale[0] : 0;                                 // E8M0 block scale of the cross-term MFMA (uniform; waited for with the prologue's DMA)
+    const int x2_t = X2 ? p.x2_scale[3] : 0;                                  // the layer's activation range shift (nope_common.h: kX2*)
+    const int x2_sc = X2 ? p.x2_scale[0] + x2_t : 0;                          // E8M0 block scale of the cross-term MFMA (uniform; waited for with the prologue's DMA)
+    const float x2_dlo = x2_div_lo(x2_t), x2_da = x2_div_a(x2_t);
+    float x2_amax = 0.f;                                                      // max |a| over the A elements this lane rewrites
     // (two halves.  bf16x3: the READ of a piece opens the LOAD phase, the DMA pieces of the phase are issued and the tap's fragment addresses
     //  formed underneath it, then the arithmetic + writes: -1.6 % on the kernel against read + rewrite back to back.  f16x2: back to back, the
     //  same order measured +1.3 % there -- same-box A/B, profiles/r05h_rewrite_order_ab.txt.  Carrying the value across the barrier from the
@@ -612,8 +628,9 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                 l[2 * e] = x[2 * e] - (float)hh.f[0];
                 l[2 * e + 1] = x[2 * e + 1] - (float)hh.f[1];
             }
-            lo8 = cvt4_e4m3_scaled<kX2ALoShift, true>(l[0], l[1], l[2], l[3]);
-            a8 = cvt4_e4m3_scaled<kX2AShift, true>(x[0], x[1], x[2], x[3]);
+            x2_amax = amax4(x2_amax, x[0], x[1], x[2], x[3]);
+            lo8 = cvt4_e4m3_div(l[0], l[1], l[2], l[3], x2_dlo);
+            a8 = cvt4_e4m3_div(x[0], x[1], x[2], x[3], x2_da);
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
             __builtin_amdgcn_wave_barrier();       // every lane's read precedes every lane's write (see below)
             *reinterpret_cast<u32x2*>(row + (((ls >> 1) ^ sw) << 4) + 8 * (ls & 1)) = u32x2{hi[0], hi[1]};
@@ -915,6 +932,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         // COMPUTE, which group 1 reached after its last LOAD), nothing is in flight: the ring is free.  Start the next tile's
         // prologue now -- it lands while the panels are filled -- and wait for it before the first store of the epilogue
         // (so the K loop's vmcnt never has to wait for a prologue behind a queue of stores).
+        if constexpr (X2) x2_publish_amax(p, x2_amax, lane);
         const int m_this = m0;
         const bool more = it + 1 < iters;
         if (more) {

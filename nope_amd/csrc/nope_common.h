@@ -183,6 +183,18 @@ template <int SHIFT, bool OVFL_MODE = false> __device__ __forceinline__ unsigned
     }
     return __builtin_bit_cast(unsigned, r);
 }
+// ... with the divisor in a register (the f16x2 kernels: 2^(shift of the layer's activation range), see kX2* below); MODE.FP16_OVFL form only
+__device__ __forceinline__ unsigned cvt4_e4m3_div(float x0, float x1, float x2, float x3, float divisor) {
+    s16x2_hw_t r = {0, 0};
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, x0, x1, divisor, false);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, x2, x3, divisor, true);
+    return __builtin_bit_cast(unsigned, r);
+}
+// running max |x| of four values (two v_max3_f32 with |.| modifiers; a NaN is ignored: it stays a NaN in the result either way)
+__device__ __forceinline__ float amax4(float m, float x0, float x1, float x2, float x3) {
+    m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(x0)), __builtin_fabsf(x1));
+    return __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(x2)), __builtin_fabsf(x3));
+}
 // MODE.FP16_OVFL (hwreg 1 = MODE, bit 23) for the rest of the wave's life: f32 -> f16 and f32 -> fp8 conversions SATURATE (+-65504 / +-448)
 // instead of producing inf / NaN; a NaN stays a NaN (tools/probes/mx_probe.hip fact 7).  The f16x2 operand rewrite runs under it: 12 clamps
 // per piece and lane gone.  NOPE_CVT_PK_F16_OVFL: the f16 pair conversion under that mode -- the plain one on the device; tests/hipemu
@@ -196,8 +208,16 @@ __device__ __forceinline__ void fp16_ovfl_on() { __builtin_amdgcn_s_setreg(1 | (
 // chosen so that BOTH products of the K-concatenated instruction, a_lo w and a w_lo, carry the same total 2^(9 + sw): one scale for all
 // lanes (the instruction's scale blocks follow byte positions, not lane halves: tools/probes/mx_probe.hip fact 3h).  |a| up to 1792
 // and |a_lo| of |a| up to 2048 stay below the clamp; beyond, the element degrades towards plain f16 accuracy.
+// The activation pre-scales carry a per-layer RANGE SHIFT t (tail word 3, 0 as packed): e4m3(a_lo * 2^(9 - t)), e4m3(a * 2^(-2 - t)), block
+// scale + t -- the window of full accuracy, 2^(t - 4) <= |a| <= 1792 * 2^t, moves with the layer's activations.  The kernels record
+// max |a| of what they converted (ConvParams::x2_amax) and the runtime that owns the layer moves t when a launch left the window
+// (unet_runtime.hip: x2_range_check); operator-level launches run at t = 0.
 constexpr int kX2ALoShift = 9, kX2AShift = -2, kX2WLoExtra = 11;
-constexpr int kX2TailBytes = 16;      // behind the packed weights: int A-scale byte (127 - 9 - sw), int sw, float max |w|, 0
+constexpr int kX2TailBytes = 16;      // behind the packed weights: int A-scale byte (127 - 9 - sw), int sw, float max |w|, int t (range shift of the activations)
+constexpr float kX2AMaxFull = 1792.f;  // |a| * 2^-t above this saturates e4m3(a * 2^(-2 - t)) = 448
+// the two divisors of a layer's conversions as floats: 2^(t - 9) for a_lo, 2^(t + 2) for a
+__device__ __forceinline__ float x2_div_lo(int t) { return __builtin_bit_cast(float, (unsigned)(127 + t - kX2ALoShift) << 23); }
+__device__ __forceinline__ float x2_div_a(int t) { return __builtin_bit_cast(float, (unsigned)(127 + t - kX2AShift) << 23); }
 
 // dtype code -> bytes per stored element / elements per 16-byte vector / the dtype the non-conv kernels see
 static inline int dt_es(int dt) { return (dt == NOPE_F32 || dt == NOPE_BF16X3 || dt == NOPE_F16X2) ? 4 : 2; }
@@ -303,6 +323,7 @@ struct ConvArgs {
     const void* w = nullptr;     // packed [Cout][ntaps][Cin]
     const void* w_x2 = nullptr;  // NOPE_BF16X3 launches only: the same weights in the NOPE_F16X2 layout (launch_pack_conv_w_x2) -- taken, with
                                  // the f16 + MX-fp8 tile, when the launch goes to a ping-pong kernel (conv_takes_x2); `w` (may be null then) otherwise
+    unsigned* x2_amax = nullptr; // NOPE_F16X2 launches: optional device word, atomicMax of the bits of max |a| over the A elements converted
     const float* bias = nullptr; // [Cout] or null
     const void* resid = nullptr; // optional NHWC [M][Cout] added in the epilogue
     void* out = nullptr;

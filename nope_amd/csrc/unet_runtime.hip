@@ -17,7 +17,9 @@
 //     f32 GEMM against the row-concatenated weights;
 //   * a bump arena over caller-provided workspace: no allocation, no host sync, one stream.
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <initializer_list>
 #include <map>
 #include <mutex>
@@ -30,7 +32,7 @@ using namespace nope;
 
 namespace {
 
-struct Conv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; void* w_x2 = nullptr; };   // w_x2: NOPE_F16X2 only: the same weights in the f16 + MX-fp8 tile's layout
+struct Conv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; void* w_x2 = nullptr; int x2_id = -1; };   // w_x2: NOPE_F16X2 only: the same weights in the f16 + MX-fp8 tile's layout; x2_id: its slot in the net's range table
 struct Norm { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct Res { Conv c1, c2, res; Norm n1, n2; bool has_res = false; int emb_off = -1; };
 // PreNorm's GroupNorm(1) is folded into the qkv conv: gamma into the packed weights, c0 = W beta, c1 = W gamma
@@ -77,6 +79,14 @@ struct nope_unet {
     mutable std::mutex graph_mu;
     mutable int graph_replays = 0;           // forwards served by a graph replay since create (tests assert the path really ran)
     long long graph_max = 0;                 // largest n_hyp * H * W that replays a graph; 0 = off
+    // NOPE_F16X2 activation ranges (nope_unet_x2_range_check).  Every layer with a second pack owns a device word that its launches
+    // atomicMax with the bits of max |a| over the A elements they converted, and a range shift t in the pack's tail (word 3) that
+    // moves the window in which the e4m3 cross-term operands are fully accurate: 2^(t - 4) <= |a| <= 1792 * 2^t.
+    std::vector<int*> x2_tails;              // per layer: device pointer to the pack's 16-byte tail
+    std::vector<int> x2_t, x2_sc0;           // host copies: current shift, the pack's E8M0 byte at t = 0 (read at the first check)
+    unsigned* x2_amax = nullptr;             // device, one word per layer
+    mutable bool x2_off = false;             // nope_unet_x2_enable(net, 0): every launch as NOPE_BF16X3 (the fallback beyond f16's range)
+    mutable std::mutex x2_mu;
 };
 
 namespace {
@@ -139,8 +149,13 @@ struct Loader {
             // takes it when the launch's shape lands on one of them
             if (net->x2 && (mode == NOPE_CONV_PLAIN || mode == NOPE_CONV_DOWN2 || mode == NOPE_CONV_UP2P) && (ksz == 3 || ksz == 1 || mode != NOPE_CONV_PLAIN) &&
                 !cin_scale && Csrc == Cin && Cin % 32 == 0) {
-                c.w_x2 = dmalloc(conv_w_x2_bytes(Cout, Cin, c.ntaps, mode));
-                if (c.w_x2) { int e = launch_pack_conv_w_x2((const float*)d->data, c.w_x2, Cout, Cin, s, convT ? 16 : c.ntaps, mode); if (e && err == NOPE_OK) err = e; }
+                const size_t x2b = conv_w_x2_bytes(Cout, Cin, c.ntaps, mode);
+                c.w_x2 = dmalloc(x2b);
+                if (c.w_x2) {
+                    int e = launch_pack_conv_w_x2((const float*)d->data, c.w_x2, Cout, Cin, s, convT ? 16 : c.ntaps, mode); if (e && err == NOPE_OK) err = e;
+                    c.x2_id = (int)net->x2_tails.size();
+                    net->x2_tails.push_back(reinterpret_cast<int*>((unsigned char*)c.w_x2 + x2b - kX2TailBytes));
+                }
             }
         }
         if (has_bias) c.bias = copy_f32(pfx + "bias", {Cout});
@@ -229,7 +244,8 @@ struct Fwd {
         ca.src1 = a.p; ca.C1 = a.C; ca.rep1 = rep1;
         if (b) { ca.src2 = b->p; ca.C2 = b->C; ca.rep2 = rep2; }
         ca.Hs = a.H; ca.Ws = a.W; ca.Ho = Ho; ca.Wo = Wo;
-        ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.w_x2 = c.w_x2; ca.bias = c.bias; ca.resid = resid;
+        ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.w_x2 = net->x2_off ? nullptr : c.w_x2; ca.bias = c.bias; ca.resid = resid;
+        if (ca.w_x2 && net->x2_amax && c.x2_id >= 0) ca.x2_amax = net->x2_amax + c.x2_id;
         ca.out = out; ca.Cout = c.Cout; ca.nhyp = n; ca.out_nchw = out_nchw; ca.out_dt = out_dt;
         if (a.C + (b ? b->C : 0) != c.Cin) { chk(NOPE_ERR_ARG); return; }
         float* colstats = nullptr;
@@ -607,6 +623,12 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
         }
         off += e.second;
     }
+    if (ld.err == NOPE_OK && !net->x2_tails.empty()) {
+        const size_t n = net->x2_tails.size();
+        net->x2_amax = (unsigned*)ld.dmalloc(n * sizeof(unsigned));
+        if (net->x2_amax && hipMemsetAsync(net->x2_amax, 0, n * sizeof(unsigned), s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
+        net->x2_t.assign(n, 0);
+    }
     if (ld.err == NOPE_OK && hipStreamSynchronize(s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
     if (ld.err != NOPE_OK) {
         if (!ld.missing.empty()) fprintf(stderr, "nope_unet_create: missing or mis-shaped tensor '%s'\n", ld.missing.c_str());
@@ -652,6 +674,83 @@ int nope_unet_profile_launches(nope_unet* net, nope_conv_launch_info* out, int m
         ++i;
     }
     *n = i;
+    return NOPE_OK;
+}
+
+// ---- NOPE_F16X2 activation ranges ---------------------------------------------------------------------------------------------------------
+// The f16 + MX-fp8 tile converts every A element three ways: f16(a) (saturates at 65504), e4m3(a_lo * 2^(9 - t)) and e4m3(a * 2^(-2 - t))
+// (saturates at |a| = 1792 * 2^t, flushes to zero below 2^(t - 11)); t is per layer.  A launch whose max |a| left [2^(t - 5), 1792 * 2^t]
+// computed its cross terms from saturated or all-subnormal operands -- plain-f16 accuracy instead of ~2^-15 per product.  The check reads
+// what the launches since the previous check recorded, moves t where needed (window re-centred: max |a| * 2^-t in [16, 32)) and reports.
+int nope_unet_x2_range_check(nope_unet* net, nope_stream_t stream, int* n_out_of_range, int* n_adjusted, float* max_abs) {
+    if (n_out_of_range) *n_out_of_range = 0;
+    if (n_adjusted) *n_adjusted = 0;
+    if (max_abs) *max_abs = 0.f;
+    if (!net) return NOPE_ERR_ARG;
+    if (!net->x2 || !net->x2_amax || net->x2_off) return NOPE_OK;
+    std::lock_guard<std::mutex> lock(net->x2_mu);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = net->x2_tails.size();
+    std::vector<unsigned> bits(n);
+    if (hipMemcpyAsync(bits.data(), net->x2_amax, n * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    if (hipMemsetAsync(net->x2_amax, 0, n * sizeof(unsigned), s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    if (net->x2_sc0.empty()) {                 // the packs' E8M0 bytes at t = 0 (device-computed at create time): once
+        net->x2_sc0.assign(n, 0);
+        for (size_t i = 0; i < n; ++i)
+            if (hipMemcpy(&net->x2_sc0[i], net->x2_tails[i], sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return NOPE_ERR_LAUNCH;
+    }
+    int bad = 0, moved = 0, fatal = 0;
+    float worst = 0.f;
+    for (size_t i = 0; i < n; ++i) {
+        if (!bits[i]) continue;                 // the layer ran no f16x2 launch (or saw only zeros)
+        float amax;
+        memcpy(&amax, &bits[i], 4);
+        if (!(amax == amax)) continue;
+        if (amax > worst) worst = amax;
+        if (amax > 65504.f) { ++fatal; continue; }          // the f16 hi part saturated: no shift repairs that
+        const int t = net->x2_t[i];
+        const float v = ldexpf(amax, -t);
+        const bool out = v > kX2AMaxFull || v < 0.03125f;    // saturated / every cross-term operand subnormal
+        const bool uneasy = v > kX2AMaxFull / 4 || v < 0.25f; // within two binades of either end: re-centre for the next call
+        if (!out && !uneasy) continue;
+        int e = 0;
+        frexpf(amax, &e);                                    // amax = m * 2^e, m in [0.5, 1)
+        int tn = (e - 1) - 4;                                // max |a| * 2^-tn in [16, 32)
+        const int lo = 1 - net->x2_sc0[i], hi = 254 - net->x2_sc0[i];      // keep the instruction's scale byte inside E8M0
+        tn = tn < lo ? lo : (tn > hi ? hi : tn);
+        tn = tn < -64 ? -64 : (tn > 64 ? 64 : tn);
+        if (out) ++bad;
+        if (tn != t) {
+            if (hipMemcpy(net->x2_tails[i] + 3, &tn, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return NOPE_ERR_LAUNCH;
+            net->x2_t[i] = tn;
+            ++moved;
+        }
+    }
+    if (n_out_of_range) *n_out_of_range = bad + fatal;
+    if (n_adjusted) *n_adjusted = moved;
+    if (max_abs) *max_abs = worst;
+    if (moved) {                                // a cached graph replays the same kernels and pointers: the shifts live in device memory, nothing to rebuild
+    }
+    return fatal ? NOPE_ERR_RANGE_F16 : (bad ? NOPE_ERR_RANGE : NOPE_OK);
+}
+
+int nope_unet_x2_enable(nope_unet* net, int on) {
+    if (!net) return NOPE_ERR_ARG;
+    std::lock_guard<std::mutex> lock(net->graph_mu);
+    if (net->x2_off != (on == 0)) {            // the launch plan changes: cached graphs are stale
+        for (const UGraph& g : net->graphs) hipGraphExecDestroy(g.exec);
+        net->graphs.clear();
+    }
+    net->x2_off = on == 0;
+    return NOPE_OK;
+}
+
+int nope_unet_x2_shifts(const nope_unet* net, int* shifts, int max, int* n) {
+    if (!net || !n || (max > 0 && !shifts)) return NOPE_ERR_ARG;
+    std::lock_guard<std::mutex> lock(net->x2_mu);
+    *n = (int)net->x2_t.size();
+    for (int i = 0; i < *n && i < max; ++i) shifts[i] = net->x2_t[i];
     return NOPE_OK;
 }
 

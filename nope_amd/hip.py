@@ -8,14 +8,15 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3      # BF16X3: compute mode only (f32 storage, three bf16 MFMA passes per product)
 F16X2 = 4                                # compute mode only: BF16X3, but the ping-pong launches (tap-resident 3x3, per-tap 1x1 / up / down) run one f16 + one MX-fp8 MFMA pass (include/nope_hip.h)
-ABI_VERSION = 5                          # NOPE_ABI_VERSION of include/nope_hip.h these ctypes structs mirror
+ABI_VERSION = 6                          # NOPE_ABI_VERSION of include/nope_hip.h these ctypes structs mirror
 CONV_PLAIN, CONV_UP2, CONV_DOWN2, CONV_UP2P, CONV_STRIDE2 = 0, 1, 2, 3, 4
+ERR_RANGE, ERR_RANGE_F16 = -7, -8        # nope_unet_x2_range_check (include/nope_hip.h)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NOPE_HIP_LIB: load another build of the SAME gfx950 library (A/B timing of kernel variants); default = in-tree build
@@ -68,6 +69,9 @@ _PROTOS = {
     "nope_unet_forward": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "nope_unet_graph_limit": (_i, [_vp, C.c_longlong]),
     "nope_unet_graph_replays": (_i, [_vp]),
+    "nope_unet_x2_range_check": (_i, [_vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_float)]),
+    "nope_unet_x2_enable": (_i, [_vp, _i]),
+    "nope_unet_x2_shifts": (_i, [_vp, C.POINTER(_i), _i, C.POINTER(_i)]),
     "nope_unet_profile": (_i, [_vp, _i]),
     "nope_unet_profile_read": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nope_unet_profile_launches": (_i, [_vp, C.POINTER(ConvLaunchInfo), _i, C.POINTER(_i)]),
@@ -448,12 +452,37 @@ class UNetHandle:
         l.check(l.dll.nope_unet_create(C.byref(c), descs, len(state_dict), stream, C.byref(h)), "nope_unet_create")
         self._h = h
         self._ws: Dict[tuple, torch.Tensor] = {}     # one arena per (device, stream): forwards on different streams never share one
+        # NOPE_F16X2: after every forward, read the largest |activation| each two-pass layer converted (nope_unet_x2_range_check: one
+        # stream synchronisation + 300 bytes) and run the forward again when a layer left its accurate window -- with re-centred
+        # shifts, or as NOPE_BF16X3 beyond f16's own range.  NOPE_X2_RANGE_CHECK=0 (or .range_check = False) trusts the shifts.
+        self.range_check = self.compute_dtype == F16X2 and os.environ.get("NOPE_X2_RANGE_CHECK", "1") != "0"
+        self.range_events: List[dict] = []           # one record per forward that had to be repeated
+        self.x2_enabled = self.compute_dtype == F16X2
 
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
             self._l.dll.nope_unet_destroy(h)
             self._h = None
+
+    def x2_range_check(self, stream) -> Tuple[int, int, int, float]:
+        """(code, layers out of range, layers whose shift moved, largest |activation|) of the forwards since the last check."""
+        bad, moved, amax = _i(0), _i(0), C.c_float(0)
+        code = int(self._l.dll.nope_unet_x2_range_check(self._h, stream, C.byref(bad), C.byref(moved), C.byref(amax)))
+        if code not in (0, ERR_RANGE, ERR_RANGE_F16):
+            self._l.check(code, "nope_unet_x2_range_check")
+        return code, bad.value, moved.value, float(amax.value)
+
+    def x2_enable(self, on: bool):
+        self._l.check(self._l.dll.nope_unet_x2_enable(self._h, int(bool(on))), "nope_unet_x2_enable")
+        self.x2_enabled = bool(on) and self.compute_dtype == F16X2
+
+    def x2_shifts(self) -> List[int]:
+        n = _i(0)
+        self._l.check(self._l.dll.nope_unet_x2_shifts(self._h, None, 0, C.byref(n)), "nope_unet_x2_shifts")
+        buf = (_i * max(1, n.value))()
+        self._l.check(self._l.dll.nope_unet_x2_shifts(self._h, buf, n.value, C.byref(n)), "nope_unet_x2_shifts")
+        return list(buf[:n.value])
 
     def profile(self, enable: bool):
         self._l.check(self._l.dll.nope_unet_profile(self._h, int(enable)), "nope_unet_profile")
@@ -510,8 +539,21 @@ class UNetHandle:
             self._ws.pop(key, None)          # release the smaller arena before taking a bigger one
             ws = None
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
-        self._l.check(self._l.dll.nope_unet_forward(self._h, _ptr(x), n_src, x_rep, _ptr(pose), n_hyp, H, W, _ptr(out), odt,
-                                                    _ptr(ws), ws.numel(), _stream(x)), "nope_unet_forward")
+        for attempt in range(4):
+            self._l.check(self._l.dll.nope_unet_forward(self._h, _ptr(x), n_src, x_rep, _ptr(pose), n_hyp, H, W, _ptr(out), odt,
+                                                        _ptr(ws), ws.numel(), _stream(x)), "nope_unet_forward")
+            if not (self.range_check and self.x2_enabled):
+                break
+            code, bad, moved, amax = self.x2_range_check(_stream(x))
+            if code == 0:
+                break
+            # a two-pass layer saw activations outside its accurate window: that forward has plain-f16 accuracy there -- repeat it
+            self.range_events.append({"code": code, "layers_out_of_range": bad, "layers_adjusted": moved, "max_abs": amax, "attempt": attempt})
+            if code == ERR_RANGE_F16 or attempt == 2:
+                import warnings
+                warnings.warn(f"nope_amd f16x2: activations up to {amax:.3g} " + ("exceed the f16 range" if code == ERR_RANGE_F16 else
+                              "keep leaving the layers' windows") + ": this U-Net runs as bf16x3 (three MFMA passes) from now on", RuntimeWarning)
+                self.x2_enable(False)
         return out
 
 
@@ -660,10 +702,14 @@ def pack_conv_weight(w: torch.Tensor, dt: int, mode: int = CONV_PLAIN) -> Tuple[
 def op_conv(dt: int, src1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
             src2: Optional[torch.Tensor] = None, mode: int = CONV_PLAIN, rep1: int = 1, rep2: int = 1,
             resid: Optional[torch.Tensor] = None, n_hyp: Optional[int] = None, out_nchw: bool = False,
-            out_dtype: int = F32, act_relu: bool = False, split_k: bool = False) -> torch.Tensor:
+            out_dtype: int = F32, act_relu: bool = False, split_k: bool = False, x2_shift: int = 0) -> torch.Tensor:
     """src* NHWC tensors of dtype dt; w torch Conv2d weight (f32).  Returns NHWC (or NCHW).  split_k: hand the launcher the scratch it
-    asks for (as the U-Net / encoder runtimes do), so shapes it would split along K (few tiles, long K) are."""
+    asks for (as the U-Net / encoder runtimes do), so shapes it would split along K (few tiles, long K) are.  x2_shift (F16X2 only): the
+    activation range shift t of the packed layer (word 3 of the pack's tail; include/nope_hip.h: full accuracy for 2^(t-4) <= |a| <= 1792 2^t)."""
     pw, cin, ntaps = pack_conv_weight(w, dt, mode)
+    if x2_shift:
+        assert dt == F16X2
+        pw.view(torch.int32)[-1] = int(x2_shift)
     n1, hs, ws, c1 = src1.shape
     c2 = 0 if src2 is None else src2.shape[3]
     assert c1 + c2 == cin

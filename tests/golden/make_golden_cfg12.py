@@ -93,7 +93,7 @@ def run_case(tag, ref_enc, ref, pc, sd, part_dir):
                         sha_query=digest(b["query"]), sha_poses=digest(b["all_relativeR"]),
                         sha_mid=digest(sd["mid_block1.block1.proj.weight"]),
                         sha_enc_conv1=digest(ref_enc.state_dict()["backbone.conv1.weight"]),
-                        bank_first=np.asarray(bank[:, :2]).copy(), query_feat=q_feat.numpy()[:2], reference_feat=ref_feat.numpy()[:2])
+                        bank_first=np.asarray(bank[:4, :2]).copy(), query_feat=q_feat.numpy()[:2], reference_feat=ref_feat.numpy()[:2])
     top2 = sim.topk(2, dim=1).values
     print(f"{tag}: done in {time.time() - t0:.0f}s; top-5 of query 0 {idx[0].tolist()}; smallest top-1 gap "
           f"{float((top2[:, 0] - top2[:, 1]).min() / sim.abs().max()):.2e} of the score scale", flush=True)

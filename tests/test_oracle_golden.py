@@ -72,6 +72,31 @@ def test_encoder(golden, monkeypatch):
         enc.encode_image(g["img"])
 
 
+def test_configs1_and_2_against_reference_recorded_scores(golden):
+    """BASELINE configs[1] / [2] at full size (256x256, 512 templates): the reference's own recorded run (make_golden_cfg12.py: ALL
+    512 / 16384 scores) pins the restatement on a bounded sample -- the encoder on the first recorded images, the U-Net on the first two
+    hypotheses of the first recorded queries, their scores -- the whole banks are the GPU tests' job."""
+    from nope_amd.harness import build_model, synthetic_batch
+    from nope_amd.weights import sha256_of
+    model = build_model(device="cpu")
+    sd = model.u_net.own_state_dict()
+    enc_sd = model.u_net.encoder.state_dict()
+    for name, nq in (("cfg1_scores.npz", 1), ("cfg2_scores.npz", 2)):
+        g = golden(name)
+        B, N, size, seed = (int(v) for v in g["batch"])
+        b = synthetic_batch(B, N, size, seed=seed)
+        assert sha256_of(b["query"]) == str(g["sha_query"]) and sha256_of(b["all_relativeR"]) == str(g["sha_poses"])
+        assert sha256_of(sd["mid_block1.block1.proj.weight"]) == str(g["sha_mid"])
+        ref_feat = R.encode_image(enc_sd, b["reference"][:nq])
+        q_feat = R.encode_image(enc_sd, b["query"][:nq])
+        assert rel(ref_feat, g["reference_feat"][:nq]) < TOL and rel(q_feat, g["query_feat"][:nq]) < TOL
+        bank = R.generate_templates(sd, ref_feat, b["all_relativeR"][:nq, :2])
+        assert rel(bank, g["bank_first"][:nq]) < TOL
+        s = R.similarity_scores(q_feat, bank)
+        assert float(((s - g["sim"][:nq, :2]).abs() / g["sim"][:nq, :2].abs()).max()) < 5e-6
+        assert g["sim"].shape == (B, N) and bool((g["sim"].topk(5, dim=1).indices == g["idx"]).all())
+
+
 def test_pipeline_config1(golden):
     """BASELINE config 1 (single query, 64 templates, 128x128, full-size model): check a
     4-template prefix of the bank, the scores computed from the recorded bank prefix, and the loss

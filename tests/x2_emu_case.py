@@ -103,6 +103,21 @@ def run(hip, dev, light=False):
         yy = hip.to_nchw(y, 0).cpu()
         want = x2_reference(xs, ws_, bs)
         assert rel(yy, want) < 2e-6, ("halo 4x4 x 40 samples, wide range", rel(yy, want))
+        # the per-layer range shift t (tail word 3): activations scaled by 2^12 under t = 12 give EXACTLY 2^12 x the t = 0 result (every
+        # operand conversion and the block scale move by the same power of two) -- tap-resident and per-tap kernels; at t = 0 the same
+        # input saturates the e4m3(a) operand (|a| > 1792) and the result is worse than 1e-4
+        # (|a| in [0.5, 1.5): the f16 hi part -- the one operand without a pre-scale -- stays a normal number at every scale used here)
+        xr, wr = torch.sign(rn(3, C, 10, 9)) * (0.5 + torch.rand(3, C, 10, 9, generator=g)), rn(40, C, 3, 3) / (3 * C ** 0.5)
+        y0 = hip.op_conv(X2, hip.to_nhwc(d(xr), 0), d(wr), None)
+        y12 = hip.op_conv(X2, hip.to_nhwc(d(xr * 4096.0), 0), d(wr), None, x2_shift=12)
+        assert torch.equal(y12, y0 * 4096.0), ("halo 3x3: range shift 12 is not an exact rescaling", float((y12 / 4096.0 - y0).abs().max()), float(y0.abs().max()))
+        ysat = hip.op_conv(X2, hip.to_nhwc(d(xr * 4096.0), 0), d(wr), None)
+        e_sat = rel(hip.to_nchw(ysat, 0).cpu(), F.conv2d(xr * 4096.0, wr, None, padding=1))
+        assert 5e-5 < e_sat < 2e-3, ("saturated cross-term operands should cost plain-f16 accuracy", e_sat)
+        w1r = rn(40, C, 1, 1) / C ** 0.5
+        y0 = hip.op_conv(X2, hip.to_nhwc(d(xr), 0), d(w1r), None)
+        ym = hip.op_conv(X2, hip.to_nhwc(d(xr / 1024.0), 0), d(w1r), None, x2_shift=-10)
+        assert torch.equal(ym * 1024.0, y0), "per-tap 1x1: range shift -10 is not an exact rescaling"
         # residual in the epilogue; widest supported map
         if not light:
             xw, ww = rn(1, 2 * C, 9, 32), rn(16, 2 * C, 3, 3) / (3 * (2 * C) ** 0.5)
@@ -153,6 +168,38 @@ def run(hip, dev, light=False):
     finally:
         os.environ.pop("NOPE_CONV_PP", None)
     return worst
+
+
+def run_unet_range(hip, dev, dim=64, n_hyp=5, hw=16, scales=(1.0, 1e2, 1e3, 1e4, 3e5)):
+    """The f16x2 mode OFF the benchmark's activation range: the reference embedding scaled by S reaches the first ResnetBlock's conv
+    un-normalised (model_utils.py:271-272: block1 sees the residual stream as it is), so |a| grows with S.  Every forward must stay inside
+    the mode's accuracy: the U-Net handle reads the per-layer maxima after each call (nope_unet_x2_range_check), re-centres the shifts and
+    repeats the call when a layer left its window; beyond 65504 it runs as bf16x3.  Returns [(S, rel err vs oracle, range events, x2 still on)]."""
+    import warnings
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    from oracle import nope_ref as R
+    from tests.util import StubEncoder
+    os.environ["NOPE_CONV_PP"] = "9"
+    out = []
+    try:
+        u = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype="f16x2")
+        synth_init_(u, 2022)
+        sd = {k: v.clone() for k, v in u.own_state_dict().items()}
+        u = u.to(dev)
+        g = torch.Generator().manual_seed(23)
+        x, pose = torch.randn(1, 8, hw, hw, generator=g), torch.randn(1, n_hyp, 6, generator=g)
+        for S in scales:
+            n0 = len(u._handle.range_events) if u._handle is not None else 0
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                y = u.forward_hypotheses((x * S).to(dev), pose.to(dev)).cpu()[0]
+            h = u._handle
+            want = R.unet_forward(sd, (x * S).expand(n_hyp, -1, -1, -1), pose[0])
+            out.append((S, rel(y, want), h.range_events[n0:], h.x2_enabled))
+        return out
+    finally:
+        os.environ.pop("NOPE_CONV_PP")
 
 
 def run_unet(hip, dev, dim=64, n_hyp=5, hw=16):
