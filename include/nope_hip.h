@@ -42,12 +42,14 @@ enum { NOPE_F32 = 0, NOPE_BF16 = 1,
                           per product -- the fast mode that meets the 1e-4 score tolerance.  As an element type of nope_op_conv /
                           nope_op_pack_conv_weight it names those kernels and their weight layout (modes PLAIN 1x1 / 3x3, DOWN2, UP2P;
                           Cin % 32 == 0; nope_op_conv refuses a launch whose shape no ping-pong kernel takes).
-                          RANGE.  The activation operands are f16(a) (saturates at 65504), e4m3(a_lo * 2^(9 - t)), e4m3(a * 2^(-2 - t)): full
-                          accuracy for 2^(t - 4) <= |a| <= 1792 * 2^t, where t is a per-layer shift (0 at create time and for nope_op_conv:
-                          0.06 .. 1792).  A launch whose LARGEST |a| lies above 1792 * 2^t (saturated) or below 2^(t - 5) (all cross-term
-                          operands subnormal) has plain-f16 accuracy (~2^-11 per product) on those elements.  The kernels record max |a| per
-                          layer; nope_unet_x2_range_check reads it, re-centres t and says so -- nope_amd's U-Net calls it after every forward
-                          and re-runs (beyond 65504: as NOPE_BF16X3), so the mode is never silently outside its accuracy */ };
+                          RANGE.  The tile forms its activation operands from a' = a * 2^-t, t a per-layer shift (0 at create time and for
+                          nope_op_conv): f16(a') (saturates at 65504), e4m3(a'_lo * 2^9), e4m3(a' * 2^-2) (saturates at |a'| = 1792; four significant
+                          bits down to |a'| = 2^-4); the accumulators hold 2^-t x the convolution and the epilogue multiplies by 2^t -- all
+                          exact.  Full accuracy while the LARGEST |a| of a launch lies in [2^(t - 4), 1792 * 2^t] (t = 0: 0.06 .. 1792); outside,
+                          the cross terms of the saturated / flushed elements are lost: plain-f16 accuracy (~2^-11 per product) there.  The
+                          kernels record max |a| per layer; nope_unet_x2_range_check reads it, re-centres t and says so -- nope_amd's U-Net calls
+                          it after every forward and repeats the call, so the mode is never silently outside its accuracy at any magnitude
+                          an f32 tensor can hold */ };
 /* Tap geometries of nope_op_conv.  UP2P is UP2 (nearest-x2 upsample + 3x3, pad 1) rewritten as four
  * 2x2 convolutions over the un-upsampled input, one per output-pixel parity, with the 3x3 weights that
  * fall on the same source pixel pre-summed at pack time: same function, 4/9 of the multiply-adds. */
@@ -62,7 +64,7 @@ enum {
     NOPE_ERR_ALLOC = -5,
     NOPE_ERR_UNSUPPORTED = -6,
     NOPE_ERR_RANGE = -7,      /* nope_unet_x2_range_check: a NOPE_F16X2 launch saw activations outside its layer's window; the shifts were moved -- run the forward again */
-    NOPE_ERR_RANGE_F16 = -8   /* ... outside what f16 holds (|a| > 65504): run as NOPE_BF16X3 (nope_unet_x2_enable(net, 0)) */
+    NOPE_ERR_RANGE_F16 = -8   /* ... non-finite activations (inf): no shift repairs that; nope_unet_x2_enable(net, 0) runs the NOPE_BF16X3 kernels, which propagate them as f32 does */
 };
 
 typedef void* nope_stream_t;
@@ -193,7 +195,7 @@ int nope_unet_graph_limit(nope_unet* net, long long max_hyp_pixels);
  * converted in the forwards issued on it since the previous check, and
  *   returns NOPE_OK            every launch inside its layer's window (shifts within two binades of an end were re-centred for later calls);
  *           NOPE_ERR_RANGE     some launch outside: its result has plain-f16 accuracy there; the shifts are fixed -- run the forward again;
- *           NOPE_ERR_RANGE_F16 an activation beyond 65504: no shift helps; nope_unet_x2_enable(net, 0) makes every launch NOPE_BF16X3
+ *           NOPE_ERR_RANGE_F16 an infinite activation: no shift helps; nope_unet_x2_enable(net, 0) makes every launch NOPE_BF16X3
  *                              (same weights, the three-pass kernels), nope_unet_x2_enable(net, 1) returns to the two-pass tile.
  * n_out_of_range / n_adjusted / max_abs (each may be null): layers outside their window, layers whose shift moved, largest |a| seen.
  * A net created in another mode: NOPE_OK, nothing to check.  nope_unet_x2_shifts: the current per-layer shifts (creation order). */

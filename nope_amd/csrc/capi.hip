@@ -34,7 +34,7 @@ const char* nope_strerror(int code) {
     switch (code) {
         case NOPE_OK: return "ok";
         case NOPE_ERR_RANGE: return "f16x2: activations outside a layer's accurate range (shifts adjusted: run again)";
-        case NOPE_ERR_RANGE_F16: return "f16x2: activations beyond the f16 range (run as bf16x3)";
+        case NOPE_ERR_RANGE_F16: return "f16x2: non-finite activations (run as bf16x3)";
         case NOPE_ERR_ARG: return "invalid argument";
         case NOPE_ERR_LAUNCH: return "HIP launch/runtime error";
         case NOPE_ERR_WORKSPACE: return "workspace too small";

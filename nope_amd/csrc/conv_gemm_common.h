@@ -190,16 +190,18 @@ template <> struct Tile<f16x2_t> : Tile32 {
     // (saturating conversions: the wave runs with MODE.FP16_OVFL = 1).
     static __device__ __forceinline__ int frag_slot_raw(int lane) { return (lane >> 5) * 2; }
     static __device__ __forceinline__ constexpr int raw_slot_a(int q) { return (q & 1) | ((q >> 1) << 2); }
-    static __device__ __forceinline__ void prep_hi(const u32x4 (&r)[RAW][MT], u32x4 (&x)[RAW][MT], int i, int ks) {
+    // `inv` = 2^-t, the layer's range shift (nope_common.h: kX2*): every operand is formed from a' = a * 2^-t
+    static __device__ __forceinline__ void prep_hi(const u32x4 (&r)[RAW][MT], u32x4 (&x)[RAW][MT], int i, int ks, float inv) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const unsigned u0 = r[2 * ks + q][i][2 * e], u1 = r[2 * ks + q][i][2 * e + 1];
-                x[ks][i][2 * q + e] = NOPE_CVT_PK_F16_OVFL(__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1));
+                const f32x2_t v = f32x2_t{__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1)} * inv;
+                x[ks][i][2 * q + e] = NOPE_CVT_PK_F16_OVFL(v.x, v.y);
             }
     }
-    static __device__ __forceinline__ void prep_lo(const u32x4 (&r)[RAW][MT], u32x4 (&x)[RAW][MT], int i, int q, float div_lo, float div_a, float& amax) {      // raw read q: 4 channels
+    static __device__ __forceinline__ void prep_lo(const u32x4 (&r)[RAW][MT], u32x4 (&x)[RAW][MT], int i, int q, float inv, float div_a, float& amax) {      // raw read q: 4 channels; div_a = 2^(2 + t)
         float v[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const unsigned u = r[q][i][e]; v[e] = __builtin_bit_cast(float, u); }
@@ -207,10 +209,10 @@ template <> struct Tile<f16x2_t> : Tile32 {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             union { unsigned u; f16_t f[2]; } hh; hh.u = x[q >> 1][i][2 * (q & 1) + e];
-            l[2 * e] = v[2 * e] - (float)hh.f[0];
-            l[2 * e + 1] = v[2 * e + 1] - (float)hh.f[1];
+            l[2 * e] = __builtin_fmaf(v[2 * e], inv, -(float)hh.f[0]);              // a * 2^-t - hi: the product is exact, one rounding-free subtraction
+            l[2 * e + 1] = __builtin_fmaf(v[2 * e + 1], inv, -(float)hh.f[1]);
         }
-        x[2][i][q] = cvt4_e4m3_div(l[0], l[1], l[2], l[3], div_lo);
+        x[2][i][q] = cvt4_e4m3_scaled<kX2ALoShift, true>(l[0], l[1], l[2], l[3]);
         x[3][i][q] = cvt4_e4m3_div(v[0], v[1], v[2], v[3], div_a);
     }
     static constexpr int TERMS = 3;
@@ -386,9 +388,14 @@ struct NoStamp { __device__ __forceinline__ void operator()() const {} };
 // GG: GEGLU on column pairs (ConvArgs::geglu; packed 16-bit path only -- the launcher guarantees it is the one taken).
 template <class T, bool PN, bool DRAIN = false, class Stamp = NoStamp, bool GG = false>
 __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL],
-                                              int m0, int n0, int wm, int wn, int lane, unsigned char* lds_wave, Stamp stamp = Stamp()) {
+                                              int m0, int n0, int wm, int wn, int lane, unsigned char* lds_wave, Stamp stamp = Stamp(),
+                                              float acc_scale = 1.0f) {
     typedef Tile<T> TL;
     constexpr int VEC = Elt<T>::VEC;
+    // NOPE_F16X2: the accumulators hold 2^-t x the convolution (t = the layer's activation range shift, nope_common.h: kX2*); acc_scale = 2^t
+    // enters where the bias does (an fma in place of the add).  Every other element type: 1, folded away at compile time.
+    constexpr bool SCALED = Elt<T>::DT == NOPE_F16X2;
+    const float asc = SCALED ? acc_scale : 1.0f;
     constexpr int PANW = TL::TM == 32 ? 32 : 48;   // panel width in columns
     constexpr int TPP = PANW / TL::TM;             // MFMA tiles per panel pass
     constexpr int CH = PANW / VEC;                 // 16-byte output chunks per panel row
@@ -422,7 +429,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                     f32x2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
                     for (int r = h * RH; r < (h + 1) * RH; r += 2) {
-                        const f32x2_t v = f32x2_t{acc[i][j][r], acc[i][j][r + 1]} + bv;
+                        const f32x2_t v = SCALED ? f32x2_t{acc[i][j][r], acc[i][j][r + 1]} * asc + bv : f32x2_t{acc[i][j][r], acc[i][j][r + 1]} + bv;
                         s2 += v; q2 += v * v;
                     }
                     float s = s2.x + s2.y, q = q2.x + q2.y;
@@ -453,7 +460,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
             for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
                 for (int r = 0; r < TL::R; r += 2) {
-                    const f32x2_t v = f32x2_t{acc[i][j][r], acc[i][j][r + 1]} + bv;
+                    const f32x2_t v = SCALED ? f32x2_t{acc[i][j][r], acc[i][j][r + 1]} * asc + bv : f32x2_t{acc[i][j][r], acc[i][j][r + 1]} + bv;
                     s2 += v; q2 += v * v;
                 }
             float s = s2.x + s2.y, q = q2.x + q2.y;
@@ -580,7 +587,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
             for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
                 for (int r = 0; r < TL::R; ++r)
-                    pan[(i * TL::TM + TL::out_row(lane, r)) * Ep<T>::LD + jj * TL::TM + TL::out_col(lane)] = acc[i][j][r] + bv;
+                    pan[(i * TL::TM + TL::out_row(lane, r)) * Ep<T>::LD + jj * TL::TM + TL::out_col(lane)] = SCALED ? acc[i][j][r] * asc + bv : acc[i][j][r] + bv;
         }
         // same-wave LDS write -> read: the LDS queue of a wave is in order, so no s_barrier; the wave
         // barrier only pins the compiler's ordering (and is the rendezvous point of tests/hipemu)
@@ -663,9 +670,10 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
 // Cout % VEC).  Bias, residual and activation are applied by splitk_reduce_kernel, which adds the partials in a fixed order.
 template <class T>
 __device__ __forceinline__ void epilogue_split_wide(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL], int m0, int n0,
-                                                    int wm, int wn, int lane, unsigned char* lds_wave) {
+                                                    int wm, int wn, int lane, unsigned char* lds_wave, float acc_scale = 1.0f) {
     typedef Tile<T> TL;
     constexpr int PANW = TL::TM == 32 ? 32 : 48, TPP = PANW / TL::TM, LD = Ep<T>::LD, CH = PANW / 4;
+    constexpr bool SCALED = Elt<T>::DT == NOPE_F16X2;      // (see epilogue_wide)
     float* pan = reinterpret_cast<float*>(lds_wave);
     float* so = p.split_out + (size_t)blockIdx.z * p.M * p.Cout;
 #pragma unroll
@@ -676,7 +684,7 @@ __device__ __forceinline__ void epilogue_split_wide(const ConvParams& p, const t
             for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
                 for (int r = 0; r < TL::R; ++r)
-                    pan[(i * TL::TM + TL::out_row(lane, r)) * LD + jj * TL::TM + TL::out_col(lane)] = acc[i][pass * TPP + jj][r];
+                    pan[(i * TL::TM + TL::out_row(lane, r)) * LD + jj * TL::TM + TL::out_col(lane)] = SCALED ? acc[i][pass * TPP + jj][r] * acc_scale : acc[i][pass * TPP + jj][r];
         __builtin_amdgcn_wave_barrier();       // same-wave LDS write -> read (in-order LDS queue; rendezvous point of tests/hipemu)
         for (int idx = lane; idx < 64 * CH; idx += 64) {
             const int row = idx / CH, ch = idx - row * CH;

@@ -90,9 +90,9 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
     // tap-resident kernel.  (The PreNorm instantiation is never launched for it: launch_conv.)
     constexpr bool X2 = Elt<T>::DT == NOPE_F16X2;
     if constexpr (X2) fp16_ovfl_on();
-    const int x2_t = X2 ? p.x2_scale[3] : 0;                 // the layer's activation range shift (nope_common.h: kX2*)
-    const int x2_sc = X2 ? p.x2_scale[0] + x2_t : 0;
-    const float x2_dlo = x2_div_lo(x2_t), x2_da = x2_div_a(x2_t);
+    const int x2_t = X2 ? p.x2_scale[3] : 0;                 // the layer's activation range shift t (nope_common.h: kX2*): operands from a * 2^-t,
+    const int x2_sc = X2 ? p.x2_scale[0] : 0;                // the accumulators hold 2^-t x the convolution, the epilogue multiplies by 2^t
+    const float x2_inv = x2_pow2(-x2_t), x2_out = x2_pow2(x2_t), x2_da = x2_pow2(x2_t - kX2AShift);
     float x2_amax = 0.f;                                     // max |a| over the A elements this lane converts
     int tile_m, tile_n;
     tile_coords(p, tile_m, tile_n);
@@ -328,15 +328,15 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
                 // for the hi parts, then per row tile 16 unpack + 16 subtract + 16 packed e4m3 conversions -- rides behind the MFMAs that do
                 // not need it yet: term 0 (hi x hi, channels 0..15 of the step) waits for 4 conversions only, the cross-term MFMAs come last.
                 u32x4 ax[RAW][TL::MT];
-                TL::prep_hi(af[0], ax, 0, 0);
+                TL::prep_hi(af[0], ax, 0, 0, x2_inv);
                 __builtin_amdgcn_sched_barrier(0);
-                TL::prep_hi(af[0], ax, 1, 0);
-                TL::prep_hi(af[0], ax, 0, 1);
-                TL::prep_hi(af[0], ax, 1, 1);
+                TL::prep_hi(af[0], ax, 1, 0, x2_inv);
+                TL::prep_hi(af[0], ax, 0, 1, x2_inv);
+                TL::prep_hi(af[0], ax, 1, 1, x2_inv);
 #pragma unroll
                 for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
-                    for (int q = 0; q < RAW; ++q) TL::prep_lo(af[0], ax, i, q, x2_dlo, x2_da, x2_amax);
+                    for (int q = 0; q < RAW; ++q) TL::prep_lo(af[0], ax, i, q, x2_inv, x2_da, x2_amax);
 #pragma unroll
                 for (int t = 0; t < TL::TERMS; ++t)
 #pragma unroll
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
         return;
     }
     if constexpr (X2) x2_publish_amax(p, x2_amax, lane);
-    epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + wave * Ep<T>::WAVE_BYTES);
+    epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + wave * Ep<T>::WAVE_BYTES, NoStamp(), x2_out);
 }
 
 // ---- 3x3 convolutions: the A operand stays in LDS across the 9 taps ------------------------------------------------
@@ -584,9 +584,9 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     // themselves (probe fact 7; a NaN stays a NaN, as in the f32 / bf16x3 modes) -- 16 VALU per piece and lane instead of 46 with explicit
     // pre-scale multiplies, clamps and byte packing.
     if constexpr (X2) fp16_ovfl_on();
-    const int x2_t = X2 ? p.x2_scale[3] : 0;                                  // the layer's activation range shift (nope_common.h: kX2*)
-    const int x2_sc = X2 ? p.x2_scale[0] + x2_t : 0;                          // E8M0 block scale of the cross-term MFMA (uniform; waited for with the prologue's DMA)
-    const float x2_dlo = x2_div_lo(x2_t), x2_da = x2_div_a(x2_t);
+    const int x2_t = X2 ? p.x2_scale[3] : 0;                                  // the layer's activation range shift t (nope_common.h: kX2*): the rewrite works on a * 2^-t,
+    const int x2_sc = X2 ? p.x2_scale[0] : 0;                                 // E8M0 block scale of the cross-term MFMA (uniform; waited for with the prologue's DMA)
+    const float x2_inv = x2_pow2(-x2_t), x2_out = x2_pow2(x2_t), x2_da = x2_pow2(x2_t - kX2AShift);      // the accumulators hold 2^-t x the convolution, the epilogue multiplies by 2^t
     float x2_amax = 0.f;                                                      // max |a| over the A elements this lane rewrites
     // (two halves.  bf16x3: the READ of a piece opens the LOAD phase, the DMA pieces of the phase are issued and the tap's fragment addresses
     //  formed underneath it, then the arithmetic + writes: -1.6 % on the kernel against read + rewrite back to back.  f16x2: back to back, the
@@ -612,7 +612,9 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     auto convert_load = [&](int i, int stage) __attribute__((always_inline)) -> u32x4 {
         return ld16(a_dst + stage * A_STAGE + i * 8192 + rsub * RB + lslot * 16);
     };
-    auto convert_store = [&](const u32x4& v, int i, int stage) __attribute__((always_inline)) {
+    // `track`: the piece holds fresh activations (the COMPUTE-phase rewrite of a tile's LAST chunk re-converts an already rewritten stage that
+    // nothing reads again: its bit patterns are not activations and must not reach the range word)
+    auto convert_store = [&](const u32x4& v, int i, int stage, bool track = true) __attribute__((always_inline)) {
         if constexpr (X2) {
             unsigned char* row = a_dst + stage * A_STAGE + i * 8192 + rsub * RB;
             const int sw = swz_of<RB>(r0), ls = lslot ^ sw;
@@ -620,17 +622,18 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             float x[4], l[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const unsigned u = v[e]; x[e] = __builtin_bit_cast(float, u); }
+            { const float m = amax4(x2_amax, x[0], x[1], x[2], x[3]); x2_amax = track ? m : x2_amax; }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const unsigned h = NOPE_CVT_PK_F16_OVFL(x[2 * e], x[2 * e + 1]);      // (saturating: the wave runs with MODE.FP16_OVFL = 1)
+                const f32x2_t t2 = f32x2_t{x[2 * e], x[2 * e + 1]} * x2_inv;         // a' = a * 2^-t (exact; the layer's range shift, nope_common.h: kX2*)
+                const unsigned h = NOPE_CVT_PK_F16_OVFL(t2.x, t2.y);                   // (saturating: the wave runs with MODE.FP16_OVFL = 1)
                 hi[e] = h;
                 union { unsigned u; f16_t f[2]; } hh; hh.u = h;
-                l[2 * e] = x[2 * e] - (float)hh.f[0];
-                l[2 * e + 1] = x[2 * e + 1] - (float)hh.f[1];
+                l[2 * e] = __builtin_fmaf(x[2 * e], x2_inv, -(float)hh.f[0]);          // a' - hi in one instruction (the product is exact)
+                l[2 * e + 1] = __builtin_fmaf(x[2 * e + 1], x2_inv, -(float)hh.f[1]);
             }
-            x2_amax = amax4(x2_amax, x[0], x[1], x[2], x[3]);
-            lo8 = cvt4_e4m3_div(l[0], l[1], l[2], l[3], x2_dlo);
-            a8 = cvt4_e4m3_div(x[0], x[1], x[2], x[3], x2_da);
+            lo8 = cvt4_e4m3_scaled<kX2ALoShift, true>(l[0], l[1], l[2], l[3]);
+            a8 = cvt4_e4m3_div(x[0], x[1], x[2], x[3], x2_da);                        // e4m3(a' * 2^-2) = e4m3(a / 2^(2 + t))
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
             __builtin_amdgcn_wave_barrier();       // every lane's read precedes every lane's write (see below)
             *reinterpret_cast<u32x2*>(row + (((ls >> 1) ^ sw) << 4) + 8 * (ls & 1)) = u32x2{hi[0], hi[1]};
@@ -852,7 +855,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                             __builtin_amdgcn_sched_barrier(0);
                             cv = convert_load(tap - 1, par ^ 1);
                         }
-                        if (cv_c && g == 2) convert_store(cv, tap - 1, par ^ 1);
+                        if (cv_c && g == 2) convert_store(cv, tap - 1, par ^ 1, !last);
                         if (FA_AHEAD && g == 1) {
                             if (!cv_c) __builtin_amdgcn_sched_barrier(0);
                             tap_addresses((tap + 1) % 9, fa_next);
@@ -942,14 +945,14 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             if (dma_on) tile_prologue();
         }
         if constexpr (SPLIT) {                         // (never with a tile walk: iters == 1)
-            epilogue_split_wide<T>(p, acc, m_this, n0, wm, wn, lane, lds_panel);
+            epilogue_split_wide<T>(p, acc, m_this, n0, wm, wn, lane, lds_panel, x2_out);
             if (prefetched) {
 #pragma unroll
                 for (int k = 0; k < PFN; ++k) NOPE_KEEP_VGPR(pfv[k]);
             }
             return;
-        } else if constexpr (TIMELINE) epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel, stamp);
-        else epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel);
+        } else if constexpr (TIMELINE) epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel, stamp, x2_out);
+        else epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel, NoStamp(), x2_out);
         if (more) {
 #pragma unroll
             for (int i = 0; i < TL::MT; ++i)

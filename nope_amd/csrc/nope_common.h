@@ -183,7 +183,7 @@ template <int SHIFT, bool OVFL_MODE = false> __device__ __forceinline__ unsigned
     }
     return __builtin_bit_cast(unsigned, r);
 }
-// ... with the divisor in a register (the f16x2 kernels: 2^(shift of the layer's activation range), see kX2* below); MODE.FP16_OVFL form only
+// ... with the divisor in a register (only its exponent counts); MODE.FP16_OVFL form only
 __device__ __forceinline__ unsigned cvt4_e4m3_div(float x0, float x1, float x2, float x3, float divisor) {
     s16x2_hw_t r = {0, 0};
     r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, x0, x1, divisor, false);
@@ -208,16 +208,16 @@ __device__ __forceinline__ void fp16_ovfl_on() { __builtin_amdgcn_s_setreg(1 | (
 // chosen so that BOTH products of the K-concatenated instruction, a_lo w and a w_lo, carry the same total 2^(9 + sw): one scale for all
 // lanes (the instruction's scale blocks follow byte positions, not lane halves: tools/probes/mx_probe.hip fact 3h).  |a| up to 1792
 // and |a_lo| of |a| up to 2048 stay below the clamp; beyond, the element degrades towards plain f16 accuracy.
-// The activation pre-scales carry a per-layer RANGE SHIFT t (tail word 3, 0 as packed): e4m3(a_lo * 2^(9 - t)), e4m3(a * 2^(-2 - t)), block
-// scale + t -- the window of full accuracy, 2^(t - 4) <= |a| <= 1792 * 2^t, moves with the layer's activations.  The kernels record
-// max |a| of what they converted (ConvParams::x2_amax) and the runtime that owns the layer moves t when a launch left the window
-// (unet_runtime.hip: x2_range_check); operator-level launches run at t = 0.
+// RANGE SHIFT.  A layer's activations enter the tile as a' = a * 2^-t (an exact multiplication; t per layer: tail word 3, 0 as packed): f16(a'),
+// e4m3(a'_lo * 2^9), e4m3(a' * 2^-2) -- in instructions: one packed multiply per two elements for the f16 part, a'_lo = fma(a, 2^-t, -hi) in place
+// of the subtraction, and t added to the divisor the e4m3(a') conversion takes anyway: +2 VALU per four elements -- so the window of full accuracy -- |a'| <= 1792 for the e4m3(a') operand, <= 65504 for the f16 part, and
+// >= 2^-4 for four significant bits in e4m3(a') -- moves with t; the accumulators then hold 2^-t x the convolution and the epilogue multiplies by
+// 2^t (exact) before bias / statistics / residual.  The kernels record max |a| of what they converted (ConvParams::x2_amax) and the runtime that
+// owns the layer moves t when a launch left the window (unet_runtime.hip: nope_unet_x2_range_check); operator-level launches run at t = 0.
 constexpr int kX2ALoShift = 9, kX2AShift = -2, kX2WLoExtra = 11;
 constexpr int kX2TailBytes = 16;      // behind the packed weights: int A-scale byte (127 - 9 - sw), int sw, float max |w|, int t (range shift of the activations)
 constexpr float kX2AMaxFull = 1792.f;  // |a| * 2^-t above this saturates e4m3(a * 2^(-2 - t)) = 448
-// the two divisors of a layer's conversions as floats: 2^(t - 9) for a_lo, 2^(t + 2) for a
-__device__ __forceinline__ float x2_div_lo(int t) { return __builtin_bit_cast(float, (unsigned)(127 + t - kX2ALoShift) << 23); }
-__device__ __forceinline__ float x2_div_a(int t) { return __builtin_bit_cast(float, (unsigned)(127 + t - kX2AShift) << 23); }
+__device__ __forceinline__ float x2_pow2(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }      // 2^e, |e| <= 126
 
 // dtype code -> bytes per stored element / elements per 16-byte vector / the dtype the non-conv kernels see
 static inline int dt_es(int dt) { return (dt == NOPE_F32 || dt == NOPE_BF16X3 || dt == NOPE_F16X2) ? 4 : 2; }

@@ -80,10 +80,10 @@ struct nope_unet {
     mutable int graph_replays = 0;           // forwards served by a graph replay since create (tests assert the path really ran)
     long long graph_max = 0;                 // largest n_hyp * H * W that replays a graph; 0 = off
     // NOPE_F16X2 activation ranges (nope_unet_x2_range_check).  Every layer with a second pack owns a device word that its launches
-    // atomicMax with the bits of max |a| over the A elements they converted, and a range shift t in the pack's tail (word 3) that
-    // moves the window in which the e4m3 cross-term operands are fully accurate: 2^(t - 4) <= |a| <= 1792 * 2^t.
+    // atomicMax with the bits of max |a| over the A elements they converted, and a range shift t in the pack's tail (word 3): the tile works
+    // on a * 2^-t, which moves the window in which its operands are fully accurate: 2^(t - 4) <= max |a| <= 1792 * 2^t.
     std::vector<int*> x2_tails;              // per layer: device pointer to the pack's 16-byte tail
-    std::vector<int> x2_t, x2_sc0;           // host copies: current shift, the pack's E8M0 byte at t = 0 (read at the first check)
+    std::vector<int> x2_t;                   // host copy of the current shifts
     unsigned* x2_amax = nullptr;             // device, one word per layer
     mutable bool x2_off = false;             // nope_unet_x2_enable(net, 0): every launch as NOPE_BF16X3 (the fallback beyond f16's range)
     mutable std::mutex x2_mu;
@@ -678,10 +678,11 @@ int nope_unet_profile_launches(nope_unet* net, nope_conv_launch_info* out, int m
 }
 
 // ---- NOPE_F16X2 activation ranges ---------------------------------------------------------------------------------------------------------
-// The f16 + MX-fp8 tile converts every A element three ways: f16(a) (saturates at 65504), e4m3(a_lo * 2^(9 - t)) and e4m3(a * 2^(-2 - t))
-// (saturates at |a| = 1792 * 2^t, flushes to zero below 2^(t - 11)); t is per layer.  A launch whose max |a| left [2^(t - 5), 1792 * 2^t]
-// computed its cross terms from saturated or all-subnormal operands -- plain-f16 accuracy instead of ~2^-15 per product.  The check reads
-// what the launches since the previous check recorded, moves t where needed (window re-centred: max |a| * 2^-t in [16, 32)) and reports.
+// The f16 + MX-fp8 tile forms its A operands from a' = a * 2^-t (t per layer, nope_common.h: kX2*): f16(a') (saturates at 65504),
+// e4m3(a'_lo * 2^9) and e4m3(a' * 2^-2) (saturates at |a'| = 1792, below 2^-4 it runs out of significant bits).  A launch whose LARGEST |a'|
+// lies above 1792 or below 2^-4 computed its cross terms from saturated / subnormal operands: plain-f16 accuracy instead of ~2^-15 per
+// product.  The check reads what the launches since the previous check recorded, re-centres t where needed (max |a'| in [256, 512): three
+// binades of headroom, full accuracy down to 2^-13 of the maximum) and reports.
 int nope_unet_x2_range_check(nope_unet* net, nope_stream_t stream, int* n_out_of_range, int* n_adjusted, float* max_abs) {
     if (n_out_of_range) *n_out_of_range = 0;
     if (n_adjusted) *n_adjusted = 0;
@@ -695,11 +696,6 @@ int nope_unet_x2_range_check(nope_unet* net, nope_stream_t stream, int* n_out_of
     if (hipMemcpyAsync(bits.data(), net->x2_amax, n * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) return NOPE_ERR_LAUNCH;
     if (hipMemsetAsync(net->x2_amax, 0, n * sizeof(unsigned), s) != hipSuccess) return NOPE_ERR_LAUNCH;
     if (hipStreamSynchronize(s) != hipSuccess) return NOPE_ERR_LAUNCH;
-    if (net->x2_sc0.empty()) {                 // the packs' E8M0 bytes at t = 0 (device-computed at create time): once
-        net->x2_sc0.assign(n, 0);
-        for (size_t i = 0; i < n; ++i)
-            if (hipMemcpy(&net->x2_sc0[i], net->x2_tails[i], sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return NOPE_ERR_LAUNCH;
-    }
     int bad = 0, moved = 0, fatal = 0;
     float worst = 0.f;
     for (size_t i = 0; i < n; ++i) {
@@ -708,18 +704,16 @@ int nope_unet_x2_range_check(nope_unet* net, nope_stream_t stream, int* n_out_of
         memcpy(&amax, &bits[i], 4);
         if (!(amax == amax)) continue;
         if (amax > worst) worst = amax;
-        if (amax > 65504.f) { ++fatal; continue; }          // the f16 hi part saturated: no shift repairs that
+        if (!(amax <= 3.0e38f)) { ++fatal; continue; }       // non-finite activations: nothing a shift repairs (the f32 path overflows there too)
         const int t = net->x2_t[i];
         const float v = ldexpf(amax, -t);
-        const bool out = v > kX2AMaxFull || v < 0.03125f;    // saturated / every cross-term operand subnormal
-        const bool uneasy = v > kX2AMaxFull / 4 || v < 0.25f; // within two binades of either end: re-centre for the next call
+        const bool out = v > kX2AMaxFull || v < 0.0625f;      // the e4m3(a') operand saturated / has no full-precision element
+        const bool uneasy = v > 1024.f || v < 1.f;            // near an end: re-centre for the next call
         if (!out && !uneasy) continue;
         int e = 0;
         frexpf(amax, &e);                                    // amax = m * 2^e, m in [0.5, 1)
-        int tn = (e - 1) - 4;                                // max |a| * 2^-tn in [16, 32)
-        const int lo = 1 - net->x2_sc0[i], hi = 254 - net->x2_sc0[i];      // keep the instruction's scale byte inside E8M0
-        tn = tn < lo ? lo : (tn > hi ? hi : tn);
-        tn = tn < -64 ? -64 : (tn > 64 ? 64 : tn);
+        int tn = (e - 1) - 8;                                // max |a| * 2^-tn in [256, 512)
+        tn = tn < -100 ? -100 : (tn > 100 ? 100 : tn);
         if (out) ++bad;
         if (tn != t) {
             if (hipMemcpy(net->x2_tails[i] + 3, &tn, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return NOPE_ERR_LAUNCH;
@@ -730,8 +724,7 @@ int nope_unet_x2_range_check(nope_unet* net, nope_stream_t stream, int* n_out_of
     if (n_out_of_range) *n_out_of_range = bad + fatal;
     if (n_adjusted) *n_adjusted = moved;
     if (max_abs) *max_abs = worst;
-    if (moved) {                                // a cached graph replays the same kernels and pointers: the shifts live in device memory, nothing to rebuild
-    }
+    // (a cached hipGraph replays the same kernels and pointers; the shifts live in device memory: nothing to rebuild)
     return fatal ? NOPE_ERR_RANGE_F16 : (bad ? NOPE_ERR_RANGE : NOPE_OK);
 }
 

@@ -454,7 +454,7 @@ class UNetHandle:
         self._ws: Dict[tuple, torch.Tensor] = {}     # one arena per (device, stream): forwards on different streams never share one
         # NOPE_F16X2: after every forward, read the largest |activation| each two-pass layer converted (nope_unet_x2_range_check: one
         # stream synchronisation + 300 bytes) and run the forward again when a layer left its accurate window -- with re-centred
-        # shifts, or as NOPE_BF16X3 beyond f16's own range.  NOPE_X2_RANGE_CHECK=0 (or .range_check = False) trusts the shifts.
+        # shifts (as NOPE_BF16X3 only for non-finite activations).  NOPE_X2_RANGE_CHECK=0 (or .range_check = False) trusts the shifts.
         self.range_check = self.compute_dtype == F16X2 and os.environ.get("NOPE_X2_RANGE_CHECK", "1") != "0"
         self.range_events: List[dict] = []           # one record per forward that had to be repeated
         self.x2_enabled = self.compute_dtype == F16X2
@@ -551,7 +551,7 @@ class UNetHandle:
             self.range_events.append({"code": code, "layers_out_of_range": bad, "layers_adjusted": moved, "max_abs": amax, "attempt": attempt})
             if code == ERR_RANGE_F16 or attempt == 2:
                 import warnings
-                warnings.warn(f"nope_amd f16x2: activations up to {amax:.3g} " + ("exceed the f16 range" if code == ERR_RANGE_F16 else
+                warnings.warn(f"nope_amd f16x2: activations up to {amax:.3g} " + ("are not finite" if code == ERR_RANGE_F16 else
                               "keep leaving the layers' windows") + ": this U-Net runs as bf16x3 (three MFMA passes) from now on", RuntimeWarning)
                 self.x2_enable(False)
         return out

@@ -275,7 +275,7 @@ def test_f16x2_off_the_benchmark_activation_range(model_f32):
             sim, idx = m.retrieval_from_feat(q_feat * S, bank)
             e = float((sim - sim32).abs().max() / sim32.abs().max())
             ev = m.u_net._handle.range_events[n0:]
-            line.append(f"{cdt} {e:.2e}" + (f" (top-5 {'=' if torch.equal(idx, idx32) else '!='}; repeated: {[(x['code'], x['layers_out_of_range'], round(x['max_abs'])) for x in ev]}; "
+            line.append(f"{cdt} {e:.2e}" + (f" (top-5 {'=' if torch.equal(idx, idx32) else '!='}; repeated: {[(x['code'], x['layers_out_of_range'], float('%.3g' % x['max_abs'])) for x in ev]}; "
                                              f"shifts {sorted(set(m.u_net._handle.x2_shifts()))})" if cdt == "f16x2" else ""))
             if cdt == "f16x2":
                 assert e < 5e-5 and torch.equal(idx, idx32) and m.u_net._handle.x2_enabled, (S, e, ev)

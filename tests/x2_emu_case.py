@@ -174,7 +174,7 @@ def run_unet_range(hip, dev, dim=64, n_hyp=5, hw=16, scales=(1.0, 1e2, 1e3, 1e4,
     """The f16x2 mode OFF the benchmark's activation range: the reference embedding scaled by S reaches the first ResnetBlock's conv
     un-normalised (model_utils.py:271-272: block1 sees the residual stream as it is), so |a| grows with S.  Every forward must stay inside
     the mode's accuracy: the U-Net handle reads the per-layer maxima after each call (nope_unet_x2_range_check), re-centres the shifts and
-    repeats the call when a layer left its window; beyond 65504 it runs as bf16x3.  Returns [(S, rel err vs oracle, range events, x2 still on)]."""
+    repeats the call when a layer left its window (at any magnitude: the tile works on a * 2^-t).  Returns [(S, rel err vs oracle, range events, x2 still on)]."""
     import warnings
     from nope_amd.u_net import UNet
     from nope_amd.weights import synth_init_
