@@ -58,12 +58,15 @@ def _record_usage(src: str, remarks: str, objdir: str) -> None:
         raise RuntimeError(f"{src}: kernels use scratch memory (register spill / runtime-indexed array): {bad}")
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, variant: str = "", defines=()) -> str:
+    """variant / defines: an A/B build of the same library with extra -D flags into libnope_hip_<variant>.so (own object directory;
+    loaded through NOPE_HIP_LIB for same-box timing: the `#ifndef NOPE_*` compile-time defaults of the kernel sources)."""
     hipcc = _hipcc()
-    objdir = os.path.join(ROOT, "build", "hip")
+    objdir = os.path.join(ROOT, "build", "hip" + ("_" + variant if variant else ""))
     os.makedirs(objdir, exist_ok=True)
+    LIB = os.path.join(HERE, f"libnope_hip{'_' + variant if variant else ''}.so")
     headers = [os.path.join(HERE, "nope_common.h"), os.path.join(HERE, "conv_gemm_common.h"), os.path.join(HERE, "conv_gemm_dma.h"), os.path.join(ROOT, "include", "nope_hip.h")]
-    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + list(defines)
 
     def compile_one(src: str) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -100,5 +103,9 @@ def build_probe(force: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
-    print(build_probe(force="--force" in sys.argv))
+    if "--variant" in sys.argv:
+        v = sys.argv[sys.argv.index("--variant") + 1]
+        print(build(force="--force" in sys.argv, verbose=True, variant=v, defines=[a for a in sys.argv if a.startswith("-D")]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))
+        print(build_probe(force="--force" in sys.argv))

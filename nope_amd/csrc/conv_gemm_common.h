@@ -205,7 +205,7 @@ template <> struct Tile<f16x2_t> : Tile32 {
         float v[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const unsigned u = r[q][i][e]; v[e] = __builtin_bit_cast(float, u); }
-        amax = amax4(amax, v[0], v[1], v[2], v[3]);
+        if (NOPE_X2_TRACK) amax = amax4(amax, v[0], v[1], v[2], v[3]);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             union { unsigned u; f16_t f[2]; } hh; hh.u = x[q >> 1][i][2 * (q & 1) + e];
@@ -227,6 +227,15 @@ template <> struct Tile<f16x2_t> : Tile32 {
         }
     }
 };
+// NOPE_F16X2: a wave's max |a| over the A elements it converted -> the launch's range word (one atomic per wave and tile; the word is
+// read by the runtime that owns the layer, unet_runtime.hip: x2_range_check).  Non-negative floats order like their bit patterns.
+__device__ __forceinline__ void x2_publish_amax(const ConvParams& p, float m, int lane) {
+    if (!p.x2_amax) return;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) atomicMax(p.x2_amax, __builtin_bit_cast(unsigned, m));
+}
+
 // slot offset of raw read q (= step * RAW + r) of a staged row, to be XORed into a fragment address (<< 4)
 template <class T> __device__ __forceinline__ constexpr int raw_slot(int q) { return (q / Tile<T>::RAW) * Tile<T>::STEP_SLOTS + (q % Tile<T>::RAW) * Tile<T>::RAW_STRIDE; }
 

@@ -421,9 +421,12 @@ int conv_stat_rows(int dt, const ConvArgs& a) {
     return 0;
 }
 
-// the f16 + MX-fp8 tile: ping-pong launches (tap-resident or per-tap) of a layer that carries the second pack.  NOPE_X2_PP=0: tap-resident only
+// the f16 + MX-fp8 tile: launches of a layer that carries the second pack on a ping-pong kernel (tap-resident or per-tap) or -- round 6 -- on the
+// small-tile kernel (reference-sized banks, an 8-way shard).  NOPE_X2_PP=0: tap-resident only; NOPE_X2_SMALL=0: not on the small-tile kernel
 static bool plan_takes_x2(const ConvArgs& a, const ConvPlan& plan) {
-    return a.w_x2 && plan.pp && plan.small < 0 && !a.pn_ms && !a.geglu && (a.C1 + a.C2) % 32 == 0 && (plan.halo || NOPE_ENV("NOPE_X2_PP", 1) != 0);
+    if (!a.w_x2 || a.pn_ms || a.geglu || (a.C1 + a.C2) % 32) return false;
+    if (plan.small >= 0) return NOPE_ENV("NOPE_X2_SMALL", 1) != 0;
+    return plan.pp && (plan.halo || NOPE_ENV("NOPE_X2_PP", 1) != 0);
 }
 bool conv_takes_x2(int dt, const ConvArgs& a) { return dt_base(dt) == NOPE_BF16X3 && plan_takes_x2(a, plan_conv(dt, a)); }
 

@@ -53,15 +53,6 @@ struct KPos { int tap, kc; };
 
 // TUNE: the instantiation that honours the NOPE_PP_VARIANT ablations (run-time tests inside the K loop); production launches (variant 0) take the
 // one without them.
-// NOPE_F16X2: a wave's max |a| over the A elements it converted -> the launch's range word (one atomic per wave and tile; the word is
-// read by the runtime that owns the layer, unet_runtime.hip: x2_range_check).  Non-negative floats order like their bit patterns.
-__device__ __forceinline__ void x2_publish_amax(const ConvParams& p, float m, int lane) {
-    if (!p.x2_amax) return;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
-    if (lane == 0) atomicMax(p.x2_amax, __builtin_bit_cast(unsigned, m));
-}
-
 template <class T, int MODE, bool PN, bool TUNE = false>
 __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvParams p) {
     typedef Tile<T> TL;
@@ -90,7 +81,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
     // tap-resident kernel.  (The PreNorm instantiation is never launched for it: launch_conv.)
     constexpr bool X2 = Elt<T>::DT == NOPE_F16X2;
     if constexpr (X2) fp16_ovfl_on();
-    const int x2_t = X2 ? p.x2_scale[3] : 0;                 // the layer's activation range shift t (nope_common.h: kX2*): operands from a * 2^-t,
+    const int x2_t = (X2 && NOPE_X2_TRACK) ? p.x2_scale[3] : 0;                 // the layer's activation range shift t (nope_common.h: kX2*): operands from a * 2^-t,
     const int x2_sc = X2 ? p.x2_scale[0] : 0;                // the accumulators hold 2^-t x the convolution, the epilogue multiplies by 2^t
     const float x2_inv = x2_pow2(-x2_t), x2_out = x2_pow2(x2_t), x2_da = x2_pow2(x2_t - kX2AShift);
     float x2_amax = 0.f;                                     // max |a| over the A elements this lane converts
@@ -420,7 +411,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;
         return;
     }
-    if constexpr (X2) x2_publish_amax(p, x2_amax, lane);
+    if constexpr (X2 && NOPE_X2_TRACK) x2_publish_amax(p, x2_amax, lane);
     epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + wave * Ep<T>::WAVE_BYTES, NoStamp(), x2_out);
 }
 
@@ -584,7 +575,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     // themselves (probe fact 7; a NaN stays a NaN, as in the f32 / bf16x3 modes) -- 16 VALU per piece and lane instead of 46 with explicit
     // pre-scale multiplies, clamps and byte packing.
     if constexpr (X2) fp16_ovfl_on();
-    const int x2_t = X2 ? p.x2_scale[3] : 0;                                  // the layer's activation range shift t (nope_common.h: kX2*): the rewrite works on a * 2^-t,
+    const int x2_t = (X2 && NOPE_X2_TRACK) ? p.x2_scale[3] : 0;                                  // the layer's activation range shift t (nope_common.h: kX2*): the rewrite works on a * 2^-t,
     const int x2_sc = X2 ? p.x2_scale[0] : 0;                                 // E8M0 block scale of the cross-term MFMA (uniform; waited for with the prologue's DMA)
     const float x2_inv = x2_pow2(-x2_t), x2_out = x2_pow2(x2_t), x2_da = x2_pow2(x2_t - kX2AShift);      // the accumulators hold 2^-t x the convolution, the epilogue multiplies by 2^t
     float x2_amax = 0.f;                                                      // max |a| over the A elements this lane rewrites
@@ -622,7 +613,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             float x[4], l[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const unsigned u = v[e]; x[e] = __builtin_bit_cast(float, u); }
-            { const float m = amax4(x2_amax, x[0], x[1], x[2], x[3]); x2_amax = track ? m : x2_amax; }
+            if (NOPE_X2_TRACK) { const float m = amax4(x2_amax, x[0], x[1], x[2], x[3]); x2_amax = track ? m : x2_amax; }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const f32x2_t t2 = f32x2_t{x[2 * e], x[2 * e + 1]} * x2_inv;         // a' = a * 2^-t (exact; the layer's range shift, nope_common.h: kX2*)
@@ -935,7 +926,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         // COMPUTE, which group 1 reached after its last LOAD), nothing is in flight: the ring is free.  Start the next tile's
         // prologue now -- it lands while the panels are filled -- and wait for it before the first store of the epilogue
         // (so the K loop's vmcnt never has to wait for a prologue behind a queue of stores).
-        if constexpr (X2) x2_publish_amax(p, x2_amax, lane);
+        if constexpr (X2 && NOPE_X2_TRACK) x2_publish_amax(p, x2_amax, lane);
         const int m_this = m0;
         const bool more = it + 1 < iters;
         if (more) {

@@ -30,28 +30,34 @@ namespace nope {
 namespace {
 
 // one fragment's worth of MFMA work, per element type (the Tile<T> traits fix the 64 x 96 wave tile of the big kernels)
+// (a_frag_slot / a_raw_slot: which 16-byte slots of a staged A row a lane reads -- the B row's, except for NOPE_F16X2, whose A rows are staged
+//  as raw f32 and split in registers; `sc`: the E8M0 block scale of NOPE_F16X2's cross-term MFMA, unused by the other types)
+template <class T> struct FragSlots {
+    static __device__ __forceinline__ int a_frag_slot(int lane) { return Tile<T>::frag_slot(lane); }
+    static __device__ __forceinline__ constexpr int a_raw_slot(int q) { return raw_slot<T>(q); }
+};
 template <class T> struct Frag;
-template <> struct Frag<float> {
+template <> struct Frag<float> : FragSlots<float> {
     static __device__ __forceinline__ void prep(u32x4 (&)[1]) {}
-    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[1], const u32x4 (&b)[1], f32x4& c) {
+    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[1], const u32x4 (&b)[1], f32x4& c, int = 0) {
         const f32x4 fa = __builtin_bit_cast(f32x4, a[0]), fb = __builtin_bit_cast(f32x4, b[0]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q], fb[q], c, 0, 0, 0);
     }
 };
-template <> struct Frag<bf16_t> {
+template <> struct Frag<bf16_t> : FragSlots<bf16_t> {
     static __device__ __forceinline__ void prep(u32x4 (&)[1]) {}
-    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[1], const u32x4 (&b)[1], f32x16& c) {
+    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[1], const u32x4 (&b)[1], f32x16& c, int = 0) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
     }
 };
-template <> struct Frag<f16_t> {
+template <> struct Frag<f16_t> : FragSlots<f16_t> {
     static __device__ __forceinline__ void prep(u32x4 (&)[1]) {}
-    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[1], const u32x4 (&b)[1], f32x16& c) {
+    static __device__ __forceinline__ void mma(int, const u32x4 (&a)[1], const u32x4 (&b)[1], f32x16& c, int = 0) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[0]), c, 0, 0, 0);
     }
 };
-template <> struct Frag<f32s_t> {      // NOPE_BF16X3: see Tile<f32s_t>
+template <> struct Frag<f32s_t> : FragSlots<f32s_t> {      // NOPE_BF16X3: see Tile<f32s_t>
     static __device__ __forceinline__ void prep(u32x4 (&a)[2]) {
         float x[8];
 #pragma unroll
@@ -69,8 +75,48 @@ template <> struct Frag<f32s_t> {      // NOPE_BF16X3: see Tile<f32s_t>
         }
         a[0] = hi; a[1] = lo;
     }
-    static __device__ __forceinline__ void mma(int t, const u32x4 (&a)[2], const u32x4 (&b)[2], f32x16& c) {
+    static __device__ __forceinline__ void mma(int t, const u32x4 (&a)[2], const u32x4 (&b)[2], f32x16& c, int = 0) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t == 0 ? 1 : 0]), __builtin_bit_cast(bf16x8, b[t == 1 ? 1 : 0]), c, 0, 0, 0);
+    }
+};
+// NOPE_F16X2 (round 6: the reference-sized banks, an 8-way shard of the 512-template bank): Tile<f16x2_t>'s operands -- B rows from the layer's
+// second pack, A rows staged as raw f32 (the bf16x3 loaders unchanged) and split in registers exactly as the per-tap ping-pong kernel
+// splits them: a lane of half h reads the 16 f32 channels of its channel set (raw slots 2 h, 2 h + 1, 4 + 2 h, 5 + 2 h) and forms
+// f16(a') x 2, e4m3(a'_lo * 2^9), e4m3(a' * 2^-2) from a' = a * 2^-t (the layer's range shift; saturating conversions: MODE.FP16_OVFL).
+template <> struct Frag<f16x2_t> {
+    static __device__ __forceinline__ int a_frag_slot(int lane) { return Tile<f16x2_t>::frag_slot_raw(lane); }
+    static __device__ __forceinline__ constexpr int a_raw_slot(int q) { return Tile<f16x2_t>::raw_slot_a(q); }
+    static __device__ __forceinline__ void prep(u32x4 (&a)[4], float inv, float div_a, float& amax) {
+        u32x4 x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const unsigned u = a[q][e]; v[e] = __builtin_bit_cast(float, u); }
+            if (NOPE_X2_TRACK) amax = amax4(amax, v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const f32x2_t t2 = f32x2_t{v[2 * e], v[2 * e + 1]} * inv;
+                const unsigned h = NOPE_CVT_PK_F16_OVFL(t2.x, t2.y);
+                x[q >> 1][2 * (q & 1) + e] = h;
+                union { unsigned u; f16_t f[2]; } hh; hh.u = h;
+                l[2 * e] = __builtin_fmaf(v[2 * e], inv, -(float)hh.f[0]);
+                l[2 * e + 1] = __builtin_fmaf(v[2 * e + 1], inv, -(float)hh.f[1]);
+            }
+            x[2][q] = cvt4_e4m3_scaled<kX2ALoShift, true>(l[0], l[1], l[2], l[3]);
+            x[3][q] = cvt4_e4m3_div(v[0], v[1], v[2], v[3], div_a);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = x[q];
+    }
+    static __device__ __forceinline__ void mma(int t, const u32x4 (&a)[4], const u32x4 (&b)[4], f32x16& c, int sc) {
+        if (t < 2) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[t]), __builtin_bit_cast(f16x8, b[t]), c, 0, 0, 0);
+        } else {
+            const i32x8 va = {(int)a[2][0], (int)a[2][1], (int)a[2][2], (int)a[2][3], (int)a[3][0], (int)a[3][1], (int)a[3][2], (int)a[3][3]};
+            const i32x8 vb = {(int)b[2][0], (int)b[2][1], (int)b[2][2], (int)b[2][3], (int)b[3][0], (int)b[3][1], (int)b[3][2], (int)b[3][3]};
+            c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, c, 0, 0, 0, sc, 0, 127);
+        }
     }
 };
 
@@ -109,6 +155,12 @@ __global__ __launch_bounds__(256 * KG) void conv_gemm_small_kernel(ConvParams p)
     const int lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = KG > 1 ? wave8 >> 2 : 0, wave = wave8 & 3;          // K group, wave inside the group
+    constexpr bool X2 = Elt<T>::DT == NOPE_F16X2;
+    if constexpr (X2) fp16_ovfl_on();
+    const int x2_t = (X2 && NOPE_X2_TRACK) ? p.x2_scale[3] : 0;                            // the layer's activation range shift (nope_common.h: kX2*)
+    const int x2_sc = X2 ? p.x2_scale[0] : 0;
+    const float x2_inv = x2_pow2(-x2_t), x2_out = x2_pow2(x2_t), x2_da = x2_pow2(x2_t - kX2AShift);
+    float x2_amax = 0.f;
     const int wm = wave >> 1, wn = wave & 1;
     unsigned char* const ring = lds + grp * RING;                       // this group's ring
     int tile_m, tile_n;
@@ -237,7 +289,7 @@ __global__ __launch_bounds__(256 * KG) void conv_gemm_small_kernel(ConvParams p)
 
     int fa[MT], fb[NTL];        // fragment addresses of raw read 0 inside a stage; raw read q flips slot bits
 #pragma unroll
-    for (int i = 0; i < MT; ++i) fa[i] = lds_off_rb<RB>(wm * 32 * WMT + i * TL::TM + TL::frag_row(lane), TL::frag_slot(lane));
+    for (int i = 0; i < MT; ++i) fa[i] = lds_off_rb<RB>(wm * 32 * WMT + i * TL::TM + TL::frag_row(lane), Frag<T>::a_frag_slot(lane));
 #pragma unroll
     for (int j = 0; j < NTL; ++j) fb[j] = BMS * RB + lds_off_rb<RB>(wn * 32 * WNT + j * TL::TM + TL::frag_row(lane), TL::frag_slot(lane));
 
@@ -270,18 +322,21 @@ __global__ __launch_bounds__(256 * KG) void conv_gemm_small_kernel(ConvParams p)
 #pragma unroll
             for (int r = 0; r < RAW; ++r) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) af[i][r] = ld16(base + (fa[i] ^ (raw_slot<T>(kq * RAW + r) << 4)));
+                for (int i = 0; i < MT; ++i) af[i][r] = ld16(base + (fa[i] ^ (Frag<T>::a_raw_slot(kq * RAW + r) << 4)));
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) bfr[j][r] = ld16(base + (fb[j] ^ (raw_slot<T>(kq * RAW + r) << 4)));
             }
 #pragma unroll
-            for (int i = 0; i < MT; ++i) Frag<T>::prep(af[i]);
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (X2) Frag<T>::prep(af[i], x2_inv, x2_da, x2_amax);
+                else Frag<T>::prep(af[i]);
+            }
 #pragma unroll
             for (int t = 0; t < TL::TERMS; ++t)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NTL; ++j) Frag<T>::mma(t, af[i], bfr[j], acc[i][j]);
+                    for (int j = 0; j < NTL; ++j) Frag<T>::mma(t, af[i], bfr[j], acc[i][j], x2_sc);
         }
         __builtin_amdgcn_s_waitcnt(S_WAIT_LGKMCNT0);    // my reads of stage ks are done before I pass the next barrier
         st = st + 1 == NS ? 0 : st + 1;
@@ -289,7 +344,8 @@ __global__ __launch_bounds__(256 * KG) void conv_gemm_small_kernel(ConvParams p)
     __builtin_amdgcn_s_barrier();                  // the ring is free: every read is behind this barrier, every DMA has been waited for
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- epilogue: the tile's f32 accumulators through ONE panel, then rows out
+    if constexpr (X2 && NOPE_X2_TRACK) x2_publish_amax(p, x2_amax, lane);
+    // ---- epilogue: the tile's f32 accumulators through ONE panel, then rows out (NOPE_F16X2: x 2^t, the accumulators hold 2^-t x the sums)
     float* pan = reinterpret_cast<float*>(lds);
     {
         float* mine = reinterpret_cast<float*>(ring);          // (group 0: the panel itself)
@@ -299,7 +355,7 @@ __global__ __launch_bounds__(256 * KG) void conv_gemm_small_kernel(ConvParams p)
             for (int j = 0; j < NTL; ++j)
 #pragma unroll
                 for (int r = 0; r < TL::R; ++r)
-                    mine[(wm * 32 * WMT + i * TL::TM + TL::out_row(lane, r)) * LDP + wn * 32 * WNT + j * TL::TM + TL::out_col(lane)] = acc[i][j][r];
+                    mine[(wm * 32 * WMT + i * TL::TM + TL::out_row(lane, r)) * LDP + wn * 32 * WNT + j * TL::TM + TL::out_col(lane)] = X2 ? acc[i][j][r] * x2_out : acc[i][j][r];
     }
     __syncthreads();
     if (KG > 1) {                                  // sum of the two K groups, group 0 first
@@ -466,6 +522,7 @@ void launch_conv_small(int dt, const void* params, int tile, dim3 grid, hipStrea
         else launch_small_t<T, 1, 1, 3>(p, grid, s);                           \
     } while (0)
     if (dt == NOPE_F32) NOPE_SMALL_T(float);
+    else if (dt == NOPE_BF16X3 && p.x2_scale) NOPE_SMALL_T(f16x2_t);      // the layer's second pack: launch_conv took it (plan_takes_x2)
     else if (dt == NOPE_BF16X3) NOPE_SMALL_T(f32s_t);
     else if (dt == NOPE_F16) NOPE_SMALL_T(f16_t);
     else NOPE_SMALL_T(bf16_t);

@@ -214,6 +214,11 @@ __device__ __forceinline__ void fp16_ovfl_on() { __builtin_amdgcn_s_setreg(1 | (
 // >= 2^-4 for four significant bits in e4m3(a') -- moves with t; the accumulators then hold 2^-t x the convolution and the epilogue multiplies by
 // 2^t (exact) before bias / statistics / residual.  The kernels record max |a| of what they converted (ConvParams::x2_amax) and the runtime that
 // owns the layer moves t when a launch left the window (unet_runtime.hip: nope_unet_x2_range_check); operator-level launches run at t = 0.
+// (NOPE_X2_TRACK = 0 at compile time: t == 0 folded in and no range word -- the round-5 form of the rewrite, kept for same-box A/B timing:
+//  python -m nope_amd.csrc.build --variant notrack -DNOPE_X2_TRACK=0)
+#ifndef NOPE_X2_TRACK
+#define NOPE_X2_TRACK 1
+#endif
 constexpr int kX2ALoShift = 9, kX2AShift = -2, kX2WLoExtra = 11;
 constexpr int kX2TailBytes = 16;      // behind the packed weights: int A-scale byte (127 - 9 - sw), int sw, float max |w|, int t (range shift of the activations)
 constexpr float kX2AMaxFull = 1792.f;  // |a| * 2^-t above this saturates e4m3(a * 2^(-2 - t)) = 448

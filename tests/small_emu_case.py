@@ -103,6 +103,62 @@ def run(hip, dev, dts=(1, 0), tiles=(0, 1, 2, 3), light=False):
     return worst
 
 
+def run_x2(hip, dev, tiles=(0, 1, 3)):
+    """NOPE_F16X2 on the small-tile kernel (round 6: reference-sized banks and 8-way shards keep the two-pass tile): the layer's second
+    pack as B, A rows staged as raw f32 and split in registers.  Against the restated arithmetic of the tile (2e-6), the f32 convolution
+    (3e-5) and -- same K order, same three terms per 32-channel step into one accumulator -- bit for bit against the ping-pong kernels."""
+    from tests.x2_emu_case import X2, up2p_conv, up2p_phase_weights, x2_reference
+    g = torch.Generator().manual_seed(178)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    d = lambda x: x.to(dev)
+    C = 32
+    worst = 0.0
+
+    def both(fn, what, want, want32):
+        nonlocal worst
+        os.environ["NOPE_CONV_PP"], os.environ["NOPE_CONV_SMALL"] = "13", "0"
+        y_pp = fn()
+        os.environ.pop("NOPE_CONV_PP")
+        for tile in tiles:
+            os.environ["NOPE_CONV_SMALL"], os.environ["NOPE_SMALL_TILE"] = "2", str(tile)
+            y = fn()
+            yy = y.cpu().float() if tuple(y.shape) == tuple(want.shape) else hip.to_nchw(y, 0).cpu()
+            e, e32 = rel(yy, want), rel(yy, want32)
+            worst = max(worst, e / 2e-6, e32 / 3e-5)
+            assert e < 2e-6 and e32 < 3e-5, (what, tile, e, e32)
+            if tile != 3:
+                assert torch.equal(y, y_pp), (what, tile, "small-tile f16x2 differs from the ping-pong kernel")
+            else:
+                assert torch.equal(y, fn()), (what, "the two-group tile is not reproducible")
+            os.environ.pop("NOPE_SMALL_TILE")
+        os.environ.pop("NOPE_CONV_SMALL")
+
+    x1, x2 = rn(3, C, 10, 9), rn(3, C, 10, 9)
+    w, b = rn(200, 2 * C, 3, 3) / 30, rn(200)
+    xc = torch.cat((x1, x2), 1)
+    both(lambda: hip.op_conv(X2, hip.to_nhwc(d(x1), 0), d(w), d(b), src2=hip.to_nhwc(d(x2), 0)), "3x3 concat", x2_reference(xc, w, b), F.conv2d(xc, w, b, padding=1))
+    for nkc in (1, 3, 5):
+        x3, w3, r3 = rn(2, nkc * C, 12, 11), rn(72, nkc * C, 1, 1) / (nkc * C) ** 0.5, rn(2, 72, 12, 11)
+        c1 = lambda a, ww: F.conv2d(a, ww)
+        both(lambda: hip.op_conv(X2, hip.to_nhwc(d(x3), 0), d(w3), None, resid=hip.to_nhwc(d(r3), 0)), f"1x1 nk={nkc} + residual",
+             x2_reference(x3, w3, None, c1) + r3, F.conv2d(x3, w3) + r3)
+    wu, bu = rn(40, C, 3, 3) / 24, rn(40)
+    both(lambda: hip.op_conv(X2, hip.to_nhwc(d(x2), 0), d(wu), d(bu), mode=hip.CONV_UP2P), "up2p",
+         x2_reference(x2, up2p_phase_weights(wu), bu, up2p_conv), F.conv2d(F.interpolate(x2, scale_factor=2, mode="nearest"), wu, bu, padding=1))
+    x4, wd, bd = rn(5, C, 12, 10), rn(72, 4 * C, 1, 1) / 16, rn(72)
+    wd2 = wd.view(72, C, 2, 2)
+    cs2 = lambda a, ww: F.conv2d(a, ww, None, stride=2)
+    both(lambda: hip.op_conv(X2, hip.to_nhwc(d(x4), 0), d(wd), d(bd), mode=hip.CONV_DOWN2), "down2", x2_reference(x4, wd2, bd, cs2), F.conv2d(x4, wd2, bd, stride=2))
+    # the range shift: activations x 2^12 under t = 12 = exactly 2^12 x the t = 0 result (|a| in [0.5, 1.5): the f16 part stays normal)
+    xr, wr = torch.sign(rn(3, C, 10, 9)) * (0.5 + torch.rand(3, C, 10, 9, generator=g)), rn(40, C, 3, 3) / (3 * C ** 0.5)
+    os.environ["NOPE_CONV_SMALL"], os.environ["NOPE_SMALL_TILE"] = "2", "0"
+    y0 = hip.op_conv(X2, hip.to_nhwc(d(xr), 0), d(wr), None)
+    y12 = hip.op_conv(X2, hip.to_nhwc(d(xr * 4096.0), 0), d(wr), None, x2_shift=12)
+    os.environ.pop("NOPE_CONV_SMALL"); os.environ.pop("NOPE_SMALL_TILE")
+    assert torch.equal(y12, y0 * 4096.0), "small-tile f16x2: range shift 12 is not an exact rescaling"
+    return worst
+
+
 def run_unet(hip, dev, dim, cdt, n_hyp=2, hw=8, tile=0):
     """Whole U-Net schedule with every eligible conv on the small-tile kernel (fused GroupNorm statistics, fused PreNorm, concat
     sources, phase convs, space-to-depth, NCHW bank output) against the oracle."""
@@ -141,6 +197,10 @@ if __name__ == "__main__":
         e = run_unet(hip, "cpu", 64, "f16", n_hyp=2, hw=8)
         assert e < 8e-3, e
         print(f"unet f16 (u_net_dim 64) with split-K on the tap-resident kernel: rel err {e:.2e}")
+        print("small_emu_case OK")
+        sys.exit(0)
+    if "--x2" in sys.argv:
+        print(f"small-tile f16x2 worst/tol {run_x2(hip, 'cpu'):.3f}")
         print("small_emu_case OK")
         sys.exit(0)
     if "--unet32" in sys.argv:

@@ -21,7 +21,8 @@ def test_small_tile_kernel_under_adversarial_interpreter(emu):
     runs = [({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--dts", "1,0", "--tiles", "0,1,3"]),
             ({"HIPEMU_SHUFFLE": "2"}, ["--dts", "3,2", "--tiles", "2,3", "--light"]),
             ({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "3"}, ["--unet16"]),      # a whole f16 U-Net schedule: fused statistics per 16 / 64 rows, fused PreNorm, NCHW bank
-            ({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--unet16split"])]  # ... with its 3x3 convs split along K on the tap-resident kernel
+            ({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--unet16split"]),  # ... with its 3x3 convs split along K on the tap-resident kernel
+            ({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "2"}, ["--x2"])]           # the f16 + MX-fp8 tile on the small-tile kernel (A split in registers), bit-identical to the ping-pong kernels
     procs = []
     for e, args in runs:
         env = dict(os.environ, HIPEMU_THREADS="3", **e)
@@ -36,6 +37,7 @@ def test_small_tile_kernel_under_adversarial_interpreter(emu):
 def test_small_tile_small_shapes_gpu(gpu):
     from tests import small_emu_case
     assert small_emu_case.run(gpu, "cuda", dts=(1, 0, 3, 2)) < 1.0
+    assert small_emu_case.run_x2(gpu, "cuda", tiles=(0, 1, 2, 3)) < 1.0
     errs = {cdt: small_emu_case.run_unet(gpu, "cuda", 64, cdt, n_hyp=5, hw=16, tile=t) for cdt, t in (("f32", 3), ("bf16x3", 1), ("f16", 0), ("bf16", 3))}
     print("U-Net (u_net_dim 64) with every eligible conv on the small-tile kernel: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     assert errs["f32"] < 1e-4 and errs["bf16x3"] < 1e-4 and errs["f16"] < 8e-3 and errs["bf16"] < 6e-2
