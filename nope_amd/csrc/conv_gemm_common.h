@@ -205,7 +205,7 @@ template <> struct Tile<f16x2_t> : Tile32 {
         float v[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const unsigned u = r[q][i][e]; v[e] = __builtin_bit_cast(float, u); }
-        if (NOPE_X2_TRACK) amax = amax4(amax, v[0], v[1], v[2], v[3]);
+        if (NOPE_X2_KERNEL_AMAX) amax = amax4(amax, v[0], v[1], v[2], v[3]);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             union { unsigned u; f16_t f[2]; } hh; hh.u = x[q >> 1][i][2 * (q & 1) + e];

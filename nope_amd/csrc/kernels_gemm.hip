@@ -422,10 +422,13 @@ int conv_stat_rows(int dt, const ConvArgs& a) {
 }
 
 // the f16 + MX-fp8 tile: launches of a layer that carries the second pack on a ping-pong kernel (tap-resident or per-tap) or -- round 6 -- on the
-// small-tile kernel (reference-sized banks, an 8-way shard).  NOPE_X2_PP=0: tap-resident only; NOPE_X2_SMALL=0: not on the small-tile kernel
+// small-tile kernel (reference-sized banks, an 8-way shard).  NOPE_X2_PP=0: tap-resident only.  NOPE_X2_SMALL=1: also on the small-tile kernel
+// -- built, bit-identical to the ping-pong kernels, measured SLOWER than its bf16x3 form there (26 / 64 / 91 templates 7.29 / 9.13 / 11.47 ms
+// against 6.52 / 8.59 / 11.05, same box, profiles/r06c_small_tile_x2_ab.txt: a 64 x 64 tile's wave holds ONE accumulator, so its three MFMAs per
+// K step are a dependent chain either way and the register split costs more VALU than the third pass costs matrix time): off by default
 static bool plan_takes_x2(const ConvArgs& a, const ConvPlan& plan) {
     if (!a.w_x2 || a.pn_ms || a.geglu || (a.C1 + a.C2) % 32) return false;
-    if (plan.small >= 0) return NOPE_ENV("NOPE_X2_SMALL", 1) != 0;
+    if (plan.small >= 0) return NOPE_ENV("NOPE_X2_SMALL", 0) != 0;
     return plan.pp && (plan.halo || NOPE_ENV("NOPE_X2_PP", 1) != 0);
 }
 bool conv_takes_x2(int dt, const ConvArgs& a) { return dt_base(dt) == NOPE_BF16X3 && plan_takes_x2(a, plan_conv(dt, a)); }

@@ -339,12 +339,12 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
 #pragma unroll
                 for (int g = 0; g < 12; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
                 }
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;
         return;
     }
-    if constexpr (X2 && NOPE_X2_TRACK) x2_publish_amax(p, x2_amax, lane);
+    if constexpr (X2 && NOPE_X2_KERNEL_AMAX) x2_publish_amax(p, x2_amax, lane);
     epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + wave * Ep<T>::WAVE_BYTES, NoStamp(), x2_out);
 }
 
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             float x[4], l[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const unsigned u = v[e]; x[e] = __builtin_bit_cast(float, u); }
-            if (NOPE_X2_TRACK) { const float m = amax4(x2_amax, x[0], x[1], x[2], x[3]); x2_amax = track ? m : x2_amax; }
+            if (NOPE_X2_KERNEL_AMAX) { const float m = amax4(x2_amax, x[0], x[1], x[2], x[3]); x2_amax = track ? m : x2_amax; }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const f32x2_t t2 = f32x2_t{x[2 * e], x[2 * e + 1]} * x2_inv;         // a' = a * 2^-t (exact; the layer's range shift, nope_common.h: kX2*)
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         // COMPUTE, which group 1 reached after its last LOAD), nothing is in flight: the ring is free.  Start the next tile's
         // prologue now -- it lands while the panels are filled -- and wait for it before the first store of the epilogue
         // (so the K loop's vmcnt never has to wait for a prologue behind a queue of stores).
-        if constexpr (X2 && NOPE_X2_TRACK) x2_publish_amax(p, x2_amax, lane);
+        if constexpr (X2 && NOPE_X2_KERNEL_AMAX) x2_publish_amax(p, x2_amax, lane);
         const int m_this = m0;
         const bool more = it + 1 < iters;
         if (more) {

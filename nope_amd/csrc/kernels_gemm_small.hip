@@ -93,7 +93,7 @@ template <> struct Frag<f16x2_t> {
             float v[4], l[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const unsigned u = a[q][e]; v[e] = __builtin_bit_cast(float, u); }
-            if (NOPE_X2_TRACK) amax = amax4(amax, v[0], v[1], v[2], v[3]);
+            if (NOPE_X2_KERNEL_AMAX) amax = amax4(amax, v[0], v[1], v[2], v[3]);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const f32x2_t t2 = f32x2_t{v[2 * e], v[2 * e + 1]} * inv;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256 * KG) void conv_gemm_small_kernel(ConvParams p)
     __builtin_amdgcn_s_barrier();                  // the ring is free: every read is behind this barrier, every DMA has been waited for
     __builtin_amdgcn_sched_barrier(0);
 
-    if constexpr (X2 && NOPE_X2_TRACK) x2_publish_amax(p, x2_amax, lane);
+    if constexpr (X2 && NOPE_X2_KERNEL_AMAX) x2_publish_amax(p, x2_amax, lane);
     // ---- epilogue: the tile's f32 accumulators through ONE panel, then rows out (NOPE_F16X2: x 2^t, the accumulators hold 2^-t x the sums)
     float* pan = reinterpret_cast<float*>(lds);
     {

@@ -88,6 +88,24 @@ __global__ __launch_bounds__(NT) void absmax_bits_kernel(const float* __restrict
     for (int o = 32; o >= 1; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
+// ... of an activation tensor (the NOPE_F16X2 range tracking of tensors no gn_apply produced): 16-byte loads, four in flight per thread
+__global__ __launch_bounds__(NT) void absmax_f32_kernel(const float* __restrict__ x, size_t nvec, size_t n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    const size_t stride = (size_t)gridDim.x * NT;
+    size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const f32x4*>(x)[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m = amax4(m, v[u][0], v[u][1], v[u][2], v[u][3]);
+    }
+    for (; i < nvec; i += stride) { const f32x4 v = reinterpret_cast<const f32x4*>(x)[i]; m = amax4(m, v[0], v[1], v[2], v[3]); }
+    if (blockIdx.x == 0) for (size_t k = nvec * 4 + threadIdx.x; k < n; k += NT) m = __builtin_fmaxf(m, __builtin_fabsf(x[k]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
 __device__ __forceinline__ int x2_weight_shift(unsigned maxbits) {
     const int e = (int)(maxbits >> 23) - 127;          // floor(log2 max |w|) (normal numbers; zero / subnormal maxima give e = -127)
     const int sw = 7 - e;                              // max |w| * 2^sw in [128, 256)
@@ -263,6 +281,17 @@ int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int
 
 static size_t x2_rows(int Cout, int ntaps, int mode) { return mode == NOPE_CONV_UP2P ? (size_t)16 * Cout : (size_t)Cout * ntaps; }      // (four phases x four taps)
 size_t conv_w_x2_bytes(int Cout, int Cin, int ntaps, int mode) { return x2_rows(Cout, ntaps, mode) * Cin * 4 + kX2TailBytes; }
+
+int launch_absmax_f32(const float* x, size_t n, unsigned* out, hipStream_t s) {
+    if (!x || !out) return NOPE_ERR_ARG;
+    if (n == 0) return NOPE_OK;
+    const size_t nvec = n / 4;
+    size_t blocks = (nvec + (size_t)NT * 8 - 1) / ((size_t)NT * 8);
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(absmax_f32_kernel, dim3((unsigned)blocks), dim3(NT), 0, s, x, nvec, n, out);
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
 
 int launch_pack_conv_w_x2(const float* w, void* out, int Cout, int Cin, hipStream_t s, int ntaps, int mode) {
     if (!w || !out || Cout <= 0 || Cin <= 0) return NOPE_ERR_ARG;

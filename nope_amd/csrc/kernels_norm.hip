@@ -163,8 +163,13 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
                                                       int nchunk, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       int HW, int C, int G, const float* __restrict__ emb, int emb_stride,
                                                       const T* __restrict__ resid, float eps, int blocks_per_hyp, int x_rep, int resid_rep,
-                                                      float* __restrict__ out_stats, const float* __restrict__ film, int film_stride) {
+                                                      float* __restrict__ out_stats, const float* __restrict__ film, int film_stride,
+                                                      unsigned* __restrict__ amax_out) {
     constexpr int VEC = Elt<T>::VEC, V2 = VEC / 2;
+    // AMAX (the f32-storage instantiations with the fast SiLU = the split-precision modes): max |y| over what this workgroup writes, for the
+    // range shifts of the NOPE_F16X2 convs that consume y (unet_runtime.hip) -- one v_max3_f32 per two values in a kernel that waits for HBM
+    constexpr bool AMAX = FAST && sizeof(T) == 4 && !FILM;
+    float amax = 0.f;
     __shared__ float s_mean[64];
     __shared__ float s_rstd[64];
     __shared__ float s_os[NT / 64], s_oq[NT / 64];
@@ -270,6 +275,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
                 if (RES) t += f32x2{r[2 * q], r[2 * q + 1]};
                 v[2 * q] = t.x; v[2 * q + 1] = t.y;
                 if (OS) { os2 += t; oq2 += t * t; }
+                if (AMAX) amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(t.x)), __builtin_fabsf(t.y));
             }
             return Elt<T>::pack(v);
         };
@@ -292,6 +298,11 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
             const u32x4 xr = RES ? ld16(rb + o) : xa;
             st16(yb + o, apply(xa, xr));
         }
+    }
+    if (AMAX && amax_out) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, o, 64));
+        if ((tid & 63) == 0 && amax > 0.f) atomicMax(amax_out, __builtin_bit_cast(unsigned, amax));
     }
     if (OS) {
         // per-block (sum, sum of squares) of what was just written: the GroupNorm(1) statistics of the NEXT op
@@ -404,7 +415,7 @@ int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
 #define NOPE_GN_APPLY_F(T, FAST, OS, FILM, ACT, RES, U, FOLD)                                                                    \
     hipLaunchKernelGGL((gn_apply_kernel<T, FAST, OS, FILM, ACT, RES, U, FOLD>), grid, block, 0, s, (const T*)a.x, (T*)a.y,       \
                        FOLD ? a.colstats : a.partial, FOLD ? a.stat_blocks : a.nchunk, a.gamma, a.beta, a.HW, a.C, a.G, a.emb,   \
-                       a.emb_stride, (const T*)a.resid, a.eps, bph, a.x_rep, a.resid_rep, a.out_stats, a.film, a.film_stride)
+                       a.emb_stride, (const T*)a.resid, a.eps, bph, a.x_rep, a.resid_rep, a.out_stats, a.film, a.film_stride, a.amax_out)
 #define NOPE_GN_APPLY_U(T, FAST, OS, FILM, ACT, RES, U)                                                                          \
     do { if (!FILM && fold) NOPE_GN_APPLY_F(T, FAST, OS, false, ACT, RES, U, true); else NOPE_GN_APPLY_F(T, FAST, OS, FILM, ACT, RES, U, false); } while (0)
 #define NOPE_GN_APPLY_AR(T, FAST, OS, FILM, ACT, RES) NOPE_GN_APPLY_U(T, FAST, OS, FILM, ACT, RES, 2)   /* (4 in flight: +-0) */

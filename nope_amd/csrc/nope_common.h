@@ -214,10 +214,15 @@ __device__ __forceinline__ void fp16_ovfl_on() { __builtin_amdgcn_s_setreg(1 | (
 // >= 2^-4 for four significant bits in e4m3(a') -- moves with t; the accumulators then hold 2^-t x the convolution and the epilogue multiplies by
 // 2^t (exact) before bias / statistics / residual.  The kernels record max |a| of what they converted (ConvParams::x2_amax) and the runtime that
 // owns the layer moves t when a launch left the window (unet_runtime.hip: nope_unet_x2_range_check); operator-level launches run at t = 0.
-// (NOPE_X2_TRACK = 0 at compile time: t == 0 folded in and no range word -- the round-5 form of the rewrite, kept for same-box A/B timing:
-//  python -m nope_amd.csrc.build --variant notrack -DNOPE_X2_TRACK=0)
+// (NOPE_X2_TRACK = 0 at compile time: t == 0 folded in -- the round-5 form of the rewrite, kept for same-box A/B timing:
+//  python -m nope_amd.csrc.build --variant notrack -DNOPE_X2_TRACK=0.  NOPE_X2_KERNEL_AMAX = 1: the conv kernels themselves record max |a| of
+//  what they convert into ConvParams::x2_amax -- measured +5 % on the 512-template step, profiles/r06c_*: the U-Net runtime takes the maxima from
+//  the PRODUCERS of its tensors instead, gn_apply's spare VALU slots and absmax passes over the few conv-produced ones; off by default.)
 #ifndef NOPE_X2_TRACK
 #define NOPE_X2_TRACK 1
+#endif
+#ifndef NOPE_X2_KERNEL_AMAX
+#define NOPE_X2_KERNEL_AMAX 0
 #endif
 constexpr int kX2ALoShift = 9, kX2AShift = -2, kX2WLoExtra = 11;
 constexpr int kX2TailBytes = 16;      // behind the packed weights: int A-scale byte (127 - 9 - sw), int sw, float max |w|, int t (range shift of the activations)
@@ -378,10 +383,12 @@ struct GnApplyArgs {
     int resid_rep = 1;                 // resid shared by resid_rep consecutive hypotheses
     float* out_stats = nullptr;        // optional [nhyp][gn_apply_blocks()][2]: (sum, sum sq) of the values written
     float eps = 1e-5f;
+    unsigned* amax_out = nullptr;      // f32 storage + fast_silu only (the split-precision modes): atomicMax of the bits of max |y| over what this launch wrote
     int fast_silu = 0;                 // f32 storage only: SiLU on v_exp_f32 + v_rcp_f32 (1 ulp each, what the 16-bit types always use) instead of expf + an
                                        // IEEE division -- set by the runtimes in the split-precision modes (bf16x3, f16x2), whose bar is 1e-4, not bit parity
 };
 int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s);
+int launch_absmax_f32(const float* x, size_t n, unsigned* out, hipStream_t s);      // atomicMax(out, bits of max |x[i]|) (kernels_misc.hip; NaNs ignored)
 int gn_apply_blocks(int HW, int C, int dt, int nhyp);      // workgroups per hypothesis of launch_gn_apply over nhyp samples (= chunks of out_stats)
 int launch_gn_finalize(const float* partial, float* ms, int nhyp, int nchunk, float count, float eps, hipStream_t s);
 int gn_stats_chunks(int HW, int C, int dt);

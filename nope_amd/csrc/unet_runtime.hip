@@ -17,6 +17,7 @@
 //     f32 GEMM against the row-concatenated weights;
 //   * a bump arena over caller-provided workspace: no allocation, no host sync, one stream.
 #include <cstdio>
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -79,12 +80,17 @@ struct nope_unet {
     mutable std::mutex graph_mu;
     mutable int graph_replays = 0;           // forwards served by a graph replay since create (tests assert the path really ran)
     long long graph_max = 0;                 // largest n_hyp * H * W that replays a graph; 0 = off
-    // NOPE_F16X2 activation ranges (nope_unet_x2_range_check).  Every layer with a second pack owns a device word that its launches
-    // atomicMax with the bits of max |a| over the A elements they converted, and a range shift t in the pack's tail (word 3): the tile works
-    // on a * 2^-t, which moves the window in which its operands are fully accurate: 2^(t - 4) <= max |a| <= 1792 * 2^t.
+    // NOPE_F16X2 activation ranges (nope_unet_x2_range_check).  Every layer with a second pack has a range shift t in the pack's tail (word 3):
+    // the tile works on a * 2^-t, which moves the window in which its operands are fully accurate: 2^(t - 4) <= max |a| <= 1792 * 2^t.  max |a|
+    // comes from the PRODUCERS of the tensors a layer reads: every tensor a forward writes that an f16x2 launch consumes owns a slot of
+    // x2_amax (device words, atomicMax of float bits) -- filled by gn_apply in passing (its spare VALU slots: the kernel waits for HBM), or by
+    // an absmax pass over the few tensors a conv epilogue produced (the resampling convs' outputs: 0.2 ms per 512-template step).  In-kernel
+    // tracking inside the conv kernels was measured at +5 % of the step (profiles/r06c_*) and is compiled out (NOPE_X2_KERNEL_AMAX).
+    static constexpr int X2_SLOTS = 512;
     std::vector<int*> x2_tails;              // per layer: device pointer to the pack's 16-byte tail
     std::vector<int> x2_t;                   // host copy of the current shifts
-    unsigned* x2_amax = nullptr;             // device, one word per layer
+    mutable std::vector<std::vector<int>> x2_layer_slots;      // per layer: slots of the tensors its f16x2 launches read (same every forward)
+    unsigned* x2_amax = nullptr;             // device, X2_SLOTS words
     mutable bool x2_off = false;             // nope_unet_x2_enable(net, 0): every launch as NOPE_BF16X3 (the fallback beyond f16's range)
     mutable std::mutex x2_mu;
 };
@@ -223,6 +229,25 @@ struct Fwd {
     float* pn_ms = nullptr;        // its per-hypothesis (mean, rstd)
     const float* emb_all = nullptr;
 
+    // NOPE_F16X2 range tracking: which x2_amax slot holds max |.| of the tensor that currently lives at a buffer address
+    std::map<const void*, int> slot_of;
+    int next_slot = 0;
+    bool tracking() const { return net->x2 && !net->x2_off && net->x2_amax && !ar.dry && err == NOPE_OK; }
+    int produce(const void* p) {                 // a kernel that records its output's maximum is about to write the tensor at p
+        const int sl = next_slot < nope_unet::X2_SLOTS ? next_slot++ : -1;
+        if (sl >= 0) slot_of[p] = sl; else slot_of.erase(p);
+        return sl;
+    }
+    void overwritten(const void* p) { slot_of.erase(p); }      // ... a kernel that does not
+    // the slot of the tensor at a.p, taking an absmax pass over it when its producer recorded none (conv epilogues, attention kernels)
+    int slot_for(const Act& a, int n) {
+        auto it = slot_of.find(a.p);
+        if (it != slot_of.end()) return it->second;
+        const int sl = produce(a.p);
+        if (sl >= 0) chk(launch_absmax_f32((const float*)a.p, (size_t)n * a.H * a.W * a.C, net->x2_amax + sl, s));
+        return sl;
+    }
+
     bool dry() const { return ar.dry; }
     void chk(int e) { if (e != NOPE_OK && err == NOPE_OK) err = e; }
     void* alloc_act(size_t elems) {
@@ -245,7 +270,6 @@ struct Fwd {
         if (b) { ca.src2 = b->p; ca.C2 = b->C; ca.rep2 = rep2; }
         ca.Hs = a.H; ca.Ws = a.W; ca.Ho = Ho; ca.Wo = Wo;
         ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.w_x2 = net->x2_off ? nullptr : c.w_x2; ca.bias = c.bias; ca.resid = resid;
-        if (ca.w_x2 && net->x2_amax && c.x2_id >= 0) ca.x2_amax = net->x2_amax + c.x2_id;
         ca.out = out; ca.Cout = c.Cout; ca.nhyp = n; ca.out_nchw = out_nchw; ca.out_dt = out_dt;
         if (a.C + (b ? b->C : 0) != c.Cin) { chk(NOPE_ERR_ARG); return; }
         float* colstats = nullptr;
@@ -272,6 +296,16 @@ struct Fwd {
         }
         struct Release { Arena& a; size_t m; ~Release() { a.off = m; } } release{ar, sk_mark};
         if (!live()) return;               // workspace-size query: only the arena bookkeeping above matters
+        if (tracking()) {
+            if (ca.w_x2 && c.x2_id >= 0 && conv_takes_x2(net->dt, ca)) {      // this launch runs the two-pass tile: its layer's shift follows its inputs' maxima
+                const int sa = slot_for(a, n / rep1), sb = b ? slot_for(*b, n / rep2) : -1;
+                std::lock_guard<std::mutex> lock(net->x2_mu);
+                std::vector<int>& ls = net->x2_layer_slots[c.x2_id];
+                for (int sl : {sa, sb})
+                    if (sl >= 0 && std::find(ls.begin(), ls.end(), sl) == ls.end()) ls.push_back(sl);
+            }
+            overwritten(out);              // (a conv epilogue records no maximum: a later f16x2 consumer of `out` takes an absmax pass)
+        }
         if (net->profile) {
             nope_unet::Ev ev;
             hipEventCreate(&ev.a); hipEventCreate(&ev.b);
@@ -315,6 +349,7 @@ struct Fwd {
         ga.nhyp = nhyp; ga.HW = HW; ga.C = nm.C; ga.G = G; ga.act = act;
         if (emb_off >= 0) { ga.emb = emb_all + emb_off; ga.emb_stride = net->emb_total; }
         ga.resid = resid; ga.x_rep = x_rep; ga.resid_rep = resid_rep; ga.out_stats = out_stats;
+        if (tracking()) { const int sl = produce(y); if (sl >= 0) ga.amax_out = net->x2_amax + sl; }
         ga.fast_silu = net->dt != NOPE_F32 ? 1 : 0;      // (f32 storage of the split-precision modes: hardware exp / rcp; the f32 mode keeps expf and the division)
         chk(launch_gn_apply(net->sdt, ga, s));
     }
@@ -373,7 +408,7 @@ struct Fwd {
         void* qkv = alloc_act(M * 3 * heads * dh);
         void* a = alloc_act(M * heads * dh);
         qkv_prenorm(L.qkv, L.c0, L.c1, x, qkv);
-        if (live()) chk(launch_linattn(net->sdt, qkv, a, nhyp, HW, heads, dh, s));
+        if (live()) { chk(launch_linattn(net->sdt, qkv, a, nhyp, HW, heads, dh, s)); overwritten(a); }
         Act aa{a, heads * dh, x.H, x.W, 1};
         Stats cs;
         conv(L.out, aa, nullptr, y, x.H, x.W, nhyp, 1, 1, nullptr, 0, NOPE_F32, &cs);
@@ -389,7 +424,7 @@ struct Fwd {
         void* qkv = alloc_act(M * 3 * heads * dh);
         void* a = alloc_act(M * heads * dh);
         qkv_prenorm(A.qkv, A.c0, A.c1, x, qkv);
-        if (live()) chk(launch_attn(net->sdt, qkv, a, nhyp, HW, heads, dh, s));
+        if (live()) { chk(launch_attn(net->sdt, qkv, a, nhyp, HW, heads, dh, s)); overwritten(a); }
         Act aa{a, heads * dh, x.H, x.W, 1};
         conv(A.out, aa, nullptr, out, x.H, x.W, nhyp, 1, 1, /*resid=*/x.p);
         ar.off = mark;
@@ -459,6 +494,7 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
         g.nhyp = n_src;
         g.conv(net->init_conv, xin, nullptr, x0, H, W, n_src, 1, 1);
         f.chk(g.err);
+        f.slot_of = g.slot_of; f.next_slot = g.next_slot;
     }
     Act r0{x0, dims[0], H, W, x_rep};
     Act cur = r0;
@@ -625,9 +661,10 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
     }
     if (ld.err == NOPE_OK && !net->x2_tails.empty()) {
         const size_t n = net->x2_tails.size();
-        net->x2_amax = (unsigned*)ld.dmalloc(n * sizeof(unsigned));
-        if (net->x2_amax && hipMemsetAsync(net->x2_amax, 0, n * sizeof(unsigned), s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
+        net->x2_amax = (unsigned*)ld.dmalloc(nope_unet::X2_SLOTS * sizeof(unsigned));
+        if (net->x2_amax && hipMemsetAsync(net->x2_amax, 0, nope_unet::X2_SLOTS * sizeof(unsigned), s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
         net->x2_t.assign(n, 0);
+        net->x2_layer_slots.assign(n, std::vector<int>());
     }
     if (ld.err == NOPE_OK && hipStreamSynchronize(s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
     if (ld.err != NOPE_OK) {
@@ -692,10 +729,14 @@ int nope_unet_x2_range_check(nope_unet* net, nope_stream_t stream, int* n_out_of
     std::lock_guard<std::mutex> lock(net->x2_mu);
     hipStream_t s = (hipStream_t)stream;
     const size_t n = net->x2_tails.size();
-    std::vector<unsigned> bits(n);
-    if (hipMemcpyAsync(bits.data(), net->x2_amax, n * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) return NOPE_ERR_LAUNCH;
-    if (hipMemsetAsync(net->x2_amax, 0, n * sizeof(unsigned), s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    std::vector<unsigned> words(nope_unet::X2_SLOTS);
+    if (hipMemcpyAsync(words.data(), net->x2_amax, words.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    if (hipMemsetAsync(net->x2_amax, 0, words.size() * sizeof(unsigned), s) != hipSuccess) return NOPE_ERR_LAUNCH;
     if (hipStreamSynchronize(s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    std::vector<unsigned> bits(n, 0u);         // per layer: the largest maximum among the tensors its f16x2 launches read
+    for (size_t i = 0; i < n; ++i)
+        for (int sl : net->x2_layer_slots[i])
+            if (words[sl] > bits[i] && words[sl] <= 0x7f800000u) bits[i] = words[sl];
     int bad = 0, moved = 0, fatal = 0;
     float worst = 0.f;
     for (size_t i = 0; i < n; ++i) {

@@ -457,6 +457,7 @@ class UNetHandle:
         # shifts (as NOPE_BF16X3 only for non-finite activations).  NOPE_X2_RANGE_CHECK=0 (or .range_check = False) trusts the shifts.
         self.range_check = self.compute_dtype == F16X2 and os.environ.get("NOPE_X2_RANGE_CHECK", "1") != "0"
         self.range_events: List[dict] = []           # one record per forward that had to be repeated
+        self._pending: List[tuple] = []              # forwards issued with defer_range_check: (re-launch closure, stream)
         self.x2_enabled = self.compute_dtype == F16X2
 
     def __del__(self):
@@ -517,8 +518,9 @@ class UNetHandle:
         return int(self._l.dll.nope_unet_workspace_bytes(self._h, n_hyp, n_src, H, W))
 
     def forward(self, x: torch.Tensor, pose: torch.Tensor, x_rep: int = 1, out: Optional[torch.Tensor] = None,
-                out_dtype=F32) -> torch.Tensor:
-        """out[j] = UNet(x[j // x_rep], pose[j]); x (n_src,C,H,W) f32, pose (n_src*x_rep, pose_dim)."""
+                out_dtype=F32, defer_range_check: bool = False) -> torch.Tensor:
+        """out[j] = UNet(x[j // x_rep], pose[j]); x (n_src,C,H,W) f32, pose (n_src*x_rep, pose_dim).  defer_range_check (NOPE_F16X2): the
+        caller will call finish_range_check() itself before it hands results out."""
         require_device(x)
         x = _f32c(x)
         pose = _f32c(pose)
@@ -539,22 +541,42 @@ class UNetHandle:
             self._ws.pop(key, None)          # release the smaller arena before taking a bigger one
             ws = None
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
-        for attempt in range(4):
+        def launch():
             self._l.check(self._l.dll.nope_unet_forward(self._h, _ptr(x), n_src, x_rep, _ptr(pose), n_hyp, H, W, _ptr(out), odt,
                                                         _ptr(ws), ws.numel(), _stream(x)), "nope_unet_forward")
-            if not (self.range_check and self.x2_enabled):
+        launch()
+        if self.range_check and self.x2_enabled:
+            # the check needs the forward to have finished: callers that go on issuing work on the stream (PoseConditional: scoring,
+            # top-k) call finish_range_check() at the END of their step -- one synchronisation where the results are read anyway --
+            # and repeat their own tail when it says the forward was repeated
+            self._pending.append((launch, _stream(x)))
+            if not defer_range_check:
+                self.finish_range_check()
+        return out
+
+    def finish_range_check(self) -> bool:
+        """Check the forwards issued since the last check (nope_unet_x2_range_check: synchronises their stream); every forward whose layers
+        left their accurate window is issued again -- same arguments, re-centred shifts -- until it is inside.  Returns True when anything
+        was repeated: work the caller derived from the outputs has to be repeated too."""
+        pending, self._pending = self._pending, []
+        repeated = False
+        for attempt in range(4):
+            if not pending or not (self.range_check and self.x2_enabled):
                 break
-            code, bad, moved, amax = self.x2_range_check(_stream(x))
+            code, bad, moved, amax = self.x2_range_check(pending[-1][1])
             if code == 0:
                 break
-            # a two-pass layer saw activations outside its accurate window: that forward has plain-f16 accuracy there -- repeat it
+            # a two-pass layer saw activations outside its accurate window: those forwards have plain-f16 accuracy there -- repeat them
             self.range_events.append({"code": code, "layers_out_of_range": bad, "layers_adjusted": moved, "max_abs": amax, "attempt": attempt})
             if code == ERR_RANGE_F16 or attempt == 2:
                 import warnings
                 warnings.warn(f"nope_amd f16x2: activations up to {amax:.3g} " + ("are not finite" if code == ERR_RANGE_F16 else
                               "keep leaving the layers' windows") + ": this U-Net runs as bf16x3 (three MFMA passes) from now on", RuntimeWarning)
                 self.x2_enable(False)
-        return out
+            for launch, _ in pending:
+                launch()
+            repeated = True
+        return repeated
 
 
 # --------------------------------------------------------------------------------------------

@@ -91,7 +91,14 @@ class PoseConditional(nn.Module):
         return self.generate_templates_from_feat(reference_feat, all_relativeR), None, None
 
     @torch.no_grad()
-    def generate_templates_from_feat(self, reference_feat, all_relativeR):
+    def generate_templates_from_feat(self, reference_feat, all_relativeR, defer_range_check=False):
+        """defer_range_check (f16x2): the caller finishes the U-Net's range check itself (generate_and_retrieve: after scoring)."""
+        out = self._generate_templates_from_feat(reference_feat, all_relativeR)
+        if not defer_range_check:
+            self.u_net.finish_range_check()        # (repeats the forwards in place when a layer left its accurate window: hip.UNetHandle)
+        return out
+
+    def _generate_templates_from_feat(self, reference_feat, all_relativeR):
         B, N = all_relativeR.shape[:2]
         lo, hi, ws = 0, N, 1
         if self.template_parallel:
@@ -114,21 +121,21 @@ class PoseConditional(nn.Module):
             #  single-batch result to rounding, not bit for bit -- tests/test_gpu_configs.py::test_two_stream_split_close_to_single_batch)
             n_first = (n + 1) // 2
             with hip.overlap_stream(reference_feat) as side:
-                self.u_net.forward_hypotheses(reference_feat, poses[:, n_first:].contiguous(), out=bank[:, n_first:], out_dtype=self.bank_dtype)
-            self.u_net.forward_hypotheses(reference_feat, poses[:, :n_first].contiguous(), out=bank[:, :n_first], out_dtype=self.bank_dtype)
+                self.u_net.forward_hypotheses(reference_feat, poses[:, n_first:].contiguous(), out=bank[:, n_first:], out_dtype=self.bank_dtype, defer_range_check=True)
+            self.u_net.forward_hypotheses(reference_feat, poses[:, :n_first].contiguous(), out=bank[:, :n_first], out_dtype=self.bank_dtype, defer_range_check=True)
             side.join(bank)
             return out
         if n <= self.max_hyp:
             bs = max(1, self.max_hyp // n)
             for b0 in range(0, B, bs):
                 self.u_net.forward_hypotheses(reference_feat[b0:b0 + bs], poses[b0:b0 + bs], out=bank[b0:b0 + bs],
-                                              out_dtype=self.bank_dtype)
+                                              out_dtype=self.bank_dtype, defer_range_check=True)
         else:
             for b in range(B):
                 for s in range(0, n, self.max_hyp):
                     e = min(n, s + self.max_hyp)
                     self.u_net.forward_hypotheses(reference_feat[b:b + 1], poses[b:b + 1, s:e],
-                                                  out=bank[b:b + 1, s:e], out_dtype=self.bank_dtype)
+                                                  out=bank[b:b + 1, s:e], out_dtype=self.bank_dtype, defer_range_check=True)
         return out
 
     # ---- model.py:254-266 ----------------------------------------------------------------------------
@@ -150,9 +157,17 @@ class PoseConditional(nn.Module):
             return None
         with hip.overlap_stream(query) as side:
             query_feat = self.u_net.encoder.encode_image(query, mode="mode")
-        bank, _, _ = self.generate_templates(reference, all_relativeR, None)
+        reference_feat = self.u_net.encoder.encode_image(reference, mode="mode")
+        # (a sharded step finishes the check BEFORE its collective: every rank must enter the score all-gather exactly once, and whether a
+        #  forward is repeated is a per-rank fact)
+        defer = not (self.template_parallel and ndist.world()[1] > 1)
+        bank = self.generate_templates_from_feat(reference_feat, all_relativeR, defer_range_check=defer)
         side.join(query_feat)
         similarity, nearest_idx = self.retrieval_from_feat(query_feat, bank)
+        # f16x2: the U-Net's activation-range check, at the END of the step -- one stream synchronisation where the results are read anyway.
+        # When a layer had left its accurate window the forwards were just repeated into the same bank: score and rank again.
+        if defer and self.u_net.finish_range_check():
+            similarity, nearest_idx = self.retrieval_from_feat(query_feat, bank)
         return similarity, nearest_idx, bank
 
     @torch.no_grad()

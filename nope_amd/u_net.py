@@ -178,12 +178,16 @@ class UNet(nn.Module):
         return self._get_handle(x.device).forward(x, pose, x_rep=1)
 
     @torch.no_grad()
-    def forward_hypotheses(self, x, poses, out=None, out_dtype="f32"):
+    def forward_hypotheses(self, x, poses, out=None, out_dtype="f32", defer_range_check=False):
         """x (B,C,h,w) reference embeddings, poses (B,N,rot_dim) -> (B,N,C,h,w):
         UNet(x[b], poses[b,n]) for every (b,n) -- the body of the template loop
         model.py:212-222 -- as one batched launch sequence."""
         B, N = poses.shape[:2]
         flat = poses.reshape(B * N, poses.shape[-1])
         o = None if out is None else out.view(B * N, *out.shape[2:])
-        y = self._get_handle(x.device).forward(x, flat, x_rep=N, out=o, out_dtype=hip.dtype_code(out_dtype))
+        y = self._get_handle(x.device).forward(x, flat, x_rep=N, out=o, out_dtype=hip.dtype_code(out_dtype), defer_range_check=defer_range_check)
         return y.view(B, N, *y.shape[1:])
+
+    def finish_range_check(self) -> bool:
+        """f16x2: check (and if needed repeat) the forwards issued with defer_range_check; True when any was repeated (hip.UNetHandle)."""
+        return self._handle.finish_range_check() if self._handle is not None else False
