@@ -69,7 +69,8 @@ struct ConvParams {
     const float* pn_ms; const float* pn_c0; const float* pn_c1;   // optional fused PreNorm (see ConvArgs)
     unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
     const int* x2_scale;               // NOPE_F16X2 (ping-pong kernels): the tail of the packed weights, [0] = E8M0 scale of the A operand, [3] = range shift t
-    unsigned* x2_amax;                 // NOPE_F16X2: optional device word, atomicMax of the bits of max |a| over every A element the launch converted
+    unsigned* x2_amax;                 // NOPE_F16X2: optional device word, atomicMax of the bits of max |a| over every A element the launch converted (NOPE_X2_KERNEL_AMAX builds)
+    unsigned* out_amax;                // f32-storage launches with a wide NHWC epilogue: optional range slot (amax_publish) for max |out| of what the launch writes
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -405,6 +406,8 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
     // enters where the bias does (an fma in place of the add).  Every other element type: 1, folded away at compile time.
     constexpr bool SCALED = Elt<T>::DT == NOPE_F16X2;
     const float asc = SCALED ? acc_scale : 1.0f;
+    const bool track_out = sizeof(T) == 4 && p.out_amax != nullptr;      // (wave-uniform)
+    float out_max = 0.f;
     constexpr int PANW = TL::TM == 32 ? 32 : 48;   // panel width in columns
     constexpr int TPP = PANW / TL::TM;             // MFMA tiles per panel pass
     constexpr int CH = PANW / VEC;                 // 16-byte output chunks per panel row
@@ -666,10 +669,18 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
+            if constexpr (sizeof(T) == 4) { if (track_out) out_max = amax4(out_max, v[0], v[1], v[2], v[3]); }
             st16(out + o, Elt<T>::pack(v));
         }
         __builtin_amdgcn_wave_barrier();
         stamp();
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (track_out) {       // the range slot of the tensor this launch writes (NOPE_F16X2 consumers downstream: unet_runtime.hip)
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) out_max = __builtin_fmaxf(out_max, __shfl_xor(out_max, o, 64));
+            if (lane == 0 && out_max > 0.f) amax_publish(p.out_amax, out_max, (unsigned)blockIdx.x * 8u + (unsigned)(wm * 2 + wn));
+        }
     }
 }
 

@@ -431,6 +431,12 @@ static bool plan_takes_x2(const ConvArgs& a, const ConvPlan& plan) {
     if (plan.small >= 0) return NOPE_ENV("NOPE_X2_SMALL", 0) != 0;
     return plan.pp && (plan.halo || NOPE_ENV("NOPE_X2_PP", 1) != 0);
 }
+// the wide NHWC epilogue (epilogue_wide) of a 4-byte element type, whole launch in one pass: the 128 x 192 LDS-DMA kernel and the ping-pong kernels
+static bool plan_records_out_amax(int dt, const ConvArgs& a, const ConvPlan& plan) {
+    return dt_es(dt_base(dt)) == 4 && plan.dma && plan.small < 0 && plan.hsplit <= 1 && !a.out_nchw && !a.geglu && a.Cout % 4 == 0 &&
+           (plan.pp || !a.splitk_ws || conv_splitk_factor(dt, a) <= 1);
+}
+bool conv_records_out_amax(int dt, const ConvArgs& a) { return a.out_amax && plan_records_out_amax(dt, a, plan_conv(dt, a)); }
 bool conv_takes_x2(int dt, const ConvArgs& a) { return dt_base(dt) == NOPE_BF16X3 && plan_takes_x2(a, plan_conv(dt, a)); }
 
 int conv_kernel_kind(int dt, const ConvArgs& a) {
@@ -528,6 +534,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     const bool x2 = plan_takes_x2(a, plan);
     if (!x2 && !a.w) return NOPE_ERR_UNSUPPORTED;               // (NOPE_F16X2 as an element type on a shape the ping-pong kernels do not take)
     p.x2_scale = nullptr; p.x2_amax = x2 ? a.x2_amax : nullptr;
+    p.out_amax = (a.out_amax && plan_records_out_amax(dt, a, plan)) ? a.out_amax : nullptr;
     if (x2) { p.w = (const unsigned char*)a.w_x2; p.x2_scale = reinterpret_cast<const int*>(p.w + bw * (phased ? 4 : 1)); }
     if (a.geglu && !geglu_shape_ok(dt, a, plan)) return NOPE_ERR_UNSUPPORTED;
     p.geglu = a.geglu;
@@ -630,6 +637,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
             p.persist_iters = (int)(nblocks / want);
         }
     }
+    if (p.splits > 1) p.out_amax = nullptr;        // (raw partials: the reduce kernel writes the tensor)
     const dim3 grid(gx, phased ? 4u : 1u, (unsigned)p.splits), block(NT);
     const bool trace = NOPE_ENV_SET("NOPE_CONV_TRACE");     // tuning aid: one line per launch
     if (trace && plan.small >= 0) fprintf(stderr, "conv small%d mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u xcd %d/%d\n", plan.small, a.mode, a.ntaps, Cin, a.Cout, M,

@@ -104,7 +104,16 @@ __global__ __launch_bounds__(NT) void absmax_f32_kernel(const float* __restrict_
     if (blockIdx.x == 0) for (size_t k = nvec * 4 + threadIdx.x; k < n; k += NT) m = __builtin_fmaxf(m, __builtin_fabsf(x[k]));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, m));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) amax_publish(out, m, blockIdx.x * (NT / 64) + (threadIdx.x >> 6));
+}
+// compact[i] = max over the kX2Spread lines of range slot i, which are zeroed for the next round (one 64-thread block per slot)
+__global__ __launch_bounds__(64) void amax_reduce_kernel(unsigned* __restrict__ slots, unsigned* __restrict__ compact) {
+    unsigned* p = slots + (size_t)blockIdx.x * kX2SlotWords + (threadIdx.x & (kX2Spread - 1)) * 32;
+    unsigned m = 0;
+    if (threadIdx.x < kX2Spread) { m = *p; *p = 0u; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    if (threadIdx.x == 0) compact[blockIdx.x] = m;
 }
 __device__ __forceinline__ int x2_weight_shift(unsigned maxbits) {
     const int e = (int)(maxbits >> 23) - 127;          // floor(log2 max |w|) (normal numbers; zero / subnormal maxima give e = -127)
@@ -281,6 +290,13 @@ int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int
 
 static size_t x2_rows(int Cout, int ntaps, int mode) { return mode == NOPE_CONV_UP2P ? (size_t)16 * Cout : (size_t)Cout * ntaps; }      // (four phases x four taps)
 size_t conv_w_x2_bytes(int Cout, int Cin, int ntaps, int mode) { return x2_rows(Cout, ntaps, mode) * Cin * 4 + kX2TailBytes; }
+
+int launch_amax_reduce(unsigned* slots, int nslots, unsigned* compact, hipStream_t s) {
+    if (!slots || !compact || nslots <= 0) return NOPE_ERR_ARG;
+    hipLaunchKernelGGL(amax_reduce_kernel, dim3((unsigned)nslots), dim3(64), 0, s, slots, compact);
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
 
 int launch_absmax_f32(const float* x, size_t n, unsigned* out, hipStream_t s) {
     if (!x || !out) return NOPE_ERR_ARG;

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
     if (AMAX && amax_out) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, o, 64));
-        if ((tid & 63) == 0 && amax > 0.f) atomicMax(amax_out, __builtin_bit_cast(unsigned, amax));
+        if ((tid & 63) == 0 && amax > 0.f) amax_publish(amax_out, amax, blockIdx.x * (NT / 64) + (tid >> 6));
     }
     if (OS) {
         // per-block (sum, sum of squares) of what was just written: the GroupNorm(1) statistics of the NEXT op

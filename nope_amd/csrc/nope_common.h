@@ -190,6 +190,16 @@ __device__ __forceinline__ unsigned cvt4_e4m3_div(float x0, float x1, float x2, 
     r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, x2, x3, divisor, true);
     return __builtin_bit_cast(unsigned, r);
 }
+// A range word under many writers.  One device word per tensor would take an atomic from every wave of every producer launch -- 24 576 same-
+// address atomics per level-0 gn_apply, measured +0.3 ms PER LAUNCH (profiles/r06c_*) -- so a slot is kX2Spread words, one per 128-byte line,
+// a wave picks one by its index and only issues the atomic when its value beats what the word already holds (a relaxed load: a stale
+// value costs an unnecessary atomic, never a wrong maximum); amax_reduce_kernel (kernels_misc.hip) folds the lines before the host reads them.
+constexpr int kX2Spread = 32, kX2SlotWords = kX2Spread * 32;
+__device__ __forceinline__ void amax_publish(unsigned* slot, float m, unsigned who) {
+    unsigned* p = slot + (who & (kX2Spread - 1)) * 32;
+    const unsigned b = __builtin_bit_cast(unsigned, m);
+    if (b > __atomic_load_n(p, __ATOMIC_RELAXED)) atomicMax(p, b);
+}
 // running max |x| of four values (two v_max3_f32 with |.| modifiers; a NaN is ignored: it stays a NaN in the result either way)
 __device__ __forceinline__ float amax4(float m, float x0, float x1, float x2, float x3) {
     m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(x0)), __builtin_fabsf(x1));
@@ -333,7 +343,9 @@ struct ConvArgs {
     const void* w = nullptr;     // packed [Cout][ntaps][Cin]
     const void* w_x2 = nullptr;  // NOPE_BF16X3 launches only: the same weights in the NOPE_F16X2 layout (launch_pack_conv_w_x2) -- taken, with
                                  // the f16 + MX-fp8 tile, when the launch goes to a ping-pong kernel (conv_takes_x2); `w` (may be null then) otherwise
-    unsigned* x2_amax = nullptr; // NOPE_F16X2 launches: optional device word, atomicMax of the bits of max |a| over the A elements converted
+    unsigned* x2_amax = nullptr; // NOPE_F16X2 launches: optional device word, atomicMax of the bits of max |a| over the A elements converted (NOPE_X2_KERNEL_AMAX builds)
+    unsigned* out_amax = nullptr;// f32 storage: optional range slot (kX2SlotWords words, amax_publish) for max |out| -- honoured by the launches that end in the wide NHWC
+                                 // epilogue of the 128 x 192 / ping-pong / tap-resident kernels without split-K (conv_records_out_amax); ignored otherwise
     const float* bias = nullptr; // [Cout] or null
     const void* resid = nullptr; // optional NHWC [M][Cout] added in the epilogue
     void* out = nullptr;
@@ -383,12 +395,14 @@ struct GnApplyArgs {
     int resid_rep = 1;                 // resid shared by resid_rep consecutive hypotheses
     float* out_stats = nullptr;        // optional [nhyp][gn_apply_blocks()][2]: (sum, sum sq) of the values written
     float eps = 1e-5f;
-    unsigned* amax_out = nullptr;      // f32 storage + fast_silu only (the split-precision modes): atomicMax of the bits of max |y| over what this launch wrote
+    unsigned* amax_out = nullptr;      // f32 storage + fast_silu only (the split-precision modes): a range slot (kX2SlotWords words, amax_publish) for max |y| of what this launch writes
     int fast_silu = 0;                 // f32 storage only: SiLU on v_exp_f32 + v_rcp_f32 (1 ulp each, what the 16-bit types always use) instead of expf + an
                                        // IEEE division -- set by the runtimes in the split-precision modes (bf16x3, f16x2), whose bar is 1e-4, not bit parity
 };
 int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s);
-int launch_absmax_f32(const float* x, size_t n, unsigned* out, hipStream_t s);      // atomicMax(out, bits of max |x[i]|) (kernels_misc.hip; NaNs ignored)
+bool conv_records_out_amax(int dt, const ConvArgs& a);     // would launch_conv's kernel fill a.out_amax? (kernels_gemm.hip)
+int launch_absmax_f32(const float* x, size_t n, unsigned* slot, hipStream_t s);     // amax_publish(slot, max |x[i]|) (kernels_misc.hip; NaNs ignored); slot = kX2SlotWords words
+int launch_amax_reduce(unsigned* slots, int nslots, unsigned* compact, hipStream_t s);      // compact[i] = max over slot i's lines; the lines are zeroed
 int gn_apply_blocks(int HW, int C, int dt, int nhyp);      // workgroups per hypothesis of launch_gn_apply over nhyp samples (= chunks of out_stats)
 int launch_gn_finalize(const float* partial, float* ms, int nhyp, int nchunk, float count, float eps, hipStream_t s);
 int gn_stats_chunks(int HW, int C, int dt);

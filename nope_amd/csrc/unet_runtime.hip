@@ -90,7 +90,8 @@ struct nope_unet {
     std::vector<int*> x2_tails;              // per layer: device pointer to the pack's 16-byte tail
     std::vector<int> x2_t;                   // host copy of the current shifts
     mutable std::vector<std::vector<int>> x2_layer_slots;      // per layer: slots of the tensors its f16x2 launches read (same every forward)
-    unsigned* x2_amax = nullptr;             // device, X2_SLOTS words
+    unsigned* x2_amax = nullptr;             // device, X2_SLOTS range slots of kX2SlotWords words (amax_publish, nope_common.h)
+    unsigned* x2_amax_c = nullptr;           // device, X2_SLOTS words: the slots folded by amax_reduce_kernel at check time
     mutable bool x2_off = false;             // nope_unet_x2_enable(net, 0): every launch as NOPE_BF16X3 (the fallback beyond f16's range)
     mutable std::mutex x2_mu;
 };
@@ -244,7 +245,7 @@ struct Fwd {
         auto it = slot_of.find(a.p);
         if (it != slot_of.end()) return it->second;
         const int sl = produce(a.p);
-        if (sl >= 0) chk(launch_absmax_f32((const float*)a.p, (size_t)n * a.H * a.W * a.C, net->x2_amax + sl, s));
+        if (sl >= 0) chk(launch_absmax_f32((const float*)a.p, (size_t)n * a.H * a.W * a.C, net->x2_amax + (size_t)sl * kX2SlotWords, s));
         return sl;
     }
 
@@ -262,7 +263,7 @@ struct Fwd {
     // maps on the small-tile kernel); the scratch comes from the arena and lives until the caller's release.
     void conv(const Conv& c, const Act& a, const Act* b, void* out, int Ho, int Wo, int n, int rep1, int rep2,
               const void* resid = nullptr, int out_nchw = 0, int out_dt = NOPE_F32, Stats* stats = nullptr,
-              const float* pn_c0 = nullptr, const float* pn_c1 = nullptr) {
+              const float* pn_c0 = nullptr, const float* pn_c1 = nullptr, bool track_out = false) {
         if (err != NOPE_OK) return;
         ConvArgs ca;
         if (pn_c0) { ca.pn_ms = pn_ms; ca.pn_c0 = pn_c0; ca.pn_c1 = pn_c1; }
@@ -304,7 +305,15 @@ struct Fwd {
                 for (int sl : {sa, sb})
                     if (sl >= 0 && std::find(ls.begin(), ls.end(), sl) == ls.end()) ls.push_back(sl);
             }
-            overwritten(out);              // (a conv epilogue records no maximum: a later f16x2 consumer of `out` takes an absmax pass)
+            // `track_out`: this conv's output goes straight into f16x2 convs (the resampling convs, the bottleneck attention's output
+            // projection): its epilogue records max |out| when it is one that can (the wide NHWC epilogue); otherwise a later f16x2
+            // consumer of `out` takes an absmax pass over it
+            ConvArgs probe = ca;
+            probe.out_amax = net->x2_amax;
+            if (track_out && conv_records_out_amax(net->dt, probe)) {
+                const int sl = produce(out);
+                if (sl >= 0) ca.out_amax = net->x2_amax + (size_t)sl * kX2SlotWords;
+            } else overwritten(out);
         }
         if (net->profile) {
             nope_unet::Ev ev;
@@ -349,7 +358,7 @@ struct Fwd {
         ga.nhyp = nhyp; ga.HW = HW; ga.C = nm.C; ga.G = G; ga.act = act;
         if (emb_off >= 0) { ga.emb = emb_all + emb_off; ga.emb_stride = net->emb_total; }
         ga.resid = resid; ga.x_rep = x_rep; ga.resid_rep = resid_rep; ga.out_stats = out_stats;
-        if (tracking()) { const int sl = produce(y); if (sl >= 0) ga.amax_out = net->x2_amax + sl; }
+        if (tracking()) { const int sl = produce(y); if (sl >= 0) ga.amax_out = net->x2_amax + (size_t)sl * kX2SlotWords; }
         ga.fast_silu = net->dt != NOPE_F32 ? 1 : 0;      // (f32 storage of the split-precision modes: hardware exp / rcp; the f32 mode keeps expf and the division)
         chk(launch_gn_apply(net->sdt, ga, s));
     }
@@ -426,7 +435,7 @@ struct Fwd {
         qkv_prenorm(A.qkv, A.c0, A.c1, x, qkv);
         if (live()) { chk(launch_attn(net->sdt, qkv, a, nhyp, HW, heads, dh, s)); overwritten(a); }
         Act aa{a, heads * dh, x.H, x.W, 1};
-        conv(A.out, aa, nullptr, out, x.H, x.W, nhyp, 1, 1, /*resid=*/x.p);
+        conv(A.out, aa, nullptr, out, x.H, x.W, nhyp, 1, 1, /*resid=*/x.p, 0, NOPE_F32, nullptr, nullptr, nullptr, /*track_out=*/true);
         ar.off = mark;
     }
 };
@@ -515,7 +524,7 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
         }
         Act nxt{curbuf[slot], dims[l + 1], cur.H, cur.W, 1};
         if (l < L - 1) { nxt.H = cur.H / 2; nxt.W = cur.W / 2; }
-        f.conv(D.resample, h2, nullptr, nxt.p, nxt.H, nxt.W, n_hyp, 1, 1);
+        f.conv(D.resample, h2, nullptr, nxt.p, nxt.H, nxt.W, n_hyp, 1, 1, nullptr, 0, NOPE_F32, nullptr, nullptr, nullptr, /*track_out=*/true);
         cur = nxt;
         slot ^= 1;
     }
@@ -548,7 +557,7 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
         f.linattn(U.attn, b, a.p);
         Act nxt{curbuf[slot], dims[r], cur.H, cur.W, 1};
         if (l < L - 1) { nxt.H = cur.H * 2; nxt.W = cur.W * 2; }
-        f.conv(U.resample, a, nullptr, nxt.p, nxt.H, nxt.W, n_hyp, 1, 1);
+        f.conv(U.resample, a, nullptr, nxt.p, nxt.H, nxt.W, n_hyp, 1, 1, nullptr, 0, NOPE_F32, nullptr, nullptr, nullptr, /*track_out=*/true);
         f.ar.off = mark;
         cur = nxt;
         slot ^= 1;
@@ -661,8 +670,9 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
     }
     if (ld.err == NOPE_OK && !net->x2_tails.empty()) {
         const size_t n = net->x2_tails.size();
-        net->x2_amax = (unsigned*)ld.dmalloc(nope_unet::X2_SLOTS * sizeof(unsigned));
-        if (net->x2_amax && hipMemsetAsync(net->x2_amax, 0, nope_unet::X2_SLOTS * sizeof(unsigned), s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
+        net->x2_amax = (unsigned*)ld.dmalloc((size_t)nope_unet::X2_SLOTS * kX2SlotWords * sizeof(unsigned));
+        net->x2_amax_c = (unsigned*)ld.dmalloc(nope_unet::X2_SLOTS * sizeof(unsigned));
+        if (net->x2_amax && hipMemsetAsync(net->x2_amax, 0, (size_t)nope_unet::X2_SLOTS * kX2SlotWords * sizeof(unsigned), s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
         net->x2_t.assign(n, 0);
         net->x2_layer_slots.assign(n, std::vector<int>());
     }
@@ -730,8 +740,8 @@ int nope_unet_x2_range_check(nope_unet* net, nope_stream_t stream, int* n_out_of
     hipStream_t s = (hipStream_t)stream;
     const size_t n = net->x2_tails.size();
     std::vector<unsigned> words(nope_unet::X2_SLOTS);
-    if (hipMemcpyAsync(words.data(), net->x2_amax, words.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) return NOPE_ERR_LAUNCH;
-    if (hipMemsetAsync(net->x2_amax, 0, words.size() * sizeof(unsigned), s) != hipSuccess) return NOPE_ERR_LAUNCH;
+    if (launch_amax_reduce(net->x2_amax, nope_unet::X2_SLOTS, net->x2_amax_c, s) != NOPE_OK) return NOPE_ERR_LAUNCH;      // folds and zeroes the slots
+    if (hipMemcpyAsync(words.data(), net->x2_amax_c, words.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) return NOPE_ERR_LAUNCH;
     if (hipStreamSynchronize(s) != hipSuccess) return NOPE_ERR_LAUNCH;
     std::vector<unsigned> bits(n, 0u);         // per layer: the largest maximum among the tensors its f16x2 launches read
     for (size_t i = 0; i < n; ++i)

@@ -560,7 +560,7 @@ class UNetHandle:
         was repeated: work the caller derived from the outputs has to be repeated too."""
         pending, self._pending = self._pending, []
         repeated = False
-        for attempt in range(4):
+        for attempt in range(8):        # (a repeated forward can move the maxima of layers downstream of the repaired ones: a few rounds at most)
             if not pending or not (self.range_check and self.x2_enabled):
                 break
             code, bad, moved, amax = self.x2_range_check(pending[-1][1])
@@ -568,7 +568,7 @@ class UNetHandle:
                 break
             # a two-pass layer saw activations outside its accurate window: those forwards have plain-f16 accuracy there -- repeat them
             self.range_events.append({"code": code, "layers_out_of_range": bad, "layers_adjusted": moved, "max_abs": amax, "attempt": attempt})
-            if code == ERR_RANGE_F16 or attempt == 2:
+            if code == ERR_RANGE_F16 or attempt == 6:
                 import warnings
                 warnings.warn(f"nope_amd f16x2: activations up to {amax:.3g} " + ("are not finite" if code == ERR_RANGE_F16 else
                               "keep leaving the layers' windows") + ": this U-Net runs as bf16x3 (three MFMA passes) from now on", RuntimeWarning)
