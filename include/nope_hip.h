@@ -47,9 +47,9 @@ enum { NOPE_F32 = 0, NOPE_BF16 = 1,
                           bits down to |a'| = 2^-4); the accumulators hold 2^-t x the convolution and the epilogue multiplies by 2^t -- all
                           exact.  Full accuracy while the LARGEST |a| of a launch lies in [2^(t - 4), 1792 * 2^t] (t = 0: 0.06 .. 1792); outside,
                           the cross terms of the saturated / flushed elements are lost: plain-f16 accuracy (~2^-11 per product) there.  The
-                          kernels record max |a| per layer; nope_unet_x2_range_check reads it, re-centres t and says so -- nope_amd's U-Net calls
-                          it after every forward and repeats the call, so the mode is never silently outside its accuracy at any magnitude
-                          an f32 tensor can hold */ };
+                          producers of a layer's inputs record max |a|; every forward is judged on the device and an out-of-range forward's
+                          output is NaN (nope_unet_x2_poll / _range_check re-centre t and say so; nope_amd's U-Net repeats the call on request),
+                          so the mode is never silently outside its accuracy at any magnitude an f32 tensor can hold */ };
 /* Tap geometries of nope_op_conv.  UP2P is UP2 (nearest-x2 upsample + 3x3, pad 1) rewritten as four
  * 2x2 convolutions over the un-upsampled input, one per output-pixel parity, with the 3x3 weights that
  * fall on the same source pixel pre-summed at pack time: same function, 4/9 of the multiply-adds. */
@@ -73,7 +73,7 @@ typedef void* nope_stream_t;
  * 3: NOPE_F16 / NOPE_BF16X3 compute modes, 4x4 STRIDE2, nope_ldm_config.transformer_depth;
  * 4: nope_op_geodesic, nope_unet_graph_limit -- hipGraph replay became opt-in;
  * 5: NOPE_F16X2, nope_tuning_reload, nope_gather_topk, nope_topk_merge;
- * 6: nope_unet_x2_range_check / _x2_enable / _x2_shifts, NOPE_ERR_RANGE*).  Callers compare nope_abi_version() against the header they were
+ * 6: nope_unet_x2_poll / _x2_range_check / _x2_enable / _x2_shifts, NOPE_ERR_RANGE*).  Callers compare nope_abi_version() against the header they were
  * built with before passing any struct (nope_amd/hip.py does at load time). */
 #define NOPE_ABI_VERSION 6
 const char* nope_strerror(int code);
@@ -191,14 +191,18 @@ int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep
 int nope_unet_graph_limit(nope_unet* net, long long max_hyp_pixels);
 
 /* NOPE_F16X2 activation ranges (no reference counterpart: the reference computes in fp32, model_utils.py:240-252,271-279 see whatever
- * magnitude the residual stream has).  nope_unet_x2_range_check SYNCHRONISES `stream`, reads the largest |activation| each f16x2 layer
- * converted in the forwards issued on it since the previous check, and
- *   returns NOPE_OK            every launch inside its layer's window (shifts within two binades of an end were re-centred for later calls);
- *           NOPE_ERR_RANGE     some launch outside: its result has plain-f16 accuracy there; the shifts are fixed -- run the forward again;
- *           NOPE_ERR_RANGE_F16 an infinite activation: no shift helps; nope_unet_x2_enable(net, 0) makes every launch NOPE_BF16X3
- *                              (same weights, the three-pass kernels), nope_unet_x2_enable(net, 1) returns to the two-pass tile.
- * n_out_of_range / n_adjusted / max_abs (each may be null): layers outside their window, layers whose shift moved, largest |a| seen.
- * A net created in another mode: NOPE_OK, nothing to check.  nope_unet_x2_shifts: the current per-layer shifts (creation order). */
+ * magnitude the residual stream has).  Every nope_unet_forward of a NOPE_F16X2 net ends with a verdict formed ON THE DEVICE: the largest
+ * |activation| each two-pass layer read (recorded by the producers of its inputs) against the layer's window.  A forward with a layer outside
+ * its window leaves NaNs in `out` -- inaccurate values never pass for accurate ones -- and no host synchronisation is involved.
+ *   nope_unet_x2_poll         reads, WITHOUT synchronising, the verdicts that have reached the host since the previous poll, re-centres the
+ *                             shifts of the layers that were out of (or within two binades of an end of) their windows -- the new shifts are
+ *                             enqueued on `stream` -- and returns NOPE_OK, NOPE_ERR_RANGE (a judged forward was out of range: its output is
+ *                             NaN, issue it again) or NOPE_ERR_RANGE_F16 (an activation was infinite: no shift helps; nope_unet_x2_enable(net, 0)
+ *                             makes every launch NOPE_BF16X3 -- same weights, the three-pass kernels).  nope_unet_forward polls at entry.
+ *   nope_unet_x2_range_check  synchronises `stream` first: the verdict of every forward issued on it so far.
+ * n_out_of_range / n_adjusted / max_abs (each may be null): layers out of range in the judged forwards, layers whose shift moved, largest
+ * |a| seen.  A net created in another mode: NOPE_OK, nothing to check.  nope_unet_x2_shifts: the current per-layer shifts (creation order). */
+int nope_unet_x2_poll(nope_unet* net, nope_stream_t stream, int* n_out_of_range, int* n_adjusted, float* max_abs);
 int nope_unet_x2_range_check(nope_unet* net, nope_stream_t stream, int* n_out_of_range, int* n_adjusted, float* max_abs);
 int nope_unet_x2_enable(nope_unet* net, int on);
 int nope_unet_x2_shifts(const nope_unet* net, int* shifts, int max, int* n);

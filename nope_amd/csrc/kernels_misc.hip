@@ -115,6 +115,55 @@ __global__ __launch_bounds__(64) void amax_reduce_kernel(unsigned* __restrict__ 
     for (int o = 32; o >= 1; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
     if (threadIdx.x == 0) compact[blockIdx.x] = m;
 }
+// The verdict of one forward (NOPE_F16X2 range tracking; one block, enqueued behind the forward's last kernel): fold every range slot (and
+// zero it for the next forward), take each layer's largest input maximum through `tab` -- [layer] = {t, slot, slot, slot, slot}, slot -1 =
+// none; a layer that ran no two-pass launch in this forward has no slots -- and judge it against the layer's window (nope_common.h: kX2*):
+// out = the e4m3(a') operand saturated (max |a| 2^-t > 1792), has no full-precision element (< 2^-4), or the maximum is not finite.
+// status[0] = layers out in THIS forward (read by x2_poison_kernel), status[1] = forwards judged, status[2] / [3] = out / non-finite layers
+// since create.  `host` (mapped host memory, polled without a synchronisation: nope_unet_x2_poll): [0] = status[1], [1] = status[0],
+// [2] = status[2], [3] = status[3], [4 + l] = bits of the maximum that put layer l out of or near the end of its window (the host
+// re-centres t from it and clears the word), [4 + n + l] = bits of layer l's maximum in this forward.
+__global__ __launch_bounds__(NT) void x2_verdict_kernel(unsigned* __restrict__ slots, int nslots, const int* __restrict__ tab, int n_layers,
+                                                        unsigned* __restrict__ status, volatile unsigned* __restrict__ host) {
+    __shared__ unsigned compact[512];
+    __shared__ unsigned n_out, n_inf;
+    if (threadIdx.x == 0) { n_out = 0; n_inf = 0; }
+    for (int i = threadIdx.x; i < nslots && i < 512; i += NT) {
+        unsigned m = 0;
+        unsigned* p = slots + (size_t)i * kX2SlotWords;
+#pragma unroll 4
+        for (int k = 0; k < kX2Spread; ++k) { const unsigned v = p[k * 32]; p[k * 32] = 0u; m = v > m ? v : m; }
+        compact[i] = m;
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < n_layers; l += NT) {
+        const int t = tab[l * 5];
+        unsigned b = 0;
+#pragma unroll
+        for (int k = 1; k < 5; ++k) { const int sl = tab[l * 5 + k]; if (sl >= 0 && sl < 512 && compact[sl] > b) b = compact[sl]; }
+        host[4 + n_layers + l] = b;
+        if (!b) continue;
+        const float amax = __builtin_bit_cast(float, b);
+        if (b >= 0x7f800000u) { atomicAdd(&n_out, 1u); atomicAdd(&n_inf, 1u); host[4 + l] = b; continue; }      // inf (a NaN never enters a slot)
+        const float v = ldexpf(amax, -t);
+        const bool out = v > kX2AMaxFull || v < 0.0625f, uneasy = v > 1024.f || v < 1.f;
+        if (out) atomicAdd(&n_out, 1u);
+        if (out || uneasy) host[4 + l] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        status[0] = n_out; status[1] += 1u; status[2] += n_out; status[3] += n_inf;
+        host[1] = n_out; host[2] = status[2]; host[3] = status[3];
+        __threadfence_system();
+        host[0] = status[1];
+    }
+}
+// ... and what an out-of-range forward leaves in its output: NaNs, so that no caller reads inaccurate values for accurate ones (status[0] == 0:
+// every block returns at once)
+__global__ __launch_bounds__(NT) void x2_poison_kernel(unsigned* __restrict__ out, size_t nwords, unsigned pattern, const unsigned* __restrict__ status) {
+    if (status[0] == 0u) return;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < nwords; i += (size_t)gridDim.x * NT) out[i] = pattern;
+}
 __device__ __forceinline__ int x2_weight_shift(unsigned maxbits) {
     const int e = (int)(maxbits >> 23) - 127;          // floor(log2 max |w|) (normal numbers; zero / subnormal maxima give e = -127)
     const int sw = 7 - e;                              // max |w| * 2^sw in [128, 256)
@@ -290,6 +339,23 @@ int launch_pack_conv_w(int dt, const float* w, void* out, int Cout, int Cin, int
 
 static size_t x2_rows(int Cout, int ntaps, int mode) { return mode == NOPE_CONV_UP2P ? (size_t)16 * Cout : (size_t)Cout * ntaps; }      // (four phases x four taps)
 size_t conv_w_x2_bytes(int Cout, int Cin, int ntaps, int mode) { return x2_rows(Cout, ntaps, mode) * Cin * 4 + kX2TailBytes; }
+
+int launch_x2_verdict(unsigned* slots, int nslots, const int* tab, int n_layers, unsigned* status, unsigned* host_mapped, hipStream_t s) {
+    if (!slots || !tab || !status || !host_mapped || nslots <= 0 || nslots > 512 || n_layers <= 0) return NOPE_ERR_ARG;
+    hipLaunchKernelGGL(x2_verdict_kernel, dim3(1), dim3(NT), 0, s, slots, nslots, tab, n_layers, status, (volatile unsigned*)host_mapped);
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+int launch_x2_poison(void* out, size_t bytes, int out_dt, const unsigned* status, hipStream_t s) {
+    if (!out || !status || bytes % 4) return NOPE_ERR_ARG;
+    const unsigned pattern = out_dt == NOPE_F32 ? 0x7fc00000u : out_dt == NOPE_F16 ? 0x7e007e00u : 0x7fc07fc0u;      // quiet NaNs of the output type
+    const size_t nwords = bytes / 4;
+    size_t blocks = (nwords + (size_t)NT * 16 - 1) / ((size_t)NT * 16);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(x2_poison_kernel, dim3((unsigned)blocks), dim3(NT), 0, s, (unsigned*)out, nwords, pattern, status);
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
 
 int launch_amax_reduce(unsigned* slots, int nslots, unsigned* compact, hipStream_t s) {
     if (!slots || !compact || nslots <= 0) return NOPE_ERR_ARG;

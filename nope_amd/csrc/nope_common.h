@@ -402,7 +402,10 @@ struct GnApplyArgs {
 int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s);
 bool conv_records_out_amax(int dt, const ConvArgs& a);     // would launch_conv's kernel fill a.out_amax? (kernels_gemm.hip)
 int launch_absmax_f32(const float* x, size_t n, unsigned* slot, hipStream_t s);     // amax_publish(slot, max |x[i]|) (kernels_misc.hip; NaNs ignored); slot = kX2SlotWords words
-int launch_amax_reduce(unsigned* slots, int nslots, unsigned* compact, hipStream_t s);      // compact[i] = max over slot i's lines; the lines are zeroed
+int launch_amax_reduce(unsigned* slots, int nslots, unsigned* compact, hipStream_t s);
+// the verdict of a forward over its range slots and the NaN fill of an out-of-range forward's output (kernels_misc.hip; unet_runtime.hip)
+int launch_x2_verdict(unsigned* slots, int nslots, const int* tab, int n_layers, unsigned* status, unsigned* host_mapped, hipStream_t s);
+int launch_x2_poison(void* out, size_t bytes, int out_dt, const unsigned* status, hipStream_t s);      // compact[i] = max over slot i's lines; the lines are zeroed
 int gn_apply_blocks(int HW, int C, int dt, int nhyp);      // workgroups per hypothesis of launch_gn_apply over nhyp samples (= chunks of out_stats)
 int launch_gn_finalize(const float* partial, float* ms, int nhyp, int nchunk, float count, float eps, hipStream_t s);
 int gn_stats_chunks(int HW, int C, int dt);

@@ -89,9 +89,19 @@ struct nope_unet {
     static constexpr int X2_SLOTS = 512;
     std::vector<int*> x2_tails;              // per layer: device pointer to the pack's 16-byte tail
     std::vector<int> x2_t;                   // host copy of the current shifts
-    mutable std::vector<std::vector<int>> x2_layer_slots;      // per layer: slots of the tensors its f16x2 launches read (same every forward)
     unsigned* x2_amax = nullptr;             // device, X2_SLOTS range slots of kX2SlotWords words (amax_publish, nope_common.h)
-    unsigned* x2_amax_c = nullptr;           // device, X2_SLOTS words: the slots folded by amax_reduce_kernel at check time
+    // The verdict of every forward is formed ON THE DEVICE, behind its last kernel (x2_verdict_kernel): each layer's largest input maximum
+    // against its window; an out-of-range forward's output is overwritten with NaNs (x2_poison_kernel) -- no caller reads inaccurate values
+    // for accurate ones, and no host synchronisation sits in the step.  The host learns of it from mapped memory the next time it looks
+    // (nope_unet_x2_poll: at the start of every forward, or behind a synchronisation in nope_unet_x2_range_check) and re-centres the shifts.
+    static constexpr int X2_RING = 16;
+    int* x2_tab_dev = nullptr;               // device [n][5]: {t, four slots} of the forward being judged
+    int* x2_tab_pin = nullptr;               // pinned host ring of X2_RING such tables (one per forward in flight)
+    int* x2_t_pin = nullptr;                 // pinned host [n]: staging of re-centred shifts on their way into the packs' tails
+    unsigned* x2_status_dev = nullptr;       // device [4]: see x2_verdict_kernel
+    unsigned* x2_host = nullptr;             // mapped host [4 + 2 n]
+    unsigned* x2_host_dev = nullptr;         // ... its device address
+    mutable unsigned x2_ring_i = 0, x2_seen_serial = 0, x2_seen_bad = 0, x2_seen_inf = 0;
     mutable bool x2_off = false;             // nope_unet_x2_enable(net, 0): every launch as NOPE_BF16X3 (the fallback beyond f16's range)
     mutable std::mutex x2_mu;
 };
@@ -233,6 +243,7 @@ struct Fwd {
     // NOPE_F16X2 range tracking: which x2_amax slot holds max |.| of the tensor that currently lives at a buffer address
     std::map<const void*, int> slot_of;
     int next_slot = 0;
+    std::vector<int> tab;                        // [layer][5] = {t, slots of the tensors the layer's two-pass launches of THIS forward read}
     bool tracking() const { return net->x2 && !net->x2_off && net->x2_amax && !ar.dry && err == NOPE_OK; }
     int produce(const void* p) {                 // a kernel that records its output's maximum is about to write the tensor at p
         const int sl = next_slot < nope_unet::X2_SLOTS ? next_slot++ : -1;
@@ -300,10 +311,14 @@ struct Fwd {
         if (tracking()) {
             if (ca.w_x2 && c.x2_id >= 0 && conv_takes_x2(net->dt, ca)) {      // this launch runs the two-pass tile: its layer's shift follows its inputs' maxima
                 const int sa = slot_for(a, n / rep1), sb = b ? slot_for(*b, n / rep2) : -1;
-                std::lock_guard<std::mutex> lock(net->x2_mu);
-                std::vector<int>& ls = net->x2_layer_slots[c.x2_id];
-                for (int sl : {sa, sb})
-                    if (sl >= 0 && std::find(ls.begin(), ls.end(), sl) == ls.end()) ls.push_back(sl);
+                if (tab.empty()) tab.assign(net->x2_tails.size() * 5, -1);
+                int* row = &tab[(size_t)c.x2_id * 5];
+                for (int sl : {sa, sb}) {
+                    if (sl < 0) continue;
+                    int k = 1;
+                    while (k < 5 && row[k] >= 0 && row[k] != sl) ++k;
+                    if (k < 5) row[k] = sl;            // (a layer launched more than twice with four different inputs: none in these networks)
+                }
             }
             // `track_out`: this conv's output goes straight into f16x2 convs (the resampling convs, the bottleneck attention's output
             // projection): its epilogue records max |out| when it is one that can (the wide NHWC epilogue); otherwise a later f16x2
@@ -573,6 +588,22 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
         f.conv(net->final_conv1, b, nullptr, out, H, W, n_hyp, 1, 1, nullptr, /*out_nchw=*/1, out_dtype);
         f.ar.off = mark;
     }
+    if (f.tracking()) {
+        // the forward's verdict and, if a layer left its window, NaNs over its output -- device side, no synchronisation (see nope_unet)
+        const size_t nl = net->x2_tails.size();
+        if (f.tab.empty()) f.tab.assign(nl * 5, -1);
+        int* pin;
+        {
+            std::lock_guard<std::mutex> lock(net->x2_mu);
+            for (size_t l = 0; l < nl; ++l) f.tab[l * 5] = net->x2_t[l];
+            pin = net->x2_tab_pin + (size_t)(net->x2_ring_i++ % nope_unet::X2_RING) * nl * 5;
+        }
+        memcpy(pin, f.tab.data(), nl * 5 * sizeof(int));
+        if (hipMemcpyAsync(net->x2_tab_dev, pin, nl * 5 * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) f.chk(NOPE_ERR_LAUNCH);
+        f.chk(launch_x2_verdict(net->x2_amax, nope_unet::X2_SLOTS, net->x2_tab_dev, (int)nl, net->x2_status_dev, net->x2_host_dev, s));
+        const size_t out_bytes = (size_t)n_hyp * cfg.out_dim * HW * (size_t)(out_dtype == NOPE_F32 ? 4 : 2);
+        if (out_bytes % 4 == 0) f.chk(launch_x2_poison(out, out_bytes, out_dtype, net->x2_status_dev, s));
+    }
     if (peak) *peak = f.ar.peak;
     return f.err;
 }
@@ -671,10 +702,18 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
     if (ld.err == NOPE_OK && !net->x2_tails.empty()) {
         const size_t n = net->x2_tails.size();
         net->x2_amax = (unsigned*)ld.dmalloc((size_t)nope_unet::X2_SLOTS * kX2SlotWords * sizeof(unsigned));
-        net->x2_amax_c = (unsigned*)ld.dmalloc(nope_unet::X2_SLOTS * sizeof(unsigned));
+        net->x2_tab_dev = (int*)ld.dmalloc(n * 5 * sizeof(int));
+        net->x2_status_dev = (unsigned*)ld.dmalloc(4 * sizeof(unsigned));
         if (net->x2_amax && hipMemsetAsync(net->x2_amax, 0, (size_t)nope_unet::X2_SLOTS * kX2SlotWords * sizeof(unsigned), s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
+        if (net->x2_status_dev && hipMemsetAsync(net->x2_status_dev, 0, 4 * sizeof(unsigned), s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
+        const size_t hostw = 4 + 2 * n;
+        if (hipHostMalloc((void**)&net->x2_tab_pin, (size_t)nope_unet::X2_RING * n * 5 * sizeof(int), 0) != hipSuccess ||
+            hipHostMalloc((void**)&net->x2_t_pin, n * sizeof(int), 0) != hipSuccess ||
+            hipHostMalloc((void**)&net->x2_host, hostw * sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&net->x2_host_dev, net->x2_host, 0) != hipSuccess) {
+            if (ld.err == NOPE_OK) ld.err = NOPE_ERR_ALLOC;
+        } else memset(net->x2_host, 0, hostw * sizeof(unsigned));
         net->x2_t.assign(n, 0);
-        net->x2_layer_slots.assign(n, std::vector<int>());
     }
     if (ld.err == NOPE_OK && hipStreamSynchronize(s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
     if (ld.err != NOPE_OK) {
@@ -728,55 +767,62 @@ int nope_unet_profile_launches(nope_unet* net, nope_conv_launch_info* out, int m
 // The f16 + MX-fp8 tile forms its A operands from a' = a * 2^-t (t per layer, nope_common.h: kX2*): f16(a') (saturates at 65504),
 // e4m3(a'_lo * 2^9) and e4m3(a' * 2^-2) (saturates at |a'| = 1792, below 2^-4 it runs out of significant bits).  A launch whose LARGEST |a'|
 // lies above 1792 or below 2^-4 computed its cross terms from saturated / subnormal operands: plain-f16 accuracy instead of ~2^-15 per
-// product.  The check reads what the launches since the previous check recorded, re-centres t where needed (max |a'| in [256, 512): three
-// binades of headroom, full accuracy down to 2^-13 of the maximum) and reports.
-int nope_unet_x2_range_check(nope_unet* net, nope_stream_t stream, int* n_out_of_range, int* n_adjusted, float* max_abs) {
+// product.  Every forward is judged on the device (x2_verdict_kernel) and an out-of-range forward's output is NaN.  The poll reads the verdicts
+// that have arrived in mapped host memory since the previous poll -- no synchronisation -- and re-centres t where a layer was out of, or within
+// a binade or two of the end of, its window (max |a'| in [256, 512): three binades of headroom, full accuracy down to 2^-13 of the maximum);
+// the new shifts travel on `stream`, ordered before whatever is enqueued on it next.
+int nope_unet_x2_poll(nope_unet* net, nope_stream_t stream, int* n_out_of_range, int* n_adjusted, float* max_abs) {
     if (n_out_of_range) *n_out_of_range = 0;
     if (n_adjusted) *n_adjusted = 0;
     if (max_abs) *max_abs = 0.f;
     if (!net) return NOPE_ERR_ARG;
-    if (!net->x2 || !net->x2_amax || net->x2_off) return NOPE_OK;
+    if (!net->x2 || !net->x2_host || net->x2_off) return NOPE_OK;
     std::lock_guard<std::mutex> lock(net->x2_mu);
-    hipStream_t s = (hipStream_t)stream;
+    volatile unsigned* h = net->x2_host;
+    const unsigned serial = h[0];
+    if (serial == net->x2_seen_serial) return NOPE_OK;            // no forward has finished since the last look
+    __sync_synchronize();
+    const unsigned bad_total = h[2], inf_total = h[3];
+    const int bad = (int)(bad_total - net->x2_seen_bad), fatal = (int)(inf_total - net->x2_seen_inf);
+    net->x2_seen_serial = serial; net->x2_seen_bad = bad_total; net->x2_seen_inf = inf_total;
     const size_t n = net->x2_tails.size();
-    std::vector<unsigned> words(nope_unet::X2_SLOTS);
-    if (launch_amax_reduce(net->x2_amax, nope_unet::X2_SLOTS, net->x2_amax_c, s) != NOPE_OK) return NOPE_ERR_LAUNCH;      // folds and zeroes the slots
-    if (hipMemcpyAsync(words.data(), net->x2_amax_c, words.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) return NOPE_ERR_LAUNCH;
-    if (hipStreamSynchronize(s) != hipSuccess) return NOPE_ERR_LAUNCH;
-    std::vector<unsigned> bits(n, 0u);         // per layer: the largest maximum among the tensors its f16x2 launches read
-    for (size_t i = 0; i < n; ++i)
-        for (int sl : net->x2_layer_slots[i])
-            if (words[sl] > bits[i] && words[sl] <= 0x7f800000u) bits[i] = words[sl];
-    int bad = 0, moved = 0, fatal = 0;
+    hipStream_t s = (hipStream_t)stream;
+    int moved = 0;
     float worst = 0.f;
     for (size_t i = 0; i < n; ++i) {
-        if (!bits[i]) continue;                 // the layer ran no f16x2 launch (or saw only zeros)
+        const unsigned cur = h[4 + n + i];
+        if (cur && cur < 0x7f800000u) { float c; memcpy(&c, &cur, 4); if (c > worst) worst = c; }
+        const unsigned b = h[4 + i];
+        if (!b) continue;
+        h[4 + i] = 0u;                                            // (taken; the device writes it again when the layer is flagged again)
+        if (b >= 0x7f800000u) continue;                           // non-finite: nothing a shift repairs (the f32 path overflows there too)
         float amax;
-        memcpy(&amax, &bits[i], 4);
-        if (!(amax == amax)) continue;
+        memcpy(&amax, &b, 4);
         if (amax > worst) worst = amax;
-        if (!(amax <= 3.0e38f)) { ++fatal; continue; }       // non-finite activations: nothing a shift repairs (the f32 path overflows there too)
-        const int t = net->x2_t[i];
-        const float v = ldexpf(amax, -t);
-        const bool out = v > kX2AMaxFull || v < 0.0625f;      // the e4m3(a') operand saturated / has no full-precision element
-        const bool uneasy = v > 1024.f || v < 1.f;            // near an end: re-centre for the next call
-        if (!out && !uneasy) continue;
         int e = 0;
-        frexpf(amax, &e);                                    // amax = m * 2^e, m in [0.5, 1)
-        int tn = (e - 1) - 8;                                // max |a| * 2^-tn in [256, 512)
+        frexpf(amax, &e);                                        // amax = m * 2^e, m in [0.5, 1)
+        int tn = (e - 1) - 8;                                    // max |a| * 2^-tn in [256, 512)
         tn = tn < -100 ? -100 : (tn > 100 ? 100 : tn);
-        if (out) ++bad;
-        if (tn != t) {
-            if (hipMemcpy(net->x2_tails[i] + 3, &tn, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return NOPE_ERR_LAUNCH;
+        if (tn != net->x2_t[i]) {
+            net->x2_t_pin[i] = tn;
+            if (hipMemcpyAsync(net->x2_tails[i] + 3, &net->x2_t_pin[i], sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) return NOPE_ERR_LAUNCH;
             net->x2_t[i] = tn;
             ++moved;
         }
     }
-    if (n_out_of_range) *n_out_of_range = bad + fatal;
+    if (n_out_of_range) *n_out_of_range = bad;
     if (n_adjusted) *n_adjusted = moved;
     if (max_abs) *max_abs = worst;
     // (a cached hipGraph replays the same kernels and pointers; the shifts live in device memory: nothing to rebuild)
-    return fatal ? NOPE_ERR_RANGE_F16 : (bad ? NOPE_ERR_RANGE : NOPE_OK);
+    return fatal > 0 ? NOPE_ERR_RANGE_F16 : (bad > 0 ? NOPE_ERR_RANGE : NOPE_OK);
+}
+
+// ... behind a synchronisation of `stream`: the verdicts of every forward issued on it so far.  NOPE_ERR_RANGE: at least one of them was out of
+// range (its output is NaN); the shifts are re-centred -- issue it again.
+int nope_unet_x2_range_check(nope_unet* net, nope_stream_t stream, int* n_out_of_range, int* n_adjusted, float* max_abs) {
+    if (!net) return NOPE_ERR_ARG;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return NOPE_ERR_LAUNCH;
+    return nope_unet_x2_poll(net, stream, n_out_of_range, n_adjusted, max_abs);
 }
 
 int nope_unet_x2_enable(nope_unet* net, int on) {
@@ -816,6 +862,9 @@ void nope_unet_destroy(nope_unet* net) {
     for (const UGraph& g : net->graphs) hipGraphExecDestroy(g.exec);
     for (auto& e : net->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (void* p : net->allocs) hipFree(p);
+    if (net->x2_tab_pin) hipHostFree(net->x2_tab_pin);
+    if (net->x2_t_pin) hipHostFree(net->x2_t_pin);
+    if (net->x2_host) hipHostFree(net->x2_host);
     delete net;
 }
 
@@ -859,7 +908,10 @@ int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep
     const size_t avail = workspace_bytes - lost;
     // Opt-in (net->graph_max > 0): batches of at most that many hypothesis-pixels replay a captured launch sequence; everything else
     // launches directly.
-    const bool want_graph = net->graph_max > 0 && net->graphs_ok && !net->profile && avail > sb && (long long)n_hyp * H * W <= net->graph_max;
+    // (NOPE_F16X2 with range tracking launches directly: the per-forward table of the verdict kernel is a host-to-device copy)
+    const bool want_graph = net->graph_max > 0 && net->graphs_ok && !net->profile && avail > sb && (long long)n_hyp * H * W <= net->graph_max &&
+                            !(net->x2 && !net->x2_off);
+    if (net->x2 && !net->x2_off) (void)nope_unet_x2_poll(const_cast<nope_unet*>(net), stream, nullptr, nullptr, nullptr);      // verdicts that have arrived: re-centre first
     if (!want_graph)
         return run_forward(net, x, n_src, x_rep, pose, n_hyp, H, W, out, out_dtype, base, avail, s, false, nullptr);
     std::lock_guard<std::mutex> lock(net->graph_mu);

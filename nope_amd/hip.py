@@ -70,6 +70,7 @@ _PROTOS = {
     "nope_unet_graph_limit": (_i, [_vp, C.c_longlong]),
     "nope_unet_graph_replays": (_i, [_vp]),
     "nope_unet_x2_range_check": (_i, [_vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_float)]),
+    "nope_unet_x2_poll": (_i, [_vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_float)]),
     "nope_unet_x2_enable": (_i, [_vp, _i]),
     "nope_unet_x2_shifts": (_i, [_vp, C.POINTER(_i), _i, C.POINTER(_i)]),
     "nope_unet_profile": (_i, [_vp, _i]),
@@ -452,12 +453,19 @@ class UNetHandle:
         l.check(l.dll.nope_unet_create(C.byref(c), descs, len(state_dict), stream, C.byref(h)), "nope_unet_create")
         self._h = h
         self._ws: Dict[tuple, torch.Tensor] = {}     # one arena per (device, stream): forwards on different streams never share one
-        # NOPE_F16X2: after every forward, read the largest |activation| each two-pass layer converted (nope_unet_x2_range_check: one
-        # stream synchronisation + 300 bytes) and run the forward again when a layer left its accurate window -- with re-centred
-        # shifts (as NOPE_BF16X3 only for non-finite activations).  NOPE_X2_RANGE_CHECK=0 (or .range_check = False) trusts the shifts.
-        self.range_check = self.compute_dtype == F16X2 and os.environ.get("NOPE_X2_RANGE_CHECK", "1") != "0"
+        # NOPE_F16X2 activation ranges.  The library judges every forward on the device and overwrites the output of one whose layers left
+        # their accurate windows with NaNs (include/nope_hip.h: nope_unet_x2_poll) -- no synchronisation in the step.  range_mode:
+        #   "poison" (default)  nothing more: the verdicts that have arrived are read at the start of the next forward (shifts re-centred,
+        #                       an event recorded, one warning); a caller that finds NaNs in a bank repeats its call;
+        #   "repeat"            after a forward (or, deferred, at the end of the caller's step) synchronise, read the verdict and issue
+        #                       the forward again until it is inside its windows: never a NaN, one host synchronisation per step;
+        #   "off"               do not look (the device still judges and poisons).
+        # NOPE_X2_RANGE_CHECK = 0 / 1 / 2 selects off / poison / repeat.
+        self.range_mode = {"0": "off", "1": "poison", "2": "repeat"}.get(os.environ.get("NOPE_X2_RANGE_CHECK", "1"), "poison") \
+            if self.compute_dtype == F16X2 else "off"
         self.range_events: List[dict] = []           # one record per forward that had to be repeated
         self._pending: List[tuple] = []              # forwards issued with defer_range_check: (re-launch closure, stream)
+        self._warned = False
         self.x2_enabled = self.compute_dtype == F16X2
 
     def __del__(self):
@@ -466,10 +474,12 @@ class UNetHandle:
             self._l.dll.nope_unet_destroy(h)
             self._h = None
 
-    def x2_range_check(self, stream) -> Tuple[int, int, int, float]:
-        """(code, layers out of range, layers whose shift moved, largest |activation|) of the forwards since the last check."""
+    def x2_range_check(self, stream, sync: bool = True) -> Tuple[int, int, int, float]:
+        """(code, layers out of range, layers whose shift moved, largest |activation|) of the forwards judged since the last look; sync:
+        synchronise `stream` first (every forward issued on it is judged), else only the verdicts that have already arrived."""
         bad, moved, amax = _i(0), _i(0), C.c_float(0)
-        code = int(self._l.dll.nope_unet_x2_range_check(self._h, stream, C.byref(bad), C.byref(moved), C.byref(amax)))
+        fn = self._l.dll.nope_unet_x2_range_check if sync else self._l.dll.nope_unet_x2_poll
+        code = int(fn(self._h, stream, C.byref(bad), C.byref(moved), C.byref(amax)))
         if code not in (0, ERR_RANGE, ERR_RANGE_F16):
             self._l.check(code, "nope_unet_x2_range_check")
         return code, bad.value, moved.value, float(amax.value)
@@ -544,8 +554,21 @@ class UNetHandle:
         def launch():
             self._l.check(self._l.dll.nope_unet_forward(self._h, _ptr(x), n_src, x_rep, _ptr(pose), n_hyp, H, W, _ptr(out), odt,
                                                         _ptr(ws), ws.numel(), _stream(x)), "nope_unet_forward")
+        if self.range_mode != "off" and self.x2_enabled:
+            # verdicts of EARLIER forwards that have reached the host (no waiting): their outputs were NaN; the shifts are re-centred now
+            code, bad, moved, amax = self.x2_range_check(_stream(x), sync=False)
+            if code != 0:
+                self.range_events.append({"code": code, "layers_out_of_range": bad, "layers_adjusted": moved, "max_abs": amax, "attempt": -1})
+                if self.range_mode == "poison" and not self._warned:
+                    import warnings
+                    self._warned = True
+                    warnings.warn(f"nope_amd f16x2: an earlier U-Net forward saw activations up to {amax:.3g}, outside the accurate range of "
+                                  f"{bad} layer(s): its output was overwritten with NaNs (never silently inaccurate); the layers' range shifts "
+                                  "are re-centred now -- repeat that call (or use range_mode = 'repeat' / NOPE_X2_RANGE_CHECK=2)", RuntimeWarning)
+                if code == ERR_RANGE_F16:
+                    self.x2_enable(False)
         launch()
-        if self.range_check and self.x2_enabled:
+        if self.range_mode == "repeat" and self.x2_enabled:
             # the check needs the forward to have finished: callers that go on issuing work on the stream (PoseConditional: scoring,
             # top-k) call finish_range_check() at the END of their step -- one synchronisation where the results are read anyway --
             # and repeat their own tail when it says the forward was repeated
@@ -561,7 +584,7 @@ class UNetHandle:
         pending, self._pending = self._pending, []
         repeated = False
         for attempt in range(8):        # (a repeated forward can move the maxima of layers downstream of the repaired ones: a few rounds at most)
-            if not pending or not (self.range_check and self.x2_enabled):
+            if not pending or not (self.range_mode == "repeat" and self.x2_enabled):
                 break
             code, bad, moved, amax = self.x2_range_check(pending[-1][1])
             if code == 0:

@@ -59,6 +59,7 @@ def test_f16x2_tile_gpu(gpu):
         print(f"f16x2 U-Net, reference embedding x {S:g}: {e:.2e} vs the oracle; repeated forwards {[(ev['code'], ev['layers_out_of_range'], float('%.3g' % ev['max_abs'])) for ev in events]}; two-pass tile {'on' if x2_on else 'OFF (bf16x3)'}")
         assert e < 1e-4 and x2_on, (S, e, events)
     by = {S: events for S, e, events, x2_on in res}
+    assert res[-1][0] > 1e6 and any(ev["attempt"] == -1 for ev in res[-1][2]), "last entry: the default 'poison' mode (NaN output, verdict at the next forward)"
     assert by[1.0] == [] and by[1e2] == [], "inside the initial window nothing is repeated"
     assert any(ev["code"] == hip.ERR_RANGE for ev in by[1e4]), "|a| ~ 1e4 leaves the t = 0 window: shifts moved, call repeated"
     assert any(ev["code"] == hip.ERR_RANGE for ev in by[3e5]), "beyond 65504 (where a plain f16 operand saturates) the shifts still repair it"

@@ -181,6 +181,8 @@ def run_unet_range(hip, dev, dim=64, n_hyp=5, hw=16, scales=(1.0, 1e2, 1e3, 1e4,
     from oracle import nope_ref as R
     from tests.util import StubEncoder
     os.environ["NOPE_CONV_PP"] = "9"
+    saved_mode = os.environ.get("NOPE_X2_RANGE_CHECK")
+    os.environ["NOPE_X2_RANGE_CHECK"] = "2"         # range_mode "repeat": synchronise, read the verdict, issue the forward again (hip.UNetHandle)
     out = []
     try:
         u = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(8), pose_mlp_name="single_layer", compute_dtype="f16x2")
@@ -197,9 +199,29 @@ def run_unet_range(hip, dev, dim=64, n_hyp=5, hw=16, scales=(1.0, 1e2, 1e3, 1e4,
             h = u._handle
             want = R.unet_forward(sd, (x * S).expand(n_hyp, -1, -1, -1), pose[0])
             out.append((S, rel(y, want), h.range_events[n0:], h.x2_enabled))
+        # the default mode ("poison"): no host look in the step -- a forward whose layers left their windows returns NaNs, the next forward
+        # finds the verdict, re-centres the shifts (one warning) and is accurate
+        h = u._handle
+        h.range_mode = "poison"
+        S = scales[-1] * 64.0
+        n0 = len(h.range_events)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            y1 = u.forward_hypotheses((x * S).to(dev), pose.to(dev)).cpu()[0]
+            if str(dev) != "cpu":
+                torch.cuda.synchronize()
+            y2 = u.forward_hypotheses((x * S).to(dev), pose.to(dev)).cpu()[0]
+        want = R.unet_forward(sd, (x * S).expand(n_hyp, -1, -1, -1), pose[0])
+        assert bool(torch.isnan(y1).all()), "an out-of-range forward must leave NaNs, not inaccurate values"
+        assert any(ev["attempt"] == -1 for ev in h.range_events[n0:]), "the next forward reports the verdict"
+        out.append((S, rel(y2, want), h.range_events[n0:], h.x2_enabled))
         return out
     finally:
         os.environ.pop("NOPE_CONV_PP")
+        if saved_mode is None:
+            os.environ.pop("NOPE_X2_RANGE_CHECK", None)
+        else:
+            os.environ["NOPE_X2_RANGE_CHECK"] = saved_mode
 
 
 def run_unet(hip, dev, dim=64, n_hyp=5, hw=16):

@@ -14,7 +14,7 @@ for rep in 1 2; do
   done
 done
 unset NOPE_HIP_LIB NOPE_X2_RANGE_CHECK
-NOPE_X2_RANGE_CHECK=0 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 3 --skip-extras > $OUT/r06c_bench_default_nocheck.json 2>> $OUT/r06c_bench.err
+NOPE_X2_RANGE_CHECK=2 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 3 --skip-extras > $OUT/r06c_bench_default_repeat_mode.json 2>> $OUT/r06c_bench.err
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob("gpurun_out/r06c_bench_*.json")):
@@ -23,4 +23,4 @@ for f in sorted(glob.glob("gpurun_out/r06c_bench_*.json")):
         print(f.split("/")[-1], round(r["ms_per_step"],3), "halo ms/step", rf.get("kernel_ms_per_step"), "family", (rf.get("family") or {}).get("kernel_ms_per_step"))
     except Exception as e: print(f, e)
 PY
-timeout 900 python tools/small_bank_sweep.py --dtype f16x2 --banks 26,64,91,128,256,341,512 --steps 20 --settings "NOPE_X2_SMALL=1;NOPE_X2_SMALL=0;NOPE_X2_SMALL=1;NOPE_X2_SMALL=0" > $OUT/r06c_small_banks_f16x2.txt 2>&1; cat $OUT/r06c_small_banks_f16x2.txt | tail -5
+timeout 900 python tools/small_bank_sweep.py --dtype f16x2 --banks 26,64,91,128,256,341,512 --steps 20 --settings "NOPE_X2_SMALL=0;NOPE_X2_SMALL=1;NOPE_X2_SMALL=0" > $OUT/r06c_small_banks_f16x2.txt 2>&1; cat $OUT/r06c_small_banks_f16x2.txt | tail -5
