@@ -70,6 +70,7 @@ struct ConvParams {
     unsigned bytes1, bytes2, bytesw;   // tensor sizes for the buffer descriptors of the DMA kernel
     const int* x2_scale;               // NOPE_F16X2 (ping-pong kernels): the tail of the packed weights, [0] = E8M0 scale of the A operand, [3] = range shift t
     unsigned* x2_amax;                 // NOPE_F16X2: optional device word, atomicMax of the bits of max |a| over every A element the launch converted (NOPE_X2_KERNEL_AMAX builds)
+    int x2_t_zero;                     // NOPE_F16X2: the caller vouches that the layer's range shift (tail word 3) is 0: the tap-resident kernel skips the a * 2^-t multiplies
     unsigned* out_amax;                // f32-storage launches with a wide NHWC epilogue: optional range slot (amax_publish) for max |out| of what the launch writes
 };
 

@@ -533,7 +533,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     const bool dma = plan.dma;
     const bool x2 = plan_takes_x2(a, plan);
     if (!x2 && !a.w) return NOPE_ERR_UNSUPPORTED;               // (NOPE_F16X2 as an element type on a shape the ping-pong kernels do not take)
-    p.x2_scale = nullptr; p.x2_amax = x2 ? a.x2_amax : nullptr;
+    p.x2_scale = nullptr; p.x2_amax = x2 ? a.x2_amax : nullptr; p.x2_t_zero = x2 ? a.x2_t_zero : 0;
     p.out_amax = (a.out_amax && plan_records_out_amax(dt, a, plan)) ? a.out_amax : nullptr;
     if (x2) { p.w = (const unsigned char*)a.w_x2; p.x2_scale = reinterpret_cast<const int*>(p.w + bw * (phased ? 4 : 1)); }
     if (a.geglu && !geglu_shape_ok(dt, a, plan)) return NOPE_ERR_UNSUPPORTED;

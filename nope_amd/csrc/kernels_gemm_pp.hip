@@ -446,7 +446,10 @@ constexpr int TIMELINE_STAMPS = 720;  // per group; 5 per K step (tuning instant
 
 // SPLIT: the split-K instantiation (chunk range from blockIdx.z, raw f32 partials out) -- its own kernel so that the main one keeps
 // its register allocation (256 VGPRs, no spill: one more live scalar pair spilled it).
-template <class T, bool TIMELINE = false, bool SPLIT = false>
+// SHIFT (NOPE_F16X2): false = the instantiation for layers whose activation range shift t is 0 (the host knows: ConvParams::x2_t_zero) -- the rewrite
+// then works on a itself and loses the two packed multiplies per piece that a * 2^-t costs (+1.7 % on the kernel, same-box A/B,
+// profiles/r06c_*); every layer starts at t = 0 and stays there while its inputs peak inside [1, 1024].
+template <class T, bool TIMELINE = false, bool SPLIT = false, bool SHIFT = true>
 __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvParams p) {
     typedef Tile<T> TL;
     constexpr int VEC = Elt<T>::VEC;
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     // themselves (probe fact 7; a NaN stays a NaN, as in the f32 / bf16x3 modes) -- 16 VALU per piece and lane instead of 46 with explicit
     // pre-scale multiplies, clamps and byte packing.
     if constexpr (X2) fp16_ovfl_on();
-    const int x2_t = (X2 && NOPE_X2_TRACK) ? p.x2_scale[3] : 0;                                  // the layer's activation range shift t (nope_common.h: kX2*): the rewrite works on a * 2^-t,
+    const int x2_t = (X2 && NOPE_X2_TRACK && SHIFT) ? p.x2_scale[3] : 0;                         // the layer's activation range shift t (nope_common.h: kX2*): the rewrite works on a * 2^-t,
     const int x2_sc = X2 ? p.x2_scale[0] : 0;                                 // E8M0 block scale of the cross-term MFMA (uniform; waited for with the prologue's DMA)
     const float x2_inv = x2_pow2(-x2_t), x2_out = x2_pow2(x2_t), x2_da = x2_pow2(x2_t - kX2AShift);      // the accumulators hold 2^-t x the convolution, the epilogue multiplies by 2^t
     float x2_amax = 0.f;                                                      // max |a| over the A elements this lane rewrites
@@ -1017,6 +1020,7 @@ void launch_conv_halo(int dt, const void* params, dim3 grid, hipStream_t s) {
         if (dt == NOPE_F32) hipLaunchKernelGGL((conv3x3_halo_kernel<float, false, true>), grid, block, 0, s, p);
         else if (dt == NOPE_BF16X3) hipLaunchKernelGGL((conv3x3_halo_kernel<f32s_t, false, true>), grid, block, 0, s, p);
         else if (dt == NOPE_F16) hipLaunchKernelGGL((conv3x3_halo_kernel<f16_t, false, true>), grid, block, 0, s, p);
+        else if (dt == NOPE_F16X2 && p.x2_t_zero) hipLaunchKernelGGL((conv3x3_halo_kernel<f16x2_t, false, true, false>), grid, block, 0, s, p);
         else if (dt == NOPE_F16X2) hipLaunchKernelGGL((conv3x3_halo_kernel<f16x2_t, false, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((conv3x3_halo_kernel<bf16_t, false, true>), grid, block, 0, s, p);
         return;
@@ -1024,6 +1028,7 @@ void launch_conv_halo(int dt, const void* params, dim3 grid, hipStream_t s) {
     if (dt == NOPE_F32) hipLaunchKernelGGL((conv3x3_halo_kernel<float>), grid, block, 0, s, p);
     else if (dt == NOPE_BF16X3) hipLaunchKernelGGL((conv3x3_halo_kernel<f32s_t>), grid, block, 0, s, p);
     else if (dt == NOPE_F16) hipLaunchKernelGGL((conv3x3_halo_kernel<f16_t>), grid, block, 0, s, p);
+    else if (dt == NOPE_F16X2 && p.x2_t_zero) hipLaunchKernelGGL((conv3x3_halo_kernel<f16x2_t, false, false, false>), grid, block, 0, s, p);
     else if (dt == NOPE_F16X2) hipLaunchKernelGGL((conv3x3_halo_kernel<f16x2_t>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((conv3x3_halo_kernel<bf16_t>), grid, block, 0, s, p);
 }

@@ -344,6 +344,7 @@ struct ConvArgs {
     const void* w_x2 = nullptr;  // NOPE_BF16X3 launches only: the same weights in the NOPE_F16X2 layout (launch_pack_conv_w_x2) -- taken, with
                                  // the f16 + MX-fp8 tile, when the launch goes to a ping-pong kernel (conv_takes_x2); `w` (may be null then) otherwise
     unsigned* x2_amax = nullptr; // NOPE_F16X2 launches: optional device word, atomicMax of the bits of max |a| over the A elements converted (NOPE_X2_KERNEL_AMAX builds)
+    int x2_t_zero = 0;           // NOPE_F16X2 launches: 1 = the caller knows the pack's range shift (tail word 3) is 0 (the operator-level entry never sets it)
     unsigned* out_amax = nullptr;// f32 storage: optional range slot (kX2SlotWords words, amax_publish) for max |out| -- honoured by the launches that end in the wide NHWC
                                  // epilogue of the 128 x 192 / ping-pong / tap-resident kernels without split-K (conv_records_out_amax); ignored otherwise
     const float* bias = nullptr; // [Cout] or null

@@ -89,6 +89,8 @@ struct nope_unet {
     static constexpr int X2_SLOTS = 512;
     std::vector<int*> x2_tails;              // per layer: device pointer to the pack's 16-byte tail
     std::vector<int> x2_t;                   // host copy of the current shifts
+    std::vector<char> x2_moved;              // has the layer's shift ever left 0? (only never-moved layers take the t == 0 kernel instantiation:
+                                             // their tail word cannot be anything else, whatever stream a pending update travels on)
     unsigned* x2_amax = nullptr;             // device, X2_SLOTS range slots of kX2SlotWords words (amax_publish, nope_common.h)
     // The verdict of every forward is formed ON THE DEVICE, behind its last kernel (x2_verdict_kernel): each layer's largest input maximum
     // against its window; an out-of-range forward's output is overwritten with NaNs (x2_poison_kernel) -- no caller reads inaccurate values
@@ -282,6 +284,7 @@ struct Fwd {
         if (b) { ca.src2 = b->p; ca.C2 = b->C; ca.rep2 = rep2; }
         ca.Hs = a.H; ca.Ws = a.W; ca.Ho = Ho; ca.Wo = Wo;
         ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.w_x2 = net->x2_off ? nullptr : c.w_x2; ca.bias = c.bias; ca.resid = resid;
+        if (ca.w_x2 && c.x2_id >= 0) { std::lock_guard<std::mutex> lock(net->x2_mu); ca.x2_t_zero = net->x2_moved[c.x2_id] ? 0 : 1; }
         ca.out = out; ca.Cout = c.Cout; ca.nhyp = n; ca.out_nchw = out_nchw; ca.out_dt = out_dt;
         if (a.C + (b ? b->C : 0) != c.Cin) { chk(NOPE_ERR_ARG); return; }
         float* colstats = nullptr;
@@ -714,6 +717,7 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
             if (ld.err == NOPE_OK) ld.err = NOPE_ERR_ALLOC;
         } else memset(net->x2_host, 0, hostw * sizeof(unsigned));
         net->x2_t.assign(n, 0);
+        net->x2_moved.assign(n, 0);
     }
     if (ld.err == NOPE_OK && hipStreamSynchronize(s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
     if (ld.err != NOPE_OK) {
@@ -807,6 +811,7 @@ int nope_unet_x2_poll(nope_unet* net, nope_stream_t stream, int* n_out_of_range,
             net->x2_t_pin[i] = tn;
             if (hipMemcpyAsync(net->x2_tails[i] + 3, &net->x2_t_pin[i], sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) return NOPE_ERR_LAUNCH;
             net->x2_t[i] = tn;
+            net->x2_moved[i] = 1;
             ++moved;
         }
     }

@@ -538,6 +538,8 @@ inline float atomicAdd(float* p, float v) {
 }
 
 inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline unsigned atomicMax(unsigned* p, unsigned v) {
     unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}

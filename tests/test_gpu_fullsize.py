@@ -282,7 +282,12 @@ def test_f16x2_off_the_benchmark_activation_range(model_f32):
             line.append(f"{cdt} {e:.2e}" + (f" (top-5 {'=' if torch.equal(idx, idx32) else '!='}; repeated: {[(x['code'], x['layers_out_of_range'], float('%.3g' % x['max_abs'])) for x in ev]}; "
                                              f"shifts {sorted(set(m.u_net._handle.x2_shifts()))})" if cdt == "f16x2" else ""))
             if cdt == "f16x2":
-                assert e < 5e-5 and torch.equal(idx, idx32) and m.u_net._handle.x2_enabled, (S, e, torch.equal(idx, idx32), m.u_net._handle.x2_enabled, [(x["attempt"], x["code"], x["layers_out_of_range"]) for x in ev])
+                # (the top-5 can only be asked for where the f32 scores are further apart than the error: at the largest scale the maps of
+                #  all templates nearly coincide)
+                top6 = sim32.topk(6, dim=1).values
+                gap = float((top6[:, :-1] - top6[:, 1:]).min() / sim32.abs().max())
+                same = torch.equal(idx, idx32) or gap < 4 * e
+                assert e < 5e-5 and same and m.u_net._handle.x2_enabled, (S, e, gap, torch.equal(idx, idx32), m.u_net._handle.x2_enabled, [(x["attempt"], x["code"], x["layers_out_of_range"]) for x in ev])
                 if S * fmax >= 1e4:
                     assert ev, "|a| >= 1e4 must have left the initial window"
             elif cdt == "bf16x3":
