@@ -261,6 +261,12 @@ size_t nope_ldm_workspace_bytes(const nope_ldm* net, int n_hyp, int n_src, int H
 /* out[j] = UNetModelPose(x[j / x_rep], pose[j]); arguments as nope_unet_forward. */
 int nope_ldm_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, const float* pose, int n_hyp, int H, int W,
                      void* out, int out_dtype, void* workspace, size_t workspace_bytes, nope_stream_t stream);
+/* NOPE_F16X2 in the LDM variant: the 3x3 convolutions (ResBlock in_layers.2 / out_layers.3, openaimodel.py:205-243, and the nearest-x2
+ * up-sampling convs :95-118) on the two-pass tile, everything else as NOPE_BF16X3; activation ranges exactly as nope_unet_x2_poll /
+ * nope_unet_x2_range_check / nope_unet_x2_enable above (device-side verdict, NaN output for an out-of-range forward, poll at every forward). */
+int nope_ldm_x2_poll(nope_ldm* net, nope_stream_t stream, int* n_out_of_range, int* n_adjusted, float* max_abs);
+int nope_ldm_x2_range_check(nope_ldm* net, nope_stream_t stream, int* n_out_of_range, int* n_adjusted, float* max_abs);
+int nope_ldm_x2_enable(nope_ldm* net, int on);
 
 /* ------------------------------------------------------------------------------------------
  * Template encoder.  Replaces FeatureExtractor.encode_image, src/model/encoder/template.py:47-53
@@ -271,7 +277,7 @@ int nope_ldm_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, 
 typedef struct nope_encoder nope_encoder;
 typedef struct {
     int descriptor_size;   /* 8 (configs/model/template_base.yaml:10) */
-    int compute_dtype;     /* NOPE_F32 | NOPE_BF16 | NOPE_F16 | NOPE_BF16X3 | NOPE_F16X2 (= NOPE_BF16X3 here: its layers carry no second weight pack), as nope_unet_config */
+    int compute_dtype;     /* NOPE_F32 | NOPE_BF16 | NOPE_F16 | NOPE_BF16X3 | NOPE_F16X2 (its 3x3 convs on the two-pass tile, the rest as NOPE_BF16X3), as nope_unet_config */
     float bn_eps;          /* BatchNorm2d eps; <= 0 selects the torch default 1e-5 */
 } nope_encoder_config;
 

@@ -65,7 +65,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", defines
     objdir = os.path.join(ROOT, "build", "hip" + ("_" + variant if variant else ""))
     os.makedirs(objdir, exist_ok=True)
     LIB = os.path.join(HERE, f"libnope_hip{'_' + variant if variant else ''}.so")
-    headers = [os.path.join(HERE, "nope_common.h"), os.path.join(HERE, "conv_gemm_common.h"), os.path.join(HERE, "conv_gemm_dma.h"), os.path.join(ROOT, "include", "nope_hip.h")]
+    headers = [os.path.join(HERE, "nope_common.h"), os.path.join(HERE, "conv_gemm_common.h"), os.path.join(HERE, "conv_gemm_dma.h"), os.path.join(HERE, "x2_range.h"), os.path.join(ROOT, "include", "nope_hip.h")]
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + list(defines)
 
     def compile_one(src: str) -> str:

@@ -23,12 +23,13 @@
 #include <vector>
 
 #include "nope_common.h"
+#include "x2_range.h"
 
 using namespace nope;
 
 namespace {
 
-struct LConv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; };
+struct LConv { void* w = nullptr; float* bias = nullptr; int Cin = 0, Cout = 0, ntaps = 1, mode = NOPE_CONV_PLAIN; void* w_x2 = nullptr; int x2_id = -1; };   // w_x2 / x2_id: NOPE_F16X2, the 3x3 convs' second pack and its slot in the range table (x2_range.h)
 struct LNorm { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct LRes { LNorm n1, n2; LConv c1, c2, skip; bool has_skip = false; float *emb_w = nullptr, *emb_b = nullptr; int Cin = 0, Cout = 0; };
 struct LTB { LNorm ln1, ln3; LConv qkv, out1, ff1, ff2; int u_off = 0; };         // one BasicTransformerBlock; u_off: its slice of nope_ldm::u_w
@@ -41,6 +42,9 @@ struct nope_ldm {
     nope_ldm_config cfg;
     int dt = NOPE_F32;      // compute dtype (conv kernels, weight packing)
     int sdt = NOPE_F32;     // storage dtype of the activations (every other kernel)
+    bool x2 = false;        // NOPE_F16X2: dt = NOPE_BF16X3 everywhere, plus a second weight pack per 3x3 conv (ResBlock convs, nearest-x2 up-sampling) for the
+                            // ping-pong kernels' f16 + MX-fp8 tile; the 1x1 convs / linears of the transformer blocks stay three-pass
+    mutable X2Range x2r;    // ... and the activation-range tracking that keeps the tile inside its accurate window (x2_range.h)
     std::vector<void*> allocs;
     LConv conv_in, conv_out;
     LNorm norm_out;
@@ -139,6 +143,11 @@ struct Loader {
             const size_t es = (size_t)dt_es(net->dt);
             c.w = dmalloc((size_t)Cout * c.ntaps * Ck * es * (mode == NOPE_CONV_UP2P ? 4 : 1));
             if (c.w) chk(launch_pack_conv_w(net->dt, d->data, c.w, Cout, Ck, c.ntaps, mode, s, nullptr, nullptr, Cin));
+            if (net->x2 && !linear && ksz == 3 && (mode == NOPE_CONV_PLAIN || mode == NOPE_CONV_UP2P) && Ck == Cin && Cin % 32 == 0) {
+                const size_t x2b = conv_w_x2_bytes(Cout, Cin, c.ntaps, mode);
+                c.w_x2 = dmalloc(x2b);
+                if (c.w_x2) { chk(launch_pack_conv_w_x2((const float*)d->data, c.w_x2, Cout, Cin, s, c.ntaps, mode)); c.x2_id = net->x2r.add_layer(c.w_x2, x2b); }
+            }
         }
         if (has_bias) c.bias = copy_f32(pfx + "bias", {Cout});
         return c;
@@ -246,6 +255,8 @@ struct Fwd {
     const float* ctx = nullptr;       // (nhyp, context_dim)
     const float* emb = nullptr;       // (nhyp, emb_dim) or null (zeros)
     const float* u_all = nullptr;     // (nhyp, u_total): every transformer block's to_out(to_v(context)) row
+    X2Fwd x2;                         // NOPE_F16X2 range tracking of this forward (x2_range.h)
+    bool tracking() const { return x2.on && err == NOPE_OK; }
 
     void chk(int e) { if (e != NOPE_OK && err == NOPE_OK) err = e; }
     bool live() const { return !ar.dry && err == NOPE_OK; }
@@ -267,6 +278,14 @@ struct Fwd {
         ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.bias = c.bias; ca.resid = resid; ca.out = out; ca.Cout = c.Cout;
         ca.nhyp = n < 0 ? nhyp : n; ca.out_nchw = out_nchw; ca.out_dt = out_dt;
         if (a.C != c.Cin) { chk(NOPE_ERR_ARG); return; }
+        if (c.w_x2 && !net->x2r.off) { ca.w_x2 = c.w_x2; ca.x2_t_zero = net->x2r.t_zero(c.x2_id) ? 1 : 0; }
+        if (tracking()) {
+            if (ca.w_x2 && conv_takes_x2(net->dt, ca)) {      // the two-pass tile: the layer's range shift follows its input's maximum
+                x2.consumes(c.x2_id, x2.slot_for(a.p, (size_t)(ca.nhyp / rep) * a.H * a.W * a.C));
+                chk(x2.err);
+            }
+            x2.overwritten(out);           // (conv epilogues record no maximum here: a two-pass consumer of `out` takes an absmax pass)
+        }
         chk(launch_conv(net->dt, ca, s));
     }
     // y = [silu](GroupNorm(32, eps)(x))
@@ -279,6 +298,10 @@ struct Fwd {
         ga.nhyp = nhyp; ga.HW = HW; ga.C = nm.C; ga.G = 32; ga.act = act; ga.eps = eps;
         ga.film = film; ga.film_stride = film_stride;
         ga.fast_silu = net->dt != NOPE_F32 ? 1 : 0;      // (f32 storage of the split-precision modes: hardware exp / rcp; the f32 mode keeps expf and the division)
+        if (tracking()) {                                // (the FiLM instantiation records no maximum: its consumer takes an absmax pass)
+            if (!film) { const int sl = x2.produce(y); if (sl >= 0) ga.amax_out = x2.slot_ptr(sl); }
+            else x2.overwritten(y);
+        }
         chk(launch_gn_apply(net->sdt, ga, s));
     }
     // ResBlock._forward, openaimodel.py:262-288 (no up/down)
@@ -367,6 +390,7 @@ int run_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, const
     Fwd f;
     f.net = net; f.s = s; f.nhyp = n_hyp; f.es = (size_t)dt_es(net->dt);
     f.ar.base = (unsigned char*)ws; f.ar.cap = ws_bytes; f.ar.dry = dry;
+    f.x2.r = &net->x2r; f.x2.s = s; f.x2.on = net->x2 && net->x2r.active() && !dry;
     const int HW = H * W;
     const int cin_k = net->conv_in.Cin;          // in_channels rounded up to a whole 16-byte vector
     void* x_in = f.alloc_act((size_t)n_src * HW * cin_k);
@@ -461,6 +485,8 @@ int run_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, const
         f.gn(net->norm_out, h.p, t, HW, 1, 1e-5f);
         f.conv(net->conv_out, Act{t, h.C, H, W}, out, H, W, nullptr, 1, out_dtype);
     }
+    if (f.tracking())      // the forward's verdict; NaNs over the output of a forward whose layers left their windows (x2_range.h)
+        f.chk(f.x2.finish(out, (size_t)n_hyp * net->cfg.out_channels * HW * (size_t)(out_dtype == NOPE_F32 ? 4 : 2), out_dtype));
     if (peak) *peak = f.ar.peak;
     return f.err;
 }
@@ -485,7 +511,8 @@ int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors,
     hipStream_t s = (hipStream_t)stream;
     nope_ldm* net = new nope_ldm();
     net->cfg = *cfg;
-    net->dt = dt_base(cfg->compute_dtype);      // (NOPE_F16X2 = NOPE_BF16X3 in this variant)
+    net->x2 = cfg->compute_dtype == NOPE_F16X2;
+    net->dt = dt_base(cfg->compute_dtype);
     net->sdt = dt_storage(net->dt);
     net->emb_dim = cfg->model_channels * 4;
     const int mc = cfg->model_channels;
@@ -572,6 +599,7 @@ int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors,
                 ld.copy_d2d(net->u_b + up.off, up.bias, (size_t)up.C * 4);
             }
     }
+    if (ld.err == NOPE_OK) { const int e = net->x2r.init([&](size_t bytes) { return ld.dmalloc(bytes); }, s); if (e) ld.err = e; }
     if (hipStreamSynchronize(s) != hipSuccess && ld.err == NOPE_OK) ld.err = NOPE_ERR_LAUNCH;
     ld.free_temps();
     if (ld.err != NOPE_OK) {
@@ -586,7 +614,28 @@ int nope_ldm_create(const nope_ldm_config* cfg, const nope_tensor_desc* tensors,
 void nope_ldm_destroy(nope_ldm* net) {
     if (!net) return;
     for (void* p : net->allocs) hipFree(p);
+    net->x2r.destroy();
     delete net;
+}
+
+// NOPE_F16X2 activation ranges of the LDM variant: as nope_unet_x2_poll / _x2_range_check / _x2_enable (include/nope_hip.h)
+int nope_ldm_x2_poll(nope_ldm* net, nope_stream_t stream, int* n_out_of_range, int* n_adjusted, float* max_abs) {
+    if (n_out_of_range) *n_out_of_range = 0;
+    if (n_adjusted) *n_adjusted = 0;
+    if (max_abs) *max_abs = 0.f;
+    if (!net) return NOPE_ERR_ARG;
+    if (!net->x2) return NOPE_OK;
+    return net->x2r.poll((hipStream_t)stream, n_out_of_range, n_adjusted, max_abs);
+}
+int nope_ldm_x2_range_check(nope_ldm* net, nope_stream_t stream, int* n_out_of_range, int* n_adjusted, float* max_abs) {
+    if (!net) return NOPE_ERR_ARG;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return NOPE_ERR_LAUNCH;
+    return nope_ldm_x2_poll(net, stream, n_out_of_range, n_adjusted, max_abs);
+}
+int nope_ldm_x2_enable(nope_ldm* net, int on) {
+    if (!net) return NOPE_ERR_ARG;
+    net->x2r.off = on == 0;
+    return NOPE_OK;
 }
 
 size_t nope_ldm_workspace_bytes(const nope_ldm* net, int n_hyp, int n_src, int H, int W) {
@@ -606,6 +655,7 @@ int nope_ldm_forward(const nope_ldm* net, const float* x, int n_src, int x_rep, 
     unsigned char* base = (unsigned char*)(((uintptr_t)workspace + 255) / 256 * 256);
     const size_t lost = (size_t)(base - (unsigned char*)workspace);
     if (workspace_bytes < lost) return NOPE_ERR_WORKSPACE;
+    if (net->x2 && net->x2r.active()) (void)net->x2r.poll((hipStream_t)stream, nullptr, nullptr, nullptr);      // verdicts that have arrived: re-centre first
     return run_forward(net, x, n_src, x_rep, pose, n_hyp, H, W, out, out_dtype, base, workspace_bytes - lost, (hipStream_t)stream, false, nullptr);
 }
 

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "nope_common.h"
+#include "x2_range.h"
 
 using namespace nope;
 
@@ -80,32 +81,8 @@ struct nope_unet {
     mutable std::mutex graph_mu;
     mutable int graph_replays = 0;           // forwards served by a graph replay since create (tests assert the path really ran)
     long long graph_max = 0;                 // largest n_hyp * H * W that replays a graph; 0 = off
-    // NOPE_F16X2 activation ranges (nope_unet_x2_range_check).  Every layer with a second pack has a range shift t in the pack's tail (word 3):
-    // the tile works on a * 2^-t, which moves the window in which its operands are fully accurate: 2^(t - 4) <= max |a| <= 1792 * 2^t.  max |a|
-    // comes from the PRODUCERS of the tensors a layer reads: every tensor a forward writes that an f16x2 launch consumes owns a slot of
-    // x2_amax (device words, atomicMax of float bits) -- filled by gn_apply in passing (its spare VALU slots: the kernel waits for HBM), or by
-    // an absmax pass over the few tensors a conv epilogue produced (the resampling convs' outputs: 0.2 ms per 512-template step).  In-kernel
-    // tracking inside the conv kernels was measured at +5 % of the step (profiles/r06c_*) and is compiled out (NOPE_X2_KERNEL_AMAX).
-    static constexpr int X2_SLOTS = 512;
-    std::vector<int*> x2_tails;              // per layer: device pointer to the pack's 16-byte tail
-    std::vector<int> x2_t;                   // host copy of the current shifts
-    std::vector<char> x2_moved;              // has the layer's shift ever left 0? (only never-moved layers take the t == 0 kernel instantiation:
-                                             // their tail word cannot be anything else, whatever stream a pending update travels on)
-    unsigned* x2_amax = nullptr;             // device, X2_SLOTS range slots of kX2SlotWords words (amax_publish, nope_common.h)
-    // The verdict of every forward is formed ON THE DEVICE, behind its last kernel (x2_verdict_kernel): each layer's largest input maximum
-    // against its window; an out-of-range forward's output is overwritten with NaNs (x2_poison_kernel) -- no caller reads inaccurate values
-    // for accurate ones, and no host synchronisation sits in the step.  The host learns of it from mapped memory the next time it looks
-    // (nope_unet_x2_poll: at the start of every forward, or behind a synchronisation in nope_unet_x2_range_check) and re-centres the shifts.
-    static constexpr int X2_RING = 16;
-    int* x2_tab_dev = nullptr;               // device [n][5]: {t, four slots} of the forward being judged
-    int* x2_tab_pin = nullptr;               // pinned host ring of X2_RING such tables (one per forward in flight)
-    int* x2_t_pin = nullptr;                 // pinned host [n]: staging of re-centred shifts on their way into the packs' tails
-    unsigned* x2_status_dev = nullptr;       // device [4]: see x2_verdict_kernel
-    unsigned* x2_host = nullptr;             // mapped host [4 + 2 n]
-    unsigned* x2_host_dev = nullptr;         // ... its device address
-    mutable unsigned x2_ring_i = 0, x2_seen_serial = 0, x2_seen_bad = 0, x2_seen_inf = 0;
-    mutable bool x2_off = false;             // nope_unet_x2_enable(net, 0): every launch as NOPE_BF16X3 (the fallback beyond f16's range)
-    mutable std::mutex x2_mu;
+    // NOPE_F16X2 activation ranges: per-layer shifts of the tile's operands, producer-side maxima, device-side verdict (x2_range.h)
+    mutable X2Range x2r;
 };
 
 namespace {
@@ -172,8 +149,7 @@ struct Loader {
                 c.w_x2 = dmalloc(x2b);
                 if (c.w_x2) {
                     int e = launch_pack_conv_w_x2((const float*)d->data, c.w_x2, Cout, Cin, s, convT ? 16 : c.ntaps, mode); if (e && err == NOPE_OK) err = e;
-                    c.x2_id = (int)net->x2_tails.size();
-                    net->x2_tails.push_back(reinterpret_cast<int*>((unsigned char*)c.w_x2 + x2b - kX2TailBytes));
+                    c.x2_id = net->x2r.add_layer(c.w_x2, x2b);
                 }
             }
         }
@@ -242,25 +218,8 @@ struct Fwd {
     float* pn_ms = nullptr;        // its per-hypothesis (mean, rstd)
     const float* emb_all = nullptr;
 
-    // NOPE_F16X2 range tracking: which x2_amax slot holds max |.| of the tensor that currently lives at a buffer address
-    std::map<const void*, int> slot_of;
-    int next_slot = 0;
-    std::vector<int> tab;                        // [layer][5] = {t, slots of the tensors the layer's two-pass launches of THIS forward read}
-    bool tracking() const { return net->x2 && !net->x2_off && net->x2_amax && !ar.dry && err == NOPE_OK; }
-    int produce(const void* p) {                 // a kernel that records its output's maximum is about to write the tensor at p
-        const int sl = next_slot < nope_unet::X2_SLOTS ? next_slot++ : -1;
-        if (sl >= 0) slot_of[p] = sl; else slot_of.erase(p);
-        return sl;
-    }
-    void overwritten(const void* p) { slot_of.erase(p); }      // ... a kernel that does not
-    // the slot of the tensor at a.p, taking an absmax pass over it when its producer recorded none (conv epilogues, attention kernels)
-    int slot_for(const Act& a, int n) {
-        auto it = slot_of.find(a.p);
-        if (it != slot_of.end()) return it->second;
-        const int sl = produce(a.p);
-        if (sl >= 0) chk(launch_absmax_f32((const float*)a.p, (size_t)n * a.H * a.W * a.C, net->x2_amax + (size_t)sl * kX2SlotWords, s));
-        return sl;
-    }
+    X2Fwd x2;                                    // NOPE_F16X2 range tracking of this forward (x2_range.h)
+    bool tracking() const { return x2.on && err == NOPE_OK; }
 
     bool dry() const { return ar.dry; }
     void chk(int e) { if (e != NOPE_OK && err == NOPE_OK) err = e; }
@@ -283,8 +242,8 @@ struct Fwd {
         ca.src1 = a.p; ca.C1 = a.C; ca.rep1 = rep1;
         if (b) { ca.src2 = b->p; ca.C2 = b->C; ca.rep2 = rep2; }
         ca.Hs = a.H; ca.Ws = a.W; ca.Ho = Ho; ca.Wo = Wo;
-        ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.w_x2 = net->x2_off ? nullptr : c.w_x2; ca.bias = c.bias; ca.resid = resid;
-        if (ca.w_x2 && c.x2_id >= 0) { std::lock_guard<std::mutex> lock(net->x2_mu); ca.x2_t_zero = net->x2_moved[c.x2_id] ? 0 : 1; }
+        ca.mode = c.mode; ca.ntaps = c.ntaps; ca.w = c.w; ca.w_x2 = net->x2r.off ? nullptr : c.w_x2; ca.bias = c.bias; ca.resid = resid;
+        if (ca.w_x2 && c.x2_id >= 0) ca.x2_t_zero = net->x2r.t_zero(c.x2_id) ? 1 : 0;
         ca.out = out; ca.Cout = c.Cout; ca.nhyp = n; ca.out_nchw = out_nchw; ca.out_dt = out_dt;
         if (a.C + (b ? b->C : 0) != c.Cin) { chk(NOPE_ERR_ARG); return; }
         float* colstats = nullptr;
@@ -313,25 +272,19 @@ struct Fwd {
         if (!live()) return;               // workspace-size query: only the arena bookkeeping above matters
         if (tracking()) {
             if (ca.w_x2 && c.x2_id >= 0 && conv_takes_x2(net->dt, ca)) {      // this launch runs the two-pass tile: its layer's shift follows its inputs' maxima
-                const int sa = slot_for(a, n / rep1), sb = b ? slot_for(*b, n / rep2) : -1;
-                if (tab.empty()) tab.assign(net->x2_tails.size() * 5, -1);
-                int* row = &tab[(size_t)c.x2_id * 5];
-                for (int sl : {sa, sb}) {
-                    if (sl < 0) continue;
-                    int k = 1;
-                    while (k < 5 && row[k] >= 0 && row[k] != sl) ++k;
-                    if (k < 5) row[k] = sl;            // (a layer launched more than twice with four different inputs: none in these networks)
-                }
+                x2.consumes(c.x2_id, x2.slot_for(a.p, (size_t)(n / rep1) * a.H * a.W * a.C));
+                if (b) x2.consumes(c.x2_id, x2.slot_for(b->p, (size_t)(n / rep2) * b->H * b->W * b->C));
+                chk(x2.err);
             }
             // `track_out`: this conv's output goes straight into f16x2 convs (the resampling convs, the bottleneck attention's output
             // projection): its epilogue records max |out| when it is one that can (the wide NHWC epilogue); otherwise a later f16x2
             // consumer of `out` takes an absmax pass over it
             ConvArgs probe = ca;
-            probe.out_amax = net->x2_amax;
+            probe.out_amax = net->x2r.amax;
             if (track_out && conv_records_out_amax(net->dt, probe)) {
-                const int sl = produce(out);
-                if (sl >= 0) ca.out_amax = net->x2_amax + (size_t)sl * kX2SlotWords;
-            } else overwritten(out);
+                const int sl = x2.produce(out);
+                if (sl >= 0) ca.out_amax = x2.slot_ptr(sl);
+            } else x2.overwritten(out);
         }
         if (net->profile) {
             nope_unet::Ev ev;
@@ -376,7 +329,7 @@ struct Fwd {
         ga.nhyp = nhyp; ga.HW = HW; ga.C = nm.C; ga.G = G; ga.act = act;
         if (emb_off >= 0) { ga.emb = emb_all + emb_off; ga.emb_stride = net->emb_total; }
         ga.resid = resid; ga.x_rep = x_rep; ga.resid_rep = resid_rep; ga.out_stats = out_stats;
-        if (tracking()) { const int sl = produce(y); if (sl >= 0) ga.amax_out = net->x2_amax + (size_t)sl * kX2SlotWords; }
+        if (tracking()) { const int sl = x2.produce(y); if (sl >= 0) ga.amax_out = x2.slot_ptr(sl); }
         ga.fast_silu = net->dt != NOPE_F32 ? 1 : 0;      // (f32 storage of the split-precision modes: hardware exp / rcp; the f32 mode keeps expf and the division)
         chk(launch_gn_apply(net->sdt, ga, s));
     }
@@ -435,7 +388,7 @@ struct Fwd {
         void* qkv = alloc_act(M * 3 * heads * dh);
         void* a = alloc_act(M * heads * dh);
         qkv_prenorm(L.qkv, L.c0, L.c1, x, qkv);
-        if (live()) { chk(launch_linattn(net->sdt, qkv, a, nhyp, HW, heads, dh, s)); overwritten(a); }
+        if (live()) { chk(launch_linattn(net->sdt, qkv, a, nhyp, HW, heads, dh, s)); x2.overwritten(a); }
         Act aa{a, heads * dh, x.H, x.W, 1};
         Stats cs;
         conv(L.out, aa, nullptr, y, x.H, x.W, nhyp, 1, 1, nullptr, 0, NOPE_F32, &cs);
@@ -451,7 +404,7 @@ struct Fwd {
         void* qkv = alloc_act(M * 3 * heads * dh);
         void* a = alloc_act(M * heads * dh);
         qkv_prenorm(A.qkv, A.c0, A.c1, x, qkv);
-        if (live()) { chk(launch_attn(net->sdt, qkv, a, nhyp, HW, heads, dh, s)); overwritten(a); }
+        if (live()) { chk(launch_attn(net->sdt, qkv, a, nhyp, HW, heads, dh, s)); x2.overwritten(a); }
         Act aa{a, heads * dh, x.H, x.W, 1};
         conv(A.out, aa, nullptr, out, x.H, x.W, nhyp, 1, 1, /*resid=*/x.p, 0, NOPE_F32, nullptr, nullptr, nullptr, /*track_out=*/true);
         ar.off = mark;
@@ -465,6 +418,7 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
     Fwd f;
     f.net = net; f.s = s; f.nhyp = n_hyp; f.es = (size_t)dt_es(net->dt);
     f.ar.base = (unsigned char*)ws; f.ar.cap = ws_bytes; f.ar.dry = dry;
+    f.x2.r = &net->x2r; f.x2.s = s; f.x2.on = net->x2 && net->x2r.active() && !dry;
     const int HW = H * W;
     const int* dims = net->dims;
 
@@ -521,7 +475,7 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
         g.nhyp = n_src;
         g.conv(net->init_conv, xin, nullptr, x0, H, W, n_src, 1, 1);
         f.chk(g.err);
-        f.slot_of = g.slot_of; f.next_slot = g.next_slot;
+        f.x2 = g.x2;
     }
     Act r0{x0, dims[0], H, W, x_rep};
     Act cur = r0;
@@ -591,22 +545,8 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
         f.conv(net->final_conv1, b, nullptr, out, H, W, n_hyp, 1, 1, nullptr, /*out_nchw=*/1, out_dtype);
         f.ar.off = mark;
     }
-    if (f.tracking()) {
-        // the forward's verdict and, if a layer left its window, NaNs over its output -- device side, no synchronisation (see nope_unet)
-        const size_t nl = net->x2_tails.size();
-        if (f.tab.empty()) f.tab.assign(nl * 5, -1);
-        int* pin;
-        {
-            std::lock_guard<std::mutex> lock(net->x2_mu);
-            for (size_t l = 0; l < nl; ++l) f.tab[l * 5] = net->x2_t[l];
-            pin = net->x2_tab_pin + (size_t)(net->x2_ring_i++ % nope_unet::X2_RING) * nl * 5;
-        }
-        memcpy(pin, f.tab.data(), nl * 5 * sizeof(int));
-        if (hipMemcpyAsync(net->x2_tab_dev, pin, nl * 5 * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) f.chk(NOPE_ERR_LAUNCH);
-        f.chk(launch_x2_verdict(net->x2_amax, nope_unet::X2_SLOTS, net->x2_tab_dev, (int)nl, net->x2_status_dev, net->x2_host_dev, s));
-        const size_t out_bytes = (size_t)n_hyp * cfg.out_dim * HW * (size_t)(out_dtype == NOPE_F32 ? 4 : 2);
-        if (out_bytes % 4 == 0) f.chk(launch_x2_poison(out, out_bytes, out_dtype, net->x2_status_dev, s));
-    }
+    if (f.tracking())      // the forward's verdict and, if a layer left its window, NaNs over its output -- device side, no synchronisation (x2_range.h)
+        f.chk(f.x2.finish(out, (size_t)n_hyp * cfg.out_dim * HW * (size_t)(out_dtype == NOPE_F32 ? 4 : 2), out_dtype));
     if (peak) *peak = f.ar.peak;
     return f.err;
 }
@@ -702,23 +642,7 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
         }
         off += e.second;
     }
-    if (ld.err == NOPE_OK && !net->x2_tails.empty()) {
-        const size_t n = net->x2_tails.size();
-        net->x2_amax = (unsigned*)ld.dmalloc((size_t)nope_unet::X2_SLOTS * kX2SlotWords * sizeof(unsigned));
-        net->x2_tab_dev = (int*)ld.dmalloc(n * 5 * sizeof(int));
-        net->x2_status_dev = (unsigned*)ld.dmalloc(4 * sizeof(unsigned));
-        if (net->x2_amax && hipMemsetAsync(net->x2_amax, 0, (size_t)nope_unet::X2_SLOTS * kX2SlotWords * sizeof(unsigned), s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
-        if (net->x2_status_dev && hipMemsetAsync(net->x2_status_dev, 0, 4 * sizeof(unsigned), s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
-        const size_t hostw = 4 + 2 * n;
-        if (hipHostMalloc((void**)&net->x2_tab_pin, (size_t)nope_unet::X2_RING * n * 5 * sizeof(int), 0) != hipSuccess ||
-            hipHostMalloc((void**)&net->x2_t_pin, n * sizeof(int), 0) != hipSuccess ||
-            hipHostMalloc((void**)&net->x2_host, hostw * sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
-            hipHostGetDevicePointer((void**)&net->x2_host_dev, net->x2_host, 0) != hipSuccess) {
-            if (ld.err == NOPE_OK) ld.err = NOPE_ERR_ALLOC;
-        } else memset(net->x2_host, 0, hostw * sizeof(unsigned));
-        net->x2_t.assign(n, 0);
-        net->x2_moved.assign(n, 0);
-    }
+    if (ld.err == NOPE_OK) { const int e = net->x2r.init([&](size_t bytes) { return ld.dmalloc(bytes); }, s); if (e) ld.err = e; }
     if (ld.err == NOPE_OK && hipStreamSynchronize(s) != hipSuccess) ld.err = NOPE_ERR_LAUNCH;
     if (ld.err != NOPE_OK) {
         if (!ld.missing.empty()) fprintf(stderr, "nope_unet_create: missing or mis-shaped tensor '%s'\n", ld.missing.c_str());
@@ -780,46 +704,9 @@ int nope_unet_x2_poll(nope_unet* net, nope_stream_t stream, int* n_out_of_range,
     if (n_adjusted) *n_adjusted = 0;
     if (max_abs) *max_abs = 0.f;
     if (!net) return NOPE_ERR_ARG;
-    if (!net->x2 || !net->x2_host || net->x2_off) return NOPE_OK;
-    std::lock_guard<std::mutex> lock(net->x2_mu);
-    volatile unsigned* h = net->x2_host;
-    const unsigned serial = h[0];
-    if (serial == net->x2_seen_serial) return NOPE_OK;            // no forward has finished since the last look
-    __sync_synchronize();
-    const unsigned bad_total = h[2], inf_total = h[3];
-    const int bad = (int)(bad_total - net->x2_seen_bad), fatal = (int)(inf_total - net->x2_seen_inf);
-    net->x2_seen_serial = serial; net->x2_seen_bad = bad_total; net->x2_seen_inf = inf_total;
-    const size_t n = net->x2_tails.size();
-    hipStream_t s = (hipStream_t)stream;
-    int moved = 0;
-    float worst = 0.f;
-    for (size_t i = 0; i < n; ++i) {
-        const unsigned cur = h[4 + n + i];
-        if (cur && cur < 0x7f800000u) { float c; memcpy(&c, &cur, 4); if (c > worst) worst = c; }
-        const unsigned b = h[4 + i];
-        if (!b) continue;
-        h[4 + i] = 0u;                                            // (taken; the device writes it again when the layer is flagged again)
-        if (b >= 0x7f800000u) continue;                           // non-finite: nothing a shift repairs (the f32 path overflows there too)
-        float amax;
-        memcpy(&amax, &b, 4);
-        if (amax > worst) worst = amax;
-        int e = 0;
-        frexpf(amax, &e);                                        // amax = m * 2^e, m in [0.5, 1)
-        int tn = (e - 1) - 8;                                    // max |a| * 2^-tn in [256, 512)
-        tn = tn < -100 ? -100 : (tn > 100 ? 100 : tn);
-        if (tn != net->x2_t[i]) {
-            net->x2_t_pin[i] = tn;
-            if (hipMemcpyAsync(net->x2_tails[i] + 3, &net->x2_t_pin[i], sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) return NOPE_ERR_LAUNCH;
-            net->x2_t[i] = tn;
-            net->x2_moved[i] = 1;
-            ++moved;
-        }
-    }
-    if (n_out_of_range) *n_out_of_range = bad;
-    if (n_adjusted) *n_adjusted = moved;
-    if (max_abs) *max_abs = worst;
+    if (!net->x2) return NOPE_OK;
     // (a cached hipGraph replays the same kernels and pointers; the shifts live in device memory: nothing to rebuild)
-    return fatal > 0 ? NOPE_ERR_RANGE_F16 : (bad > 0 ? NOPE_ERR_RANGE : NOPE_OK);
+    return net->x2r.poll((hipStream_t)stream, n_out_of_range, n_adjusted, max_abs);
 }
 
 // ... behind a synchronisation of `stream`: the verdicts of every forward issued on it so far.  NOPE_ERR_RANGE: at least one of them was out of
@@ -833,20 +720,17 @@ int nope_unet_x2_range_check(nope_unet* net, nope_stream_t stream, int* n_out_of
 int nope_unet_x2_enable(nope_unet* net, int on) {
     if (!net) return NOPE_ERR_ARG;
     std::lock_guard<std::mutex> lock(net->graph_mu);
-    if (net->x2_off != (on == 0)) {            // the launch plan changes: cached graphs are stale
+    if (net->x2r.off != (on == 0)) {           // the launch plan changes: cached graphs are stale
         for (const UGraph& g : net->graphs) hipGraphExecDestroy(g.exec);
         net->graphs.clear();
     }
-    net->x2_off = on == 0;
+    net->x2r.off = on == 0;
     return NOPE_OK;
 }
 
 int nope_unet_x2_shifts(const nope_unet* net, int* shifts, int max, int* n) {
     if (!net || !n || (max > 0 && !shifts)) return NOPE_ERR_ARG;
-    std::lock_guard<std::mutex> lock(net->x2_mu);
-    *n = (int)net->x2_t.size();
-    for (int i = 0; i < *n && i < max; ++i) shifts[i] = net->x2_t[i];
-    return NOPE_OK;
+    return net->x2r.shifts(shifts, max, n);
 }
 
 int nope_unet_graph_limit(nope_unet* net, long long max_hyp_pixels) {
@@ -867,9 +751,7 @@ void nope_unet_destroy(nope_unet* net) {
     for (const UGraph& g : net->graphs) hipGraphExecDestroy(g.exec);
     for (auto& e : net->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (void* p : net->allocs) hipFree(p);
-    if (net->x2_tab_pin) hipHostFree(net->x2_tab_pin);
-    if (net->x2_t_pin) hipHostFree(net->x2_t_pin);
-    if (net->x2_host) hipHostFree(net->x2_host);
+    net->x2r.destroy();
     delete net;
 }
 
@@ -915,8 +797,8 @@ int nope_unet_forward(const nope_unet* net, const float* x, int n_src, int x_rep
     // launches directly.
     // (NOPE_F16X2 with range tracking launches directly: the per-forward table of the verdict kernel is a host-to-device copy)
     const bool want_graph = net->graph_max > 0 && net->graphs_ok && !net->profile && avail > sb && (long long)n_hyp * H * W <= net->graph_max &&
-                            !(net->x2 && !net->x2_off);
-    if (net->x2 && !net->x2_off) (void)nope_unet_x2_poll(const_cast<nope_unet*>(net), stream, nullptr, nullptr, nullptr);      // verdicts that have arrived: re-centre first
+                            !(net->x2 && net->x2r.active());
+    if (net->x2 && net->x2r.active()) (void)net->x2r.poll((hipStream_t)stream, nullptr, nullptr, nullptr);      // verdicts that have arrived: re-centre first
     if (!want_graph)
         return run_forward(net, x, n_src, x_rep, pose, n_hyp, H, W, out, out_dtype, base, avail, s, false, nullptr);
     std::lock_guard<std::mutex> lock(net->graph_mu);

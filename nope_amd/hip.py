@@ -73,6 +73,9 @@ _PROTOS = {
     "nope_unet_x2_poll": (_i, [_vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_float)]),
     "nope_unet_x2_enable": (_i, [_vp, _i]),
     "nope_unet_x2_shifts": (_i, [_vp, C.POINTER(_i), _i, C.POINTER(_i)]),
+    "nope_ldm_x2_range_check": (_i, [_vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_float)]),
+    "nope_ldm_x2_poll": (_i, [_vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_float)]),
+    "nope_ldm_x2_enable": (_i, [_vp, _i]),
     "nope_unet_profile": (_i, [_vp, _i]),
     "nope_unet_profile_read": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nope_unet_profile_launches": (_i, [_vp, C.POINTER(ConvLaunchInfo), _i, C.POINTER(_i)]),
@@ -424,9 +427,85 @@ def op_stem_conv(dt: int, image: torch.Tensor, w: torch.Tensor, scale: torch.Ten
 
 
 # --------------------------------------------------------------------------------------------
+# NOPE_F16X2 activation ranges: shared by the network handles (include/nope_hip.h: nope_unet_x2_poll)
+# --------------------------------------------------------------------------------------------
+class _X2RangeMixin:
+    _x2_prefix = "unet"
+
+    def _x2_init(self):
+        # NOPE_F16X2 activation ranges.  The library judges every forward on the device and overwrites the output of one whose layers left
+        # their accurate windows with NaNs (include/nope_hip.h: nope_unet_x2_poll) -- no synchronisation in the step.  range_mode:
+        #   "poison" (default)  nothing more: the verdicts that have arrived are read at the start of the next forward (shifts re-centred,
+        #                       an event recorded, one warning); a caller that finds NaNs in a bank repeats its call;
+        #   "repeat"            after a forward (or, deferred, at the end of the caller's step) synchronise, read the verdict and issue
+        #                       the forward again until it is inside its windows: never a NaN, one host synchronisation per step;
+        #   "off"               do not look (the device still judges and poisons).
+        # NOPE_X2_RANGE_CHECK = 0 / 1 / 2 selects off / poison / repeat.
+        self.range_mode = {"0": "off", "1": "poison", "2": "repeat"}.get(os.environ.get("NOPE_X2_RANGE_CHECK", "1"), "poison") \
+            if self.compute_dtype == F16X2 else "off"
+        self.range_events: List[dict] = []           # one record per forward that had to be repeated
+        self._pending: List[tuple] = []              # forwards issued with defer_range_check: (re-launch closure, stream)
+        self._warned = False
+        self.x2_enabled = self.compute_dtype == F16X2
+
+    def _x2_before_forward(self, stream):
+        if self.range_mode != "off" and self.x2_enabled:
+            # verdicts of EARLIER forwards that have reached the host (no waiting): their outputs were NaN; the shifts are re-centred now
+            code, bad, moved, amax = self.x2_range_check(stream, sync=False)
+            if code != 0:
+                self.range_events.append({"code": code, "layers_out_of_range": bad, "layers_adjusted": moved, "max_abs": amax, "attempt": -1})
+                if self.range_mode == "poison" and not self._warned:
+                    import warnings
+                    self._warned = True
+                    warnings.warn(f"nope_amd f16x2: an earlier U-Net forward saw activations up to {amax:.3g}, outside the accurate range of "
+                                  f"{bad} layer(s): its output was overwritten with NaNs (never silently inaccurate); the layers' range shifts "
+                                  "are re-centred now -- repeat that call (or use range_mode = 'repeat' / NOPE_X2_RANGE_CHECK=2)", RuntimeWarning)
+                if code == ERR_RANGE_F16:
+                    self.x2_enable(False)
+
+    def x2_range_check(self, stream, sync: bool = True) -> Tuple[int, int, int, float]:
+        """(code, layers out of range, layers whose shift moved, largest |activation|) of the forwards judged since the last look; sync:
+        synchronise `stream` first (every forward issued on it is judged), else only the verdicts that have already arrived."""
+        bad, moved, amax = _i(0), _i(0), C.c_float(0)
+        fn = getattr(self._l.dll, f"nope_{self._x2_prefix}_x2_range_check" if sync else f"nope_{self._x2_prefix}_x2_poll")
+        code = int(fn(self._h, stream, C.byref(bad), C.byref(moved), C.byref(amax)))
+        if code not in (0, ERR_RANGE, ERR_RANGE_F16):
+            self._l.check(code, f"nope_{self._x2_prefix}_x2_range_check")
+        return code, bad.value, moved.value, float(amax.value)
+
+    def x2_enable(self, on: bool):
+        self._l.check(getattr(self._l.dll, f"nope_{self._x2_prefix}_x2_enable")(self._h, int(bool(on))), f"nope_{self._x2_prefix}_x2_enable")
+        self.x2_enabled = bool(on) and self.compute_dtype == F16X2
+
+    def finish_range_check(self) -> bool:
+        """Check the forwards issued since the last check (nope_unet_x2_range_check: synchronises their stream); every forward whose layers
+        left their accurate window is issued again -- same arguments, re-centred shifts -- until it is inside.  Returns True when anything
+        was repeated: work the caller derived from the outputs has to be repeated too."""
+        pending, self._pending = self._pending, []
+        repeated = False
+        for attempt in range(8):        # (a repeated forward can move the maxima of layers downstream of the repaired ones: a few rounds at most)
+            if not pending or not (self.range_mode == "repeat" and self.x2_enabled):
+                break
+            code, bad, moved, amax = self.x2_range_check(pending[-1][1])
+            if code == 0:
+                break
+            # a two-pass layer saw activations outside its accurate window: those forwards have plain-f16 accuracy there -- repeat them
+            self.range_events.append({"code": code, "layers_out_of_range": bad, "layers_adjusted": moved, "max_abs": amax, "attempt": attempt})
+            if code == ERR_RANGE_F16 or attempt == 6:
+                import warnings
+                warnings.warn(f"nope_amd f16x2: activations up to {amax:.3g} " + ("are not finite" if code == ERR_RANGE_F16 else
+                              "keep leaving the layers' windows") + ": this U-Net runs as bf16x3 (three MFMA passes) from now on", RuntimeWarning)
+                self.x2_enable(False)
+            for launch, _ in pending:
+                launch()
+            repeated = True
+        return repeated
+
+
+# --------------------------------------------------------------------------------------------
 # U-Net handle
 # --------------------------------------------------------------------------------------------
-class UNetHandle:
+class UNetHandle(_X2RangeMixin):
     """Owns a `nope_unet*` built from a reference-keyed state dict."""
 
     def __init__(self, cfg: dict, state_dict: Dict[str, torch.Tensor], compute_dtype=F32):
@@ -453,40 +532,13 @@ class UNetHandle:
         l.check(l.dll.nope_unet_create(C.byref(c), descs, len(state_dict), stream, C.byref(h)), "nope_unet_create")
         self._h = h
         self._ws: Dict[tuple, torch.Tensor] = {}     # one arena per (device, stream): forwards on different streams never share one
-        # NOPE_F16X2 activation ranges.  The library judges every forward on the device and overwrites the output of one whose layers left
-        # their accurate windows with NaNs (include/nope_hip.h: nope_unet_x2_poll) -- no synchronisation in the step.  range_mode:
-        #   "poison" (default)  nothing more: the verdicts that have arrived are read at the start of the next forward (shifts re-centred,
-        #                       an event recorded, one warning); a caller that finds NaNs in a bank repeats its call;
-        #   "repeat"            after a forward (or, deferred, at the end of the caller's step) synchronise, read the verdict and issue
-        #                       the forward again until it is inside its windows: never a NaN, one host synchronisation per step;
-        #   "off"               do not look (the device still judges and poisons).
-        # NOPE_X2_RANGE_CHECK = 0 / 1 / 2 selects off / poison / repeat.
-        self.range_mode = {"0": "off", "1": "poison", "2": "repeat"}.get(os.environ.get("NOPE_X2_RANGE_CHECK", "1"), "poison") \
-            if self.compute_dtype == F16X2 else "off"
-        self.range_events: List[dict] = []           # one record per forward that had to be repeated
-        self._pending: List[tuple] = []              # forwards issued with defer_range_check: (re-launch closure, stream)
-        self._warned = False
-        self.x2_enabled = self.compute_dtype == F16X2
+        self._x2_init()
 
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
             self._l.dll.nope_unet_destroy(h)
             self._h = None
-
-    def x2_range_check(self, stream, sync: bool = True) -> Tuple[int, int, int, float]:
-        """(code, layers out of range, layers whose shift moved, largest |activation|) of the forwards judged since the last look; sync:
-        synchronise `stream` first (every forward issued on it is judged), else only the verdicts that have already arrived."""
-        bad, moved, amax = _i(0), _i(0), C.c_float(0)
-        fn = self._l.dll.nope_unet_x2_range_check if sync else self._l.dll.nope_unet_x2_poll
-        code = int(fn(self._h, stream, C.byref(bad), C.byref(moved), C.byref(amax)))
-        if code not in (0, ERR_RANGE, ERR_RANGE_F16):
-            self._l.check(code, "nope_unet_x2_range_check")
-        return code, bad.value, moved.value, float(amax.value)
-
-    def x2_enable(self, on: bool):
-        self._l.check(self._l.dll.nope_unet_x2_enable(self._h, int(bool(on))), "nope_unet_x2_enable")
-        self.x2_enabled = bool(on) and self.compute_dtype == F16X2
 
     def x2_shifts(self) -> List[int]:
         n = _i(0)
@@ -554,19 +606,7 @@ class UNetHandle:
         def launch():
             self._l.check(self._l.dll.nope_unet_forward(self._h, _ptr(x), n_src, x_rep, _ptr(pose), n_hyp, H, W, _ptr(out), odt,
                                                         _ptr(ws), ws.numel(), _stream(x)), "nope_unet_forward")
-        if self.range_mode != "off" and self.x2_enabled:
-            # verdicts of EARLIER forwards that have reached the host (no waiting): their outputs were NaN; the shifts are re-centred now
-            code, bad, moved, amax = self.x2_range_check(_stream(x), sync=False)
-            if code != 0:
-                self.range_events.append({"code": code, "layers_out_of_range": bad, "layers_adjusted": moved, "max_abs": amax, "attempt": -1})
-                if self.range_mode == "poison" and not self._warned:
-                    import warnings
-                    self._warned = True
-                    warnings.warn(f"nope_amd f16x2: an earlier U-Net forward saw activations up to {amax:.3g}, outside the accurate range of "
-                                  f"{bad} layer(s): its output was overwritten with NaNs (never silently inaccurate); the layers' range shifts "
-                                  "are re-centred now -- repeat that call (or use range_mode = 'repeat' / NOPE_X2_RANGE_CHECK=2)", RuntimeWarning)
-                if code == ERR_RANGE_F16:
-                    self.x2_enable(False)
+        self._x2_before_forward(_stream(x))
         launch()
         if self.range_mode == "repeat" and self.x2_enabled:
             # the check needs the forward to have finished: callers that go on issuing work on the stream (PoseConditional: scoring,
@@ -577,35 +617,13 @@ class UNetHandle:
                 self.finish_range_check()
         return out
 
-    def finish_range_check(self) -> bool:
-        """Check the forwards issued since the last check (nope_unet_x2_range_check: synchronises their stream); every forward whose layers
-        left their accurate window is issued again -- same arguments, re-centred shifts -- until it is inside.  Returns True when anything
-        was repeated: work the caller derived from the outputs has to be repeated too."""
-        pending, self._pending = self._pending, []
-        repeated = False
-        for attempt in range(8):        # (a repeated forward can move the maxima of layers downstream of the repaired ones: a few rounds at most)
-            if not pending or not (self.range_mode == "repeat" and self.x2_enabled):
-                break
-            code, bad, moved, amax = self.x2_range_check(pending[-1][1])
-            if code == 0:
-                break
-            # a two-pass layer saw activations outside its accurate window: those forwards have plain-f16 accuracy there -- repeat them
-            self.range_events.append({"code": code, "layers_out_of_range": bad, "layers_adjusted": moved, "max_abs": amax, "attempt": attempt})
-            if code == ERR_RANGE_F16 or attempt == 6:
-                import warnings
-                warnings.warn(f"nope_amd f16x2: activations up to {amax:.3g} " + ("are not finite" if code == ERR_RANGE_F16 else
-                              "keep leaving the layers' windows") + ": this U-Net runs as bf16x3 (three MFMA passes) from now on", RuntimeWarning)
-                self.x2_enable(False)
-            for launch, _ in pending:
-                launch()
-            repeated = True
-        return repeated
-
 
 # --------------------------------------------------------------------------------------------
 # LDM cross-attention U-Net handle
 # --------------------------------------------------------------------------------------------
-class LdmHandle:
+class LdmHandle(_X2RangeMixin):
+    _x2_prefix = "ldm"
+
     """Owns a `nope_ldm*` built from a UNetModelPose state dict (reference keys)."""
 
     def __init__(self, cfg: dict, state_dict: Dict[str, torch.Tensor], compute_dtype=F32):
@@ -631,6 +649,8 @@ class LdmHandle:
         l.check(l.dll.nope_ldm_create(C.byref(c), descs, len(state_dict), stream, C.byref(h)), "nope_ldm_create")
         self._h = h
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self.compute_dtype = c.compute_dtype
+        self._x2_init()
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -658,8 +678,14 @@ class LdmHandle:
             self._ws.pop(key, None)
             ws = None
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
-        self._l.check(self._l.dll.nope_ldm_forward(self._h, _ptr(x), n_src, x_rep, _ptr(pose), n_hyp, H, W, _ptr(out), odt,
-                                                   _ptr(ws), ws.numel(), _stream(x)), "nope_ldm_forward")
+        def launch():
+            self._l.check(self._l.dll.nope_ldm_forward(self._h, _ptr(x), n_src, x_rep, _ptr(pose), n_hyp, H, W, _ptr(out), odt,
+                                                       _ptr(ws), ws.numel(), _stream(x)), "nope_ldm_forward")
+        self._x2_before_forward(_stream(x))          # NOPE_F16X2: verdicts of earlier forwards (no waiting), _X2RangeMixin
+        launch()
+        if self.range_mode == "repeat" and self.x2_enabled:
+            self._pending.append((launch, _stream(x)))
+            self.finish_range_check()
         return out
 
 

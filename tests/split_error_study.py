@@ -194,6 +194,12 @@ class FShim:
         if w.shape[-1] == 3 and stride == 1 and padding == 1 and w.shape[1] % 32 == 0:
             self.n3 += 1
             return self.st(self.scheme.conv3(x, w, b))
+        if self.other == "x2both":          # the full two-term tile on the other convs whatever the 3x3 scheme drops
+            if w.shape[1] % 32 == 0:
+                if not hasattr(self, "_both"):
+                    self._both = F16Cross8("both", sa_lo=9, sa=-2)
+                return self.st(self._both.conv3(x, w, b, stride, padding))
+            return self.st(TF.conv2d(x, w, b, stride, padding, *a, **kw))
         if self.other == "x2":              # the same split-precision arithmetic on every other conv whose K the MX MFMA can tile
             if w.shape[1] % 32 == 0:
                 return self.st(self.scheme.conv3(x, w, b, stride, padding))
@@ -263,6 +269,10 @@ CONFIGS = {
     "f16+e4m3 on every conv, f16 conv->GN(8) intermediate": ("f16+e4m3(alo:2^9,a:2^-2)", None, "x2", None, None, H),
     "f16+e4m3 on every conv, bf16 conv->GN(8) intermediate": ("f16+e4m3(alo:2^9,a:2^-2)", None, "x2", None, None, torch.bfloat16),
     "f32, f16 conv->GN(8) intermediate": ("f32", None, None, None, None, H),
+    # round 6 sizing: ONE cross term (a . w_lo) on the 3x3 launches -- the tap-resident kernel could then pair two taps in one K = 64 MX
+    # instruction (5 instead of 9 per channel chunk) -- the per-tap launches keeping both
+    "f16+only a.w_lo on 3x3, both terms on the other convs": ("f16+only a.w_lo", None, "x2both", None, None),
+    "f16+only a.w_lo on every conv": ("f16+only a.w_lo", None, "x2", None, None),
     "f16+e4m3(alo:2^7,a:2^-4)": ("f16+e4m3(alo:2^7,a:2^-4)", None, None, None, None),
     "f16+e4m3(alo:2^5,a:2^-6)": ("f16+e4m3(alo:2^5,a:2^-6)", None, None, None, None),
     "f16+e4m3(alo:2^4,a:2^-7)": ("f16+e4m3(alo:2^4,a:2^-7)", None, None, None, None),

@@ -382,3 +382,30 @@ def test_ldm_variant_full_size(gpu):
     eb = rel(yb.float(), y32)
     print(f"LDM variant, {nparam / 1e6:.1f} M parameters, 32x32 latent: f32 vs oracle {e:.2e}; bf16 vs f32 {eb:.2e}; bf16 {32 / dt:.0f} hypotheses/s (batch of 32)")
     assert e < 1e-4 and eb < 8e-2
+    del mb
+    # the split-precision modes at 128 hypotheses (the launches that take the ping-pong kernels): f16x2 = the 3x3 convs on the two-pass
+    # tile with range tracking (x2_range.h), everything else as bf16x3; both inside 1e-4 of the f32 mode; then the same input x 1e4
+    # (un-normalised activations reach the first convolutions): range_mode "repeat" re-centres the shifts and stays accurate
+    poses128 = torch.randn(1, 128, 6, generator=g)
+    y32 = m.forward_hypotheses(x.cuda(), poses128.cuda())
+    y32s = m.forward_hypotheses(x.cuda() * 1e4, poses128.cuda())
+    for cdt in ("bf16x3", "f16x2"):
+        mm = UNetModelPose(encoder=StubEncoder(8), compute_dtype=cdt, **kw)
+        mm.load_state_dict(m.state_dict())
+        mm = mm.cuda()
+        y = mm.forward_hypotheses(x.cuda(), poses128.cuda())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y = mm.forward_hypotheses(x.cuda(), poses128.cuda())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ex = rel(y.float(), y32)
+        h = mm._handle
+        if cdt == "f16x2":
+            h.range_mode = "repeat"
+        ys = mm.forward_hypotheses(x.cuda() * 1e4, poses128.cuda())
+        exs = rel(ys.float(), y32s)
+        print(f"LDM variant {cdt}, 128 hypotheses: {ex:.2e} vs f32, {dt * 1e3:.1f} ms per forward; input x 1e4: {exs:.2e}"
+              + (f", repeated {[(ev['attempt'], ev['code'], ev['layers_out_of_range']) for ev in h.range_events]}" if cdt == "f16x2" else ""))
+        assert ex < 1e-4 and exs < 1e-4, (cdt, ex, exs)
+        del mm

@@ -683,11 +683,19 @@ def test_ldm_unet_vs_reference_golden(be, golden, tag):
     from tests.test_oracle_golden import build_ldm
     g = golden("ldm_tiny.npz")
     x, pose, ref = g[f"{tag}/x"], g[f"{tag}/pose"], g[f"{tag}/out"]
-    for cdt, tol in (("f32", F32_TOL), ("bf16", 8e-2)):
-        if name == "emu" and (cdt == "bf16" or tag in ("m64two", "m64film", "m32film")):
+    import os
+    for cdt, tol in (("f32", F32_TOL), ("bf16", 8e-2), ("bf16x3", 1e-4), ("f16x2", 1e-4)):
+        if name == "emu" and (cdt != "f32" or tag in ("m64two", "m64film", "m32film")):
             continue      # keep the CPU suite short (FiLM's coefficient fold is exercised by the operator tests; m32d2 = two blocks per transformer)
-        m = build_ldm(tag, cdt).to(dev)
-        y = m(x.to(dev), pose.to(dev)).cpu()
+        # (f16x2: the 3x3 convs on the ping-pong kernels' two-pass tile -- forced onto them here, three samples would not reach them --
+        #  with the activation-range verdict and, for the FiLM configurations, the absmax pass behind the FiLM GroupNorm: x2_range.h)
+        if cdt == "f16x2":
+            os.environ["NOPE_CONV_PP"] = "11"
+        try:
+            m = build_ldm(tag, cdt).to(dev)
+            y = m(x.to(dev), pose.to(dev)).cpu()
+        finally:
+            os.environ.pop("NOPE_CONV_PP", None)
         assert rel(y, ref) < tol, (cdt, rel(y, ref))
         if cdt == "f32":
             yh = m.forward_hypotheses(x[:1].to(dev), pose[None].to(dev)).cpu()[0]

@@ -14,11 +14,12 @@ from tests.util import StubEncoder
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 128
+    dtype = sys.argv[sys.argv.index("--dtype") + 1] if "--dtype" in sys.argv else "bf16"
     kw = dict(injecting_condition_twice=False, pose_mlp_name="single_layer", rot_representation_dim=6, image_size=32, in_channels=8,
               model_channels=256, out_channels=8, num_res_blocks=2, attention_resolutions=[4, 2, 1], channel_mult=(1, 2, 4),
               num_head_channels=32, use_spatial_transformer=True, transformer_depth=1, context_dim=512)
-    m = UNetModelPose(encoder=StubEncoder(8), compute_dtype="bf16", **kw)
+    m = UNetModelPose(encoder=StubEncoder(8), compute_dtype=dtype, **kw)
     synth_init_(m, 2022)
     m = m.cuda()
     g = torch.Generator().manual_seed(3)
@@ -31,7 +32,7 @@ def main():
         m.forward_hypotheses(x, poses)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    print(f"LDM bf16, {n} hypotheses at 32x32: {dt * 1e3:.1f} ms per forward = {n / dt:.0f} hypotheses/s")
+    print(f"LDM {dtype}, {n} hypotheses at 32x32: {dt * 1e3:.1f} ms per forward = {n / dt:.0f} hypotheses/s")
 
 
 if __name__ == "__main__":
