@@ -393,7 +393,11 @@ def test_ldm_variant_full_size(gpu):
         mm = UNetModelPose(encoder=StubEncoder(8), compute_dtype=cdt, **kw)
         mm.load_state_dict(m.state_dict())
         mm = mm.cuda()
-        y = mm.forward_hypotheses(x.cuda(), poses128.cuda())
+        os.environ["NOPE_X2_RANGE_CHECK"] = "2"        # (handles are created at the first forward: range_mode "repeat" for the f16x2 one)
+        try:
+            y = mm.forward_hypotheses(x.cuda(), poses128.cuda())
+        finally:
+            os.environ.pop("NOPE_X2_RANGE_CHECK")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         y = mm.forward_hypotheses(x.cuda(), poses128.cuda())
@@ -401,8 +405,6 @@ def test_ldm_variant_full_size(gpu):
         dt = time.perf_counter() - t0
         ex = rel(y.float(), y32)
         h = mm._handle
-        if cdt == "f16x2":
-            h.range_mode = "repeat"
         ys = mm.forward_hypotheses(x.cuda() * 1e4, poses128.cuda())
         exs = rel(ys.float(), y32s)
         print(f"LDM variant {cdt}, 128 hypotheses: {ex:.2e} vs f32, {dt * 1e3:.1f} ms per forward; input x 1e4: {exs:.2e}"
