@@ -435,26 +435,36 @@ class _X2RangeMixin:
     def _x2_init(self):
         # NOPE_F16X2 activation ranges.  The library judges every forward on the device and overwrites the output of one whose layers left
         # their accurate windows with NaNs (include/nope_hip.h: nope_unet_x2_poll) -- no synchronisation in the step.  range_mode:
-        #   "poison" (default)  nothing more: the verdicts that have arrived are read at the start of the next forward (shifts re-centred,
+        #   "poison"            nothing more: the verdicts that have arrived are read at the start of the next forward (shifts re-centred,
         #                       an event recorded, one warning); a caller that finds NaNs in a bank repeats its call;
         #   "repeat"            after a forward (or, deferred, at the end of the caller's step) synchronise, read the verdict and issue
         #                       the forward again until it is inside its windows: never a NaN, one host synchronisation per step;
+        #   "auto" (default)    "repeat" until three forwards in a row were inside their windows without any shift moving -- a network's
+        #                       first calls settle its shifts without a NaN -- then "poison"; back to "repeat" when a verdict says so;
         #   "off"               do not look (the device still judges and poisons).
-        # NOPE_X2_RANGE_CHECK = 0 / 1 / 2 selects off / poison / repeat.
-        self.range_mode = {"0": "off", "1": "poison", "2": "repeat"}.get(os.environ.get("NOPE_X2_RANGE_CHECK", "1"), "poison") \
+        # NOPE_X2_RANGE_CHECK = 0 / 1 / 2 / 3 selects off / auto / repeat / poison.
+        self.range_mode = {"0": "off", "1": "auto", "2": "repeat", "3": "poison"}.get(os.environ.get("NOPE_X2_RANGE_CHECK", "1"), "auto") \
             if self.compute_dtype == F16X2 else "off"
+        self._settled = 0                            # "auto": forwards in a row that needed nothing
         self.range_events: List[dict] = []           # one record per forward that had to be repeated
         self._pending: List[tuple] = []              # forwards issued with defer_range_check: (re-launch closure, stream)
         self._warned = False
         self.x2_enabled = self.compute_dtype == F16X2
 
+    def _x2_mode(self) -> str:
+        if self.range_mode == "auto":
+            return "repeat" if self._settled < 3 else "poison"
+        return self.range_mode
+
     def _x2_before_forward(self, stream):
         if self.range_mode != "off" and self.x2_enabled:
             # verdicts of EARLIER forwards that have reached the host (no waiting): their outputs were NaN; the shifts are re-centred now
             code, bad, moved, amax = self.x2_range_check(stream, sync=False)
+            if code != 0 or moved:
+                self._settled = 0
             if code != 0:
                 self.range_events.append({"code": code, "layers_out_of_range": bad, "layers_adjusted": moved, "max_abs": amax, "attempt": -1})
-                if self.range_mode == "poison" and not self._warned:
+                if self._x2_mode() == "poison" and not self._warned:
                     import warnings
                     self._warned = True
                     warnings.warn(f"nope_amd f16x2: an earlier U-Net forward saw activations up to {amax:.3g}, outside the accurate range of "
@@ -484,10 +494,11 @@ class _X2RangeMixin:
         pending, self._pending = self._pending, []
         repeated = False
         for attempt in range(8):        # (a repeated forward can move the maxima of layers downstream of the repaired ones: a few rounds at most)
-            if not pending or not (self.range_mode == "repeat" and self.x2_enabled):
+            if not pending or not (self._x2_mode() == "repeat" and self.x2_enabled):
                 break
             code, bad, moved, amax = self.x2_range_check(pending[-1][1])
             if code == 0:
+                self._settled = 0 if (moved or repeated) else self._settled + 1
                 break
             # a two-pass layer saw activations outside its accurate window: those forwards have plain-f16 accuracy there -- repeat them
             self.range_events.append({"code": code, "layers_out_of_range": bad, "layers_adjusted": moved, "max_abs": amax, "attempt": attempt})
@@ -608,7 +619,7 @@ class UNetHandle(_X2RangeMixin):
                                                         _ptr(ws), ws.numel(), _stream(x)), "nope_unet_forward")
         self._x2_before_forward(_stream(x))
         launch()
-        if self.range_mode == "repeat" and self.x2_enabled:
+        if self._x2_mode() == "repeat" and self.x2_enabled:
             # the check needs the forward to have finished: callers that go on issuing work on the stream (PoseConditional: scoring,
             # top-k) call finish_range_check() at the END of their step -- one synchronisation where the results are read anyway --
             # and repeat their own tail when it says the forward was repeated
@@ -683,7 +694,7 @@ class LdmHandle(_X2RangeMixin):
                                                        _ptr(ws), ws.numel(), _stream(x)), "nope_ldm_forward")
         self._x2_before_forward(_stream(x))          # NOPE_F16X2: verdicts of earlier forwards (no waiting), _X2RangeMixin
         launch()
-        if self.range_mode == "repeat" and self.x2_enabled:
+        if self._x2_mode() == "repeat" and self.x2_enabled:
             self._pending.append((launch, _stream(x)))
             self.finish_range_check()
         return out

@@ -160,7 +160,7 @@ class PoseConditional(nn.Module):
         reference_feat = self.u_net.encoder.encode_image(reference, mode="mode")
         # (a sharded step finishes the check BEFORE its collective: every rank must enter the score all-gather exactly once, and whether a
         #  forward is repeated is a per-rank fact)
-        # (range_mode "repeat" only -- the default, "poison", needs no host look at all: an out-of-range bank is NaN, and so are its scores)
+        # (the handle's "repeat" behaviour only -- in its "poison" behaviour no host look is needed at all: an out-of-range bank is NaN, and so are its scores)
         defer = not (self.template_parallel and ndist.world()[1] > 1)
         bank = self.generate_templates_from_feat(reference_feat, all_relativeR, defer_range_check=defer)
         side.join(query_feat)
