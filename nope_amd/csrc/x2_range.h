@@ -177,7 +177,8 @@ struct X2Fwd {
         }
         memcpy(pin, tab.data(), nl * 5 * sizeof(int));
         if (hipMemcpyAsync(r->tab_dev, pin, nl * 5 * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) return NOPE_ERR_LAUNCH;
-        int e = launch_x2_verdict(r->amax, X2Range::SLOTS, r->tab_dev, (int)nl, r->status_dev, r->host_dev, s);
+        // (only the slots this forward handed out: the others are zero since the last verdict)
+        int e = launch_x2_verdict(r->amax, next_slot > 0 ? next_slot : 1, r->tab_dev, (int)nl, r->status_dev, r->host_dev, s);
         if (!e && out && out_bytes % 4 == 0) e = launch_x2_poison(out, out_bytes, out_dt, r->status_dev, s);
         return e ? e : err;
     }
