@@ -219,7 +219,7 @@ int nope_unet_profile_read(nope_unet* net, int* n_launches, double* total_ms, do
 /* ... and launch by launch, in issue order: which kernel took the launch, its shape, its HIP-event time.  `flops` counts the
  * convolution's multiply-adds x 2 as executed (NOPE_BF16X3 issues three MFMA passes per product: mfma_passes = 3).  Writes at
  * most `max` records and the total number of recorded launches to *n. */
-enum { NOPE_CONV_KERNEL_GENERIC = 0, NOPE_CONV_KERNEL_DMA128 = 1, NOPE_CONV_KERNEL_PP256 = 2, NOPE_CONV_KERNEL_HALO256 = 3, NOPE_CONV_KERNEL_SMALL = 4 };
+enum { NOPE_CONV_KERNEL_GENERIC = 0, NOPE_CONV_KERNEL_DMA128 = 1, NOPE_CONV_KERNEL_PP256 = 2, NOPE_CONV_KERNEL_HALO256 = 3, NOPE_CONV_KERNEL_SMALL = 4, NOPE_CONV_KERNEL_STREAM = 5 };
 typedef struct {
     double ms, flops, bytes;
     int kernel;            /* NOPE_CONV_KERNEL_* */

@@ -16,7 +16,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SOURCES = ["kernels_gemm_dma_bf16_variants.hip", "kernels_gemm_dma_f32.hip", "kernels_gemm_dma_bf16.hip", "kernels_gemm_dma_f16.hip", "kernels_gemm_dma_bf16x3.hip",      # (longest first)
-           "kernels_gemm.hip", "kernels_gemm_pp.hip", "kernels_gemm_small.hip", "kernels_norm.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_retrieval.hip", "kernels_metric.hip",
+           "kernels_gemm.hip", "kernels_gemm_pp.hip", "kernels_gemm_small.hip", "kernels_gemm_stream.hip", "kernels_norm.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_retrieval.hip", "kernels_metric.hip",
            "kernels_encoder.hip", "kernels_ldm.hip", "unet_runtime.hip", "encoder_runtime.hip", "ldm_runtime.hip", "capi.hip"]
 LIB = os.path.join(HERE, "libnope_hip.so")
 ARCH = "gfx950"

@@ -4,6 +4,10 @@
 #pragma once
 #include "nope_common.h"
 
+#ifndef NOPE_EPILOGUE_LEAN_GROUP
+#define NOPE_EPILOGUE_LEAN_GROUP 2      // 16-byte chunks a lane keeps in flight between the panel read and the store (1, 2, 4 or 8)
+#endif
+
 namespace nope {
 
 namespace {
@@ -71,6 +75,7 @@ struct ConvParams {
     const int* x2_scale;               // NOPE_F16X2 (ping-pong kernels): the tail of the packed weights, [0] = E8M0 scale of the A operand, [3] = range shift t
     unsigned* x2_amax;                 // NOPE_F16X2: optional device word, atomicMax of the bits of max |a| over every A element the launch converted (NOPE_X2_KERNEL_AMAX builds)
     int x2_t_zero;                     // NOPE_F16X2: the caller vouches that the layer's range shift (tail word 3) is 0: the tap-resident kernel skips the a * 2^-t multiplies
+    int lean;                          // 1: f32 storage, every wave tile of the launch whole and in NHWC row order (see epilogue_wide, LEANM): the kernels' LEAN instantiations
     unsigned* out_amax;                // f32-storage launches with a wide NHWC epilogue: optional range slot (amax_publish) for max |out| of what the launch writes
 };
 
@@ -397,7 +402,9 @@ template <class T> struct Ep {
 // first store.
 struct NoStamp { __device__ __forceinline__ void operator()() const {} };
 // GG: GEGLU on column pairs (ConvArgs::geglu; packed 16-bit path only -- the launcher guarantees it is the one taken).
-template <class T, bool PN, bool DRAIN = false, class Stamp = NoStamp, bool GG = false>
+// LEANM = 1 (f32 storage on the 32 x 32 tiles only; ConvParams::lean: the launcher vouches for EVERY wave tile of the launch): the lean row
+// walk below instead of the generic loop -- a kernel instantiation of its own, because both forms in one kernel spill.
+template <class T, bool PN, bool DRAIN = false, class Stamp = NoStamp, bool GG = false, int LEANM = 0>
 __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL],
                                               int m0, int n0, int wm, int wn, int lane, unsigned char* lds_wave, Stamp stamp = Stamp(),
                                               float acc_scale = 1.0f) {
@@ -586,6 +593,98 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                 }
                 __builtin_amdgcn_wave_barrier();
                 stamp();
+            }
+            return;
+        }
+    }
+    static_assert(LEANM == 0 || (sizeof(T) == 4 && TL::TM == 32 && !GG), "the lean epilogue: f32 storage, 32 x 32 tiles");
+    if constexpr (LEANM == 1) {
+        // f32 storage on the 32 x 32 tiles (NOPE_BF16X3 / NOPE_F16X2: the modes the benchmark runs in), whole wave tile inside the tensor, rows in
+        // NHWC order, one sample per wave tile under a fused PreNorm: the same arithmetic as the loop below with everything that does not
+        // depend on the row hoisted and the chunk loop unrolled.  With CH = 8 chunks per panel row a lane keeps ONE column chunk (lane & 7)
+        // and walks rows (lane >> 3) + 8 c: one base pointer + a constant stride, no division, no bounds test, no per-element constant
+        // load -- the loop below (a real loop around out_row()'s uniform branches, the PreNorm division and per-element bias loads) cost a
+        // level-0 1x1 launch more than its MFMAs and its memory traffic together (profiles/r06i_dma_ablations_bf16x3.txt).
+        const int mw = m0 + wm * 64, nw = n0 + wn * 96;
+        const unsigned long long obytes = (unsigned long long)p.M * (unsigned)p.Cout * 4ull;      // (< 4 GiB: launch_conv)
+        {
+            const int ch = lane & 7, r0 = lane >> 3;
+            float pmean = 0.f, prstd = 1.f;
+            if (PN) { const int b = mw / (p.Hm * p.Wm); pmean = p.pn_ms[2 * b]; prstd = p.pn_ms[2 * b + 1]; }
+            // Buffer addressing: ONE per-lane byte offset for all 24 stores (and residual loads) of the wave tile, the pass / row-group part in
+            // the instruction's scalar offset -- no 64-bit address arithmetic in a kernel that has no register to spare.
+            const auto ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, (short)0, (int)(unsigned)obytes, 0x00020000);
+            const auto rr = __builtin_amdgcn_make_buffer_rsrc((void*)(resid ? (const void*)resid : (const void*)p.out), (short)0, (int)(unsigned)obytes, 0x00020000);
+            const unsigned vo = ((unsigned)(mw + r0) * (unsigned)p.Cout + (unsigned)(nw + ch * 4)) * 4u;
+            const unsigned rstep = 8u * (unsigned)p.Cout * 4u;   // bytes between the rows of consecutive chunks
+            constexpr int LG = NOPE_EPILOGUE_LEAN_GROUP;
+            auto run = [&](auto resid_tag) {
+                constexpr bool RESID = decltype(resid_tag)::value;
+#pragma unroll
+                for (int pass = 0; pass < 3; ++pass) {
+                    __builtin_amdgcn_sched_barrier(0);            // (keeps the next pass's constant loads and panel fill out of this pass: registers)
+                    float pc0[4], pc1[4], pb[4];
+                    if (PN) {
+                        const int nn = nw + pass * 32 + ch * 4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            pb[e] = p.bias ? p.bias[nn + e] : 0.f;      // (qkv has no bias: a uniform branch around four loads)
+                            pc1[e] = p.pn_c1[nn + e];
+                            pc0[e] = p.pn_c0[nn + e] + pb[e];            // v = rstd * (pan - bias - mean * c1) + c0 + bias: the panel holds acc + bias
+                        }
+                    }
+                    const float bv = bvj[pass];
+#pragma unroll
+                    for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                        for (int r = 0; r < TL::R; ++r)
+                            pan[(i * TL::TM + TL::out_row(lane, r)) * Ep<T>::LD + TL::out_col(lane)] = SCALED ? acc[i][pass][r] * asc + bv : acc[i][pass][r] + bv;
+                    __builtin_amdgcn_wave_barrier();              // (same-wave LDS write -> read: in-order LDS queue; rendezvous point of tests/hipemu)
+                    stamp();
+                    if (DRAIN && pass == 0) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+                    stamp();
+#pragma unroll
+                    for (int grp = 0; grp < 8 / LG; ++grp) {           // LG chunks at a time: LG LDS reads (and residual loads) in flight
+                        u32x4 rv[LG];
+                        f32x4 t[LG];
+                        if (RESID) {
+#pragma unroll
+                            for (int c = 0; c < LG; ++c) rv[c] = __builtin_amdgcn_raw_buffer_load_b128(rr, vo, (unsigned)(pass * 128) + (unsigned)(grp * LG + c) * rstep, 0);
+                        }
+#pragma unroll
+                        for (int c = 0; c < LG; ++c) t[c] = *reinterpret_cast<const f32x4*>(&pan[(r0 + 8 * (grp * LG + c)) * Ep<T>::LD + ch * 4]);
+#pragma unroll
+                        for (int c = 0; c < LG; ++c) {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = t[c][e];
+                            if (PN) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = prstd * (v[e] - pb[e] - pmean * pc1[e]) + pc0[e];
+                            }
+                            if (RESID) {
+                                float rf[4];
+                                Elt<T>::unpack(rv[c], rf);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += rf[e];
+                            }
+                            if (p.act) {                          // (uniform branch: the encoder's convs)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                            }
+                            if (track_out) out_max = amax4(out_max, v[0], v[1], v[2], v[3]);
+                            __builtin_amdgcn_raw_buffer_store_b128(Elt<T>::pack(v), ro, vo, (unsigned)(pass * 128) + (unsigned)(grp * LG + c) * rstep, 0);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    stamp();
+                }
+            };
+            if (resid) run(BoolTag<true>()); else run(BoolTag<false>());
+            if (track_out) {
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) out_max = __builtin_fmaxf(out_max, __shfl_xor(out_max, o, 64));
+                if (lane == 0 && out_max > 0.f) amax_publish(p.out_amax, out_max, (unsigned)blockIdx.x * 8u + (unsigned)(wm * 2 + wn));
             }
             return;
         }

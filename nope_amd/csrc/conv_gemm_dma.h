@@ -43,7 +43,8 @@ __device__ __forceinline__ void epilogue_split(const ConvParams& p, const typena
 // step k+1 fly under the MFMAs of step k, and nothing passes through VGPRs or ds_write.
 
 // RB = bytes of K per row per stage (128), NS = LDS stages (2), BMT = tile rows (128: 4 waves, 256: 8 waves).
-template <class T, int MODE, int RB, int NS, int BMT, bool PN, bool GG = false>
+// LEAN (f32s_t, PLAIN): the launcher vouches that every wave tile takes the lean wide epilogue (ConvParams::lean) -- the only one compiled in.
+template <class T, int MODE, int RB, int NS, int BMT, bool PN, bool GG = false, bool LEAN = false>
 __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p) {
     constexpr int VEC = Elt<T>::VEC;
     constexpr unsigned ES = (unsigned)sizeof(T);
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
                     ld_tap = 0; ld_kc = 0;
                     if (nk > 0) issue(0);          // stage 0 of the next tile; the panels below sit in stage 1
                 }
-                epilogue_wide<T, PN, false, NoStamp, GG>(p, acc, m0e, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
+                epilogue_wide<T, PN, false, NoStamp, GG, LEAN ? 1 : 0>(p, acc, m0e, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
 #pragma unroll
                 for (int i = 0; i < Tile<T>::MT; ++i)
 #pragma unroll
@@ -276,6 +277,11 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
             }
         }
         if (iters > 1) return;
+    }
+    if constexpr (LEAN) {
+        __syncthreads();                       // every wave is done reading the last stage
+        epilogue_wide<T, PN, false, NoStamp, GG, 1>(p, acc, m0, n0, wm, wn, lane, lds + PANEL_BASE + wave * Ep<T>::WAVE_BYTES);
+        return;
     }
     if (p.variant & 64) {                      // tuning only: no epilogue (keeps the accumulators live)
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;
@@ -299,6 +305,13 @@ template <class T, int RB, int NS, int BMT>
 void launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
     if constexpr (sizeof(T) == 2 && BMT == 128 && RB == 128) {
         if (p.geglu) { hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT, false, true>), grid, dim3(BMT * 2), 0, s, p); return; }
+    }
+    if constexpr (sizeof(T) == 4 && Tile<T>::TM == 32 && BMT == 128 && RB == 128) {
+        if (p.lean && p.mode == NOPE_CONV_PLAIN) {
+            if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT, true, false, true>), grid, dim3(BMT * 2), 0, s, p);
+            else hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT, false, false, true>), grid, dim3(BMT * 2), 0, s, p);
+            return;
+        }
     }
     if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT, true>), grid, dim3(BMT * 2), 0, s, p);   // 1x1 only
     else if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT, false>), grid, dim3(BMT * 2), 0, s, p);

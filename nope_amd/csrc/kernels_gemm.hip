@@ -254,6 +254,7 @@ void launch_conv_dma_bf16_variant(const void* params, int bm, dim3 grid, hipStre
 void launch_conv_pp(int dt, const void* params, dim3 grid, hipStream_t s);   // kernels_gemm_pp.hip
 void launch_conv_small(int dt, const void* params, int tile, dim3 grid, hipStream_t s);   // kernels_gemm_small.hip
 void launch_conv_halo(int dt, const void* params, dim3 grid, hipStream_t s);
+void launch_conv_stream(int dt, const void* params, dim3 grid, hipStream_t s);   // kernels_gemm_stream.hip
 int conv_halo_max_width();
 
 // Which kernel a conv takes.  NOPE_CONV_PP (tuning; default 3): bit 0 = the 256 x 192 ping-pong kernels for launches with
@@ -262,7 +263,7 @@ int conv_halo_max_width();
 // 1536 -> 1536 at 4 x 4 x 512 although it executes the 31 % of MACs the position-major order skips), bit 2 = those run position-major on the
 // ping-pong kernel (needs nhyp % 256 == 0), bit 3 = no minimum tile count (tests: small shapes on the ping-pong kernel),
 // bit 4 = 3x3 convs per tap on the ping-pong kernel instead of the tap-resident (halo) kernel.
-struct ConvPlan { bool dma, pp, posmajor, halo; int small; int hsplit; };      // hsplit > 1: tap-resident kernel with that many K splits      // small: -1, or the tile of conv_gemm_small_kernel (0 = 64 x 64, 1 = 128 x 128, 2 = 64 x 64 / 6-stage ring, 3 = 64 x 64 by two K groups)
+struct ConvPlan { bool dma, pp, posmajor, halo; int small; int hsplit; bool stream; };      // hsplit > 1: tap-resident kernel with that many K splits      // small: -1, or the tile of conv_gemm_small_kernel (0 = 64 x 64, 1 = 128 x 128, 2 = 64 x 64 / 6-stage ring, 3 = 64 x 64 by two K groups)
 
 // Launches that cannot give every CU a 128 x 192 tile take the small-tile kernel (kernels_gemm_small.hip): fewer than
 // NOPE_SMALL_MAX_TILES (default 320) tiles of 128 x 192.  NOPE_CONV_SMALL: 0 = never, 1 = that policy (default), 2 = whenever the
@@ -330,13 +331,16 @@ static int halo_split_factor(int dt, const ConvArgs& a) {
     return S < 2 ? 1 : S;
 }
 
+// workgroups of a streaming launch: one per CU (NOPE_STREAM_GRID: the tests walk small grids; a multiple of 8)
+static int stream_grid() { const int g = NOPE_ENV("NOPE_STREAM_GRID", 256); return g >= 8 && g % 8 == 0 ? g : 256; }
+
 static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     dt = dt_base(dt);      // (NOPE_F16X2 plans as NOPE_BF16X3: same storage, same tiles)
     // (read per launch: the tests toggle it.  f32 -- the parity mode -- stays on the 128 x 192 kernel unless asked: its MFMA phase is
     //  16x longer per K step, loads were never its bound, and two workgroups per CU beat one: 126 vs 135 ms per 512-template step)
     const int pp_mode = NOPE_ENV("NOPE_CONV_PP", (dt != NOPE_F32 ? 3 : 0));
     const int variant = NOPE_ENV("NOPE_CONV_VARIANT", 0);
-    ConvPlan pl{false, false, false, false, -1, 1};
+    ConvPlan pl{false, false, false, false, -1, 1, false};
     const int vec = dt_vec(dt), es = dt_es(dt), bk = 8 * vec;
     const int Cin = a.C1 + a.C2;
     const unsigned long long lim = 0x7fffffffULL;
@@ -379,6 +383,22 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     // (the first source must not be broadcast: its A offsets are linear in the flat pixel index; a broadcast second source is fine)
     pl.halo = pl.pp && !pl.posmajor && a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.Ws <= conv_halo_max_width() && a.rep1 == 1 &&
               !(pp_mode & 16);
+    // The streaming 1x1 kernel (kernels_gemm_stream.hip: one persistent workgroup per CU, the activations through a five-stage ring that runs
+    // across tile boundaries) for 1x1 convs with thousands of 128 x 192 tiles.  OFF by default: built on the premise that these HBM-bound
+    // launches wait for memory round trips, measured 20-25 % SLOWER than the 128 x 192 kernel they would leave (profiles/r06h_stream_bench_*.txt,
+    // r06l_*): what bounds them is the epilogue -- its instruction stream (the lean form of epilogue_wide took 12 % off) and, on gfx9, a wave's
+    // stores draining through the same in-order vmcnt as its loads (r06i ablations: stores alone 166 us + MFMA 100 us + loads 96 us ~ the
+    // launch's 375 us) -- and two workgroups per CU overlap that better than one.  NOPE_CONV_STREAM: bit 0 = the launches the 128 x 192 kernel
+    // would take, bit 1 = also the long 1x1 convs of the per-tap ping-pong kernel; NOPE_STREAM_MIN_ITERS = tiles per workgroup from which on.
+    {
+        const int sm = NOPE_ENV("NOPE_CONV_STREAM", 0);
+        const long long tm = M / BM, tn = cdiv(a.Cout, BN);
+        if (sm && dt != NOPE_F32 && a.mode == NOPE_CONV_PLAIN && a.ntaps == 1 && !pl.posmajor && !a.out_nchw && a.Cout % vec == 0 && a.w &&
+            a.rep1 == 1 && a.rep2 == 1 && variant == 0 && (!pl.pp || (sm & 2)) && M % BM == 0 && (tn == 1 || tn == 2 || tn == 4 || tn == 8) &&
+            tm % 8 == 0 && (tm * tn) % stream_grid() == 0 && (tm * tn) / stream_grid() >= NOPE_ENV("NOPE_STREAM_MIN_ITERS", 2)) {
+            pl.stream = true; pl.pp = false; pl.halo = false;
+        }
+    }
     return pl;
 }
 
@@ -441,7 +461,7 @@ bool conv_takes_x2(int dt, const ConvArgs& a) { return dt_base(dt) == NOPE_BF16X
 
 int conv_kernel_kind(int dt, const ConvArgs& a) {
     const ConvPlan pl = plan_conv(dt, a);
-    return pl.small >= 0 ? NOPE_CONV_KERNEL_SMALL : pl.halo ? NOPE_CONV_KERNEL_HALO256 : pl.pp ? NOPE_CONV_KERNEL_PP256 : pl.dma ? NOPE_CONV_KERNEL_DMA128 : NOPE_CONV_KERNEL_GENERIC;
+    return pl.small >= 0 ? NOPE_CONV_KERNEL_SMALL : pl.stream ? NOPE_CONV_KERNEL_STREAM : pl.halo ? NOPE_CONV_KERNEL_HALO256 : pl.pp ? NOPE_CONV_KERNEL_PP256 : pl.dma ? NOPE_CONV_KERNEL_DMA128 : NOPE_CONV_KERNEL_GENERIC;
 }
 
 // Multiply-adds x2 the launch actually executes (position-major launches skip the taps that lie in the padding:
@@ -615,14 +635,15 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         const long long hw = (long long)a.Hs * a.Ws;
         const int persist_on = NOPE_ENV("NOPE_CONV_PERSIST", 1);
         const int span = p.xcd_map == 2 ? tn / p.xcd_gn : 1;
+        const int pg = NOPE_ENV("NOPE_PERSIST_GRID", 512) == 256 ? 256 : 512;      // (tuning: 256 = one workgroup per CU)
         if (persist_on && dma && plan.small < 0 && bm == BM && dt != NOPE_F32 && a.mode == NOPE_CONV_PLAIN && !p.posmajor && p.splits == 1 && p.xcd_map && p.xcd_map != 4 &&
-            p.wide_out && a.rep1 == 1 && a.rep2 == 1 && M % BM == 0 && nblocks > 512 && nblocks % 512 == 0 && 64 % span == 0 &&
-            ((64ll / span) * BM) % hw == 0 && !(variant & 2)) {
-            p.persist_iters = (int)(nblocks / 512);
-            p.persist_dm = (64 / span) * BM;
+            p.wide_out && a.rep1 == 1 && a.rep2 == 1 && M % BM == 0 && nblocks > pg && nblocks % pg == 0 && (pg / 8) % span == 0 &&
+            ((long long)(pg / 8 / span) * BM) % hw == 0 && !(variant & 2)) {
+            p.persist_iters = (int)(nblocks / pg);
+            p.persist_dm = (pg / 8 / span) * BM;
             p.persist_d1 = (unsigned)((long long)p.persist_dm * a.C1 * es);
             p.persist_d2 = (unsigned)((long long)p.persist_dm * a.C2 * es);
-            gx = 512;
+            gx = (unsigned)pg;
         }
     }
     // The tap-resident kernel walks tiles too (bf16): one workgroup per CU, tiles gx / 8 apart inside the XCD's run of M tiles,
@@ -637,16 +658,32 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
             p.persist_iters = (int)(nblocks / want);
         }
     }
+    // The streaming 1x1 kernel: 256 workgroups (one per CU), each `iters` tiles 32 / span tile_m apart (same XCD, same weight panel).
+    const int sgrid = stream_grid(), sspan = p.xcd_map == 2 ? tn / p.xcd_gn : 1;
+    const bool stream = plan.stream && p.splits == 1 && (p.xcd_map == 1 || p.xcd_map == 2) && nblocks % sgrid == 0 && (sgrid / 8) % sspan == 0;
+    if (stream) {
+        p.persist_iters = (int)(nblocks / sgrid);
+        p.persist_dm = (sgrid / 8 / sspan) * BM;
+        p.persist_d1 = (unsigned)((long long)p.persist_dm * a.C1 * es);
+        p.persist_d2 = (unsigned)((long long)p.persist_dm * a.C2 * es);
+        gx = (unsigned)sgrid;
+    }
+    // The lean wide epilogue (epilogue_wide, LEANM = 1): f32 storage on the 32 x 32 tiles, EVERY wave tile of the launch whole, rows in NHWC order,
+    // one sample per wave tile under a fused PreNorm, 32-bit byte offsets.  NOPE_EPILOGUE_LEAN=0: the generic row loop everywhere (A/B).
+    p.lean = (dt == NOPE_BF16X3 && dma && plan.small < 0 && p.wide_out && !p.posmajor && !phased && p.splits == 1 && !a.geglu && M % bm == 0 && a.Cout % BN == 0 &&
+              (!a.pn_ms || ((long long)p.Hm * p.Wm) % 64 == 0) && (unsigned long long)M * a.Cout * 4ull < 0xffffffffull && NOPE_ENV("NOPE_EPILOGUE_LEAN", 1) != 0) ? 1 : 0;
     if (p.splits > 1) p.out_amax = nullptr;        // (raw partials: the reduce kernel writes the tensor)
     const dim3 grid(gx, phased ? 4u : 1u, (unsigned)p.splits), block(NT);
     const bool trace = NOPE_ENV_SET("NOPE_CONV_TRACE");     // tuning aid: one line per launch
     if (trace && plan.small >= 0) fprintf(stderr, "conv small%d mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u xcd %d/%d\n", plan.small, a.mode, a.ntaps, Cin, a.Cout, M,
                                         p.tiles_m, p.tiles_n, grid.x, grid.y, grid.z, p.xcd_map, p.xcd_gn);
-    else if (trace) fprintf(stderr, "conv %s mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u posmajor %d persist %d xcd %d/%d%s\n",
-                       plan.halo ? "halo256" : plan.pp ? "pp256" : dma ? "dma128" : "generic", a.mode, a.ntaps, Cin, a.Cout, M, p.tiles_m, p.tiles_n, grid.x, grid.y, grid.z,
-                       p.posmajor, p.persist_iters, p.xcd_map, p.xcd_gn, a.geglu ? " geglu" : x2 ? " x2" : "");
+    else if (trace) fprintf(stderr, "conv %s mode %d taps %d Cin %d Cout %d M %lld tiles %dx%d grid %u,%u,%u posmajor %d persist %d xcd %d/%d%s%s\n",
+                       stream ? "stream128" : plan.halo ? "halo256" : plan.pp ? "pp256" : dma ? "dma128" : "generic", a.mode, a.ntaps, Cin, a.Cout, M, p.tiles_m, p.tiles_n, grid.x, grid.y, grid.z,
+                       p.posmajor, p.persist_iters, p.xcd_map, p.xcd_gn, a.geglu ? " geglu" : x2 ? " x2" : "", p.lean ? " lean" : "");
     if (plan.small >= 0) {
         launch_conv_small(dt, &p, plan.small, grid, s);
+    } else if (stream) {
+        launch_conv_stream(dt, &p, grid, s);
     } else if (plan.pp) {
         if (NOPE_ENV_SET("NOPE_PP_VARIANT")) p.variant = NOPE_ENV("NOPE_PP_VARIANT", 0);      // tuning ablations of the ping-pong kernel
         if (plan.halo) launch_conv_halo(x2 ? NOPE_F16X2 : dt, &p, grid, s);

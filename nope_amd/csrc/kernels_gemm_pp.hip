@@ -53,7 +53,7 @@ struct KPos { int tap, kc; };
 
 // TUNE: the instantiation that honours the NOPE_PP_VARIANT ablations (run-time tests inside the K loop); production launches (variant 0) take the
 // one without them.
-template <class T, int MODE, bool PN, bool TUNE = false>
+template <class T, int MODE, bool PN, bool TUNE = false, bool LEAN = false>
 __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvParams p) {
     typedef Tile<T> TL;
     constexpr int VEC = Elt<T>::VEC;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv_gemm_pp_kernel(ConvPara
         return;
     }
     if constexpr (X2 && NOPE_X2_KERNEL_AMAX) x2_publish_amax(p, x2_amax, lane);
-    epilogue_wide<T, PN>(p, acc, m0, n0, wm, wn, lane, lds + wave * Ep<T>::WAVE_BYTES, NoStamp(), x2_out);
+    epilogue_wide<T, PN, false, NoStamp, false, LEAN ? 1 : 0>(p, acc, m0, n0, wm, wn, lane, lds + wave * Ep<T>::WAVE_BYTES, NoStamp(), x2_out);
 }
 
 // ---- 3x3 convolutions: the A operand stays in LDS across the 9 taps ------------------------------------------------
@@ -449,7 +449,7 @@ constexpr int TIMELINE_STAMPS = 720;  // per group; 5 per K step (tuning instant
 // SHIFT (NOPE_F16X2): false = the instantiation for layers whose activation range shift t is 0 (the host knows: ConvParams::x2_t_zero) -- the rewrite
 // then works on a itself and loses the two packed multiplies per piece that a * 2^-t costs (+1.7 % on the kernel, same-box A/B,
 // profiles/r06c_*); every layer starts at t = 0 and stays there while its inputs peak inside [1, 1024].
-template <class T, bool TIMELINE = false, bool SPLIT = false, bool SHIFT = true>
+template <class T, bool TIMELINE = false, bool SPLIT = false, bool SHIFT = true, bool LEAN = false>
 __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvParams p) {
     typedef Tile<T> TL;
     constexpr int VEC = Elt<T>::VEC;
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             }
             return;
         } else if constexpr (TIMELINE) epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel, stamp, x2_out);
-        else epilogue_wide<T, false, true>(p, acc, m_this, n0, wm, wn, lane, lds_panel, NoStamp(), x2_out);
+        else epilogue_wide<T, false, true, NoStamp, false, LEAN ? 1 : 0>(p, acc, m_this, n0, wm, wn, lane, lds_panel, NoStamp(), x2_out);
         if (more) {
 #pragma unroll
             for (int i = 0; i < TL::MT; ++i)
@@ -968,6 +968,10 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
 template <class T, bool TUNE>
 void launch_pp_tt(const ConvParams& p, dim3 grid, hipStream_t s) {
     const dim3 block(PP_WAVES * 64);
+    if constexpr (sizeof(T) == 4 && Tile<T>::TM == 32 && !TUNE) {
+        if (p.lean && !p.pn_ms && p.mode == NOPE_CONV_PLAIN) { hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NOPE_CONV_PLAIN, false, false, true>), grid, block, 0, s, p); return; }
+        if (p.lean && p.mode == NOPE_CONV_DOWN2) { hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NOPE_CONV_DOWN2, false, false, true>), grid, block, 0, s, p); return; }
+    }
     if (p.pn_ms) hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NOPE_CONV_PLAIN, true, TUNE>), grid, block, 0, s, p);
     else if (p.mode == NOPE_CONV_PLAIN) hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NOPE_CONV_PLAIN, false, TUNE>), grid, block, 0, s, p);
     else if (p.mode == NOPE_CONV_UP2P) hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NOPE_CONV_UP2P, false, TUNE>), grid, block, 0, s, p);
@@ -1023,6 +1027,12 @@ void launch_conv_halo(int dt, const void* params, dim3 grid, hipStream_t s) {
         else if (dt == NOPE_F16X2 && p.x2_t_zero) hipLaunchKernelGGL((conv3x3_halo_kernel<f16x2_t, false, true, false>), grid, block, 0, s, p);
         else if (dt == NOPE_F16X2) hipLaunchKernelGGL((conv3x3_halo_kernel<f16x2_t, false, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((conv3x3_halo_kernel<bf16_t, false, true>), grid, block, 0, s, p);
+        return;
+    }
+    if (p.lean && dt == NOPE_BF16X3) { hipLaunchKernelGGL((conv3x3_halo_kernel<f32s_t, false, false, true, true>), grid, block, 0, s, p); return; }
+    if (p.lean && dt == NOPE_F16X2) {
+        if (p.x2_t_zero) hipLaunchKernelGGL((conv3x3_halo_kernel<f16x2_t, false, false, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<f16x2_t, false, false, true, true>), grid, block, 0, s, p);
         return;
     }
     if (dt == NOPE_F32) hipLaunchKernelGGL((conv3x3_halo_kernel<float>), grid, block, 0, s, p);

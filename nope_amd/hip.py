@@ -47,7 +47,7 @@ class ConvLaunchInfo(C.Structure):
                 ("Cout", _i), ("Hs", _i), ("Ws", _i), ("n_hyp", _i), ("mfma_passes", _i), ("posmajor", _i)]
 
 
-CONV_KERNEL_NAMES = ("conv_gemm_kernel", "conv_gemm_dma_kernel", "conv_gemm_pp_kernel", "conv3x3_halo_kernel", "conv_gemm_small_kernel")
+CONV_KERNEL_NAMES = ("conv_gemm_kernel", "conv_gemm_dma_kernel", "conv_gemm_pp_kernel", "conv3x3_halo_kernel", "conv_gemm_small_kernel", "conv1x1_stream_kernel")
 
 
 class EncoderConfig(C.Structure):

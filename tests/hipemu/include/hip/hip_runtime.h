@@ -474,6 +474,7 @@ inline hipemu_f32x16 hipemu_mfma_scale_f32_32x32x64_f8f6f4(hipemu_i32x8 a, hipem
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_s_memrealtime() 0ull   // (clock stamps of the tuning instantiations: no clock on the host)
@@ -517,6 +518,23 @@ inline void hipemu_buffer_load_lds(hipemu_rsrc r, P ldsptr, unsigned size, unsig
 }
 #define __builtin_amdgcn_make_buffer_rsrc hipemu_make_rsrc
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds hipemu_buffer_load_lds
+// buffer_load / buffer_store_dwordx4 (address = base + vector offset + scalar offset; the range check covers the vector offset: out-of-range
+// loads return zeros, out-of-range stores are dropped)
+typedef __attribute__((ext_vector_type(4))) unsigned int hipemu_u32x4;
+inline hipemu_u32x4 hipemu_buffer_load_b128(hipemu_rsrc r, unsigned voffset, unsigned soffset, int) {
+    hipemu_u32x4 v = {0u, 0u, 0u, 0u};
+    if ((unsigned long long)voffset + 16 > r.num) return v;
+    if ((unsigned long long)voffset + soffset + 16 > r.num) { fprintf(stderr, "hipemu: buffer load passes the range check but reads beyond the buffer (scalar offset)\n"); abort(); }
+    memcpy(&v, r.base + voffset + soffset, 16);
+    return v;
+}
+inline void hipemu_buffer_store_b128(hipemu_u32x4 v, hipemu_rsrc r, unsigned voffset, unsigned soffset, int) {
+    if ((unsigned long long)voffset + 16 > r.num) return;
+    if ((unsigned long long)voffset + soffset + 16 > r.num) { fprintf(stderr, "hipemu: buffer store passes the range check but writes beyond the buffer (scalar offset)\n"); abort(); }
+    memcpy(const_cast<unsigned char*>(r.base) + voffset + soffset, &v, 16);
+}
+#define __builtin_amdgcn_raw_buffer_load_b128 hipemu_buffer_load_b128
+#define __builtin_amdgcn_raw_buffer_store_b128 hipemu_buffer_store_b128
 
 // v_med3_f32: with a NaN among the operands the hardware returns MIN3 of them (IEEE minNum: the NaN is ignored), else the median
 inline float hipemu_fmed3f(float a, float b, float c) {
