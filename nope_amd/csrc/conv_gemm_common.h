@@ -332,6 +332,12 @@ __device__ __forceinline__ size_t out_row(const ConvParams& p, int m) {
     return ((size_t)b * p.Ho + 2 * y + py) * p.Wo + 2 * x + px;
 }
 
+// Fused PreNorm on an accumulator: rstd * (acc - mean * c1) + c0 with the two roundings pinned in the source (two fmas) -- the generic loop, the
+// lean row walk and the small-tile kernel's epilogue must agree bit for bit whatever the compiler would contract or hoist in each of them.
+__device__ __forceinline__ float pn_apply(float acc, float mean, float rstd, float c1, float c0) {
+    return __builtin_fmaf(rstd, __builtin_fmaf(-mean, c1, acc), c0);
+}
+
 // C/D map of the 16x16 MFMA tiles: col = lane & 15, row = (lane >> 4) * 4 + r
 template <class T, bool PN>
 __device__ __forceinline__ void epilogue(const ConvParams& p, const typename Tile<T>::acc_t (&acc)[Tile<T>::MT][Tile<T>::NTL], int m0,
@@ -370,7 +376,7 @@ __device__ __forceinline__ void epilogue(const ConvParams& p, const typename Til
                 const int n = ncol[j];
                 if (!row_ok || n >= p.Cout) continue;
                 float v = acc[i][j][r] + bv[j];
-                if (PN) v = pn_rstd * (acc[i][j][r] - pn_mean * p.pn_c1[n]) + p.pn_c0[n] + bv[j];
+                if (PN) v = pn_apply(acc[i][j][r], pn_mean, pn_rstd, p.pn_c1[n], p.pn_c0[n] + bv[j]);
                 if (resid) v += Elt<T>::ld(resid + mo * p.Cout + n);
                 if (p.act) v = v > 0.f ? v : 0.f;
                 if (p.out_nchw) {
@@ -611,8 +617,12 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
             const int ch = lane & 7, r0 = lane >> 3;
             float pmean = 0.f, prstd = 1.f;
             if (PN) { const int b = mw / (p.Hm * p.Wm); pmean = p.pn_ms[2 * b]; prstd = p.pn_ms[2 * b + 1]; }
-            // Buffer addressing: ONE per-lane byte offset for all 24 stores (and residual loads) of the wave tile, the pass / row-group part in
-            // the instruction's scalar offset -- no 64-bit address arithmetic in a kernel that has no register to spare.
+            // Buffer addressing: 32-bit byte offsets (one per-lane base + a uniform pass / row-group term: one v_add per access) -- no 64-bit
+            // address arithmetic in a kernel that has no register to spare.  The uniform term goes into the VECTOR offset, not the
+            // instruction's scalar offset, on purpose: with an SGPR offset hipcc (ROCm 7.2) assumes a dwordx4 store has read its data before
+            // the next instruction and lets a VALU overwrite the data registers right behind it -- measured on gfx950: the first dword of
+            // lanes 12-15 (mod 16) of a pass's last store took the NEXT pass's panel-fill temporaries (tests/test_conv_pingpong.py caught it).
+            // Without a scalar offset register the compiler inserts the wait state itself.
             const auto ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, (short)0, (int)(unsigned)obytes, 0x00020000);
             const auto rr = __builtin_amdgcn_make_buffer_rsrc((void*)(resid ? (const void*)resid : (const void*)p.out), (short)0, (int)(unsigned)obytes, 0x00020000);
             const unsigned vo = ((unsigned)(mw + r0) * (unsigned)p.Cout + (unsigned)(nw + ch * 4)) * 4u;
@@ -649,7 +659,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                         f32x4 t[LG];
                         if (RESID) {
 #pragma unroll
-                            for (int c = 0; c < LG; ++c) rv[c] = __builtin_amdgcn_raw_buffer_load_b128(rr, vo, (unsigned)(pass * 128) + (unsigned)(grp * LG + c) * rstep, 0);
+                            for (int c = 0; c < LG; ++c) rv[c] = __builtin_amdgcn_raw_buffer_load_b128(rr, vo + (unsigned)(pass * 128) + (unsigned)(grp * LG + c) * rstep, 0, 0);
                         }
 #pragma unroll
                         for (int c = 0; c < LG; ++c) t[c] = *reinterpret_cast<const f32x4*>(&pan[(r0 + 8 * (grp * LG + c)) * Ep<T>::LD + ch * 4]);
@@ -660,7 +670,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                             for (int e = 0; e < 4; ++e) v[e] = t[c][e];
                             if (PN) {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = prstd * (v[e] - pb[e] - pmean * pc1[e]) + pc0[e];
+                                for (int e = 0; e < 4; ++e) v[e] = pn_apply(v[e] - pb[e], pmean, prstd, pc1[e], pc0[e]);
                             }
                             if (RESID) {
                                 float rf[4];
@@ -673,7 +683,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                             }
                             if (track_out) out_max = amax4(out_max, v[0], v[1], v[2], v[3]);
-                            __builtin_amdgcn_raw_buffer_store_b128(Elt<T>::pack(v), ro, vo, (unsigned)(pass * 128) + (unsigned)(grp * LG + c) * rstep, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(Elt<T>::pack(v), ro, vo + (unsigned)(pass * 128) + (unsigned)(grp * LG + c) * rstep, 0, 0);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -751,10 +761,10 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                 for (int e = 0; e < VEC; ++e) {
                     if (PN_COLS_FIXED) {
                         const float bias_e = p.bias ? p.bias[n + e] : 0.f;   // (qkv has no bias: folds away)
-                        v[e] = rstd * (v[e] - bias_e - mean * pc1[e]) + pc0[e];
+                        v[e] = pn_apply(v[e] - bias_e, mean, rstd, pc1[e], pc0[e]);
                     } else {
                         const float bias_e = p.bias ? p.bias[n + e] : 0.f;
-                        v[e] = rstd * (v[e] - bias_e - mean * p.pn_c1[n + e]) + p.pn_c0[n + e] + bias_e;
+                        v[e] = pn_apply(v[e] - bias_e, mean, rstd, p.pn_c1[n + e], p.pn_c0[n + e] + bias_e);
                     }
                 }
             }

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256 * KG) void conv_gemm_small_kernel(ConvParams p)
                 const int b = m / HWo;
                 const float mean = p.pn_ms[2 * b], rstd = p.pn_ms[2 * b + 1];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] = rstd * (v[e] - mean * cbias[BNS + ch * VEC + e]) + cbias[ch * VEC + e];
+                for (int e = 0; e < VEC; ++e) v[e] = pn_apply(v[e], mean, rstd, cbias[BNS + ch * VEC + e], cbias[ch * VEC + e]);
             }
             const size_t o = out_row(p, m) * p.Cout + n;
             if (resid) {
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256 * KG) void conv_gemm_small_kernel(ConvParams p)
         const int m = m0 + row, n = n0 + c;
         if (m >= p.M) continue;
         float v = pan[row * LDP + c];
-        if (PN) { const int b = m / HWo; v = p.pn_ms[2 * b + 1] * (v - p.pn_ms[2 * b] * p.pn_c1[n]) + p.pn_c0[n]; }
+        if (PN) { const int b = m / HWo; v = pn_apply(v, p.pn_ms[2 * b], p.pn_ms[2 * b + 1], p.pn_c1[n], p.pn_c0[n]); }
         if (p.bias) v += p.bias[n];
         const size_t o = out_row(p, m) * p.Cout + n;
         if (resid) v += Elt<T>::ld(resid + o);
