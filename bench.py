@@ -7,8 +7,10 @@
 One "step" = one pass of the hot path over one batch, inputs resident in HBM:
     generate_templates(reference, all_relativeR)   encoder(reference) once + U-Net for every pose hypothesis
     retrieval(query, bank)                         encoder(query) + scoring + top-5
-issued as ONE call, PoseConditional.generate_and_retrieve (same values; the query's encoder pass runs on a second HIP
-stream underneath the reference encoder and the first U-Net kernels); --two-calls times the literal two-call sequence.
+issued as ONE call, PoseConditional.generate_and_retrieve (same values; the encoder passes run on a second HIP stream, and -- consecutive
+steps being independent queries whose images are resident -- those of step k+1 do not wait for step k: they run in the gaps of its U-Net,
+`config.schedule`; `value_unpipelined` = each step waiting for the previous one, --no-pipeline times that); --two-calls times the literal
+two-call sequence.
 Workload: BASELINE.json configs[1] -- one 256x256 query against 512 viewpoint templates.  north_star asks for scores "within 1e-4 ... and
 bit-exact on the argmax pose index" of the reference's fp32 path, so the TIMED mode is the fastest one that delivers that: `f16x2` (f32
 storage; the convolutions of the ping-pong kernels -- the tap-resident 3x3 ones = 9/10 of the work, the per-tap 1x1 / up / down ones -- as one f16
@@ -362,6 +364,7 @@ def main():
     ap.add_argument("--skip-extras", action="store_true", help="skip roofline / cpu_baseline legs")
     ap.add_argument("--extras", default="scaling,roofline,parity,scoring,cpu", help="comma list of the extra legs to run (scaling, roofline, parity, scoring, cpu)")
     ap.add_argument("--two-calls", action="store_true", help="generate_templates then retrieval as two calls (no stream overlap)")
+    ap.add_argument("--no-pipeline", action="store_true", help="each step's encoder passes wait for the previous step (PoseConditional.pipeline_encoders off)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -402,6 +405,11 @@ def main():
         return scoring_only(a, dev, rank, world)
     bank_dtype = a.bank_dtype or (a.dtype if a.dtype in ("bf16", "f16") else "f32")
     model = build_model(seed=2022, compute_dtype=a.dtype, bank_dtype=bank_dtype, device=dev, template_parallel=world > 1)
+    # The timed schedule: consecutive steps are independent queries whose images are resident and complete, so the two encoder passes of step
+    # k + 1 (launch-latency-bound, a few CUs wide) are issued on the side stream WITHOUT waiting for step k and run in the gaps of its U-Net
+    # (PoseConditional.pipeline_encoders; same bits: tests/test_gpu_configs.py::test_pipelined_encoders_equal_bits).  Every step's work lies
+    # inside the timed region (synchronisation on both sides); `value_unpipelined` is the same run with each step waiting for the previous one.
+    model.pipeline_encoders = not (a.no_pipeline or a.two_calls)
     # Headline: a FIXED bank sharded over the GPUs (strong scaling; 512 templates = BASELINE configs[1] and north_star's scaling claim).
     # --templates-per-gpu N makes the headline the weak-scaling line instead.
     weak = a.templates_per_gpu > 0
@@ -460,8 +468,17 @@ def main():
                                f"template encoder + l2 scoring + top-5",
                    "batch": a.batch, "templates_total": n_total, "templates_per_gpu": per_gpu, "image": a.size,
                    "parallelism": f"template-shard x{world} + score all-gather" if world > 1 else "single GPU",
-                   "bank_dtype": bank_dtype, "top5": idx[0].tolist()},
+                   "bank_dtype": bank_dtype, "top5": idx[0].tolist(),
+                   "schedule": ("encoder passes of step k+1 on a side stream under step k's U-Net (pipeline_encoders); every step's work inside the timed region"
+                                if model.pipeline_encoders else "each step waits for the previous one")},
     }
+    if model.pipeline_encoders and not a.skip_extras:
+        model.pipeline_encoders = False
+        c = run_case(a.batch, n_total, a.steps, 1)
+        model.pipeline_encoders = True
+        res["value_unpipelined"], res["ms_per_step_unpipelined"] = c["value"], c["ms_per_step"]
+        assert torch.equal(c["idx"], idx) and torch.equal(c["sim"], sim), "pipelined and unpipelined steps differ"
+        del c
     if not a.skip_extras and "scaling" in a.extras.split(",") and not weak and a.batch == 1 and n_total == 512:
         # The other two scaling lines, measured by the same ranks (few steps: they are whole-job rates, not tuning runs): N = 1 gives
         # their baselines, so the driver's 1 / 2 / 4 / 8 sweep yields all three curves.

@@ -174,8 +174,12 @@ class overlap_stream:
     streams: the body simply runs in place.)"""
     _streams: Dict[str, "torch.cuda.Stream"] = {}
 
-    def __init__(self, t: torch.Tensor):
+    def __init__(self, t: torch.Tensor, wait_current: bool = True):
+        """wait_current=False: the side work does NOT wait for what the current stream has queued -- the caller vouches that the inputs of the
+        body are complete (PoseConditional.pipeline_encoders: the encoder passes of the next query may then run under the previous query's
+        U-Net); the side stream itself stays in order."""
         self.dev = t.device if t.is_cuda else None
+        self.wait_current = wait_current
 
     def __enter__(self):
         if self.dev is None:
@@ -185,7 +189,8 @@ class overlap_stream:
         if side is None:
             side = self._streams[str(self.dev)] = torch.cuda.Stream(device=self.dev)
         self.side = side
-        side.wait_stream(self.cur)                  # whatever produced the inputs is ordered before the side work
+        if self.wait_current:
+            side.wait_stream(self.cur)              # whatever produced the inputs is ordered before the side work
         self._ctx = torch.cuda.stream(side)
         self._ctx.__enter__()
         return self
@@ -194,6 +199,17 @@ class overlap_stream:
         if self.dev is not None:
             self._ctx.__exit__(*exc)
         return False
+
+    def mark(self):
+        """An event on the side stream at this point of the body (for join_at: the current stream then waits only for the work before it)."""
+        return self.side.record_event() if self.dev is not None else None
+
+    def join_at(self, event, *tensors):
+        if self.dev is not None:
+            self.cur.wait_event(event)
+            for t in tensors:
+                t.record_stream(self.cur)
+                t.record_stream(self.side)
 
     def join(self, *tensors):
         if self.dev is not None:

@@ -36,7 +36,7 @@ def _cfg_get(cfg, key, default=None):
 
 class PoseConditional(nn.Module):
     def __init__(self, u_net, optim_config=None, testing_config=None, save_dir=None, bank_dtype="f32",
-                 max_hypotheses_per_launch=512, template_parallel=False, two_stream_below=None, **kwargs):
+                 max_hypotheses_per_launch=512, template_parallel=False, two_stream_below=None, pipeline_encoders=False, **kwargs):
         super().__init__()
         self.u_net = u_net
         self.save_dir = save_dir
@@ -50,6 +50,12 @@ class PoseConditional(nn.Module):
         self.bank_dtype = bank_dtype
         self.max_hyp = int(max_hypotheses_per_launch)
         self.template_parallel = bool(template_parallel)
+        # generate_and_retrieve: both encoder passes on the side stream WITHOUT waiting for what the current stream has queued, so that the
+        # (launch-latency-bound, few CUs wide) encoder passes of query k + 1 run in the gaps of query k's U-Net instead of in front of their
+        # own.  Only for callers whose `query` / `reference` tensors are complete when the call is made (not still being produced by work
+        # queued on the current stream): results are the same bits, consecutive calls overlap on the device.  NOPE_PIPELINE_ENCODERS overrides.
+        env = os.environ.get("NOPE_PIPELINE_ENCODERS")
+        self.pipeline_encoders = bool(int(env)) if env is not None else bool(pipeline_encoders)
         # Single-query banks of at most this many templates (the reference's 26 / 91-template grids) are generated as two half
         # batches on two HIP streams: with a few dozen hypotheses most launches of a forward have fewer tiles than the chip has
         # workgroup slots, and two independent launch sequences fill each other's idle CUs (NOPE_TWO_STREAM_BELOW overrides; 0 = off).
@@ -155,9 +161,16 @@ class PoseConditional(nn.Module):
         stream and runs underneath the reference encoder and the first U-Net kernels."""
         if self.similarity_metric != "l2":
             return None
-        with hip.overlap_stream(query) as side:
-            query_feat = self.u_net.encoder.encode_image(query, mode="mode")
-        reference_feat = self.u_net.encoder.encode_image(reference, mode="mode")
+        if self.pipeline_encoders and query.is_cuda:
+            with hip.overlap_stream(query, wait_current=False) as side:
+                reference_feat = self.u_net.encoder.encode_image(reference, mode="mode")
+                ref_done = side.mark()
+                query_feat = self.u_net.encoder.encode_image(query, mode="mode")
+            side.join_at(ref_done, reference_feat)          # the U-Net waits for the reference's pass only
+        else:
+            with hip.overlap_stream(query) as side:
+                query_feat = self.u_net.encoder.encode_image(query, mode="mode")
+            reference_feat = self.u_net.encoder.encode_image(reference, mode="mode")
         # (a sharded step finishes the check BEFORE its collective: every rank must enter the score all-gather exactly once, and whether a
         #  forward is repeated is a per-rank fact)
         # (the handle's "repeat" behaviour only -- in its "poison" behaviour no host look is needed at all: an out-of-range bank is NaN, and so are its scores)

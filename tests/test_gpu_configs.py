@@ -301,6 +301,33 @@ def test_encoder_graph_replay_matches_direct(gpu):
     assert torch.equal(outs["graph"], outs["direct"])
 
 
+def test_pipelined_encoders_equal_bits(gpu):
+    """PoseConditional.pipeline_encoders (bench.py's headline schedule): both encoder passes of a call on the side stream without waiting for
+    what the current stream has queued, so consecutive calls overlap on the device.  Three different (query, reference) pairs issued back to
+    back, twice: every call returns the bits of the unpipelined call on the same inputs (a call that picked up its neighbour's embeddings or
+    a workspace still in use would not)."""
+    from nope_amd.harness import build_model, synthetic_batch
+    m = build_model(seed=2022, compute_dtype="bf16x3", device="cuda", u_net_dim=64)
+    batches = [synthetic_batch(1, 40, 128, seed=s, device="cuda") for s in (11, 12, 13)]
+    torch.cuda.synchronize()                       # the inputs are complete: the flag's precondition
+    want = []
+    m.pipeline_encoders = False
+    for b in batches:
+        sim, idx, bank = m.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"])
+        want.append((sim.clone(), idx.clone(), bank.clone()))
+    torch.cuda.synchronize()
+    assert not torch.equal(want[0][0], want[1][0])
+    m.pipeline_encoders = True
+    got = []
+    for rep in range(2):
+        for b in batches:
+            got.append(m.generate_and_retrieve(b["query"], b["reference"], b["all_relativeR"]))      # no synchronisation in between
+    torch.cuda.synchronize()
+    for i, (sim, idx, bank) in enumerate(got):
+        w = want[i % 3]
+        assert torch.equal(sim, w[0]) and torch.equal(idx, w[1]) and torch.equal(bank, w[2]), i
+
+
 def test_two_stream_split_close_to_single_batch(gpu):
     """`two_stream_below` (off by default): the two half batches on two HIP streams agree with the single batch to rounding -- not bit
     for bit, the halves have other GEMM row counts and so other launch plans -- and the bank is complete when the call returns."""
