@@ -25,6 +25,7 @@ batches = {n: synthetic_batch(1, n, 256, seed=2022, device="cuda") for n in bank
 for env in settings:
     for k, v in env.items():
         os.environ[k] = v
+    m.pipeline_encoders = os.environ.get("NOPE_PIPELINE_ENCODERS", "0") == "1"      # (read at construction by the model: follow the setting)
     row = []
     for n in banks:
         b = batches[n]
