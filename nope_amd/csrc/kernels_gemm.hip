@@ -383,6 +383,17 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     // (the first source must not be broadcast: its A offsets are linear in the flat pixel index; a broadcast second source is fine)
     pl.halo = pl.pp && !pl.posmajor && a.mode == NOPE_CONV_PLAIN && a.ntaps == 9 && a.Ws <= conv_halo_max_width() && a.rep1 == 1 &&
               !(pp_mode & 16);
+    // ... and so do the four phase convs of an up-sampling (conv3x3_halo_kernel<..., UP>: the stage is the 3 x 3 neighbourhood the phases' 2 x 2 taps
+    // come from) under the two-pass tile, whose per-tap launches are bound by staging 256 f32 rows per tap and splitting them in registers at every
+    // read: 512-hypothesis launches 0.77 / 0.72 / 0.67 -> ~0.59 ms, step -1.2 % (profiles/r06w_up2p_tap_resident_ab.txt).  As bf16x3 (three MFMA
+    // passes per step: the per-tap kernel's LOAD phase is hidden) it is +-2 % per launch: per tap stays.  NOPE_UP2P_HALO: 0 = per tap, 2 = bf16x3 too.
+    {
+        const int uh = NOPE_ENV("NOPE_UP2P_HALO", 1);
+        const bool x2_layer = a.w_x2 && !a.pn_ms && !a.geglu && Cin % 32 == 0;
+        if (pl.pp && phased && !pl.posmajor && a.ntaps == 4 && dt == NOPE_BF16X3 && a.C2 == 0 && a.Ws <= conv_halo_max_width() && a.rep1 == 1 && !(pp_mode & 16) &&
+            (uh == 2 || (uh == 1 && x2_layer)))
+            pl.halo = true;
+    }
     // The streaming 1x1 kernel (kernels_gemm_stream.hip: one persistent workgroup per CU, the activations through a five-stage ring that runs
     // across tile boundaries) for 1x1 convs with thousands of 128 x 192 tiles.  OFF by default: built on the premise that these HBM-bound
     // launches wait for memory round trips, measured 20-25 % SLOWER than the 128 x 192 kernel they would leave (profiles/r06h_stream_bench_*.txt,
@@ -649,7 +660,7 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
     // The tap-resident kernel walks tiles too (bf16): one workgroup per CU, tiles gx / 8 apart inside the XCD's run of M tiles,
     // the next tile's prologue in flight under the epilogue.  NOPE_HALO_PERSIST = workgroups (default 256, 0 = one tile per
     // workgroup; the tests use small grids).
-    if (plan.halo && dt != NOPE_F32 && p.xcd_map && p.xcd_map != 4 && p.splits == 1) {      // (the split-K instantiation returns after its first tile)
+    if (plan.halo && !phased && dt != NOPE_F32 && p.xcd_map && p.xcd_map != 4 && p.splits == 1) {      // (the split-K instantiation returns after its first tile; the phase-conv form walks no tiles)
         const int want = NOPE_ENV("NOPE_HALO_PERSIST", 256);
         const long long hw = (long long)a.Hs * a.Ws;
         const int span = p.xcd_map == 2 ? tn / p.xcd_gn : 1;     // workgroups of one XCD that share an M tile

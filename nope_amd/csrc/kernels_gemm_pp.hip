@@ -449,8 +449,25 @@ constexpr int TIMELINE_STAMPS = 720;  // per group; 5 per K step (tuning instant
 // SHIFT (NOPE_F16X2): false = the instantiation for layers whose activation range shift t is 0 (the host knows: ConvParams::x2_t_zero) -- the rewrite
 // then works on a itself and loses the two packed multiplies per piece that a * 2^-t costs (+1.7 % on the kernel, same-box A/B,
 // profiles/r06c_*); every layer starts at t = 0 and stays there while its inputs peak inside [1, 1024].
-template <class T, bool TIMELINE = false, bool SPLIT = false, bool SHIFT = true, bool LEAN = false>
+// UP (NOPE_CONV_UP2P: nearest x 2 + 3 x 3 as four 2 x 2 phase convs on the low-resolution map, blockIdx.y = phase; model_utils.py:161-165): the
+// tile's pixel range + halo is the 3 x 3 neighbourhood every phase draws its four taps from, so the stage is loaded (and, f32 storage, rewritten)
+// ONCE per channel chunk and read by the phase's four taps at row offsets -- where the per-tap kernel stages 256 rows per tap and splits them in
+// registers at every read (its launches are bound by that LOAD phase: 0.32-0.37 of the pipe against 0.54 here).  A chunk is FIVE positions:
+//     pos   0      1      2      3      4
+//           tap 0  tap 1  tap 2  tap 3  light
+// The four real positions are the K steps of the 3 x 3 kernel unchanged (fragment reads, 18-24 MFMAs); the light one has no fragment reads and no
+// MFMAs, only what the next chunk needs and a real step has no room for.  A stage of the next chunk: pieces 0..3 are issued at taps 0..3 (pieces
+// 4 / 5 ride with 0 / 1), pieces 0..2 are rewritten behind the MFMAs of taps 1..3, pieces 3 / 4 / 5 in the light position's LOAD phase.  Weight
+// ring: four taps on three stages cannot rotate with immediates (4 % 3 != 0), so the stage of tap t is fixed -- 1, 2, 0, 1 -- and the one
+// conflict (tap 0 of the next chunk wants tap 3's stage) is resolved in time: group 0 issues BOTH halves of that step in the light position,
+// under group 1's last COMPUTE phase, and waits for them at the end of its own empty COMPUTE phase; everything else keeps the ring's discipline
+// (group 0 its half one tap ahead, group 1 two taps ahead; tap 1 of the next chunk goes into tap 1's stage, free since tap 2, at tap 3).  No
+// vector-memory wait of a light position waits for a piece issued in it by the same phase -- a first version (six positions, pieces issued
+// in the light ones) paid two exposed L2 round trips per chunk: 0.63 of the K steps' time instead of 0.85.  Both groups pass two barriers per
+// position.  Same K order as the per-tap kernel (chunk outer, tap inner): bit-identical to it.
+template <class T, bool TIMELINE = false, bool SPLIT = false, bool SHIFT = true, bool LEAN = false, bool UP = false>
 __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvParams p) {
+    static_assert(!UP || (!TIMELINE && !SPLIT && !LEAN), "the phase-conv form: one tile per workgroup, generic wide epilogue");
     typedef Tile<T> TL;
     constexpr int VEC = Elt<T>::VEC;
     constexpr unsigned ES = (unsigned)sizeof(T);
@@ -507,10 +524,12 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     const int halo = W + 1;
     const int Cin = p.C1 + p.C2;
     const int npieces = (PP_BM + 2 * halo + 7) >> 3;               // 8-row pieces of a stage (33 .. 41)
+    const int ph_y = UP ? ((int)blockIdx.y >> 1) : 0, ph_x = UP ? ((int)blockIdx.y & 1) : 0;      // UP: the output phase of this workgroup
+    constexpr unsigned NTAPS = UP ? 4u : 9u;
 
     const auto r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.src1, (short)0, (int)p.bytes1, 0x00020000);
     const auto r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src2 ? p.src2 : p.src1), (short)0, (int)(p.src2 ? p.bytes2 : p.bytes1), 0x00020000);
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, (short)0, (int)p.bytesw, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (UP ? (size_t)blockIdx.y * p.w_phase_bytes : (size_t)0)), (short)0, (int)p.bytesw, 0x00020000);
 
     if (tid < 16) st16(lds + A_BASE + (tid >> 3) * A_STAGE + ZROW + (tid & 7) * 16, u32x4{0u, 0u, 0u, 0u});
 
@@ -662,9 +681,22 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         const int row = brow0 + 8 * j + rsub;
         const int n = n0 + row;
         const unsigned cs = (unsigned)((lslot ^ swz_of<RB>(row)) * VEC);
-        b_off[j] = n < p.Cout ? ((unsigned)n * 9u * Cin + cs) * ES : OOB;
+        b_off[j] = n < p.Cout ? ((unsigned)n * NTAPS * Cin + cs) * ES : OOB;
     }
     unsigned char* const b_dst = lds + (brow0 >> 3) * 1024;                     // + stage * B_STAGE + j * 1024
+    // (UP: group 0 also issues group 1's half of one weight step per chunk -- rows 96 grp + 24 wl ..)
+    const int brow0_o = 96 * grp + 24 * wl;
+    unsigned b_off_o[3] = {OOB, OOB, OOB};
+    if constexpr (UP) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int row = brow0_o + 8 * j + rsub;
+            const int n = n0 + row;
+            const unsigned cs = (unsigned)((lslot ^ swz_of<RB>(row)) * VEC);
+            b_off_o[j] = n < p.Cout ? ((unsigned)n * NTAPS * Cin + cs) * ES : OOB;
+        }
+    }
+    unsigned char* const b_dst_o = lds + (brow0_o >> 3) * 1024;
     const unsigned cin_es = (unsigned)Cin * ES;
     unsigned bkofs = 0;                                            // K offset (tap * Cin + chunk * BK) * ES of the next B step this wave issues
     auto issue_b = [&](int stage) {
@@ -711,7 +743,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         c_lo = (int)((long long)z * tot / p.splits);
         nchunks = (int)((long long)(z + 1) * tot / p.splits);
     }
-    const unsigned wrap_inc = (unsigned)BK * ES - 8u * cin_es;     // K offset step from tap 8 of a chunk to tap 0 of the next
+    const unsigned wrap_inc = (unsigned)BK * ES - (NTAPS - 1u) * cin_es;     // K offset step from the last tap of a chunk to tap 0 of the next
 
     // ---- prologue of a tile: the whole A stage of chunk 0, this group's half of B(0), and (group 1) its half of B(1)
     auto tile_prologue = [&]() __attribute__((always_inline)) {
@@ -720,8 +752,13 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         for (int i = 0; i < 6; ++i)
             if (i < 4 || (i == 4 ? a_has4 : a_has5)) piece_a(i, 0);
         bkofs = (unsigned)(c_lo * BK) * ES;
-        issue_b(0); bkofs += cin_es;
-        if (grp == 1) { issue_b(1); bkofs += cin_es; }             // (nk >= 9 > 2)
+        if constexpr (UP) {                                        // tap 0 -> ring stage 1 (both groups their half), group 1 its half of tap 1 -> stage 2
+            issue_b(1); bkofs += cin_es;
+            if (grp == 1) issue_b(2);
+        } else {
+            issue_b(0); bkofs += cin_es;
+            if (grp == 1) { issue_b(1); bkofs += cin_es; }         // (nk >= 9 > 2)
+        }
     };
     // ---- the epilogue panels of a wave.  bf16: outside everything the NEXT tile's prologue writes (A stage 0, B stage 0
     // and the first half of B stage 1), so a workgroup that walks several tiles can have that prologue in flight while it
@@ -733,7 +770,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
     }
     // A workgroup walks `iters` tiles of the same weight panel, gridDim.x / 8 M tiles apart (a multiple of the image size:
     // checked by the launcher, so the padding masks above hold for every tile of the walk).
-    const int iters = TL::TM == 32 && p.persist_iters > 1 ? p.persist_iters : 1;
+    const int iters = !UP && TL::TM == 32 && p.persist_iters > 1 ? p.persist_iters : 1;
     const int walk_rows = (int)(gridDim.x >> 3) / (p.xcd_map == 2 ? p.tiles_n / p.xcd_gn : 1) * PP_BM;
     tile_prologue();
     // Tuning only (NOPE_PP_VARIANT & 2048): touch the workgroup's whole weight stream up front -- one 4-byte load per 128-byte weight row
@@ -896,7 +933,139 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             stamp();
         }
     };
-    if constexpr (FA_AHEAD) {                                      // tap 0 of the first step (the row geometry is the same for every tile of a walk)
+    // ---- UP: the five positions of channel chunk `chunk` (A stage `par`), see the kernel's header.  Weight ring stage of tap t: UP_BS(t) = 1, 2, 0, 1.
+    // K offsets are formed per issue (chunk base + tap * Cin): the two groups and the chunk-crossing issues do not walk one common sequence here.
+    unsigned up_kc = 0;                                            // (chunk * BK) * ES of the chunk being multiplied
+    auto up_issue_b = [&](int tap, bool next_chunk, bool other_half) __attribute__((always_inline)) {
+        const int stage = tap == 2 ? 0 : (tap == 1 ? 2 : 1);
+        const unsigned kofs = up_kc + (next_chunk ? (unsigned)BK * ES : 0u) + (unsigned)tap * cin_es;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)((other_half ? b_dst_o : b_dst) + stage * B_STAGE + j * 1024), 16, other_half ? b_off_o[j] : b_off[j], kofs, 0, 0);
+    };
+    auto up_tap_addresses = [&](int tp, int frow, int (&dst)[TL::MT]) __attribute__((always_inline)) {
+        // tap tp = (ty, tx) of this workgroup's phase sits at (ty + ph_y, tx + ph_x) of the 3 x 3 neighbourhood (uniform at run time)
+        const int dy = (tp >> 1) + ph_y, dx = (tp & 1) + ph_x;
+        const int toff = (dy - 1) * W + (dx - 1);
+        const unsigned bit = (unsigned)(dy * 3 + dx);
+#pragma unroll
+        for (int i = 0; i < TL::MT; ++i) {
+            const int rr = frow + i * TL::TM + toff;
+            const int off = A_BASE + (rr << 7) + (((fslot ^ (rr >> 1)) & 7) << 4);
+            dst[i] = ((f_mask[i] >> bit) & 1u) ? off : A_BASE + ZROW;   // (absolute, stage 0)
+        }
+    };
+    auto chunk_steps_up = [&](const int chunk, const int par) __attribute__((always_inline)) {
+        const bool last = chunk + 1 == nchunks;
+        if (!last) set_chunk(chunk + 1);
+        up_kc = (unsigned)(chunk * BK) * ES;
+        int frow = f_row0;
+        NOPE_OPAQUE_VGPR(frow);
+#pragma unroll
+        for (int pos = 0; pos < 5; ++pos) {
+            const bool real = pos < 4;
+            const int tap = pos;                                   // (real positions)
+            // ---- LOAD
+            if (!real && A_SPLIT_LDS && dma_on && !last) {         // pieces 3 / 4 / 5 of the next chunk (landed at taps 3 / 0 / 1): rewritten where nothing is multiplied
+                convert_piece(3, par ^ 1);
+                if (a_has4) convert_piece(4, par ^ 1);
+                if (a_has5) convert_piece(5, par ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (dma_on) {
+                if (!last && real) {
+                    piece_a(pos, par ^ 1);
+                    if (pos == 0 && a_has4) piece_a(4, par ^ 1);
+                    if (pos == 1 && a_has5) piece_a(5, par ^ 1);
+                }
+                if (grp == 0) {
+                    if (pos < 3) up_issue_b(pos + 1, false, false);                          // my half of the next tap
+                    else if (!real && !last) { up_issue_b(0, true, false); up_issue_b(0, true, true); }      // tap 0 of the next chunk, BOTH halves: its stage was tap 3's
+                } else {
+                    if (pos < 2) up_issue_b(pos + 2, false, false);                          // my half, two taps ahead
+                    else if (pos == 3 && !last) up_issue_b(1, true, false);                  // tap 1 of the next chunk (its stage is free since tap 1)
+                }
+            }
+            if (real) {
+                u32x4 af[KS][RAW][TL::MT], bfr[KS][RAW][TL::NTL];
+                int fa[TL::MT];
+                if constexpr (FA_AHEAD) {
+#pragma unroll
+                    for (int i = 0; i < TL::MT; ++i) fa[i] = fa_next[i];
+                } else up_tap_addresses(tap, frow, fa);
+                constexpr int BSTG[4] = {1, 2, 0, 1};
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < TL::MT; ++i) af[kk / RAW][kk % RAW][i] = ld16(lds + (fa[i] ^ (raw_slot<T>(kk) << 4)) + par * A_STAGE);
+#pragma unroll
+                    for (int j = 0; j < TL::NTL; ++j) bfr[kk / RAW][kk % RAW][j] = ld16(lds + fbk[kk] + (BSTG[tap] * B_STAGE + j * TL::TM * RB));
+                }
+                __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- COMPUTE: as the 3 x 3 kernel's; pieces 0..2 of the next chunk (issued at taps 0..2) are rewritten behind the MFMAs of taps 1..3
+                __builtin_amdgcn_s_setprio(1);
+                constexpr bool CV = CV_IN_COMPUTE;
+                const bool cv_c = CV && tap >= 1;
+                const bool fa_c = FA_AHEAD && tap < 3;
+                u32x4 cv = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int t = 0; t < TL::TERMS; ++t) {
+                        const int g = ks * TL::TERMS + t;
+                        if (cv_c && g == 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            cv = convert_load(tap - 1, par ^ 1);
+                        }
+                        if (cv_c && g == 2) convert_store(cv, tap - 1, par ^ 1, !last);
+                        if (fa_c && g == 1) {
+                            if (!cv_c) __builtin_amdgcn_sched_barrier(0);
+                            up_tap_addresses(tap + 1, frow, fa_next);
+                        }
+#pragma unroll
+                        for (int i = 0; i < TL::MT; ++i)
+#pragma unroll
+                            for (int j = 0; j < TL::NTL; ++j) TL::mma(t, af[ks], bfr[ks], i, j, acc[i][j], x2_sc);
+                        if (cv_c && g == 2) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#pragma unroll
+                            for (int q = 0; q < 9; ++q) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002 | 0x080, 4, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (fa_c && !cv_c && g == 2) {
+#pragma unroll
+                            for (int q = 0; q < 12; ++q) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);         // (the rewritten pieces are in LDS before the barrier publishes them)
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- COMPUTE of the light position: nothing to multiply; the fragment addresses of tap 0
+                if (FA_AHEAD) up_tap_addresses(0, frow, fa_next);
+                __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);           // (group 0: tap 0 of the next chunk has landed -- it had group 1's last COMPUTE phase and this one)
+                if (!(grp == 1 && last)) {                         // (group 1 started one barrier late: it skips the last one)
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+    if constexpr (FA_AHEAD && UP) up_tap_addresses(0, f_row0, fa_next);
+    if constexpr (FA_AHEAD && !UP) {                               // tap 0 of the first step (the row geometry is the same for every tile of a walk)
 #pragma unroll
         for (int i = 0; i < TL::MT; ++i) {
             const int rr = f_row0 + i * TL::TM - W - 1;
@@ -918,8 +1087,13 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         }
         stamp();
         for (int chunk = c_lo; chunk < nchunks; chunk += 2) {
-            chunk_steps(chunk, 0);
-            if (chunk + 1 < nchunks) chunk_steps(chunk + 1, 1);
+            if constexpr (UP) {
+                chunk_steps_up(chunk, 0);
+                if (chunk + 1 < nchunks) chunk_steps_up(chunk + 1, 1);
+            } else {
+                chunk_steps(chunk, 0);
+                if (chunk + 1 < nchunks) chunk_steps(chunk + 1, 1);
+            }
         }
         if (p.variant & 64) {                          // tuning only: no epilogue (keeps the accumulators live)
             if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;
@@ -1018,6 +1192,12 @@ void launch_conv_halo(int dt, const void* params, dim3 grid, hipStream_t s) {
                 }
                 fclose(f);
             }
+        return;
+    }
+    if (p.mode == NOPE_CONV_UP2P) {                    // the four phase convs of an up-sampling (plan_conv: f32 storage only)
+        if (dt == NOPE_F16X2 && p.x2_t_zero) hipLaunchKernelGGL((conv3x3_halo_kernel<f16x2_t, false, false, false, false, true>), grid, block, 0, s, p);
+        else if (dt == NOPE_F16X2) hipLaunchKernelGGL((conv3x3_halo_kernel<f16x2_t, false, false, true, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<f32s_t, false, false, true, false, true>), grid, block, 0, s, p);
         return;
     }
     if (p.splits > 1) {

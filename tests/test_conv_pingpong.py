@@ -37,9 +37,13 @@ def test_pingpong_kernel_under_adversarial_interpreter(emu):
         envs.append(e)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "x2_emu_case.py")] + extra, env=dict(os.environ, HIPEMU_THREADS="2", **e),
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    # sixth: the up-sampling phase convs on the tap-resident kernel (six positions per channel chunk) in bf16x3 and f16x2: bit for bit the per-tap kernel
+    envs.append({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"})
+    procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "up2p_emu_case.py"), "--light"], env=dict(os.environ, HIPEMU_THREADS="2", **envs[-1]),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     for e, pr in zip(envs, procs):
         out, _ = pr.communicate(timeout=1500)
-        assert pr.returncode == 0 and ("pp_emu_case OK" in out or "x2 ok" in out or "x2 unet ok" in out), (e, out[-2000:])
+        assert pr.returncode == 0 and ("pp_emu_case OK" in out or "x2 ok" in out or "x2 unet ok" in out or "up2p ok" in out), (e, out[-2000:])
 
 
 @pytest.mark.gpu
@@ -81,6 +85,32 @@ def test_f16x2_tile_gpu(gpu):
         y1 = hip.op_conv(hip.F16X2, s1, w, b, src2=s2)
         os.environ.pop("NOPE_HALO_PERSIST")
         assert torch.equal(ys[0], y1), ("tile walk differs", c1, c2, cout, h)
+
+
+@pytest.mark.gpu
+def test_up2p_tap_resident_gpu(gpu):
+    """The up-sampling phase convs on the tap-resident kernel (f32-storage modes): the op-level cases on the device, then the three up-sampling
+    launches of a 512-hypothesis step -- reproducible and the bits of the per-tap ping-pong kernel (NOPE_UP2P_HALO=0), in bf16x3 and f16x2."""
+    from tests import up2p_emu_case
+    hip = gpu
+    assert up2p_emu_case.run(hip, "cuda") < 1.0
+    g = torch.Generator(device="cuda").manual_seed(6)
+    for dt in (hip.F16X2, hip.BF16X3):
+        for cin, cout, h in ((384, 192, 16), (768, 384, 8), (1536, 768, 4)):
+            w = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (cin * 9) ** 0.5
+            x = torch.randn(512, h, h, cin, device="cuda", generator=g)
+            b = torch.randn(cout, device="cuda", generator=g)
+            os.environ["NOPE_UP2P_HALO"] = "2"         # (2: bf16x3 layers too; the default takes the tap-resident form for f16x2 layers only)
+            try:
+                ys = [hip.op_conv(dt, x, w, b, mode=hip.CONV_UP2P) for _ in range(3)]
+                os.environ["NOPE_UP2P_HALO"] = "0"
+                y_tap = hip.op_conv(dt, x, w, b, mode=hip.CONV_UP2P)
+            finally:
+                os.environ.pop("NOPE_UP2P_HALO")
+            torch.cuda.synchronize()
+            assert all(torch.equal(ys[0], y) for y in ys[1:]), ("not reproducible", dt, cin, cout, h)
+            assert torch.equal(ys[0], y_tap), ("tap-resident phase convs != per-tap kernel", dt, cin, cout, h)
+            assert bool(torch.isfinite(ys[0]).all()) and float(ys[0].abs().max()) > 0.1
 
 
 @pytest.mark.gpu

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_stream_kernel_and_lean_epilogue_under_adversarial_interpreter(emu):
     runs = [("stream_emu_case.py", {"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--dts", "3", "--light"]),
-            ("stream_emu_case.py", {"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "3"}, ["--unet"]),      # fused PreNorm, residual, GroupNorm statistics: bit-identical forward
+            # (the streaming kernel is off by default -- measured slower, DESIGN.md section 8: its whole-U-Net interpreter case, 3 CPU-minutes,
+            #  runs by hand: `HIPEMU_DMA=late HIPEMU_SHUFFLE=3 python tests/stream_emu_case.py --unet`; the GPU test below keeps it)
             ("lean_emu_case.py", {"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--dts", "3"]),
             ("lean_emu_case.py", {"HIPEMU_SHUFFLE": "2"}, ["--dts", "4", "--light"])]
     procs = []
