@@ -458,10 +458,11 @@ constexpr int TIMELINE_STAMPS = 720;  // per group; 5 per K step (tuning instant
 // The four real positions are the K steps of the 3 x 3 kernel unchanged (fragment reads, 18-24 MFMAs); the light one has no fragment reads and no
 // MFMAs, only what the next chunk needs and a real step has no room for.  A stage of the next chunk: pieces 0..3 are issued at taps 0..3 (pieces
 // 4 / 5 ride with 0 / 1), pieces 0..2 are rewritten behind the MFMAs of taps 1..3, pieces 3 / 4 / 5 in the light position's LOAD phase.  Weight
-// ring: four taps on three stages cannot rotate with immediates (4 % 3 != 0), so the stage of tap t is fixed -- 1, 2, 0, 1 -- and the one
-// conflict (tap 0 of the next chunk wants tap 3's stage) is resolved in time: group 0 issues BOTH halves of that step in the light position,
-// under group 1's last COMPUTE phase, and waits for them at the end of its own empty COMPUTE phase; everything else keeps the ring's discipline
-// (group 0 its half one tap ahead, group 1 two taps ahead; tap 1 of the next chunk goes into tap 1's stage, free since tap 2, at tap 3).  No
+// ring: four taps on three stages cannot rotate with immediates (4 % 3 != 0), so the stage of tap t is fixed -- 1, 2, 0, 2 -- and the ring's
+// discipline (group 0 issues its half one tap ahead, group 1 two taps ahead) is bent where two taps share a stage: tap 3 goes into tap 1's stage,
+// which group 1 is still reading when it would issue its half, so group 0 issues BOTH halves of tap 3 (at tap 2); tap 0 of the next chunk goes
+// into its own stage, free since tap 1 (group 1 at tap 2, group 0 at tap 3); tap 1 of the next chunk follows tap 3 (group 1 in the light
+// position, group 0 at the next tap 0).  Every piece has at least one whole K step's COMPUTE phase to land, as in the 3 x 3 kernel.  No
 // vector-memory wait of a light position waits for a piece issued in it by the same phase -- a first version (six positions, pieces issued
 // in the light ones) paid two exposed L2 round trips per chunk: 0.63 of the K steps' time instead of 0.85.  Both groups pass two barriers per
 // position.  Same K order as the per-tap kernel (chunk outer, tap inner): bit-identical to it.
@@ -933,11 +934,11 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             stamp();
         }
     };
-    // ---- UP: the five positions of channel chunk `chunk` (A stage `par`), see the kernel's header.  Weight ring stage of tap t: UP_BS(t) = 1, 2, 0, 1.
+    // ---- UP: the five positions of channel chunk `chunk` (A stage `par`), see the kernel's header.  Weight ring stage of tap t: 1, 2, 0, 2.
     // K offsets are formed per issue (chunk base + tap * Cin): the two groups and the chunk-crossing issues do not walk one common sequence here.
     unsigned up_kc = 0;                                            // (chunk * BK) * ES of the chunk being multiplied
     auto up_issue_b = [&](int tap, bool next_chunk, bool other_half) __attribute__((always_inline)) {
-        const int stage = tap == 2 ? 0 : (tap == 1 ? 2 : 1);
+        const int stage = tap == 2 ? 0 : (tap == 0 ? 1 : 2);
         const unsigned kofs = up_kc + (next_chunk ? (unsigned)BK * ES : 0u) + (unsigned)tap * cin_es;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -978,12 +979,14 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                     if (pos == 0 && a_has4) piece_a(4, par ^ 1);
                     if (pos == 1 && a_has5) piece_a(5, par ^ 1);
                 }
-                if (grp == 0) {
-                    if (pos < 3) up_issue_b(pos + 1, false, false);                          // my half of the next tap
-                    else if (!real && !last) { up_issue_b(0, true, false); up_issue_b(0, true, true); }      // tap 0 of the next chunk, BOTH halves: its stage was tap 3's
-                } else {
-                    if (pos < 2) up_issue_b(pos + 2, false, false);                          // my half, two taps ahead
-                    else if (pos == 3 && !last) up_issue_b(1, true, false);                  // tap 1 of the next chunk (its stage is free since tap 1)
+                if (grp == 0) {                                    // one tap ahead; tap 3 for both groups (group 1 reads tap 3's stage while it would issue it)
+                    if (pos < 2) up_issue_b(pos + 1, false, false);
+                    else if (pos == 2) { up_issue_b(3, false, false); up_issue_b(3, false, true); }
+                    else if (pos == 3 && !last) up_issue_b(0, true, false);
+                } else {                                           // two taps ahead; tap 1 of the next chunk once tap 3 has left its stage
+                    if (pos == 0) up_issue_b(2, false, false);
+                    else if (pos == 2 && !last) up_issue_b(0, true, false);
+                    else if (!real && !last) up_issue_b(1, true, false);
                 }
             }
             if (real) {
@@ -993,7 +996,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
 #pragma unroll
                     for (int i = 0; i < TL::MT; ++i) fa[i] = fa_next[i];
                 } else up_tap_addresses(tap, frow, fa);
-                constexpr int BSTG[4] = {1, 2, 0, 1};
+                constexpr int BSTG[4] = {1, 2, 0, 2};
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
@@ -1056,7 +1059,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- COMPUTE of the light position: nothing to multiply; the fragment addresses of tap 0
                 if (FA_AHEAD) up_tap_addresses(0, frow, fa_next);
-                __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);           // (group 0: tap 0 of the next chunk has landed -- it had group 1's last COMPUTE phase and this one)
+                __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);           // (group 1: its half of the next chunk's tap 1, first read two positions from now)
                 if (!(grp == 1 && last)) {                         // (group 1 started one barrier late: it skips the last one)
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
