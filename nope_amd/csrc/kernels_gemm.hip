@@ -390,7 +390,7 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     {
         const int uh = NOPE_ENV("NOPE_UP2P_HALO", 1);
         const bool x2_layer = a.w_x2 && !a.pn_ms && !a.geglu && Cin % 32 == 0;
-        if (pl.pp && phased && !pl.posmajor && a.ntaps == 4 && dt == NOPE_BF16X3 && a.C2 == 0 && a.Ws <= conv_halo_max_width() && a.rep1 == 1 && !(pp_mode & 16) &&
+        if (pl.pp && phased && !pl.posmajor && a.ntaps == 4 && dt == NOPE_BF16X3 && a.C2 == 0 && a.Ws <= 30 && a.rep1 == 1 && !(pp_mode & 16) &&      // (Ws <= 30: at most five A pieces per wave)
             (uh == 2 || (uh == 1 && x2_layer)))
             pl.halo = true;
     }

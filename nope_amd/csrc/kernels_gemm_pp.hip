@@ -452,20 +452,20 @@ constexpr int TIMELINE_STAMPS = 720;  // per group; 5 per K step (tuning instant
 // UP (NOPE_CONV_UP2P: nearest x 2 + 3 x 3 as four 2 x 2 phase convs on the low-resolution map, blockIdx.y = phase; model_utils.py:161-165): the
 // tile's pixel range + halo is the 3 x 3 neighbourhood every phase draws its four taps from, so the stage is loaded (and, f32 storage, rewritten)
 // ONCE per channel chunk and read by the phase's four taps at row offsets -- where the per-tap kernel stages 256 rows per tap and splits them in
-// registers at every read (its launches are bound by that LOAD phase: 0.32-0.37 of the pipe against 0.54 here).  A chunk is FIVE positions:
-//     pos   0      1      2      3      4
-//           tap 0  tap 1  tap 2  tap 3  light
-// The four real positions are the K steps of the 3 x 3 kernel unchanged (fragment reads, 18-24 MFMAs); the light one has no fragment reads and no
-// MFMAs, only what the next chunk needs and a real step has no room for.  A stage of the next chunk: pieces 0..3 are issued at taps 0..3 (pieces
-// 4 / 5 ride with 0 / 1), pieces 0..2 are rewritten behind the MFMAs of taps 1..3, pieces 3 / 4 / 5 in the light position's LOAD phase.  Weight
-// ring: four taps on three stages cannot rotate with immediates (4 % 3 != 0), so the stage of tap t is fixed -- 1, 2, 0, 2 -- and the ring's
-// discipline (group 0 issues its half one tap ahead, group 1 two taps ahead) is bent where two taps share a stage: tap 3 goes into tap 1's stage,
-// which group 1 is still reading when it would issue its half, so group 0 issues BOTH halves of tap 3 (at tap 2); tap 0 of the next chunk goes
-// into its own stage, free since tap 1 (group 1 at tap 2, group 0 at tap 3); tap 1 of the next chunk follows tap 3 (group 1 in the light
-// position, group 0 at the next tap 0).  Every piece has at least one whole K step's COMPUTE phase to land, as in the 3 x 3 kernel.  No
-// vector-memory wait of a light position waits for a piece issued in it by the same phase -- a first version (six positions, pieces issued
-// in the light ones) paid two exposed L2 round trips per chunk: 0.63 of the K steps' time instead of 0.85.  Both groups pass two barriers per
-// position.  Same K order as the per-tap kernel (chunk outer, tap inner): bit-identical to it.
+// registers at every read (its launches are bound by that LOAD phase: 0.32-0.37 of the pipe against 0.54 here).  A chunk is FOUR K steps, each
+// the 3 x 3 kernel's (fragment reads, 18-24 MFMAs from registers), and everything the next chunk needs rides in them:
+//   * A stage of the next chunk (<= 5 pieces per wave: maps up to 30 pixels wide, checked by the launcher): pieces {0, 4} / {1} / {2, 3} are
+//     issued at taps 0 / 1 / 2 and rewritten (f32 storage) behind the MFMAs of the NEXT tap -- two pieces in one COMPUTE phase at taps 1 and 3:
+//     ~44 VALU + 8 LDS instructions behind 15 MFMAs.  Piece 4 is rewritten by every wave (not every wave loads one: its rows exist in every
+//     stage and are read only where a wave loaded them), so the phase stays one basic block.
+//   * Weight ring: four taps on three stages cannot rotate with immediates (4 % 3 != 0), so the stage of tap t is fixed -- 1, 2, 0, 2 -- and
+//     the ring's discipline (group 0 issues its half one tap ahead, group 1 two taps ahead) is bent where two taps share a stage: taps 1 and 3
+//     share stage 2, which group 1 is still reading when it would issue its half of the other, so group 0 issues BOTH halves of taps 1 and 3
+//     (at taps 0 and 2); tap 0 of the next chunk has its own stage (group 1 at tap 2, group 0 at tap 3).  Every piece has a whole COMPUTE
+//     phase to land, as in the 3 x 3 kernel.
+// Earlier forms, both bit-identical and slower: six positions per chunk with pieces issued in two MFMA-less ones (two exposed L2 round trips
+// per chunk: 0.63 of the K steps' rate, profiles/r06v_*), five positions with one light position (0.78, r06w_*).  Both groups pass two
+// barriers per K step.  Same K order as the per-tap kernel (chunk outer, tap inner): bit-identical to it.
 template <class T, bool TIMELINE = false, bool SPLIT = false, bool SHIFT = true, bool LEAN = false, bool UP = false>
 __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvParams p) {
     static_assert(!UP || (!TIMELINE && !SPLIT && !LEAN), "the phase-conv form: one tile per workgroup, generic wide epilogue");
@@ -753,9 +753,8 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         for (int i = 0; i < 6; ++i)
             if (i < 4 || (i == 4 ? a_has4 : a_has5)) piece_a(i, 0);
         bkofs = (unsigned)(c_lo * BK) * ES;
-        if constexpr (UP) {                                        // tap 0 -> ring stage 1 (both groups their half), group 1 its half of tap 1 -> stage 2
-            issue_b(1); bkofs += cin_es;
-            if (grp == 1) issue_b(2);
+        if constexpr (UP) {                                        // tap 0 -> ring stage 1 (both groups their half)
+            issue_b(1);                                            // (tap 1: both halves by group 0 at tap 0)
         } else {
             issue_b(0); bkofs += cin_es;
             if (grp == 1) { issue_b(1); bkofs += cin_es; }         // (nk >= 9 > 2)
@@ -934,7 +933,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
             stamp();
         }
     };
-    // ---- UP: the five positions of channel chunk `chunk` (A stage `par`), see the kernel's header.  Weight ring stage of tap t: 1, 2, 0, 2.
+    // ---- UP: the four K steps of channel chunk `chunk` (A stage `par`), see the kernel's header.  Weight ring stage of tap t: 1, 2, 0, 2.
     // K offsets are formed per issue (chunk base + tap * Cin): the two groups and the chunk-crossing issues do not walk one common sequence here.
     unsigned up_kc = 0;                                            // (chunk * BK) * ES of the chunk being multiplied
     auto up_issue_b = [&](int tap, bool next_chunk, bool other_half) __attribute__((always_inline)) {
@@ -963,75 +962,82 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
         int frow = f_row0;
         NOPE_OPAQUE_VGPR(frow);
 #pragma unroll
-        for (int pos = 0; pos < 5; ++pos) {
-            const bool real = pos < 4;
-            const int tap = pos;                                   // (real positions)
-            // ---- LOAD
-            if (!real && A_SPLIT_LDS && dma_on && !last) {         // pieces 3 / 4 / 5 of the next chunk (landed at taps 3 / 0 / 1): rewritten where nothing is multiplied
-                convert_piece(3, par ^ 1);
-                if (a_has4) convert_piece(4, par ^ 1);
-                if (a_has5) convert_piece(5, par ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int tap = 0; tap < 4; ++tap) {
+            // ---- LOAD: DMA pieces first, then the fragments
             if (dma_on) {
-                if (!last && real) {
-                    piece_a(pos, par ^ 1);
-                    if (pos == 0 && a_has4) piece_a(4, par ^ 1);
-                    if (pos == 1 && a_has5) piece_a(5, par ^ 1);
+                if (!last) {                                       // A pieces of the next chunk: {0, 4} / {1} / {2, 3} at taps 0 / 1 / 2 (piece 5 never exists: launcher, Ws <= 30)
+                    if (tap == 0) { piece_a(0, par ^ 1); if (a_has4) piece_a(4, par ^ 1); }
+                    if (tap == 1) piece_a(1, par ^ 1);
+                    if (tap == 2) { piece_a(2, par ^ 1); piece_a(3, par ^ 1); }
                 }
-                if (grp == 0) {                                    // one tap ahead; tap 3 for both groups (group 1 reads tap 3's stage while it would issue it)
-                    if (pos < 2) up_issue_b(pos + 1, false, false);
-                    else if (pos == 2) { up_issue_b(3, false, false); up_issue_b(3, false, true); }
-                    else if (pos == 3 && !last) up_issue_b(0, true, false);
-                } else {                                           // two taps ahead; tap 1 of the next chunk once tap 3 has left its stage
-                    if (pos == 0) up_issue_b(2, false, false);
-                    else if (pos == 2 && !last) up_issue_b(0, true, false);
-                    else if (!real && !last) up_issue_b(1, true, false);
+                if (grp == 0) {                                    // one tap ahead; BOTH halves of the two taps whose stage group 1 is reading when it would issue them
+                    if (tap == 0) { up_issue_b(1, false, false); up_issue_b(1, false, true); }
+                    else if (tap == 1) up_issue_b(2, false, false);
+                    else if (tap == 2) { up_issue_b(3, false, false); up_issue_b(3, false, true); }
+                    else if (!last) up_issue_b(0, true, false);
+                } else {                                           // two taps ahead
+                    if (tap == 0) up_issue_b(2, false, false);
+                    else if (tap == 2 && !last) up_issue_b(0, true, false);
                 }
             }
-            if (real) {
-                u32x4 af[KS][RAW][TL::MT], bfr[KS][RAW][TL::NTL];
-                int fa[TL::MT];
-                if constexpr (FA_AHEAD) {
+            u32x4 af[KS][RAW][TL::MT], bfr[KS][RAW][TL::NTL];
+            int fa[TL::MT];
+            if constexpr (FA_AHEAD) {
 #pragma unroll
-                    for (int i = 0; i < TL::MT; ++i) fa[i] = fa_next[i];
-                } else up_tap_addresses(tap, frow, fa);
-                constexpr int BSTG[4] = {1, 2, 0, 2};
+                for (int i = 0; i < TL::MT; ++i) fa[i] = fa_next[i];
+            } else up_tap_addresses(tap, frow, fa);
+            constexpr int BSTG[4] = {1, 2, 0, 2};
 #pragma unroll
-                for (int kk = 0; kk < KK; ++kk) {
+            for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-                    for (int i = 0; i < TL::MT; ++i) af[kk / RAW][kk % RAW][i] = ld16(lds + (fa[i] ^ (raw_slot<T>(kk) << 4)) + par * A_STAGE);
+                for (int i = 0; i < TL::MT; ++i) af[kk / RAW][kk % RAW][i] = ld16(lds + (fa[i] ^ (raw_slot<T>(kk) << 4)) + par * A_STAGE);
 #pragma unroll
-                    for (int j = 0; j < TL::NTL; ++j) bfr[kk / RAW][kk % RAW][j] = ld16(lds + fbk[kk] + (BSTG[tap] * B_STAGE + j * TL::TM * RB));
-                }
-                __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- COMPUTE: as the 3 x 3 kernel's; pieces 0..2 of the next chunk (issued at taps 0..2) are rewritten behind the MFMAs of taps 1..3
-                __builtin_amdgcn_s_setprio(1);
-                constexpr bool CV = CV_IN_COMPUTE;
-                const bool cv_c = CV && tap >= 1;
-                const bool fa_c = FA_AHEAD && tap < 3;
-                u32x4 cv = {0u, 0u, 0u, 0u};
+                for (int j = 0; j < TL::NTL; ++j) bfr[kk / RAW][kk % RAW][j] = ld16(lds + fbk[kk] + (BSTG[tap] * B_STAGE + j * TL::TM * RB));
+            }
+            __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- COMPUTE: the 3 x 3 kernel's, with the next chunk's stage rewritten behind the MFMAs of taps 1..3: pieces {0, 4} / {1} / {2, 3}
+            // (each landed one tap earlier; piece 4 is rewritten by every wave -- its rows exist in every stage, and nothing reads them where no wave loaded them)
+            __builtin_amdgcn_s_setprio(1);
+            constexpr bool CV = CV_IN_COMPUTE;
+            const bool cv_c = CV && tap >= 1;
+            const int pa = tap == 1 ? 0 : (tap == 2 ? 1 : 2), pb = tap == 1 ? 4 : 3;      // pieces rewritten in this phase (pb: taps 1 and 3 only)
+            const bool two = tap != 2;
+            u32x4 cva = {0u, 0u, 0u, 0u}, cvb = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int t = 0; t < TL::TERMS; ++t) {
-                        const int g = ks * TL::TERMS + t;
-                        if (cv_c && g == 1) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            cv = convert_load(tap - 1, par ^ 1);
-                        }
-                        if (cv_c && g == 2) convert_store(cv, tap - 1, par ^ 1, !last);
-                        if (fa_c && g == 1) {
-                            if (!cv_c) __builtin_amdgcn_sched_barrier(0);
-                            up_tap_addresses(tap + 1, frow, fa_next);
-                        }
+                for (int t = 0; t < TL::TERMS; ++t) {
+                    const int g = ks * TL::TERMS + t;
+                    if (cv_c && g == 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        cva = convert_load(pa, par ^ 1);
+                        if (two) cvb = convert_load(pb, par ^ 1);
+                    }
+                    if (cv_c && g == 2) {
+                        convert_store(cva, pa, par ^ 1, !last);
+                        if (two) convert_store(cvb, pb, par ^ 1, !last);
+                    }
+                    if (FA_AHEAD && g == 1) {
+                        if (!cv_c) __builtin_amdgcn_sched_barrier(0);
+                        up_tap_addresses((tap + 1) & 3, frow, fa_next);
+                    }
 #pragma unroll
-                        for (int i = 0; i < TL::MT; ++i)
+                    for (int i = 0; i < TL::MT; ++i)
 #pragma unroll
-                            for (int j = 0; j < TL::NTL; ++j) TL::mma(t, af[ks], bfr[ks], i, j, acc[i][j], x2_sc);
-                        if (cv_c && g == 2) {
+                        for (int j = 0; j < TL::NTL; ++j) TL::mma(t, af[ks], bfr[ks], i, j, acc[i][j], x2_sc);
+                    if (cv_c && g == 2) {
+                        // the read(s); three MFMAs cover their latency; then one MFMA, up to four (one piece) / six (two) of the rewrite's / the address arithmetic's instructions
+                        if (two) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#pragma unroll
+                            for (int q = 0; q < 9; ++q) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002 | 0x080, 6, 0);
+                            }
+                        } else {
                             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
 #pragma unroll
@@ -1039,31 +1045,22 @@ __global__ __launch_bounds__(PP_WAVES * 64, 2) void conv3x3_halo_kernel(ConvPara
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                                 __builtin_amdgcn_sched_group_barrier(0x002 | 0x080, 4, 0);
                             }
-                            __builtin_amdgcn_sched_barrier(0);
-                        } else if (fa_c && !cv_c && g == 2) {
-#pragma unroll
-                            for (int q = 0; q < 12; ++q) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (FA_AHEAD && !cv_c && g == 2) {
+#pragma unroll
+                        for (int q = 0; q < 12; ++q) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                __builtin_amdgcn_s_waitcnt(WAIT_LGKMCNT0);         // (the rewritten pieces are in LDS before the barrier publishes them)
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- COMPUTE of the light position: nothing to multiply; the fragment addresses of tap 0
-                if (FA_AHEAD) up_tap_addresses(0, frow, fa_next);
-                __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);           // (group 1: its half of the next chunk's tap 1, first read two positions from now)
-                if (!(grp == 1 && last)) {                         // (group 1 started one barrier late: it skips the last one)
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
+            if (!(grp == 1 && last && tap == 3)) {                 // (group 1 started one barrier late: it skips the last one)
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };

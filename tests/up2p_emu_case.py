@@ -2,7 +2,7 @@
 kernels_gemm_pp.hip: six positions per channel chunk, four of them K steps) in the f32-storage modes (bf16x3, f16x2), on small shapes under
 tests/hipemu: against the f32 convolution of the nearest-x2 map, against the restated f16x2 arithmetic, and BIT FOR BIT against the per-tap
 ping-pong kernel (NOPE_UP2P_HALO=0) -- same K order, same operands, same accumulation chain.  One, two and three channel chunks (both A stages,
-the last-chunk path), maps from 4 x 4 with many samples per tile to the widest supported one (pieces 4 / 5 of a stage), one and two weight
+the last-chunk path), maps from 4 x 4 with many samples per tile to the widest supported one (30 pixels: every wave has a fifth piece), one and two weight
 panels, ragged M.  Run by tests/test_conv_pingpong.py with the interpreter's adversarial settings; `run(hip, "cuda")` is the GPU form."""
 import os
 import sys
@@ -46,7 +46,7 @@ def run(hip, dev, light=False):
     C = 32
     worst = 0.0
     # samples, channels, H, W, Cout
-    shapes = [(3, C, 5, 6, 40), (3, 2 * C, 10, 9, 200), (40, 3 * C, 4, 4, 24), (1, 2 * C, 9, 32, 16)]
+    shapes = [(3, C, 5, 6, 40), (3, 2 * C, 10, 9, 200), (40, 3 * C, 4, 4, 24), (1, 2 * C, 9, 30, 16)]
     if light:
         shapes = shapes[1:2]       # two chunks (both A stages, the last-chunk path), ragged M, two weight panels
     try:
