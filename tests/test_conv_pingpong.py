@@ -7,8 +7,6 @@ too short gives wrong numbers here, before a GPU-minute is spent (the mutations 
 GPU: same small shapes, then the U-Net's real launch shapes, where the kernel must agree BIT FOR BIT with the
 128 x 192 kernel (same K order, same MFMA shape, same accumulation chain) on every one of several repetitions."""
 import os
-import subprocess
-import sys
 
 import pytest
 import torch
@@ -16,34 +14,15 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_pingpong_kernel_under_adversarial_interpreter(emu):
-    # (compute modes: 1 = bf16, 3 = bf16x3 split precision on f32 data, 0 = f32, 2 = f16)
-    envs = [{"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, {"HIPEMU_SHUFFLE": "2"}]
-    dts = ["1,3", "0,2"]
-    procs = []
-    for e, dd in zip(envs, dts):
-        env = dict(os.environ, HIPEMU_THREADS="4", **e)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pp_emu_case.py"), "--light", "--dts", dd], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    # third process: a whole 16-bit U-Net schedule (fused statistics / PreNorm epilogues of the 16-bit types)
-    envs.append({"HIPEMU_SHUFFLE": "1"})
-    procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pp_emu_case.py"), "--unet16"], env=dict(os.environ, HIPEMU_THREADS="4", **envs[-1]),
-                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    # fourth: the tap-resident kernel's NOPE_F16X2 tile (in-LDS operand rewrite + MX-scaled fp8 MFMA) with late DMA + shuffled waves; fifth: a
-    # whole U-Net in the f16x2 compute mode (second weight pack per 3x3 layer, block scale read from the packed tail, the other launches as
-    # bf16x3) with the tap-resident kernel forced onto every eligible launch, against the oracle.  (The remaining op-level cases -- tile walk,
-    # split-K, residual epilogue, widest map -- run on the GPU, test_f16x2_tile_gpu, and by hand: python tests/x2_emu_case.py.)
-    for e, extra in (({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--light"]), ({"HIPEMU_SHUFFLE": "2"}, ["--unet"])):
-        envs.append(e)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "x2_emu_case.py")] + extra, env=dict(os.environ, HIPEMU_THREADS="2", **e),
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    # sixth: the up-sampling phase convs on the tap-resident kernel (six positions per channel chunk) in bf16x3 and f16x2: bit for bit the per-tap kernel
-    envs.append({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"})
-    procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "up2p_emu_case.py"), "--light"], env=dict(os.environ, HIPEMU_THREADS="2", **envs[-1]),
-                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    for e, pr in zip(envs, procs):
-        out, _ = pr.communicate(timeout=1500)
-        assert pr.returncode == 0 and ("pp_emu_case OK" in out or "x2 ok" in out or "x2 unet ok" in out or "up2p ok" in out), (e, out[-2000:])
+def test_pingpong_kernel_under_adversarial_interpreter(emu_jobs):
+    """tests/conftest.py: EMU_JOBS.  pp_light_*: the op-level cases of the per-tap and tap-resident kernels in the two adversarial settings; x2_light / x2_unet:
+    the tap-resident kernel's NOPE_F16X2 tile (in-LDS operand rewrite + MX-scaled fp8 MFMA) with late DMA + shuffled waves, and a whole U-Net in the
+    f16x2 mode (second weight pack per 3x3 layer, block scale from the packed tail, the other launches as bf16x3) with the tap-resident kernel forced
+    onto every eligible launch, against the oracle; up2p_light: the up-sampling phase convs on the tap-resident kernel (four K steps per channel
+    chunk) in bf16x3 and f16x2, bit for bit the per-tap kernel; pp_unet16 (NOPE_EMU_FULL=1; on the GPU otherwise: test_pingpong_small_shapes_gpu): a
+    whole 16-bit U-Net schedule.  (The remaining op-level cases -- tile walk, split-K, residual epilogue, widest map -- run on the GPU,
+    test_f16x2_tile_gpu, and by hand: python tests/x2_emu_case.py.)"""
+    emu_jobs.collect(["pp_light_13", "pp_light_02", "x2_light", "x2_unet", "up2p_light", "pp_unet16"])
 
 
 @pytest.mark.gpu

@@ -7,8 +7,6 @@ time as far ahead of each other as the workgroup barriers permit -- against torc
 128 x 192 kernel (same K order, one accumulator per output element).
 GPU: the same cases, then the U-Net's real launch shapes at 64 hypotheses, bit-identical to the 128 x 192 kernel without split-K."""
 import os
-import subprocess
-import sys
 
 import pytest
 import torch
@@ -16,21 +14,11 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_small_tile_kernel_under_adversarial_interpreter(emu):
-    # (compute modes: 1 = bf16, 3 = bf16x3 split precision on f32 data, 0 = f32, 2 = f16; tiles: 0 = 64 x 64 / 3 stages, 1 = 128 x 128, 2 = 64 x 64 / 6 stages, 3 = 64 x 64 by two K groups)
-    runs = [({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--dts", "1,0", "--tiles", "0,1,3"]),
-            ({"HIPEMU_SHUFFLE": "2"}, ["--dts", "3,2", "--tiles", "2,3", "--light"]),
-            ({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "3"}, ["--unet16"]),      # a whole f16 U-Net schedule: fused statistics per 16 / 64 rows, fused PreNorm, NCHW bank
-            ({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--unet16split"]),  # ... with its 3x3 convs split along K on the tap-resident kernel
-            ({"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "2"}, ["--x2"])]           # the f16 + MX-fp8 tile on the small-tile kernel (A split in registers), bit-identical to the ping-pong kernels
-    procs = []
-    for e, args in runs:
-        env = dict(os.environ, HIPEMU_THREADS="3", **e)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "small_emu_case.py")] + args, env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    for (e, args), pr in zip(runs, procs):
-        out, _ = pr.communicate(timeout=2400)
-        assert pr.returncode == 0 and "small_emu_case OK" in out, (e, args, out[-2000:])
+def test_small_tile_kernel_under_adversarial_interpreter(emu_jobs):
+    """tests/conftest.py: EMU_JOBS.  small_10 / small_32: the op-level cases per compute mode and tile; small_unet16: a whole f16 U-Net schedule (fused
+    statistics per 16 / 64 rows, fused PreNorm, NCHW bank); small_unet16split (NOPE_EMU_FULL=1): ... with its 3x3 convs split along K on the
+    tap-resident kernel; small_x2: the f16 + MX-fp8 tile on the small-tile kernel (A split in registers), bit-identical to the ping-pong kernels."""
+    emu_jobs.collect(["small_10", "small_32", "small_unet16", "small_unet16split", "small_x2"])
 
 
 @pytest.mark.gpu

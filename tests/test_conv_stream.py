@@ -6,27 +6,17 @@ LinearAttention / Attention / ResnetBlock.res_conv (model_utils.py:269,373-374,3
 CPU: the kernel sources run under tests/hipemu in its adversarial settings (LDS-DMA landing as late as the counted vmcnt waits allow, waves
 scheduled as far apart as the barriers permit).  GPU: the same cases on the device."""
 import os
-import subprocess
-import sys
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_stream_kernel_and_lean_epilogue_under_adversarial_interpreter(emu):
-    runs = [("stream_emu_case.py", {"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--dts", "3", "--light"]),
-            # (the streaming kernel is off by default -- measured slower, DESIGN.md section 8: its whole-U-Net interpreter case, 3 CPU-minutes,
-            #  runs by hand: `HIPEMU_DMA=late HIPEMU_SHUFFLE=3 python tests/stream_emu_case.py --unet`; the GPU test below keeps it)
-            ("lean_emu_case.py", {"HIPEMU_DMA": "late", "HIPEMU_SHUFFLE": "1"}, ["--dts", "3"]),
-            ("lean_emu_case.py", {"HIPEMU_SHUFFLE": "2"}, ["--dts", "4", "--light"])]
-    procs = []
-    for script, e, args in runs:
-        env = dict(os.environ, HIPEMU_THREADS="3", **e)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", script)] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    for (script, e, args), pr in zip(runs, procs):
-        out, _ = pr.communicate(timeout=3000)
-        assert pr.returncode == 0 and script.replace(".py", "") + " OK" in out, (script, e, args, out[-2000:])
+def test_stream_kernel_and_lean_epilogue_under_adversarial_interpreter(emu_jobs):
+    """tests/conftest.py: EMU_JOBS.  stream_light: the streaming kernel's op-level cases; lean_3 / lean_4: the lean epilogue in bf16x3 and f16x2 against
+    the generic row loop; stream_unet (NOPE_EMU_FULL=1 -- the streaming kernel is off by default, measured slower; the GPU test
+    below keeps it): fused PreNorm, residual, GroupNorm statistics in a whole forward, bit-identical."""
+    emu_jobs.collect(["stream_light", "lean_3", "lean_4", "stream_unet"])
 
 
 def test_plan_keeps_ragged_launches_off_the_lean_path():
