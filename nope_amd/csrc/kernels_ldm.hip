@@ -283,6 +283,151 @@ __global__ __launch_bounds__(NT) void token_attn_mfma_kernel(const bf16_t* __res
     }
 }
 
+// ---- ... and for the f32 STORAGE of the split-precision compute modes (NOPE_BF16X3, and NOPE_F16X2 = NOPE_BF16X3 outside the 3x3 convs) ----
+// Same schedule and operand order as token_attn_mfma_kernel; every matrix product is the three bf16 passes of Tile<f32s_t>
+// (conv_gemm_common.h): x = hi + lo with hi = bf16(x), lo = bf16(x - hi), product = lo*hi + hi*lo + hi*hi accumulated in f32 (the
+// small terms first), i.e. 2^-16 relative per product where one bf16 pass has 2^-8.  K and V are split once per block when they
+// are staged (two LDS images each), Q once per wave, P = exp2(...) in registers right where the accumulator layout leaves it.
+// Scores, max, sums and the output accumulate in f32; the row sum adds the UNSPLIT exponentials.  (The VALU kernel above was 18.7
+// of the 63 ms of a 128-hypothesis NOPE_F16X2 forward of the shipped LDM size: profiles/r06t_timeline_ldm_128_f16x2_summary.txt.)
+__device__ __forceinline__ void split8_bf16(const u32x4 a, const u32x4 b, u32x4& hi, u32x4& lo) {      // 8 f32 (a | b) -> 8 bf16 hi + 8 bf16 lo
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {      // (through a scalar: __builtin_bit_cast straight from a vector-element lvalue reads element 0)
+        const unsigned u0 = a[e], u1 = b[e];
+        x[e] = __builtin_bit_cast(float, u0); x[4 + e] = __builtin_bit_cast(float, u1);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned h = cvt_pk_bf16(x[2 * e], x[2 * e + 1]);
+        const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xffff0000u);
+        hi[e] = h;
+        lo[e] = cvt_pk_bf16(x[2 * e] - h0, x[2 * e + 1] - h1);
+    }
+}
+__global__ __launch_bounds__(NT) void token_attn_mfma_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int C, float scale_log2e) {
+    typedef __attribute__((ext_vector_type(16))) float f32x16;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    __shared__ __attribute__((aligned(16))) bf16_t s_k[2][MK][K_LD];          // [hi | lo]
+    __shared__ __attribute__((aligned(16))) bf16_t s_vt[2][AD][VT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = blockIdx.y, smp = blockIdx.z;
+    const int h = lane >> 5, li = lane & 31;
+    const float* base = qkv + (size_t)smp * N * 3 * C + head * AD;
+    const int q = blockIdx.x * MQ + wave * 32 + li;            // this lane's query (accumulator column)
+    u32x4 qh[2], ql[2];                                        // Q^T fragments (B operand): column = query, k = d: 8 consecutive d at 8 h (+ 16 for the second step)
+    {
+        const float* qp = base + (size_t)(q < N ? q : N - 1) * 3 * C + 8 * h;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) split8_bf16(ld16(qp + 16 * kk), ld16(qp + 16 * kk + 4), qh[kk], ql[kk]);
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float mx = -3.0e38f, den = 0.f;                              // (in log2 units; den: this lane's half of the row sum)
+    // staging role: thread -> (key, 8 channels of its K row and of its V row); the next block's loads fly under the MFMAs
+    const int skey = tid >> 2, svec = tid & 3;
+    u32x4 nk[2], nv[2];
+    auto fetch = [&](int k0) {
+        const int key = k0 + skey;
+        const float* kp = base + (size_t)(key < N ? key : N - 1) * 3 * C + C + svec * 8;
+        nk[0] = ld16(kp); nk[1] = ld16(kp + 4); nv[0] = ld16(kp + C); nv[1] = ld16(kp + C + 4);
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < N; k0 += MK) {
+        __syncthreads();                                         // everyone is done reading the previous block
+        {
+            u32x4 kh, kl, vh, vl;
+            split8_bf16(nk[0], nk[1], kh, kl);
+            split8_bf16(nv[0], nv[1], vh, vl);
+            st16(&s_k[0][skey][svec * 8], kh);
+            st16(&s_k[1][skey][svec * 8], kl);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                        // V^T: [d][key]
+                const unsigned wh = vh[e >> 1], wl = vl[e >> 1];
+                s_vt[0][svec * 8 + e][skey] = (bf16_t)((e & 1) ? (wh >> 16) : (wh & 0xffffu));
+                s_vt[1][svec * 8 + e][skey] = (bf16_t)((e & 1) ? (wl >> 16) : (wl & 0xffffu));
+            }
+        }
+        __syncthreads();
+        if (k0 + MK < N) fetch(k0 + MK);
+        f32x16 sc[2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[sb][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)                               // term outer: (lo, hi), (hi, lo), (hi, hi) -- MFMAs on one accumulator sit apart
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const u32x4 kf = ld16(&s_k[t == 0 ? 1 : 0][sb * 32 + li][8 * h + 16 * kk]);
+                    const u32x4 qf = t == 1 ? ql[kk] : qh[kk];
+                    sc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf), sc[sb], 0, 0, 0);
+                }
+        // scores in log2 units; keys behind N (last block of a ragged N) drop out
+        float bm = -3.0e38f;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + sb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                const float v = key < N ? sc[sb][r] * scale_log2e : -3.0e38f;
+                sc[sb][r] = v;
+                bm = fmaxf(bm, v);
+            }
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));                  // the other half of this query's keys
+        const float nm = fmaxf(mx, bm);
+        const float corr = __builtin_amdgcn_exp2f(mx - nm);
+        mx = nm;
+        float ps = 0.f;
+        u32x4 ph[2][2], pl[2][2];                                // P^T fragments: [32-key block][MFMA step], hi and lo
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p0 = __builtin_amdgcn_exp2f(sc[sb][8 * t + 2 * j] - nm), p1 = __builtin_amdgcn_exp2f(sc[sb][8 * t + 2 * j + 1] - nm);
+                    ps += p0 + p1;
+                    const unsigned hh = cvt_pk_bf16(p0, p1);
+                    ph[sb][t][j] = hh;
+                    pl[sb][t][j] = cvt_pk_bf16(p0 - __builtin_bit_cast(float, hh << 16), p1 - __builtin_bit_cast(float, hh & 0xffff0000u));
+                }
+        den = den * corr + ps;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= corr;
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm)
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int kb = sb * 32 + 16 * t + 4 * h;        // keys kb .. kb + 3 and kb + 8 .. kb + 11 are this lane's 8 k slots
+                    const bf16_t* vr = &s_vt[tm == 0 ? 1 : 0][li][kb];
+                    const u32x2 v0 = *reinterpret_cast<const u32x2*>(vr);
+                    const u32x2 v1 = *reinterpret_cast<const u32x2*>(vr + 8);
+                    const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+                    const u32x4 pf = tm == 1 ? pl[sb][t] : ph[sb][t];
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), o, 0, 0, 0);
+                }
+    }
+    den += __shfl_xor(den, 32, 64);
+    if (q < N) {
+        const float inv = 1.0f / den;
+        float* op = out + ((size_t)smp * N + q) * C + head * AD + 4 * h;        // rows of O^T this lane holds: d = 8 g + 4 h + (r & 3)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float t4[4] = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+            u32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = __builtin_bit_cast(unsigned, t4[e]);
+            st16(op + 8 * g, w);
+        }
+    }
+}
+
 // x (M, C) -> y (M, C2) [:, off .. off + C): concatenation of token tensors along the channel axis (th.cat of the skip,
 // adapt_openaimodel.py:152: GroupNorm(32) groups of the ResBlock that follows may straddle the two sources)
 template <class T>
@@ -341,11 +486,17 @@ int launch_token_attention(int dt, const void* qkv, void* out, int nsmp, int N, 
     const float scale = 1.0f / sqrtf((float)dim_head);
     // bf16: the matrix-core kernel (NOPE_LDM_ATTN=0 keeps the VALU one: the tests compare the two); f32 -- the parity mode -- stays
     // on the all-f32 VALU kernel
-    const bool mfma = dt == NOPE_BF16 && (NOPE_ENV("NOPE_LDM_ATTN", -1) != 0);
-    if (mfma) {
-        const dim3 g2((unsigned)cdiv(N, MQ), (unsigned)(C / AD), (unsigned)nsmp);
+    // on the all-f32 VALU kernel; the compute tags NOPE_BF16X3 / NOPE_F16X2 (f32 storage): the same schedule on three bf16 passes per product
+    const bool mfma = NOPE_ENV("NOPE_LDM_ATTN", -1) != 0;
+    const dim3 g2((unsigned)cdiv(N, MQ), (unsigned)(C / AD), (unsigned)nsmp);
+    if (dt == NOPE_BF16 && mfma) {
         hipLaunchKernelGGL(token_attn_mfma_kernel, g2, dim3(NT), 0, s, (const bf16_t*)qkv, (bf16_t*)out, N, C, scale * 1.4426950408889634f);
-    } else NOPE_DISPATCH_T(dt, T, hipLaunchKernelGGL((token_attn_kernel<T>), grid, dim3(NT), 0, s, (const T*)qkv, (T*)out, N, C, scale));
+    } else if ((dt == NOPE_BF16X3 || dt == NOPE_F16X2) && mfma) {
+        hipLaunchKernelGGL(token_attn_mfma_x3_kernel, g2, dim3(NT), 0, s, (const float*)qkv, (float*)out, N, C, scale * 1.4426950408889634f);
+    } else {
+        const int sdt = dt_storage(dt);
+        NOPE_DISPATCH_T(sdt, T, hipLaunchKernelGGL((token_attn_kernel<T>), grid, dim3(NT), 0, s, (const T*)qkv, (T*)out, N, C, scale));
+    }
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

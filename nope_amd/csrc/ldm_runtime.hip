@@ -356,7 +356,7 @@ struct Fwd {
             void* a = xn;                                    // reuse: LN1(tok)
             if (live()) chk(launch_layernorm(net->sdt, tok, a, B.ln1.gamma, B.ln1.beta, M, C, 1e-5f, s));
             conv(B.qkv, Act{a, C, x.H, x.W}, qkv, x.H, x.W);
-            if (live()) chk(launch_token_attention(net->sdt, qkv, o, nhyp, HW, C, 32, s));
+            if (live()) chk(launch_token_attention(net->dt, qkv, o, nhyp, HW, C, 32, s));
             conv(B.out1, Act{o, C, x.H, x.W}, tok1, x.H, x.W, tok);
             // attn2 against the single pose token: + to_out(to_v(context)) for every token -- this block's slice of u_all
             if (live()) chk(launch_add_rowvec(net->sdt, tok1, tok1, u_all + B.u_off, M, HW, C, s, net->u_total));

@@ -674,6 +674,24 @@ def test_ldm_token_ops(be, dt):
         assert rel(got.float().cpu(), want) < tol, (n, N, C)
 
 
+def test_ldm_token_attention_split_precision(be):
+    """The same op on f32 storage under the compute tags NOPE_BF16X3 / NOPE_F16X2 (token_attn_mfma_x3_kernel: three bf16 MFMA passes per
+    product over (hi, lo) splits of q, k, v and of the exponentials) against torch in f64 and against the all-f32 VALU kernel of the
+    parity mode: ragged token counts, several key blocks, several heads, small scores, and scores of +-50 (softmax close to one-hot: a
+    score's ABSOLUTE error, 2^-17 of sum |q_d k_d|, is the relative error of its exponential -- 6e-5 observed there, bound 2e-4)."""
+    hip, dev, _ = be
+    g = torch.Generator().manual_seed(62)
+    for (n, N, C, gain, tol) in ((2, 37, 64, 1.0, OP_TOL[3]), (1, 300, 32, 1.0, OP_TOL[3]), (3, 16, 96, 1.0, OP_TOL[3]), (1, 130, 64, 4.0, 2e-4), (1, 64, 32, 0.05, OP_TOL[3])):
+        qkv = torch.randn(n, N, 3 * C, generator=g) * gain
+        qq, kk, vv = (t.reshape(n, N, C // 32, 32).permute(0, 2, 1, 3) for t in qkv.double().chunk(3, dim=-1))
+        want = ((qq @ kk.transpose(-1, -2) * 32 ** -0.5).softmax(-1) @ vv).permute(0, 2, 1, 3).reshape(n, N, C).float()
+        plain = hip.op_token_attention(0, qkv.to(dev)).cpu()
+        assert rel(plain, want) < OP_TOL[0], (n, N, C, gain)
+        for dt in (3, 4):
+            got = hip.op_token_attention(dt, qkv.to(dev)).cpu()
+            assert got.dtype == torch.float32 and rel(got, want) < tol, (dt, n, N, C, gain, rel(got, want))
+
+
 @pytest.mark.parametrize("tag", ["m32", "m64two", "m32film", "m64film", "m32d2"])
 def test_ldm_unet_vs_reference_golden(be, golden, tag):
     """Whole LDM variant through the C ABI (nope_ldm_*: ResBlocks with GroupNorm(32), SpatialTransformers with fused q|k|v,
