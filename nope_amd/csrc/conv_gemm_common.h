@@ -769,6 +769,13 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                 }
             }
             const size_t o = out_row(p, m) * p.Cout + n;
+            if constexpr (GG && sizeof(T) == 4) {
+                // f32 storage: the lane's four columns are two (x, gate) pairs -> two values = 8 bytes per row into the [M][Cout / 2] output (no residual /
+                // activation / PreNorm: geglu_shape_ok); same operands and formula as geglu_kernel<float, true>: bit-identical to conv + geglu
+                const f32x2_t y = {geglu_f(v[0], v[1]), geglu_f(v[2], v[3])};
+                *reinterpret_cast<f32x2_t*>(out + (o >> 1)) = y;
+                continue;
+            }
             if (resid) {
                 float rv[VEC];
                 Elt<T>::unpack(ld16(resid + o), rv);

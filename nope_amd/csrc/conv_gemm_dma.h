@@ -303,7 +303,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void conv_gemm_dma_kernel(ConvParams p)
 
 template <class T, int RB, int NS, int BMT>
 void launch_dma(const ConvParams& p, dim3 grid, hipStream_t s) {
-    if constexpr (sizeof(T) == 2 && BMT == 128 && RB == 128) {
+    if constexpr (BMT == 128 && RB == 128) {       // (16-bit storage: the packed path of epilogue_wide; f32 storage: its generic row loop)
         if (p.geglu) { hipLaunchKernelGGL((conv_gemm_dma_kernel<T, NOPE_CONV_PLAIN, RB, NS, BMT, false, true>), grid, dim3(BMT * 2), 0, s, p); return; }
     }
     if constexpr (sizeof(T) == 4 && Tile<T>::TM == 32 && BMT == 128 && RB == 128) {

@@ -413,11 +413,12 @@ static ConvPlan plan_conv(int dt, const ConvArgs& a) {
     return pl;
 }
 
-// ConvArgs::geglu: 16-bit storage, a plain 1x1 conv on the 128 x 192 LDS-DMA kernel's packed wide epilogue (no residual / statistics / PreNorm /
-// activation / split), column pairs whole inside a lane's 8-column chunk and 8-byte output rows
+// ConvArgs::geglu: a plain 1x1 conv on the 128 x 192 LDS-DMA kernel's wide epilogue (no residual / statistics / PreNorm / activation / split):
+// 16-bit storage on the packed path, column pairs whole inside a lane's 8-column chunk and 8-byte output rows; f32 storage (round 6; NOPE_GEGLU_FUSED_F32=0:
+// A/B switch) in the generic row loop, two pairs per 4-column chunk
 static bool geglu_shape_ok(int dt, const ConvArgs& a, const ConvPlan& pl) {
     const int variant = NOPE_ENV("NOPE_CONV_VARIANT", 0);
-    return dt_es(dt) == 2 && a.mode == NOPE_CONV_PLAIN && a.ntaps == 1 && !a.resid && !a.colstats && !a.pn_ms && !a.out_nchw && !a.act && !a.splitk_ws &&
+    return (dt_es(dt) == 2 || NOPE_ENV("NOPE_GEGLU_FUSED_F32", 1)) && a.mode == NOPE_CONV_PLAIN && a.ntaps == 1 && !a.resid && !a.colstats && !a.pn_ms && !a.out_nchw && !a.act && !a.splitk_ws &&
            a.Cout % 16 == 0 && pl.dma && !pl.pp && pl.small < 0 && !pl.posmajor && variant == 0;
 }
 bool conv_geglu_fusable(int dt, const ConvArgs& a0) {
