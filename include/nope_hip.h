@@ -346,7 +346,9 @@ int nope_op_warp_perspective(const void* src, int src_is_u8, int Hs, int Ws, int
                              float scale, float shift, nope_stream_t s);
 /* Token-space operators of the LDM variant (ldm/attention.py), tokens = NHWC pixels [M][C]:
  * LayerNorm over C (:210-212); GEGLU in [M][2D] -> out [M][D] (:37-44); softmax self-attention over the N tokens of each
- * sample on a fused [n][N][3C] q|k|v tensor, heads of 32 channels (:168-189). */
+ * sample on a fused [n][N][3C] q|k|v tensor, heads of 32 channels (:168-189).  dtype = a storage code; nope_op_token_attention also takes the
+ * compute tags NOPE_BF16X3 / NOPE_F16X2 (f32 tensors, every product as three bf16 MFMA passes over (hi, lo) splits: what the LDM runtime
+ * launches in those modes; NOPE_F32 = all-f32 VALU arithmetic, the parity mode). */
 int nope_op_layer_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, int64_t M, int C, float eps, nope_stream_t s);
 int nope_op_geglu(int dtype, const void* in, void* out, int64_t M, int D, nope_stream_t s);
 int nope_op_token_attention(int dtype, const void* qkv, void* out, int n, int N, int C, int dim_head, nope_stream_t s);
