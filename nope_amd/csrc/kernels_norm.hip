@@ -369,6 +369,160 @@ int launch_gn_fold(const float* colstats, float* partial, int nhyp, int blocks, 
     return NOPE_OK;
 }
 
+// ---- GroupNorm + SiLU (+ residual) + a 1x1 projection to <= 8 channels, NCHW out: the tail of the U-Net ---------------------------------
+// final_conv = ResnetBlock(dim, dim) -> Conv2d(dim, out_dim, 1) (u_net.py:154-157,197): block2's normalised output (0.4 GB at 512 hypotheses)
+// has ONE reader, a 1x1 conv to 8 channels that ran at 0.014 of the matrix peak -- as its own launch it re-read what gn_apply had just written.
+// Here the projection is applied where the value is produced.  A wave takes FOUR pixels at a time, 16 lanes each; lane j of a pixel owns the
+// 16-byte channel vectors j, j + 16, .. (K of them: C <= 64 K; K = 3 at 192 channels, every lane busy) with their affine coefficients and
+// 8 x 4 K projection weights in registers, so a load instruction reads 256 contiguous bytes per pixel.  The 8 partial dot products are folded
+// across the 16 lanes with a halving butterfly (exchange 4 values over lane ^ 8, 2 over ^ 4, 1 over ^ 2, then one plain step: 8 cross-lane moves
+// per four pixels), and lane 2 o of a pixel writes its output channel o.  (First form, one pixel per wave and one vector per lane: 250
+// instructions per pixel, the launch VALU-bound at ~250 us where its 0.8 GB take 150.)  f32 storage + hardware SiLU only (the split-precision
+// modes): GroupNorm arithmetic as gn_apply_kernel<float, true, ...> (same folds, same coefficients), the dot product in f32 FMAs where the conv
+// kernel used three bf16 MFMA passes -- not bit-identical to the two-launch form, closer to the f32 result.
+template <bool RES, int K>
+__global__ __launch_bounds__(NT) void gn_apply_proj_kernel(const float* __restrict__ x, const float* __restrict__ colstats, int stat_blocks,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C, int G,
+                                                           const float* __restrict__ resid, float eps, int blocks_per_hyp, int resid_rep,
+                                                           const float* __restrict__ pw, const float* __restrict__ pb, int OC,
+                                                           void* __restrict__ out, int out_dt) {
+    __shared__ float s_mean[64];
+    __shared__ float s_rstd[64];
+    __shared__ float ch_s[256];
+    __shared__ float ch_q[256];
+    const int hyp = blockIdx.x / blocks_per_hyp, blk = blockIdx.x % blocks_per_hyp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cpg = C / G;
+    {
+        const float* base = colstats + (size_t)hyp * stat_blocks * C * 2;
+        for (int c = tid; c < C; c += NT) {          // (gn_apply_kernel's FOLD: same order, same bits)
+            float s = 0.f, q = 0.f;
+            int b = 0;
+            for (; b + 8 <= stat_blocks; b += 8) {
+                f32x2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x2*>(base + ((size_t)(b + u) * C + c) * 2);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s += v[u][0]; q += v[u][1]; }
+            }
+            for (; b < stat_blocks; ++b) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(base + ((size_t)b * C + c) * 2);
+                s += v[0]; q += v[1];
+            }
+            ch_s[c] = s; ch_q[c] = q;
+        }
+        __syncthreads();
+        group_sums(ch_s, ch_q, cpg, G, tid, [&](int g, float S, float Q) {
+            const float cnt = (float)cpg * (float)HW;
+            const float mean = S / cnt;
+            float var = Q / cnt - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            s_mean[g] = mean;
+            s_rstd[g] = 1.0f / sqrtf(var + eps);
+        });
+    }
+    __syncthreads();
+    const int pper = (HW + blocks_per_hyp - 1) / blocks_per_hyp;
+    const int p0 = blk * pper;
+    const int p1 = p0 + pper < HW ? p0 + pper : HW;
+    const float* xb = x + (size_t)hyp * HW * C;
+    const float* rb = RES ? resid + (size_t)(hyp / resid_rep) * HW * C : nullptr;
+    const int j = lane & 15, pl = lane >> 4;             // lane j of pixel slot pl
+    bool own[K];
+    int c0[K];
+    f32x2 sc[K][2], sh[K][2];
+    float w[8][K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        own[k] = (j + 16 * k) * 4 < C;                   // this lane holds channels 4 (j + 16 k) .. + 3
+        c0[k] = own[k] ? (j + 16 * k) * 4 : 0;
+        float ga[4], be[4];
+        Elt<float>::unpack(ld16(gamma + c0[k]), ga);
+        Elt<float>::unpack(ld16(beta + c0[k]), be);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (c0[k] + e) / cpg;
+            const float a = s_rstd[g] * ga[e];
+            const float b = be[e] - s_mean[g] * a;
+            sc[k][e >> 1][e & 1] = own[k] ? a : 0.f;
+            sh[k][e >> 1][e & 1] = own[k] ? b : 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {                    // (one 16-byte load per output row: C % 4 == 0)
+            float wv[4];
+            Elt<float>::unpack(ld16(pw + (size_t)(o < OC ? o : 0) * C + c0[k]), wv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[o][k][e] = (own[k] && o < OC) ? wv[e] : 0.f;
+        }
+    }
+    // after the butterfly the even lane 2 o of a pixel holds output channel o
+    const int oo = j >> 1;
+    const float bias_o = (oo < OC && pb) ? pb[oo] : 0.f;
+    const bool hi8 = j & 8, hi4 = j & 4, hi2 = j & 2;
+    auto project = [&](const u32x4 (&xa)[K], const u32x4 (&xr)[K], int pix) {
+        float d[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) d[o] = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float v[4], r[4];
+            Elt<float>::unpack(xa[k], v);
+            if (RES) Elt<float>::unpack(xr[k], r);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x2 t = f32x2{v[2 * q], v[2 * q + 1]} * sc[k][q] + sh[k][q];
+                t = silu2<true>(t);
+                if (RES) t += f32x2{r[2 * q], r[2 * q + 1]};
+                v[2 * q] = t.x; v[2 * q + 1] = t.y;
+            }
+#pragma unroll
+            for (int o = 0; o < 8; ++o) d[o] += ((v[0] * w[o][k][0] + v[1] * w[o][k][1]) + v[2] * w[o][k][2]) + v[3] * w[o][k][3];
+        }
+        float e4[4], e2[2], e1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                      // lanes 8.. of the pixel keep outputs 4..7, lanes ..7 outputs 0..3
+            const float give = hi8 ? d[i] : d[4 + i], keep = hi8 ? d[4 + i] : d[i];
+            e4[i] = keep + __shfl_xor(give, 8, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float give = hi4 ? e4[i] : e4[2 + i], keep = hi4 ? e4[2 + i] : e4[i];
+            e2[i] = keep + __shfl_xor(give, 4, 64);
+        }
+        {
+            const float give = hi2 ? e2[0] : e2[1], keep = hi2 ? e2[1] : e2[0];
+            e1 = keep + __shfl_xor(give, 2, 64);
+        }
+        e1 += __shfl_xor(e1, 1, 64);
+        if (!(j & 1) && oo < OC && pix < p1) {
+            const float val = e1 + bias_o;
+            const size_t o = ((size_t)hyp * OC + oo) * HW + pix;
+            if (out_dt == NOPE_F32) reinterpret_cast<float*>(out)[o] = val;
+            else if (out_dt == NOPE_F16) reinterpret_cast<f16_t*>(out)[o] = f32_to_f16_sat(val);
+            else reinterpret_cast<bf16_t*>(out)[o] = f32_to_bf16(val);
+        }
+    };
+    constexpr int U = 2, PPI = NT / 16;                   // pixel groups in flight per wave; pixels per workgroup iteration
+    // (every lane of a wave walks the same number of iterations -- the butterfly is wave-collective; a slot behind the range loads its last pixel again)
+    for (int base = p0; base < p1; base += U * PPI) {
+        u32x4 xa[U][K], xr[U][K];
+        int px[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            px[u] = base + u * PPI + wave * 4 + pl;
+            const int pc = px[u] < p1 ? px[u] : p1 - 1;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const size_t o = (size_t)pc * C + c0[k];
+                xa[u][k] = ld16(xb + o);
+                xr[u][k] = RES ? ld16(rb + o) : xa[u][k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) project(xa[u], xr[u], px[u]);
+    }
+}
+
 int gn_apply_blocks(int HW, int C, int dt, int nhyp) {
     // Streaming bytes per workgroup.  Every workgroup first rebuilds (mean, rstd) and its per-channel coefficients (a barrier and
     // ~25 dependent loads): at 32 KiB that set-up was a third of a workgroup's instructions; 16 / 32 / 64 / 128 KiB measured
@@ -441,6 +595,38 @@ int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s) {
 #undef NOPE_GN_APPLY_AR
 #undef NOPE_GN_APPLY_U
 #undef NOPE_GN_APPLY_F
+    NOPE_CHECK_LAUNCH();
+    return NOPE_OK;
+}
+
+// GnApplyArgs::proj_*: the fused tail above.  Eligible: f32 storage with the hardware SiLU (the split-precision modes), SiLU on, statistics folded
+// inline (colstats), no embedding / FiLM / output statistics / shared x, C <= 256 in whole 16-byte vectors, <= 8 output channels.
+bool gn_apply_proj_ok(int dt, const GnApplyArgs& a) {
+    return dt == NOPE_F32 && a.fast_silu && a.act && a.colstats && a.stat_blocks >= 1 && !a.emb && !a.film && !a.out_stats && a.x_rep == 1 &&
+           a.C % 4 == 0 && a.C <= 256 && a.G >= 1 && a.G <= 64 && a.C % a.G == 0 && a.proj_cout >= 1 && a.proj_cout <= 8 && a.proj_w && a.proj_out &&
+           (a.proj_out_dt == NOPE_F32 || a.proj_out_dt == NOPE_F16 || a.proj_out_dt == NOPE_BF16) && NOPE_ENV("NOPE_FINAL_FUSED", 1) != 0;
+}
+int launch_gn_apply_proj(int dt, const GnApplyArgs& a, hipStream_t s) {
+    if (!a.x || !a.gamma || !a.beta || a.nhyp <= 0 || a.resid_rep < 1 || !gn_apply_proj_ok(dt, a)) return NOPE_ERR_ARG;
+    int bph = 1;
+    {   // a workgroup iteration is 2 x 16 pixels, and a workgroup's set-up (statistics fold, two barriers, 8 x 4 K weights + coefficients per lane) costs
+        // several iterations: NOPE_PROJ_PIXELS pixels per workgroup (whole iterations), fewer only to keep ~1024 workgroups in the grid
+        int pper = NOPE_ENV("NOPE_PROJ_PIXELS", 256);
+        while (pper > 32 && (long long)a.nhyp * ((a.HW + pper - 1) / pper) < 1024) pper >>= 1;
+        if (pper > a.HW) pper = a.HW;
+        pper = pper >= 32 ? pper / 32 * 32 : (pper > 16 ? 32 : 16);
+        bph = (a.HW + pper - 1) / pper;
+    }
+    dim3 grid((unsigned)(a.nhyp * bph)), block(NT);
+    const int K = (a.C + 63) / 64;                                    // 16-byte channel vectors per lane
+#define NOPE_GN_PROJ(RES, KK)                                                                                                                    \
+    hipLaunchKernelGGL((gn_apply_proj_kernel<RES, KK>), grid, block, 0, s, (const float*)a.x, a.colstats, a.stat_blocks, a.gamma, a.beta, a.HW, a.C, a.G, \
+                       (const float*)a.resid, a.eps, bph, RES ? a.resid_rep : 1, a.proj_w, a.proj_b, a.proj_cout, a.proj_out, a.proj_out_dt)
+#define NOPE_GN_PROJ_K(RES)                                                                                                                      \
+    do { if (K == 1) NOPE_GN_PROJ(RES, 1); else if (K == 2) NOPE_GN_PROJ(RES, 2); else if (K == 3) NOPE_GN_PROJ(RES, 3); else NOPE_GN_PROJ(RES, 4); } while (0)
+    if (a.resid) NOPE_GN_PROJ_K(true); else NOPE_GN_PROJ_K(false);
+#undef NOPE_GN_PROJ_K
+#undef NOPE_GN_PROJ
     NOPE_CHECK_LAUNCH();
     return NOPE_OK;
 }

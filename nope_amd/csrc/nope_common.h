@@ -397,10 +397,18 @@ struct GnApplyArgs {
     float* out_stats = nullptr;        // optional [nhyp][gn_apply_blocks()][2]: (sum, sum sq) of the values written
     float eps = 1e-5f;
     unsigned* amax_out = nullptr;      // f32 storage + fast_silu only (the split-precision modes): a range slot (kX2SlotWords words, amax_publish) for max |y| of what this launch writes
+    // gn_apply_proj only (kernels_norm.hip: GroupNorm + SiLU + residual + a 1x1 projection to <= 8 channels in one pass, NCHW out; y is not written):
+    const float* proj_w = nullptr;     // [proj_cout][C] f32, the 1x1 conv's weight as stored in the state dict
+    const float* proj_b = nullptr;     // [proj_cout] or null
+    int proj_cout = 0;
+    void* proj_out = nullptr;          // [nhyp][proj_cout][HW], element type proj_out_dt (NOPE_F32 / NOPE_F16 / NOPE_BF16)
+    int proj_out_dt = NOPE_F32;
     int fast_silu = 0;                 // f32 storage only: SiLU on v_exp_f32 + v_rcp_f32 (1 ulp each, what the 16-bit types always use) instead of expf + an
                                        // IEEE division -- set by the runtimes in the split-precision modes (bf16x3, f16x2), whose bar is 1e-4, not bit parity
 };
 int launch_gn_apply(int dt, const GnApplyArgs& a, hipStream_t s);
+bool gn_apply_proj_ok(int dt, const GnApplyArgs& a);          // would launch_gn_apply_proj take these arguments?
+int launch_gn_apply_proj(int dt, const GnApplyArgs& a, hipStream_t s);
 bool conv_records_out_amax(int dt, const ConvArgs& a);     // would launch_conv's kernel fill a.out_amax? (kernels_gemm.hip)
 int launch_absmax_f32(const float* x, size_t n, unsigned* slot, hipStream_t s);     // amax_publish(slot, max |x[i]|) (kernels_misc.hip; NaNs ignored); slot = kX2SlotWords words
 int launch_amax_reduce(unsigned* slots, int nslots, unsigned* compact, hipStream_t s);

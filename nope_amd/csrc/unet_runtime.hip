@@ -60,6 +60,7 @@ struct nope_unet {
     int dims[9];
     int classes = 0;
     Conv init_conv, final_conv1;
+    float* final_w_raw = nullptr;      // final_conv.1.weight as stored, [out_dim][u_net_dim] f32: the fused tail (gn_apply_proj, kernels_norm.hip)
     Level downs[8], ups[8];
     Res mid1, mid2, final_res, final_conv0;
     Attn mid_attn;
@@ -306,9 +307,11 @@ struct Fwd {
     }
     // y = act(GN(x)) [+emb] [+resid]; x holds n_x = nhyp / x_rep samples; `colstats` != null: statistics were
     // produced by the conv epilogue and only need folding.
-    void gn(const Norm& nm, int G, const void* x, int x_rep, void* y, int HW, int act, int emb_off, const void* resid,
-            int resid_rep, const Stats& st = Stats(), float* out_stats = nullptr) {
-        if (!live()) return;
+    // proj (with proj_out): GroupNorm + SiLU + residual + this 1x1 conv in one pass (launch_gn_apply_proj: y is not written) when the arguments
+    // qualify; returns whether it did -- the caller launches the conv itself otherwise
+    bool gn(const Norm& nm, int G, const void* x, int x_rep, void* y, int HW, int act, int emb_off, const void* resid,
+            int resid_rep, const Stats& st = Stats(), float* out_stats = nullptr, const Conv* proj = nullptr, void* proj_out = nullptr, int proj_out_dt = NOPE_F32) {
+        if (!live()) return false;
         const int nx = nhyp / x_rep;
         int nch = 1;
         GnApplyArgs ga;
@@ -331,13 +334,25 @@ struct Fwd {
         ga.resid = resid; ga.x_rep = x_rep; ga.resid_rep = resid_rep; ga.out_stats = out_stats;
         if (tracking()) { const int sl = x2.produce(y); if (sl >= 0) ga.amax_out = x2.slot_ptr(sl); }
         ga.fast_silu = net->dt != NOPE_F32 ? 1 : 0;      // (f32 storage of the split-precision modes: hardware exp / rcp; the f32 mode keeps expf and the division)
+        if (proj && proj_out && net->final_w_raw) {
+            ga.proj_w = net->final_w_raw; ga.proj_b = proj->bias; ga.proj_cout = proj->Cout; ga.proj_out = proj_out; ga.proj_out_dt = proj_out_dt;
+            if (gn_apply_proj_ok(net->sdt, ga)) {
+                if (tracking()) x2.overwritten(y);        // (y keeps whatever it held: no maximum recorded for it)
+                chk(launch_gn_apply_proj(net->sdt, ga, s));
+                return true;
+            }
+        }
         chk(launch_gn_apply(net->sdt, ga, s));
+        return false;
     }
 
     // ResnetBlock, model_utils.py:271-279.  `a` may be shared by a.rep hypotheses (rep > 1 only
     // for the very first block, where b == nullptr).
     // `next_is_attention`: also emit the GroupNorm(1) partials of the block's output into pn_partial.
-    void resnet(const Res& R, const Act& a, const Act* b, bool use_emb, void* out, bool next_is_attention = false) {
+    // proj / proj_out: the 1x1 conv that is the ONLY reader of the block's output (the U-Net's tail), fused into the block's last pass where gn() can;
+    // returns whether it was (then `out` holds the un-normalised conv output and must not be read)
+    bool resnet(const Res& R, const Act& a, const Act* b, bool use_emb, void* out, bool next_is_attention = false, const Conv* proj = nullptr,
+                void* proj_out = nullptr, int proj_out_dt = NOPE_F32) {
         const int HW = a.H * a.W, G = net->cfg.groups;
         const size_t M = (size_t)nhyp * HW;
         const size_t mark = ar.off;
@@ -365,8 +380,9 @@ struct Fwd {
             conv(R.res, a, b, t3, a.H, a.W, nhyp, a.rep, b ? b->rep : 1);
             resid = t3; resid_rep = 1;
         } else if (b) { chk(NOPE_ERR_ARG); }
-        gn(R.n2, G, out, 1, out, HW, 1, -1, resid, resid_rep, cs2, next_is_attention ? pn_partial : nullptr);
+        const bool fused = gn(R.n2, G, out, 1, out, HW, 1, -1, resid, resid_rep, cs2, next_is_attention ? pn_partial : nullptr, proj, proj_out, proj_out_dt);
         ar.off = mark;
+        return fused;
     }
 
     // PreNorm folded into the qkv conv: finalize (mean, rstd) of x from the producer's partials, then
@@ -541,8 +557,10 @@ int run_forward(const nope_unet* net, const float* x, int n_src, int x_rep, cons
         Act a{f.alloc_act(e), cfg.u_net_dim, H, W, 1};
         Act b{f.alloc_act(e), cfg.u_net_dim, H, W, 1};
         f.resnet(net->final_res, cur, &r0, true, a.p);
-        f.resnet(net->final_conv0, a, nullptr, false, b.p);
-        f.conv(net->final_conv1, b, nullptr, out, H, W, n_hyp, 1, 1, nullptr, /*out_nchw=*/1, out_dtype);
+        // final_conv = ResnetBlock -> Conv2d(dim, out_dim, 1) (u_net.py:154-157,197): the 1x1 conv rides in the block's last GroupNorm pass in the
+        // split-precision modes (NOPE_FINAL_FUSED=0: its own launch, as in the other modes)
+        if (!f.resnet(net->final_conv0, a, nullptr, false, b.p, false, &net->final_conv1, out, out_dtype))
+            f.conv(net->final_conv1, b, nullptr, out, H, W, n_hyp, 1, 1, nullptr, /*out_nchw=*/1, out_dtype);
         f.ar.off = mark;
     }
     if (f.tracking())      // the forward's verdict and, if a layer left its window, NaNs over its output -- device side, no synchronisation (x2_range.h)
@@ -627,6 +645,7 @@ int nope_unet_create(const nope_unet_config* cfg, const nope_tensor_desc* tensor
     net->final_res = ld.res("final_res_block.", cfg->u_net_dim * 2, cfg->u_net_dim, true, embs);
     net->final_conv0 = ld.res("final_conv.0.", cfg->u_net_dim, cfg->u_net_dim, false, embs);
     net->final_conv1 = ld.conv("final_conv.1.", cfg->u_net_dim, cfg->out_dim, 1, NOPE_CONV_PLAIN, true);
+    net->final_w_raw = ld.copy_f32("final_conv.1.weight", {cfg->out_dim, cfg->u_net_dim, 1, 1});
     if (dims[0] != cfg->u_net_dim) ld.fail("init_dim");
 
     // row-concatenated embedding linears

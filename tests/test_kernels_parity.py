@@ -317,6 +317,36 @@ def test_tiny_unet_vs_reference_golden(be, golden, tag, dim, mlp):
             assert rel(yh, want) < tol
 
 
+@pytest.mark.parametrize("dim,hw,outc", [(8, (8, 8), 8), (24, (8, 16), 8), (64, (8, 8), 4), (96, (8, 8), 8), (160, (8, 8), 8), (192, (16, 16), 8)])
+def test_unet_tail_fused_into_the_last_groupnorm(be, dim, hw, outc, monkeypatch):
+    """final_conv = ResnetBlock(dim, dim) -> Conv2d(dim, out_dim, 1) (u_net.py:154-157,197): in the split-precision modes the 1x1 conv runs inside the
+    block's last GroupNorm + SiLU + residual pass (gn_apply_proj_kernel: one wave per pixel, f32 dot products folded across the wave), straight into the
+    NCHW output.  Against the oracle, and against the two-launch form (NOPE_FINAL_FUSED=0) -- same values up to the order of the dot product -- for
+    channel counts that fill 2, 6 and 16 lanes of a pixel's 16 with one 16-byte vector each (K = 1), two and three vectors per lane with idle tails
+    (96, 160 channels) and the shipped 192, a non-square map, fewer than 8 output channels."""
+    hip, dev, name = be
+    from nope_amd.u_net import UNet
+    from nope_amd.weights import synth_init_
+    g = torch.Generator().manual_seed(23)
+    H, W = hw
+    x, pose = torch.randn(1, outc, H, W, generator=g), torch.randn(1, 5, 6, generator=g)
+    for cdt in ("bf16x3", "f16x2"):
+        if name == "emu" and (cdt == "f16x2" or dim in (64, 96, 160, 192)):
+            continue      # keep the CPU suite short (f16x2 = the same tail; the wide cases run on the GPU -- 96 passed under the interpreter by hand, 3 CPU-minutes)
+        u = UNet(u_net_dim=dim, rot_representation_dim=6, encoder=StubEncoder(outc), pose_mlp_name="single_layer", compute_dtype=cdt)
+        synth_init_(u, 2022)
+        want = R.unet_forward({k: v.clone() for k, v in u.own_state_dict().items()}, x.expand(5, -1, -1, -1), pose[0])
+        u = u.to(dev)
+        monkeypatch.setenv("NOPE_FINAL_FUSED", "1")
+        y1 = u.forward_hypotheses(x.to(dev), pose.to(dev)).cpu()[0]
+        monkeypatch.setenv("NOPE_FINAL_FUSED", "0")
+        y0 = u.forward_hypotheses(x.to(dev), pose.to(dev)).cpu()[0]
+        monkeypatch.delenv("NOPE_FINAL_FUSED")
+        assert y1.shape == (5, outc, H, W)
+        assert rel(y1, want) < X3_TOL and rel(y0, want) < X3_TOL, (cdt, rel(y1, want), rel(y0, want))
+        assert rel(y1, y0) < 2e-5 and not torch.equal(y1, y0), (cdt, rel(y1, y0))      # (not equal: the fused form really ran)
+
+
 def test_unet_latent_channels_padded(be):
     """A latent whose channel count is not a whole 16-byte vector (4 channels, e.g. a VAE latent): init_conv's K axis is zero-padded
     to 8 at pack time and the NHWC input is padded alongside, in every compute mode; out_dim = channels = 4 through the NCHW epilogue."""
