@@ -632,6 +632,7 @@ __device__ __forceinline__ void epilogue_wide(const ConvParams& p, const typenam
                 constexpr bool RESID = decltype(resid_tag)::value;
 #pragma unroll
                 for (int pass = 0; pass < 3; ++pass) {
+                    if (nw + pass * 32 >= p.Cout) continue;       // (wave-uniform; Cout % 32 == 0: a 32-column pass is whole or absent -- channel counts that are not multiples of 192)
                     __builtin_amdgcn_sched_barrier(0);            // (keeps the next pass's constant loads and panel fill out of this pass: registers)
                     float pc0[4], pc1[4], pb[4];
                     if (PN) {

@@ -680,9 +680,9 @@ int launch_conv(int dt, const ConvArgs& a, hipStream_t s) {
         p.persist_d2 = (unsigned)((long long)p.persist_dm * a.C2 * es);
         gx = (unsigned)sgrid;
     }
-    // The lean wide epilogue (epilogue_wide, LEANM = 1): f32 storage on the 32 x 32 tiles, EVERY wave tile of the launch whole, rows in NHWC order,
+    // The lean wide epilogue (epilogue_wide, LEANM = 1): f32 storage on the 32 x 32 tiles, EVERY wave tile of the launch whole along M and in whole 32-column passes along N, rows in NHWC order,
     // one sample per wave tile under a fused PreNorm, 32-bit byte offsets.  NOPE_EPILOGUE_LEAN=0: the generic row loop everywhere (A/B).
-    p.lean = (dt == NOPE_BF16X3 && dma && plan.small < 0 && p.wide_out && !p.posmajor && !phased && p.splits == 1 && !a.geglu && M % bm == 0 && a.Cout % BN == 0 &&
+    p.lean = (dt == NOPE_BF16X3 && dma && plan.small < 0 && p.wide_out && !p.posmajor && !phased && p.splits == 1 && !a.geglu && M % bm == 0 && a.Cout % 32 == 0 &&
               (!a.pn_ms || ((long long)p.Hm * p.Wm) % 64 == 0) && (unsigned long long)M * a.Cout * 4ull < 0xffffffffull && NOPE_ENV("NOPE_EPILOGUE_LEAN", 1) != 0) ? 1 : 0;
     if (p.splits > 1) p.out_amax = nullptr;        // (raw partials: the reduce kernel writes the tensor)
     const dim3 grid(gx, phased ? 4u : 1u, (unsigned)p.splits), block(NT);

@@ -1,7 +1,7 @@
 """The lean wide epilogue of the f32-storage modes (epilogue_wide, LEANM = 1: conv_gemm_common.h) against the generic row loop it replaces, bit
 for bit, on every kernel that has a LEAN instantiation: the 128 x 192 LDS-DMA kernel, the streaming 1x1 kernel, the per-tap ping-pong kernel
 (1x1 and space-to-depth) and the tap-resident 3x3 kernel, in bf16x3 and f16x2, with bias / residual / ReLU; plus shapes the launcher must
-keep OFF the lean path (ragged rows, a channel count that is no multiple of 192).  Run by tests/test_conv_stream.py under tests/hipemu and on
+keep OFF the lean path (ragged rows, a channel count that is no multiple of 32); channel counts of 192 + 64 and 192 + 32 stay ON it (whole 32-column passes).  Run by tests/test_conv_stream.py under tests/hipemu and on
 the GPU.  The fused-PreNorm and GroupNorm-statistics forms are covered by the U-Net cases (stream_emu_case.run_unet: bit-identical too)."""
 import os
 import sys
@@ -51,6 +51,10 @@ def run(hip, dev, dts=(3, X2), light=False):
             w8, b8 = rn(192, 2 * C, 1, 1) / 8, rn(192)
             both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x8), 0), d(w8), d(b8), resid=hip.to_nhwc(d(r8), 0)), "stream 1x1 + residual", F.conv2d(x8, w8, b8) + r8,
                  NOPE_CONV_PP=0, NOPE_CONV_SMALL=0, NOPE_CONV_STREAM=1, NOPE_STREAM_GRID=8, NOPE_STREAM_MIN_ITERS=1)
+            # lean with a ragged last panel: 256 columns = 192 + 64 (whole 32-column passes: the LDM variant's channel counts), with residual
+            w6, b6, r6 = rn(256, 2 * C, 1, 1) / 8, rn(256), rn(1, 256, 16, 16)
+            both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x), 0), d(w6), d(b6), resid=hip.to_nhwc(d(r6), 0)), "dma 1x1, 256 columns + residual", F.conv2d(x, w6, b6) + r6,
+                 NOPE_CONV_PP=0, NOPE_CONV_SMALL=0, NOPE_CONV_STREAM=0)
             # NOT lean: 200 columns (the second weight panel is ragged), 270 rows
             wr, br = rn(200, 2 * C, 1, 1) / 8, rn(200)
             both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x), 0), d(wr), d(br)), "dma 1x1 ragged columns", F.conv2d(x, wr, br), NOPE_CONV_PP=0, NOPE_CONV_SMALL=0, NOPE_CONV_STREAM=0)
@@ -62,6 +66,8 @@ def run(hip, dev, dts=(3, X2), light=False):
         pp = dict(NOPE_CONV_PP=11, NOPE_CONV_SMALL=0, NOPE_CONV_STREAM=0)
         xs, ws_, bs, rs = rn(2, 2 * C, 16, 16), rn(192, 2 * C, 3, 3) / 24, rn(192), rn(2, 192, 16, 16)
         both(lambda: hip.op_conv(dt, hip.to_nhwc(d(xs), 0), d(ws_), d(bs), resid=hip.to_nhwc(d(rs), 0)), "tap-resident 3x3 + residual", F.conv2d(xs, ws_, bs, padding=1) + rs, **pp)
+        w7, b7 = rn(224, 2 * C, 3, 3) / 24, rn(224)      # 224 columns = 192 + 32: one pass of the second panel's first wave column, none of its second
+        both(lambda: hip.op_conv(dt, hip.to_nhwc(d(xs), 0), d(w7), d(b7)), "tap-resident 3x3, 224 columns", F.conv2d(xs, w7, b7, padding=1), **pp)
         if not light:
             both(lambda: hip.op_conv(dt, hip.to_nhwc(d(xs), 0), d(ws_), d(bs), act_relu=True), "tap-resident 3x3 + relu", F.relu(F.conv2d(xs, ws_, bs, padding=1)), **pp)
             both(lambda: hip.op_conv(dt, hip.to_nhwc(d(x), 0), d(w), d(b)), "per-tap 1x1", F.conv2d(x, w, b), **pp)
