@@ -230,17 +230,28 @@ __global__ __launch_bounds__(NT) void token_attn_mfma_kernel(const bf16_t* __res
                 sc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[kk]), sc[sb], 0, 0, 0);
             }
         }
-        // scores in log2 units; keys behind N (last block of a ragged N) drop out
+        // scores in log2 units; keys behind N (last block of a ragged N: a uniform branch, the other blocks pay no compare / select) drop out
         float bm = -3.0e38f;
+        if (k0 + MK > N) {
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
+            for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + sb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                const float v = key < N ? sc[sb][r] * scale_log2e : -3.0e38f;
-                sc[sb][r] = v;
-                bm = fmaxf(bm, v);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + sb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                    const float v = key < N ? sc[sb][r] * scale_log2e : -3.0e38f;
+                    sc[sb][r] = v;
+                    bm = fmaxf(bm, v);
+                }
+        } else {
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = sc[sb][r] * scale_log2e;
+                    sc[sb][r] = v;
+                    bm = fmaxf(bm, v);
+                }
+        }
         bm = fmaxf(bm, __shfl_xor(bm, 32, 64));                  // the other half of this query's keys
         const float nm = fmaxf(mx, bm);
         const float corr = __builtin_amdgcn_exp2f(mx - nm);
@@ -319,7 +330,16 @@ __global__ __launch_bounds__(NT) void token_attn_mfma_x3_kernel(const float* __r
     {
         const float* qp = base + (size_t)(q < N ? q : N - 1) * 3 * C + 8 * h;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) split8_bf16(ld16(qp + 16 * kk), ld16(qp + 16 * kk + 4), qh[kk], ql[kk]);
+        for (int kk = 0; kk < 2; ++kk) {                       // q * (scale log2 e) in f32, then split: the scores come out of the MFMAs in log2 units
+            u32x4 a = ld16(qp + 16 * kk), b = ld16(qp + 16 * kk + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned ua = a[e], ub = b[e];
+                a[e] = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, ua) * scale_log2e);
+                b[e] = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, ub) * scale_log2e);
+            }
+            split8_bf16(a, b, qh[kk], ql[kk]);
+        }
     }
     f32x16 o;
 #pragma unroll
@@ -366,17 +386,21 @@ __global__ __launch_bounds__(NT) void token_attn_mfma_x3_kernel(const float* __r
                     const u32x4 qf = t == 1 ? ql[kk] : qh[kk];
                     sc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf), sc[sb], 0, 0, 0);
                 }
-        // scores in log2 units; keys behind N (last block of a ragged N) drop out
+        // keys behind N (last block of a ragged N: a uniform branch) drop out
         float bm = -3.0e38f;
+        if (k0 + MK > N) {
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + sb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                    if (key >= N) sc[sb][r] = -3.0e38f;
+                }
+        }
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + sb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                const float v = key < N ? sc[sb][r] * scale_log2e : -3.0e38f;
-                sc[sb][r] = v;
-                bm = fmaxf(bm, v);
-            }
+            for (int r = 0; r < 16; ++r) bm = fmaxf(bm, sc[sb][r]);
         bm = fmaxf(bm, __shfl_xor(bm, 32, 64));                  // the other half of this query's keys
         const float nm = fmaxf(mx, bm);
         const float corr = __builtin_amdgcn_exp2f(mx - nm);
