@@ -20,11 +20,14 @@ def test_stream_kernel_and_lean_epilogue_under_adversarial_interpreter(emu_jobs)
 
 
 def test_plan_keeps_ragged_launches_off_the_lean_path():
-    """Host logic: `lean` needs EVERY wave tile whole -- the launcher's condition, restated (kernels_gemm.hip: launch_conv)."""
+    """Host logic: `lean` needs EVERY wave tile whole along M and made of whole 32-column passes along N (the kernel skips the passes behind the last
+    channel, conv_gemm_common.h) -- the launcher's condition, restated (kernels_gemm.hip: launch_conv)."""
     src = open(os.path.join(ROOT, "nope_amd", "csrc", "kernels_gemm.hip")).read()
     cond = src[src.index("p.lean = ("):src.index("? 1 : 0;", src.index("p.lean = ("))]
-    for must in ("M % bm == 0", "a.Cout % BN == 0", "!p.posmajor", "!phased", "p.splits == 1", "0xffffffffull", "% 64 == 0"):
+    for must in ("M % bm == 0", "a.Cout % 32 == 0", "!p.posmajor", "!phased", "p.splits == 1", "0xffffffffull", "% 64 == 0"):
         assert must in cond, must
+    common = open(os.path.join(ROOT, "nope_amd", "csrc", "conv_gemm_common.h")).read()
+    assert "if (nw + pass * 32 >= p.Cout) continue;" in common      # ... and the pass skip the relaxed column condition relies on
 
 
 @pytest.mark.gpu
