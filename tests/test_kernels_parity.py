@@ -345,6 +345,13 @@ def test_unet_tail_fused_into_the_last_groupnorm(be, dim, hw, outc, monkeypatch)
         assert y1.shape == (5, outc, H, W)
         assert rel(y1, want) < X3_TOL and rel(y0, want) < X3_TOL, (cdt, rel(y1, want), rel(y0, want))
         assert rel(y1, y0) < 2e-5 and not torch.equal(y1, y0), (cdt, rel(y1, y0))      # (not equal: the fused form really ran)
+        if dim == 8 or name == "gpu":
+            # 16-bit template banks (BASELINE configs[3] / [4]) written straight by the fused pass: its f32 values rounded once
+            from nope_amd.model import PoseConditional
+            for bdt, tdt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+                m16 = PoseConditional(u, None, {"similarity_metric": "l2"}, None, bank_dtype=bdt).to(dev)
+                bank = m16.generate_templates_from_feat(x.to(dev), pose.to(dev)).cpu()[0]
+                assert bank.dtype == tdt and torch.equal(bank, y1.to(tdt)), (cdt, bdt)
 
 
 def test_unet_latent_channels_padded(be):
