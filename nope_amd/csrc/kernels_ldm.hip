@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NT) void token_attn_kernel(const T* __restrict__ qk
     }
 }
 
-// ---- the same op on the matrix cores (bf16 storage) ---------------------------------------------------------------------
+// ---- the same op on the matrix cores (16-bit storage: bf16, and -- round 6 -- f16) ---------------------------------------------------------------------
 // One wave owns 32 queries of a (sample, head); a workgroup of four waves shares the key / value blocks (64 keys per
 // iteration) through LDS.  Everything is computed TRANSPOSED, so that a lane's accumulator column is one query throughout:
 //   S^T = K Q^T        (v_mfma_f32_32x32x16_bf16: A = 32 keys x 16 d from LDS, B = Q^T from registers, two per 32 keys)
@@ -180,20 +180,26 @@ constexpr int MQ = 128;          // queries per workgroup
 constexpr int MK = 64;           // keys per iteration
 constexpr int K_LD = 40;         // bf16 per staged K row (32 + pad: conflict-free 16-byte fragment reads)
 constexpr int VT_LD = 68;        // bf16 per staged V^T row (64 keys + pad: conflict-free 8-byte reads)
-__global__ __launch_bounds__(NT) void token_attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int N, int C, float scale_log2e) {
+template <class T>      // bf16_t or f16_t (v_mfma_f32_32x32x16_bf16 / _f16; P rounded to the same 16-bit type as V is stored in)
+__global__ __launch_bounds__(NT) void token_attn_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int C, float scale_log2e) {
+    constexpr bool F16 = Elt<T>::DT == NOPE_F16;
+    auto mma = [](const u32x4& a, const u32x4& b, const __attribute__((ext_vector_type(16))) float& c) {
+        if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
     typedef __attribute__((ext_vector_type(16))) float f32x16;
     typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-    __shared__ __attribute__((aligned(16))) bf16_t s_k[MK][K_LD];
-    __shared__ __attribute__((aligned(16))) bf16_t s_vt[AD][VT_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short s_k[MK][K_LD];          // (raw 16-bit elements of either type)
+    __shared__ __attribute__((aligned(16))) unsigned short s_vt[AD][VT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.y, smp = blockIdx.z;
     const int h = lane >> 5, li = lane & 31;
-    const bf16_t* base = qkv + (size_t)smp * N * 3 * C + head * AD;
+    const T* base = qkv + (size_t)smp * N * 3 * C + head * AD;
     const int q = blockIdx.x * MQ + wave * 32 + li;            // this lane's query (accumulator column)
     // Q^T fragments (B operand): column = query, k = d: 8 consecutive d at 8 h (+ 16 for the second step)
     u32x4 qf[2];
     {
-        const bf16_t* qp = base + (size_t)(q < N ? q : N - 1) * 3 * C + 8 * h;
+        const T* qp = base + (size_t)(q < N ? q : N - 1) * 3 * C + 8 * h;
         qf[0] = ld16(qp); qf[1] = ld16(qp + 16);
     }
     f32x16 o;
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(NT) void token_attn_mfma_kernel(const bf16_t* __res
     u32x4 nk, nv;
     auto fetch = [&](int k0) {
         const int key = k0 + skey;
-        const bf16_t* kp = base + (size_t)(key < N ? key : N - 1) * 3 * C + C + svec * 8;
+        const T* kp = base + (size_t)(key < N ? key : N - 1) * 3 * C + C + svec * 8;
         nk = ld16(kp); nv = ld16(kp + C);
     };
     fetch(0);
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(NT) void token_attn_mfma_kernel(const bf16_t* __res
 #pragma unroll
         for (int e = 0; e < 8; ++e) {                            // V^T: [d][key]
             const unsigned w = nv[e >> 1];
-            s_vt[svec * 8 + e][skey] = (bf16_t)((e & 1) ? (w >> 16) : (w & 0xffffu));
+            s_vt[svec * 8 + e][skey] = (unsigned short)((e & 1) ? (w >> 16) : (w & 0xffffu));
         }
         __syncthreads();
         if (k0 + MK < N) fetch(k0 + MK);
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(NT) void token_attn_mfma_kernel(const bf16_t* __res
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const u32x4 kf = ld16(&s_k[sb * 32 + li][8 * h + 16 * kk]);
-                sc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[kk]), sc[sb], 0, 0, 0);
+                sc[sb] = mma(kf, qf[kk], sc[sb]);
             }
         }
         // scores in log2 units; keys behind N (last block of a ragged N: a uniform branch, the other blocks pay no compare / select) drop out
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(NT) void token_attn_mfma_kernel(const bf16_t* __res
                 for (int j = 0; j < 4; ++j) {
                     const float p0 = __builtin_amdgcn_exp2f(sc[sb][8 * t + 2 * j] - nm), p1 = __builtin_amdgcn_exp2f(sc[sb][8 * t + 2 * j + 1] - nm);
                     ps += p0 + p1;
-                    pf[sb][t][j] = cvt_pk_bf16(p0, p1);
+                    pf[sb][t][j] = Elt<T>::cvt_pk_raw(p0, p1);
                 }
         den = den * corr + ps;
 #pragma unroll
@@ -279,16 +285,16 @@ __global__ __launch_bounds__(NT) void token_attn_mfma_kernel(const bf16_t* __res
                 const u32x2 v0 = *reinterpret_cast<const u32x2*>(&s_vt[li][kb]);
                 const u32x2 v1 = *reinterpret_cast<const u32x2*>(&s_vt[li][kb + 8]);
                 const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
-                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[sb][t]), o, 0, 0, 0);
+                o = mma(vf, pf[sb][t], o);
             }
     }
     den += __shfl_xor(den, 32, 64);
     if (q < N) {
         const float inv = 1.0f / den;
-        bf16_t* op = out + ((size_t)smp * N + q) * C + head * AD + 4 * h;       // rows of O^T this lane holds: d = 8 g + 4 h + (r & 3)
+        T* op = out + ((size_t)smp * N + q) * C + head * AD + 4 * h;       // rows of O^T this lane holds: d = 8 g + 4 h + (r & 3)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const unsigned long long lo = cvt_pk_bf16(o[4 * g] * inv, o[4 * g + 1] * inv), hi = cvt_pk_bf16(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            const unsigned long long lo = Elt<T>::cvt_pk(o[4 * g] * inv, o[4 * g + 1] * inv), hi = Elt<T>::cvt_pk(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
             *reinterpret_cast<unsigned long long*>(op + 8 * g) = lo | (hi << 32);
         }
     }
@@ -508,13 +514,15 @@ int launch_token_attention(int dt, const void* qkv, void* out, int nsmp, int N, 
     if (!qkv || !out || nsmp <= 0 || N <= 0 || C <= 0 || dim_head != AD || C % AD) return NOPE_ERR_ARG;
     const dim3 grid((unsigned)cdiv(N, NT), (unsigned)(C / AD), (unsigned)nsmp);
     const float scale = 1.0f / sqrtf((float)dim_head);
-    // bf16: the matrix-core kernel (NOPE_LDM_ATTN=0 keeps the VALU one: the tests compare the two); f32 -- the parity mode -- stays
+    // bf16 / f16: the matrix-core kernel (NOPE_LDM_ATTN=0 keeps the VALU one: the tests compare the two); f32 -- the parity mode -- stays
     // on the all-f32 VALU kernel
     // on the all-f32 VALU kernel; the compute tags NOPE_BF16X3 / NOPE_F16X2 (f32 storage): the same schedule on three bf16 passes per product
     const bool mfma = NOPE_ENV("NOPE_LDM_ATTN", -1) != 0;
     const dim3 g2((unsigned)cdiv(N, MQ), (unsigned)(C / AD), (unsigned)nsmp);
     if (dt == NOPE_BF16 && mfma) {
-        hipLaunchKernelGGL(token_attn_mfma_kernel, g2, dim3(NT), 0, s, (const bf16_t*)qkv, (bf16_t*)out, N, C, scale * 1.4426950408889634f);
+        hipLaunchKernelGGL((token_attn_mfma_kernel<bf16_t>), g2, dim3(NT), 0, s, (const bf16_t*)qkv, (bf16_t*)out, N, C, scale * 1.4426950408889634f);
+    } else if (dt == NOPE_F16 && mfma) {
+        hipLaunchKernelGGL((token_attn_mfma_kernel<f16_t>), g2, dim3(NT), 0, s, (const f16_t*)qkv, (f16_t*)out, N, C, scale * 1.4426950408889634f);
     } else if ((dt == NOPE_BF16X3 || dt == NOPE_F16X2) && mfma) {
         hipLaunchKernelGGL(token_attn_mfma_x3_kernel, g2, dim3(NT), 0, s, (const float*)qkv, (float*)out, N, C, scale * 1.4426950408889634f);
     } else {

@@ -686,7 +686,7 @@ def test_workspace_canary_odd_hypotheses(be, n_hyp):
 
 
 # ---- LDM cross-attention variant ---------------------------------------
-@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("dt", [0, 1, 2])
 def test_ldm_token_ops(be, dt):
     """LayerNorm over channels, GEGLU and softmax self-attention over tokens (ldm/attention.py:37-44,168-189,210-212) against
     torch on the same (storage-rounded) inputs: ragged token counts, several heads, more keys than one LDS chunk."""
